@@ -1,0 +1,186 @@
+/*
+ * woq_blob.h — on-device packed-weight blob ("WQH1") for the MI355X int4 WOQ path.
+ *
+ * Replaces the opaque BesTLA StorageWeightKBlockNInteger blob that the reference
+ * creates in qbits.repack_quantized_weight
+ *   (intel_extension_for_transformers/qbits/qbits.cpp:61-77,
+ *    qbits/dispatcher/src/bestla_packq_impl.cpp:20-41)
+ * and re-parses on every call (bestla_weightonly_dispatcher.cpp:335-340).
+ * The layout is opaque to callers of the reference too, so it is designed
+ * for gfx950, not copied: one 1-KiB "tile" = 16 output columns x 128 K rows
+ * is exactly one wave64 `global_load_dwordx4` (64 lanes x 16 B), and the lane
+ * <-> (column, k) map inside a tile is the B-operand fragment map of
+ * v_mfma_f32_16x16x32_{f16,bf16}, so the same bytes feed the decode GEMV
+ * (VALU, wave-shuffle reduce) and the prefill GEMM (MFMA) with no re-layout.
+ *
+ * Blob = [256-B header][qdata][scales][zero points][shuffle indices]
+ *
+ * qdata   : [Npad/16][Kpad/128][64 lanes][4 x u32]
+ *           lane l: column i = l & 15, k-quarter kq = l >> 4
+ *           u32 #s (0..3), nibble j (bits 4j..4j+3)  <->  k = kt*128 + s*32 + kq*8 + j
+ *                                                        n = tn*16 + i
+ *           nibble value u = q + 8, q in [-8,7]  (the reference's signed-nibble
+ *           domain, llm/quantization/nn/modules.py:225-227, re-biased to unsigned)
+ *           padding (k >= K or n >= N) is u = 8 (q = 0).
+ * scales  : scale_mode 0 (group % 128 == 0, or a single group):
+ *               [Npad/16][n_groups][16]            element (tn, g, i)
+ *           scale_mode 1 (any other group that is a multiple of 32):
+ *               [Npad/16][Kpad/128][16][4]         element (tn, kt, i, s) = scale of
+ *               the group that holds k = kt*128 + s*32 (expanded per 32-block)
+ *           element type per header.scale_type (fp32 | bf16 | fp16); padding = 0.
+ * zeros   : same indexing as scales, uint8, value uz = zp + 8 where zp is the
+ *           signed-domain zero point handed to repack (range [-8, 7]: the reference's
+ *           (zeros - 8) * 16 // 16 on int8 wraps 16 -> -8, modules.py:225-227, pinned by
+ *           tests/golden/set_weights_bias.npz); absent when !asym.
+ * shuffle : int32[K] activation shuffle indices (x'[j] = x[idx[j]]), exactly the
+ *           tensor the caller passed as g_idx (bestla_packq_impl.cpp:37-38,
+ *           round-trip pinned by qbits_ut/test_packq.py:100); absent otherwise.
+ *
+ * Dequantisation: w[k][n] = (u - uz) * scale     (uz = 8 when !asym)
+ *   == (q - zp) * scale of modules.py:264-295 / recover_qparms :349-352.
+ */
+#ifndef WOQ_BLOB_H_
+#define WOQ_BLOB_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WOQ_BLOB_MAGIC 0x31485157u /* "WQH1" */
+#define WOQ_BLOB_VERSION 1u
+#define WOQ_HEADER_BYTES 256
+#define WOQ_TILE_N 16
+#define WOQ_TILE_K 128
+#define WOQ_TILE_BYTES 1024
+
+/* element types crossing the ABI (reference: qbits.cpp:31-37 allows fp32|bf16; fp16 added
+ * because north_star asks for bf16/fp16 activations) */
+enum woq_dtype { WOQ_F32 = 0, WOQ_BF16 = 1, WOQ_F16 = 2 };
+
+/* weight types (reference strings: bestla_weightonly_dispatcher.hpp:62-70) */
+enum woq_weight_type { WOQ_W_INT4_CLIP = 0, WOQ_W_INT8 = 1 };
+
+/* compute types (reference strings "fp32" | "bf16" | "int8"; recorded) */
+enum woq_compute_type { WOQ_C_FP32 = 0, WOQ_C_BF16 = 1, WOQ_C_INT8 = 2, WOQ_C_FP16 = 3 };
+
+#define WOQ_FLAG_ASYM 1u
+#define WOQ_FLAG_ACT_SHUFFLE 2u
+
+typedef struct woq_blob_header {
+  uint32_t magic;
+  uint32_t version;
+  uint64_t total_bytes;
+  int32_t K, N;
+  int32_t group;     /* resolved group size (blocksize -1 -> K) */
+  int32_t Kpad;      /* K rounded up to 128 */
+  int32_t Npad;      /* N rounded up to 16 */
+  int32_t n_groups;  /* ceil(K / group) */
+  uint32_t weight_type;
+  uint32_t scale_type;   /* enum woq_dtype */
+  uint32_t compute_type; /* enum woq_compute_type */
+  uint32_t flags;
+  uint32_t scale_mode; /* 0 | 1, see above */
+  uint32_t reserved0;
+  uint64_t off_q, off_scale, off_zp, off_shuffle; /* byte offsets from blob start; 0 = absent */
+  uint8_t pad[WOQ_HEADER_BYTES - 96];
+} woq_blob_header;
+
+#ifdef __cplusplus
+static_assert(sizeof(woq_blob_header) == WOQ_HEADER_BYTES, "header must be 256 B");
+#else
+_Static_assert(sizeof(woq_blob_header) == WOQ_HEADER_BYTES, "header must be 256 B");
+#endif
+
+/* acquire_packed_weight_info selector — same numbering as the reference's
+ * PACKW_ACQUIRE_TYPE (qbits/dispatcher/include/bestla_packq_impl.hpp:18-31). */
+enum woq_acquire_type {
+  WOQ_ACQ_SIZE = 0,
+  WOQ_ACQ_BLOCKSIZE = 1,
+  WOQ_ACQ_K = 2,
+  WOQ_ACQ_N = 3,
+  WOQ_ACQ_ACT_SHUFFLE = 4,
+  WOQ_ACQ_G_IDX = 5,
+  WOQ_ACQ_WEI_TYPE = 6,
+  WOQ_ACQ_CMPT_TYPE = 7,
+  WOQ_ACQ_SCALE_TYPE = 8,
+  WOQ_ACQ_SCALE_TENSOR = 9,
+  WOQ_ACQ_ZP_TENSOR = 10,
+  WOQ_ACQ_IS_ASYM = 11
+};
+
+static inline size_t woq_dtype_size(uint32_t dt) { return dt == WOQ_F32 ? 4u : 2u; }
+static inline size_t woq_round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+/* Fill every derived field of a header from (K, N, group, types, flags).
+ * Returns 0, or -1 if the geometry is unsupported (group not a multiple of 32
+ * and more than one group). Pure host arithmetic, shared by the HIP library
+ * and by the CPU oracle so both agree on offsets by construction. */
+static inline int woq_header_init(woq_blob_header* h, int K, int N, int group, uint32_t weight_type,
+                                  uint32_t scale_type, uint32_t compute_type, int asym, int act_shuffle) {
+  if (K <= 0 || N <= 0) return -1;
+  if (group <= 0 || group > K) group = K;
+  int n_groups = (K + group - 1) / group;
+  if (n_groups > 1 && (group % 32) != 0) return -1;
+  for (size_t i = 0; i < sizeof(*h); ++i) ((uint8_t*)h)[i] = 0;
+  h->magic = WOQ_BLOB_MAGIC;
+  h->version = WOQ_BLOB_VERSION;
+  h->K = K;
+  h->N = N;
+  h->group = group;
+  h->Kpad = (int32_t)woq_round_up((size_t)K, WOQ_TILE_K);
+  h->Npad = (int32_t)woq_round_up((size_t)N, WOQ_TILE_N);
+  h->n_groups = n_groups;
+  h->weight_type = weight_type;
+  h->scale_type = scale_type;
+  h->compute_type = compute_type;
+  h->flags = (asym ? WOQ_FLAG_ASYM : 0u) | (act_shuffle ? WOQ_FLAG_ACT_SHUFFLE : 0u);
+  h->scale_mode = (n_groups == 1 || (group % WOQ_TILE_K) == 0) ? 0u : 1u;
+  size_t tiles_n = (size_t)h->Npad / WOQ_TILE_N, tiles_k = (size_t)h->Kpad / WOQ_TILE_K;
+  size_t n_scale = h->scale_mode == 0 ? tiles_n * (size_t)n_groups * 16u : tiles_n * tiles_k * 64u;
+  size_t off = WOQ_HEADER_BYTES;
+  h->off_q = off;
+  off += tiles_n * tiles_k * WOQ_TILE_BYTES;
+  h->off_scale = off;
+  off = woq_round_up(off + n_scale * woq_dtype_size(scale_type), 256);
+  if (asym) {
+    h->off_zp = off;
+    off = woq_round_up(off + n_scale, 256);
+  }
+  if (act_shuffle) {
+    h->off_shuffle = off;
+    off = woq_round_up(off + (size_t)K * 4u, 256);
+  }
+  h->total_bytes = off;
+  return 0;
+}
+
+/* index of the scale / zero-point element for (column n, row k) */
+static inline size_t woq_scale_index(const woq_blob_header* h, int k, int n) {
+  size_t tn = (size_t)n / WOQ_TILE_N, i = (size_t)n % WOQ_TILE_N;
+  if (h->scale_mode == 0) {
+    size_t g = (size_t)k / (size_t)h->group;
+    if (g >= (size_t)h->n_groups) g = (size_t)h->n_groups - 1;
+    return (tn * (size_t)h->n_groups + g) * 16u + i;
+  }
+  size_t kt = (size_t)k / WOQ_TILE_K, s = ((size_t)k % WOQ_TILE_K) / 32u;
+  return ((tn * ((size_t)h->Kpad / WOQ_TILE_K) + kt) * 16u + i) * 4u + s;
+}
+
+/* byte offset (from off_q) and nibble shift of weight element (k, n) */
+static inline size_t woq_q_byte(const woq_blob_header* h, int k, int n, int* shift) {
+  size_t tn = (size_t)n / WOQ_TILE_N, i = (size_t)n % WOQ_TILE_N;
+  size_t kt = (size_t)k / WOQ_TILE_K, r = (size_t)k % WOQ_TILE_K;
+  size_t s = r / 32u, kq = (r % 32u) / 8u, j = r % 8u;
+  size_t lane = kq * 16u + i;
+  size_t word = ((tn * ((size_t)h->Kpad / WOQ_TILE_K) + kt) * 64u + lane) * 4u + s;
+  *shift = (int)(j & 1u) * 4;
+  return word * 4u + j / 2u;
+}
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WOQ_BLOB_H_ */

@@ -1,0 +1,288 @@
+"""numpy front-end of the CPU oracle (oracle/woq_oracle.c).
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never by the product package. See the header of woq_oracle.c for what is
+pinned against the reference and what is "parity unpinned".
+
+Every function names the reference file:line it restates in woq_oracle.c; this module only
+marshals numpy arrays through ctypes and adds the whole-decoder composition used for logits
+parity (`LlamaOracle`).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libwoq_oracle.so")
+
+F32, BF16, F16 = 0, 1, 2  # enum woq_dtype (include/woq_blob.h)
+HEADER_BYTES = 256
+
+
+def build(force=False):
+    """Compile oracle/woq_oracle.c with gcc (idempotent)."""
+    src = os.path.join(_HERE, "woq_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "woq_blob.h")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _LIB_PATH
+    subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.orc_packed_size.restype = ctypes.c_size_t
+        L.orc_packed_size.argtypes = [ctypes.c_int] * 6
+        L.orc_load_scalar.restype = ctypes.c_float
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dt):
+    return None if a is None else np.ascontiguousarray(a, dtype=dt)
+
+
+# ---- format decode (reference: llm/quantization/utils.py:82-125, nn/modules.py:225-227) ----
+def unpack_weight(qweight, qzeros, K, N, G, bits=4, sym=True):
+    qweight = _c(qweight, np.int32)
+    qzeros = _c(qzeros, np.int32)
+    w = np.empty((K, N), np.int8)
+    z = np.empty((G, N), np.int8) if qzeros is not None else None
+    lib().orc_unpack_weight(_p(qweight), _p(qzeros), K, N, G, bits, int(sym), _p(w), _p(z))
+    return w, z
+
+
+def to_signed_nibble(t):
+    t = np.array(t, dtype=np.int8, copy=True)
+    lib().orc_to_signed_nibble(_p(t), ctypes.c_size_t(t.size))
+    return t
+
+
+def convert_idx(g_idx, K, blocksize):
+    g_idx = _c(g_idx, np.int32)
+    ret = np.zeros(K, np.int32)
+    lib().orc_convert_idx(_p(g_idx), K, blocksize, _p(ret))
+    return ret
+
+
+# ---- quantise / dequantise -------------------------------------------------------------
+def rtn_quantize(w, transpose, group, asym):
+    """PARITY UNPINNED rounding rule (see woq_oracle.c). w: [K,N] or [N,K] if transpose."""
+    w = _c(w, np.float32)
+    K, N = (w.shape[1], w.shape[0]) if transpose else w.shape
+    g = K if group in (-1, 0) or group > K else group
+    G = (K + g - 1) // g
+    q = np.empty((K, N), np.int8)
+    s = np.empty((G, N), np.float32)
+    z = np.empty((G, N), np.int8) if asym else None
+    lib().orc_rtn_quantize(_p(w), int(transpose), K, N, g, int(asym), _p(q), _p(s), _p(z))
+    return q, s, z
+
+
+def dequant_raw(q, scales, zp, group):
+    q = _c(q, np.int8)
+    K, N = q.shape
+    out = np.empty((K, N), np.float32)
+    lib().orc_dequant_raw(_p(q), _p(_c(scales, np.float32)), _p(_c(zp, np.int8)), K, N, group, _p(out))
+    return out
+
+
+def packed_size(K, N, group, scale_type=F32, asym=False, act_shuffle=False):
+    return lib().orc_packed_size(K, N, group, scale_type, int(asym), int(act_shuffle))
+
+
+def repack(q, scales, zp=None, shuffle=None, group=-1, scale_type=F32, compute_type=0):
+    """reference: qbits.cpp:61-77 / bestla_packq_impl.cpp:20-41 (layout transform only)."""
+    q = _c(q, np.int8)
+    K, N = q.shape
+    scales = _c(scales, np.float32)
+    zp = _c(zp, np.int8)
+    shuffle = _c(shuffle, np.int32)
+    size = packed_size(K, N, group, scale_type, zp is not None, shuffle is not None)
+    if size == 0:
+        raise RuntimeError("QBits: unsupported blocksize %d for K=%d" % (group, K))
+    blob = np.zeros(size, np.uint8)
+    rc = lib().orc_repack(_p(q), _p(scales), _p(zp), _p(shuffle), K, N, group, scale_type, compute_type,
+                          _p(blob), ctypes.c_size_t(size))
+    if rc != 0:
+        raise RuntimeError("orc_repack failed")
+    return blob
+
+
+def header(blob):
+    """Parse the WQH1 header (include/woq_blob.h) into a dict."""
+    h = np.frombuffer(np.ascontiguousarray(blob[:HEADER_BYTES]).tobytes(), dtype=np.uint8)
+    u32 = h.view(np.uint32)
+    i32 = h.view(np.int32)
+    u64 = h.view(np.uint64)
+    return dict(magic=int(u32[0]), version=int(u32[1]), total_bytes=int(u64[1]), K=int(i32[4]), N=int(i32[5]),
+                group=int(i32[6]), Kpad=int(i32[7]), Npad=int(i32[8]), n_groups=int(i32[9]),
+                weight_type=int(u32[10]), scale_type=int(u32[11]), compute_type=int(u32[12]), flags=int(u32[13]),
+                scale_mode=int(u32[14]), off_q=int(u64[8]), off_scale=int(u64[9]), off_zp=int(u64[10]),
+                off_shuffle=int(u64[11]))
+
+
+def dequantize_blob(blob, transpose=False):
+    """reference: qbits.cpp:102-111."""
+    blob = _c(blob, np.uint8)
+    h = header(blob)
+    out = np.empty((h["N"], h["K"]) if transpose else (h["K"], h["N"]), np.float32)
+    rc = lib().orc_dequantize_blob(_p(blob), _p(out), int(transpose))
+    if rc != 0:
+        raise RuntimeError("bad blob")
+    return out
+
+
+def _to_storage(a, dtype):
+    if dtype == F32:
+        return np.ascontiguousarray(a, np.float32)
+    out = np.empty(a.shape, np.uint16)
+    flat = np.ascontiguousarray(a, np.float32).ravel()
+    of = out.ravel()
+    for i in range(flat.size):  # small arrays only
+        lib().orc_store_scalar(_p(of), ctypes.c_size_t(i), dtype, ctypes.c_float(float(flat[i])))
+    return of.reshape(a.shape)
+
+
+def bf16_round(a):
+    """fp32 -> bf16 -> fp32 (round-to-nearest-even), vectorised."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
+def woq_linear(x, blob, bias=None, out_dtype=F32):
+    """THE parity definition — reference: llm/quantization/autograd/functions.py:41-63."""
+    x = _c(x, np.float32)
+    blob = _c(blob, np.uint8)
+    bias = _c(bias, np.float32)
+    h = header(blob)
+    M = x.shape[0]
+    out = np.empty((M, h["N"]), np.float32 if out_dtype == F32 else np.uint16)
+    rc = lib().orc_woq_linear(_p(x), x.shape[1], _p(blob), _p(bias), _p(out), out_dtype, h["N"], M)
+    if rc != 0:
+        raise RuntimeError("orc_woq_linear failed")
+    if out_dtype == BF16:
+        return (out.astype(np.uint32) << 16).view(np.float32)
+    if out_dtype == F16:
+        return out.view(np.float16).astype(np.float32)
+    return out
+
+
+def woq_gemv_stream(x, blob, bias=None):
+    """fp32-accumulate streaming GEMV straight from the packed nibbles (the cpu_baseline 'port')."""
+    x = _c(x, np.float32).ravel()
+    blob = _c(blob, np.uint8)
+    bias = _c(bias, np.float32)
+    h = header(blob)
+    out = np.empty(h["N"], np.float32)
+    rc = lib().orc_woq_gemv_stream(_p(x), _p(blob), _p(bias), _p(out))
+    if rc != 0:
+        raise RuntimeError("orc_woq_gemv_stream failed")
+    return out
+
+
+# ---- ops between the linears (HF semantics) ---------------------------------
+def rmsnorm(x, weight, eps):
+    x = _c(x, np.float32)
+    out = np.empty_like(x)
+    d = x.shape[-1]
+    lib().orc_rmsnorm(_p(x), _p(_c(weight, np.float32)), ctypes.c_float(eps), x.size // d, d, _p(out))
+    return out
+
+
+def rope(x, pos, theta=10000.0):
+    """x: [tokens, heads, D] -> rotated copy."""
+    x = np.array(x, dtype=np.float32, copy=True, order="C")
+    pos = _c(pos, np.int32)
+    lib().orc_rope(_p(x), _p(pos), x.shape[0], x.shape[1], x.shape[2], ctypes.c_float(theta))
+    return x
+
+
+def silu_mul(gate, up):
+    gate = _c(gate, np.float32)
+    up = _c(up, np.float32)
+    out = np.empty_like(gate)
+    lib().orc_silu_mul(_p(gate), _p(up), ctypes.c_size_t(gate.size), _p(out))
+    return out
+
+
+def gelu(x, approximate="tanh"):
+    x = _c(x, np.float32)
+    out = np.empty_like(x)
+    f = lib().orc_gelu_tanh if approximate == "tanh" else lib().orc_gelu_erf
+    f(_p(x), ctypes.c_size_t(x.size), _p(out))
+    return out
+
+
+def attn_decode(q, kcache, vcache):
+    """q [heads,D]; caches [ctx, kv_heads, D] -> [heads, D]."""
+    q = _c(q, np.float32)
+    kcache = _c(kcache, np.float32)
+    vcache = _c(vcache, np.float32)
+    out = np.empty_like(q)
+    lib().orc_attn_decode(_p(q), _p(kcache), _p(vcache), q.shape[0], kcache.shape[1], q.shape[1], kcache.shape[0],
+                          _p(out))
+    return out
+
+
+# ---- whole-decoder composition (Llama-class), fp32, used for logits parity ---------------------
+class LlamaOracle:
+    """fp32 CPU decoder built from the oracle ops, on the SAME (q, scale, zp) blobs as the GPU.
+
+    Composition follows HF LlamaDecoderLayer (RMSNorm -> q/k/v -> RoPE -> attention + KV cache ->
+    o ; RMSNorm -> gate/up -> SiLU*mul -> down), which is what the reference executes around its
+    QuantizedLinearQBits modules. `layers` is a list of dicts with blobs
+    'q','k','v','o','gate','up','down' (numpy uint8 WQH1 blobs) and 'ln1','ln2' fp32 vectors.
+    """
+
+    def __init__(self, cfg, embed, layers, norm, lm_head):
+        self.cfg = cfg
+        self.embed = np.asarray(embed, np.float32)
+        self.layers = layers
+        self.norm = np.asarray(norm, np.float32)
+        self.lm_head = np.asarray(lm_head, np.float32)  # [vocab, hidden], NOT quantised (F9)
+        L = len(layers)
+        self.k = [np.zeros((0, cfg["kv_heads"], cfg["head_dim"]), np.float32) for _ in range(L)]
+        self.v = [np.zeros((0, cfg["kv_heads"], cfg["head_dim"]), np.float32) for _ in range(L)]
+
+    def reset(self):
+        for i in range(len(self.k)):
+            self.k[i] = self.k[i][:0]
+            self.v[i] = self.v[i][:0]
+
+    def forward_token(self, token, pos):
+        c = self.cfg
+        H, KV, D = c["heads"], c["kv_heads"], c["head_dim"]
+        h = self.embed[token].reshape(1, -1).copy()
+        for li, ly in enumerate(self.layers):
+            x = rmsnorm(h, ly["ln1"], c["eps"])
+            q = woq_linear(x, ly["q"]).reshape(1, H, D)
+            k = woq_linear(x, ly["k"]).reshape(1, KV, D)
+            v = woq_linear(x, ly["v"]).reshape(1, KV, D)
+            q = rope(q, [pos], c["theta"])
+            k = rope(k, [pos], c["theta"])
+            self.k[li] = np.concatenate([self.k[li], k], 0)
+            self.v[li] = np.concatenate([self.v[li], v], 0)
+            a = attn_decode(q[0], self.k[li], self.v[li]).reshape(1, H * D)
+            h = h + woq_linear(a, ly["o"])
+            x = rmsnorm(h, ly["ln2"], c["eps"])
+            g = woq_linear(x, ly["gate"])
+            u = woq_linear(x, ly["up"])
+            h = h + woq_linear(silu_mul(g, u), ly["down"])
+        x = rmsnorm(h, self.norm, c["eps"])
+        return (x.astype(np.float64) @ self.lm_head.astype(np.float64).T).astype(np.float32)[0]
