@@ -17,8 +17,11 @@
  *
  * qdata   : [Npad/16][Kpad/128][64 lanes][4 x u32]
  *           lane l: column i = l & 15, k-quarter kq = l >> 4
- *           u32 #s (0..3), nibble j (bits 4j..4j+3)  <->  k = kt*128 + s*32 + kq*8 + j
- *                                                        n = tn*16 + i
+ *           u32 #s (0..3), k-offset j (0..7)  <->  k = kt*128 + s*32 + kq*8 + j,  n = tn*16 + i
+ *           k-offset j sits at nibble position pos(j) = (j >> 1) | ((j & 1) << 2)  (bits
+ *           4*pos..4*pos+3): `w & 0x000f000f` is then (j0 | j1 << 16), `(w >> 4) & ..` (j2, j3),
+ *           `(w >> 8)` (j4, j5), `(w >> 12)` (j6, j7) — consecutive-k pairs in one register, the
+ *           order an MFMA fragment wants after the int4 -> fp16/bf16 "magic number" conversion.
  *           nibble value u = q + 8, q in [-8,7]  (the reference's signed-nibble
  *           domain, llm/quantization/nn/modules.py:225-227, re-biased to unsigned)
  *           padding (k >= K or n >= N) is u = 8 (q = 0).
@@ -111,6 +114,9 @@ enum woq_acquire_type {
   WOQ_ACQ_IS_ASYM = 11
 };
 
+/* nibble position of k-offset j inside a packed u32 (see layout comment) */
+static inline int woq_nibble_pos(int j) { return (j >> 1) | ((j & 1) << 2); }
+
 static inline size_t woq_dtype_size(uint32_t dt) { return dt == WOQ_F32 ? 4u : 2u; }
 static inline size_t woq_round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
@@ -176,8 +182,9 @@ static inline size_t woq_q_byte(const woq_blob_header* h, int k, int n, int* shi
   size_t s = r / 32u, kq = (r % 32u) / 8u, j = r % 8u;
   size_t lane = kq * 16u + i;
   size_t word = ((tn * ((size_t)h->Kpad / WOQ_TILE_K) + kt) * 64u + lane) * 4u + s;
-  *shift = (int)(j & 1u) * 4;
-  return word * 4u + j / 2u;
+  int pos = woq_nibble_pos((int)j);
+  *shift = (pos & 1) * 4;
+  return word * 4u + (size_t)pos / 2u;
 }
 
 #ifdef __cplusplus

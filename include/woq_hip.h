@@ -1,0 +1,171 @@
+/*
+ * woq_hip.h — C ABI of libwoq_hip.so, the MI355X (gfx950) replacement for the reference's
+ * `qbits_py` operator module on the int4 weight-only-quantized linear path.
+ *
+ * Every entry point below replaces one function of the reference boundary
+ *   intel_extension_for_transformers/qbits/qbits.cpp:192-206   (PYBIND11_MODULE qbits_py)
+ * or, for the ops between the linears, one stock-HF module forward that the reference executes
+ * on the CPU. The reference-side binding a maintainer would add is shown in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C types only; every `*_dev` / `const void*` tensor argument is a DEVICE pointer owned by
+ *    the caller (torch allocates it); the library never frees or keeps caller memory, except the
+ *    pointers stored in a woq_engine, which must outlive it (same rule as the reference's
+ *    set_woq_workspace, bestla_weightonly_dispatcher.cpp:394-397).
+ *  - `stream` is a hipStream_t passed as void* (0 = default stream). All work is asynchronous on
+ *    that stream; nothing here synchronises or allocates on the hot calls, so every hot call can
+ *    be captured into a hipGraph.
+ *  - return value: 0 on success, non-zero on error; woq_last_error() returns a thread-local
+ *    message that starts with "QBits:" like the reference's TORCH_CHECK strings
+ *    (bestla_weightonly_dispatcher.cpp:289,368; qbits.cpp:35,150). The Python shim raises
+ *    RuntimeError with it, which is what c10::Error becomes in the reference.
+ *  - dtype codes: enum woq_dtype in woq_blob.h (0 fp32, 1 bf16, 2 fp16).
+ */
+#ifndef WOQ_HIP_H_
+#define WOQ_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "woq_blob.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WOQ_API __attribute__((visibility("default")))
+
+WOQ_API const char* woq_last_error(void);
+WOQ_API int woq_abi_version(void);
+/* number of visible HIP devices (0 when there is no GPU); never fails. */
+WOQ_API int woq_device_count(void);
+
+/* ---- packed-weight management (load time) ---------------------------------------------------- */
+
+/* replaces qbits.get_packed_weight_size (qbits.cpp:79-88). 0 = unsupported geometry. */
+WOQ_API size_t woq_packed_weight_size(int K, int N, int blocksize, int weight_type, int scale_type, int asym,
+                                      int act_shuffle);
+
+/* replaces qbits.repack_quantized_weight (qbits.cpp:61-77 -> bestla_packq_impl.cpp:20-41).
+ * qweight int8 [K,N] (int4 values, signed domain, modules.py:225-227), scale fp32 [G,N],
+ * zp int8 [G,N] or NULL (sym), g_idx int32 [K] shuffle indices or NULL. blob_dev: caller-allocated,
+ * woq_packed_weight_size() bytes, 256-B aligned. Layout transform only; device-side. */
+WOQ_API int woq_repack_quantized_weight(const int8_t* qweight_dev, const float* scale_dev, const int8_t* zp_dev,
+                                        const int32_t* g_idx_dev, int K, int N, int blocksize, int weight_type,
+                                        int scale_type, int compute_type, void* blob_dev, size_t blob_bytes,
+                                        void* stream);
+
+/* replaces qbits.quantize_to_packed_weight (qbits.cpp:90-100): RTN of an fp32 weight straight into a
+ * blob. transpose != 0: weight is [N,K] (nn.Linear layout). Rounding rule: DESIGN.md (parity unpinned). */
+WOQ_API int woq_quantize_to_packed_weight(const float* weight_dev, int transpose, int K, int N, int blocksize,
+                                          int weight_type, int scale_type, int compute_type, int asym,
+                                          void* blob_dev, size_t blob_bytes, void* stream);
+
+/* replaces qbits.dequantize_packed_weight (qbits.cpp:102-111): blob -> fp32 [K,N] or [N,K]. The
+ * geometry is passed by value (hdr = host copy of the blob header) so the call never reads device
+ * memory from the host. */
+WOQ_API int woq_dequantize_packed_weight(const void* blob_dev, const woq_blob_header* hdr, float* out_dev,
+                                         int transpose, void* stream);
+
+/* copy the 256-B header of a device blob to host memory (synchronises `stream`). Load-time only;
+ * the Python module caches the result so the hot path never re-parses it (the reference re-parses
+ * per call, bestla_weightonly_dispatcher.cpp:335). */
+WOQ_API int woq_read_header(const void* blob_dev, woq_blob_header* hdr_out, void* stream);
+
+/* replaces qbits.acquire_packed_weight_info for the tensor-valued selectors
+ * (bestla_packq_impl.cpp:152-204): SCALE_TENSOR -> fp32 [G,N], ZP_TENSOR -> int8 [G,N] (signed
+ * domain), G_IDX -> int32 [K]. Scalar / string selectors are answered from the cached header in
+ * the Python shim. out_dev is caller-allocated. */
+WOQ_API int woq_blob_extract(const void* blob_dev, const woq_blob_header* hdr, int what, void* out_dev,
+                             void* stream);
+
+/* ---- the hot call ------------------------------------------------------------------------------ */
+
+/* replaces qbits.woq_linear (qbits.cpp:113-140): out[M,N] = act[M,K] . W_deq[K,N] (+ bias).
+ *   act: act_dtype [M, lda]; out: out_dtype [M, ldo], written in place; bias fp32 [N] or NULL
+ *   (alpha = 1, beta = bias ? 1 : 0, bestla_customop.hpp:22-40). Activation shuffle (g_idx) is
+ *   applied when the blob carries indices (autograd/functions.py:52-57).
+ * Kernel selection by M: M <= 8 decode GEMV (VALU + wave shuffle reduce), M > 8 MFMA GEMM. */
+WOQ_API int woq_linear(const void* act_dev, int act_dtype, int lda, const void* blob_dev,
+                       const woq_blob_header* hdr, const float* bias_dev, void* out_dev, int out_dtype, int ldo,
+                       int M, void* stream);
+
+/* ---- ops between the linears (replace stock-HF module forwards) -------------- */
+
+/* HF LlamaRMSNorm: out = x * rsqrt(mean(x^2) + eps) * weight ; x/out dtype [rows, d], weight fp32 [d]. */
+WOQ_API int woq_rmsnorm(const void* x_dev, int dtype, const float* weight_dev, float eps, int rows, int d,
+                        void* out_dev, int out_dtype, void* stream);
+/* HF apply_rotary_pos_emb (rotate_half) in place on x [tokens, heads, D]; cos/sin fp32 tables
+ * [max_pos, D/2]; pos int32 [tokens] (device). */
+WOQ_API int woq_rope(void* x_dev, int dtype, const int32_t* pos_dev, const float* cos_dev, const float* sin_dev,
+                     int tokens, int heads, int D, void* stream);
+/* HF LlamaMLP elementwise part: out = silu(gate) * up, n elements. */
+WOQ_API int woq_silu_mul(const void* gate_dev, const void* up_dev, int dtype, size_t n, void* out_dev, void* stream);
+/* GeLU: approximate != 0 -> tanh form ("gelu_new", GPT-2), else erf form. */
+WOQ_API int woq_gelu(const void* x_dev, int dtype, size_t n, int approximate, void* out_dev, void* stream);
+
+/* ---- fused batch-1 decode engine (Llama-class decoder; the measured path of bench.py) ----------
+ * A woq_engine owns no weights: it holds device pointers to the per-layer WQH1 blobs and norm
+ * vectors plus its own activation scratch and KV cache, and launches the whole token step
+ * (5 kernels per layer) from C++, optionally replayed as one hipGraph. */
+typedef struct woq_engine woq_engine;
+
+typedef struct woq_engine_config {
+  int32_t hidden, inter, heads, kv_heads, head_dim, layers, vocab, max_ctx;
+  float rms_eps, rope_theta;
+  int32_t tp_rank, tp_size; /* tensor parallel: heads/inter are PER-RANK sizes when tp_size > 1 */
+  int32_t kv_dtype;         /* WOQ_F16 | WOQ_BF16 */
+  int32_t reserved[3];
+} woq_engine_config;
+
+typedef struct woq_layer_weights {
+  const void* qkv_blob;     /* [hidden -> (heads + 2 kv_heads) * head_dim] */
+  const void* o_blob;       /* [heads*head_dim -> hidden] */
+  const void* gate_up_blob; /* [hidden -> 2*inter], 16-column tiles interleaved gate/up */
+  const void* down_blob;    /* [inter -> hidden] */
+  const float* ln1;         /* input_layernorm weight fp32 [hidden] */
+  const float* ln2;         /* post_attention_layernorm weight fp32 [hidden] */
+  woq_blob_header qkv_hdr, o_hdr, gate_up_hdr, down_hdr;
+} woq_layer_weights;
+
+WOQ_API int woq_engine_create(const woq_engine_config* cfg, woq_engine** out);
+WOQ_API void woq_engine_destroy(woq_engine* e);
+WOQ_API int woq_engine_set_layer(woq_engine* e, int layer, const woq_layer_weights* w);
+/* embed: fp16/bf16 [vocab, hidden]; final norm fp32 [hidden]; lm_head fp16/bf16 [vocab_shard, hidden]
+ * (NOT quantised, like the reference: utils/config.py:836-837 llm_int8_skip_modules). */
+WOQ_API int woq_engine_set_head(woq_engine* e, const void* embed_dev, int embed_dtype, const float* final_norm_dev,
+                                const void* lm_head_dev, int lm_head_dtype, const float* cos_dev,
+                                const float* sin_dev);
+/* optional: make the engine use caller-owned device buffers (e.g. torch tensors) for its I/O instead of
+ * its own: token int32[1], pos int32[1], logits fp32[vocab], hidden fp32[hidden]. NULL keeps the internal one. */
+WOQ_API int woq_engine_bind_io(woq_engine* e, void* token_dev, void* pos_dev, void* logits_dev, void* hidden_dev);
+/* device buffers the caller reads/writes between steps */
+WOQ_API void* woq_engine_token_ptr(woq_engine* e);  /* int32[1]: token fed to the next step */
+WOQ_API void* woq_engine_pos_ptr(woq_engine* e);    /* int32[1]: its position */
+WOQ_API void* woq_engine_logits_ptr(woq_engine* e); /* fp32[vocab] of the last step */
+WOQ_API void* woq_engine_hidden_ptr(woq_engine* e); /* fp32[hidden] residual stream (TP all-reduce target) */
+/* one decode step: embed(token) -> layers -> final norm -> lm_head -> logits; if greedy != 0 also
+ * argmax -> token_ptr and pos_ptr += 1, so steps can be chained with no host round trip. */
+WOQ_API int woq_engine_step(woq_engine* e, int greedy, void* stream);
+/* capture one step into a hipGraph and replay it `n` times (greedy chaining). */
+WOQ_API int woq_engine_capture(woq_engine* e, int greedy, void* stream);
+WOQ_API int woq_engine_replay(woq_engine* e, int n, void* stream);
+/* tensor-parallel seam: when set, the engine calls `fn(user, buf_dev, count_f32, stream)` after
+ * o_proj and after down_proj (row-parallel partial sums -> sum over ranks). The Python host binds it
+ * to RCCL via torch.distributed. NULL = single GPU. */
+typedef int (*woq_allreduce_fn)(void* user, void* buf_dev, size_t count, void* stream);
+WOQ_API int woq_engine_set_allreduce(woq_engine* e, woq_allreduce_fn fn, void* user);
+/* run only the kernels of one sub-block, for TP where the collective is issued by the host
+ * between them: phase 0 = embed + attention block up to o_proj partial, 1 = MLP block up to
+ * down partial, 2 = head. layer ignored for phase 2. */
+WOQ_API int woq_engine_phase(woq_engine* e, int layer, int phase, int greedy, void* stream);
+/* time the dominant kernel (int4 GEMV) alone over all layers with HIP events on `stream`:
+ * runs `reps` passes over every layer's 4 GEMVs, returns total ms and the algorithmic bytes of one pass. */
+WOQ_API int woq_engine_time_gemv(woq_engine* e, int reps, void* stream, float* total_ms, double* bytes_per_pass,
+                                 int* launches_per_pass);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WOQ_HIP_H_ */

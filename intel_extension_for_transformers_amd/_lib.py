@@ -1,0 +1,145 @@
+"""ctypes binding of libwoq_hip.so (C ABI declared in include/woq_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, a RuntimeError with
+the library's "QBits: ..." message is raised — the same exception type the reference's TORCH_CHECKs
+surface as (qbits/dispatcher/src/bestla_weightonly_dispatcher.cpp:289,368).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwoq_hip.so")
+
+F32, BF16, F16 = 0, 1, 2
+W_INT4_CLIP, W_INT8 = 0, 1
+C_FP32, C_BF16, C_INT8, C_FP16 = 0, 1, 2, 3
+HEADER_BYTES = 256
+
+WEIGHT_TYPES = {"int4_clip": W_INT4_CLIP, "int4": W_INT4_CLIP}
+SCALE_TYPES = {"fp32": F32, "bf16": BF16, "fp16": F16}
+COMPUTE_TYPES = {"fp32": C_FP32, "bf16": C_BF16, "int8": C_INT8, "fp16": C_FP16}
+SCALE_NAMES = {v: k for k, v in SCALE_TYPES.items()}
+COMPUTE_NAMES = {v: k for k, v in COMPUTE_TYPES.items()}
+WEIGHT_NAMES = {W_INT4_CLIP: "int4_clip", W_INT8: "int8"}
+
+
+class BlobHeader(ctypes.Structure):
+    """struct woq_blob_header (include/woq_blob.h)."""
+
+    _fields_ = [
+        ("magic", ctypes.c_uint32), ("version", ctypes.c_uint32), ("total_bytes", ctypes.c_uint64),
+        ("K", ctypes.c_int32), ("N", ctypes.c_int32), ("group", ctypes.c_int32), ("Kpad", ctypes.c_int32),
+        ("Npad", ctypes.c_int32), ("n_groups", ctypes.c_int32),
+        ("weight_type", ctypes.c_uint32), ("scale_type", ctypes.c_uint32), ("compute_type", ctypes.c_uint32),
+        ("flags", ctypes.c_uint32), ("scale_mode", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
+        ("off_q", ctypes.c_uint64), ("off_scale", ctypes.c_uint64), ("off_zp", ctypes.c_uint64),
+        ("off_shuffle", ctypes.c_uint64), ("pad", ctypes.c_uint8 * (HEADER_BYTES - 96)),
+    ]
+
+
+assert ctypes.sizeof(BlobHeader) == HEADER_BYTES
+
+
+class EngineConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("hidden", "inter", "heads", "kv_heads", "head_dim", "layers", "vocab",
+                                              "max_ctx")] + [("rms_eps", ctypes.c_float), ("rope_theta", ctypes.c_float),
+                                                             ("tp_rank", ctypes.c_int32), ("tp_size", ctypes.c_int32),
+                                                             ("kv_dtype", ctypes.c_int32),
+                                                             ("reserved", ctypes.c_int32 * 3)]
+
+
+class LayerWeights(ctypes.Structure):
+    _fields_ = [("qkv_blob", ctypes.c_void_p), ("o_blob", ctypes.c_void_p), ("gate_up_blob", ctypes.c_void_p),
+                ("down_blob", ctypes.c_void_p), ("ln1", ctypes.c_void_p), ("ln2", ctypes.c_void_p),
+                ("qkv_hdr", BlobHeader), ("o_hdr", BlobHeader), ("gate_up_hdr", BlobHeader), ("down_hdr", BlobHeader)]
+
+
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+# every symbol include/woq_hip.h declares (tests check the .so exports all of them)
+EXPORTS = [
+    "woq_last_error", "woq_abi_version", "woq_device_count", "woq_packed_weight_size",
+    "woq_repack_quantized_weight", "woq_quantize_to_packed_weight", "woq_dequantize_packed_weight",
+    "woq_read_header", "woq_blob_extract", "woq_linear", "woq_rmsnorm", "woq_rope", "woq_silu_mul", "woq_gelu",
+    "woq_engine_create", "woq_engine_destroy", "woq_engine_set_layer", "woq_engine_set_head",
+    "woq_engine_bind_io", "woq_engine_token_ptr", "woq_engine_pos_ptr", "woq_engine_logits_ptr", "woq_engine_hidden_ptr",
+    "woq_engine_step", "woq_engine_capture", "woq_engine_replay", "woq_engine_set_allreduce", "woq_engine_phase",
+    "woq_engine_time_gemv",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libwoq_hip.so or raise — never falls back to a CPU/eager path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "QBits: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback for the MI355X path." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, cs, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_float
+    L.woq_last_error.restype = ctypes.c_char_p
+    L.woq_packed_weight_size.restype = cs
+    L.woq_packed_weight_size.argtypes = [ci] * 7
+    L.woq_repack_quantized_weight.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, cs, vp]
+    L.woq_quantize_to_packed_weight.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, cs, vp]
+    L.woq_dequantize_packed_weight.argtypes = [vp, ctypes.POINTER(BlobHeader), vp, ci, vp]
+    L.woq_read_header.argtypes = [vp, ctypes.POINTER(BlobHeader), vp]
+    L.woq_blob_extract.argtypes = [vp, ctypes.POINTER(BlobHeader), ci, vp, vp]
+    L.woq_linear.argtypes = [vp, ci, ci, vp, ctypes.POINTER(BlobHeader), vp, vp, ci, ci, ci, vp]
+    L.woq_rmsnorm.argtypes = [vp, ci, vp, cf, ci, ci, vp, ci, vp]
+    L.woq_rope.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, vp]
+    L.woq_silu_mul.argtypes = [vp, vp, ci, cs, vp, vp]
+    L.woq_gelu.argtypes = [vp, ci, cs, ci, vp, vp]
+    L.woq_engine_create.argtypes = [ctypes.POINTER(EngineConfig), ctypes.POINTER(vp)]
+    L.woq_engine_destroy.argtypes = [vp]
+    L.woq_engine_destroy.restype = None
+    L.woq_engine_set_layer.argtypes = [vp, ci, ctypes.POINTER(LayerWeights)]
+    L.woq_engine_set_head.argtypes = [vp, vp, ci, vp, vp, ci, vp, vp]
+    for f in ("woq_engine_bind_io", "woq_engine_token_ptr", "woq_engine_pos_ptr", "woq_engine_logits_ptr", "woq_engine_hidden_ptr"):
+        getattr(L, f).restype = vp
+        getattr(L, f).argtypes = [vp]
+    L.woq_engine_bind_io.argtypes = [vp, vp, vp, vp, vp]
+    L.woq_engine_step.argtypes = [vp, ci, vp]
+    L.woq_engine_capture.argtypes = [vp, ci, vp]
+    L.woq_engine_replay.argtypes = [vp, ci, vp]
+    L.woq_engine_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
+    L.woq_engine_phase.argtypes = [vp, ci, ci, ci, vp]
+    L.woq_engine_time_gemv.argtypes = [vp, ci, vp, ctypes.POINTER(cf), ctypes.POINTER(ctypes.c_double),
+                                       ctypes.POINTER(ci)]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(lib().woq_last_error().decode())
+
+
+def require_gpu():
+    """The product path needs a real device: fail loudly instead of silently doing something else."""
+    import torch
+
+    if not torch.cuda.is_available() or lib().woq_device_count() == 0:
+        raise RuntimeError("QBits: no MI355X/HIP device visible; the gfx950 WOQ path has no CPU fallback")
+
+
+def torch_dtype_code(dt):
+    import torch
+
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    if dt == torch.float16:
+        return F16
+    raise RuntimeError("QBits: unsupported qbits data type.")  # text of qbits.cpp:35
+
+
+def stream_ptr():
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

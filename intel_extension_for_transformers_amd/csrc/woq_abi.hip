@@ -1,0 +1,56 @@
+// woq_abi.hip — C-ABI glue: error string, version, and the woq_linear dispatcher.
+//
+// woq_linear replaces qbits.woq_linear (qbits/qbits.cpp:113-140) and the string-driven template
+// selection under it (bestla_weightonly_dispatcher.cpp:230-382: parse_launcher / parse_store /
+// parse_activation / parse_weight / parse_gemm_core). Here the "dispatcher" is a few integer
+// compares on the cached header: M <= 8 -> decode GEMV, else the MFMA GEMM.
+#include "woq_device.h"
+#include "woq_launch.h"
+
+namespace woq {
+std::string& last_error_ref() {
+  static thread_local std::string s;
+  return s;
+}
+
+struct GemvArgs;
+int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
+                            const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w,
+                            float eps, const float* residual, int ld_res, int epi, int nt, hipStream_t st);
+int launch_gemm_mfma(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
+                     const float* bias, void* out, int out_dtype, int ldo, int M, hipStream_t st);
+}  // namespace woq
+
+using namespace woq;
+
+extern "C" {
+
+const char* woq_last_error(void) { return last_error_ref().c_str(); }
+int woq_abi_version(void) { return 1; }
+int woq_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int woq_linear(const void* act_dev, int act_dtype, int lda, const void* blob_dev, const woq_blob_header* hdr,
+               const float* bias_dev, void* out_dev, int out_dtype, int ldo, int M, void* stream) {
+  WOQ_TRY
+  WOQ_CHECK(hdr && hdr->magic == WOQ_BLOB_MAGIC, "QBits: not a WQH1 packed weight");
+  WOQ_CHECK(act_dtype >= WOQ_F32 && act_dtype <= WOQ_F16, "QBits: unsupported qbits data type.");
+  WOQ_CHECK(out_dtype >= WOQ_F32 && out_dtype <= WOQ_F16, "QBits: unsupported qbits data type.");
+  WOQ_CHECK(lda >= hdr->K && ldo >= hdr->N, "QBits: activation/output leading dimension smaller than K/N");
+  if (M <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (M <= 8 || hdr->off_shuffle != 0)
+    rc = launch_gemv_from_header(act_dev, act_dtype, lda, blob_dev, *hdr, bias_dev, out_dev, out_dtype, ldo, M,
+                                 nullptr, 0.f, nullptr, 0, 0, 1, st);
+  else
+    rc = launch_gemm_mfma(act_dev, act_dtype, lda, blob_dev, *hdr, bias_dev, out_dev, out_dtype, ldo, M, st);
+  if (rc != 0) return rc;
+  WOQ_HIP(hipGetLastError());
+  WOQ_END
+}
+
+}  // extern "C"

@@ -1,0 +1,360 @@
+// woq_ops.hip — the ops between the quantised linears, as gfx950 kernels.
+//
+// In the reference these are stock HF transformers module forwards run by PyTorch CPU ops
+// (LlamaRMSNorm, apply_rotary_pos_emb, SiLU*mul in LlamaMLP, GPT-2 gelu_new,
+// eager attention over the KV cache); ITREX contributes no code there. All are HBM/latency-bound
+// vector kernels: 16-byte loads, fp32 math, wave64 shuffles; no MFMA.
+#include "woq_device.h"
+#include "woq_launch.h"
+
+namespace woq {
+
+// ---- RMSNorm: one workgroup (256 threads) per row ------------------------------------------------
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const void* __restrict__ x, int dtype,
+                                                      const float* __restrict__ w, float eps, int d,
+                                                      void* __restrict__ out, int out_dtype) {
+  __shared__ float part[4];
+  const size_t row = blockIdx.x;
+  const int tid = threadIdx.x;
+  float ss = 0.f;
+  for (int i = tid; i < d; i += 256) {
+    float v = load_f32(x, row * d + i, dtype);
+    ss = fmaf(v, v, ss);
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) part[tid >> 6] = ss;
+  __syncthreads();
+  const float tot = part[0] + part[1] + part[2] + part[3];
+  const float inv = 1.0f / sqrtf(tot / (float)d + eps);
+  for (int i = tid; i < d; i += 256) {
+    float v = load_f32(x, row * d + i, dtype);
+    store_f32(out, row * d + i, out_dtype, v * inv * w[i]);
+  }
+}
+
+// ---- RoPE (rotate_half), in place on [tokens, heads, D] -------------------------------------------
+__global__ void rope_kernel(void* __restrict__ x, int dtype, const int32_t* __restrict__ pos,
+                            const float* __restrict__ cs, const float* __restrict__ sn, int heads, int D,
+                            size_t total_pairs) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total_pairs) return;
+  const int half = D >> 1;
+  const int i = (int)(idx % half);
+  const size_t th = idx / half;  // token*heads + head
+  const int t = (int)(th / heads);
+  const int p = pos[t];
+  const float c = cs[(size_t)p * half + i], s = sn[(size_t)p * half + i];
+  const size_t base = th * D;
+  const float a = load_f32(x, base + i, dtype), b = load_f32(x, base + i + half, dtype);
+  store_f32(x, base + i, dtype, a * c - b * s);
+  store_f32(x, base + i + half, dtype, b * c + a * s);
+}
+
+__global__ void silu_mul_kernel(const void* __restrict__ g, const void* __restrict__ u, int dtype, size_t n,
+                                void* __restrict__ out) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; idx < n; idx += stride) {
+    const float a = load_f32(g, idx, dtype), b = load_f32(u, idx, dtype);
+    store_f32(out, idx, dtype, a / (1.0f + expf(-a)) * b);
+  }
+}
+
+__global__ void gelu_kernel(const void* __restrict__ x, int dtype, size_t n, int approximate,
+                            void* __restrict__ out) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; idx < n; idx += stride) {
+    const float v = load_f32(x, idx, dtype);
+    float r;
+    if (approximate)
+      r = 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v)));
+    else
+      r = 0.5f * v * (1.0f + erff(v * 0.7071067811865476f));
+    store_f32(out, idx, dtype, r);
+  }
+}
+
+// ---- engine kernels (batch-1 decode) --------------------------------------------------------------
+
+// hidden[h] = embed[token][h]  (fp32 residual stream)
+__global__ void embed_kernel(const void* __restrict__ embed, int dtype, const int32_t* __restrict__ token, int hidden,
+                             float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < hidden) out[i] = load_f32(embed, (size_t)token[0] * hidden + i, dtype);
+}
+
+// Single-query attention for one new token, one workgroup (256 threads) per query head.
+//   qkv: fp32 [(heads + 2*kv_heads) * D] un-rotated projections of the new token
+//   RoPE is applied here to q and to the new k; the rotated k and v are appended to the cache
+//   (by the first query head of each kv group) at position pos. kv caches: [max_ctx, kv_heads, D].
+//   out: fp32 [heads * D].
+// Scores live in LDS (ctx <= max_ctx floats). 4 lanes share one cached position (32 dims each).
+template <typename KV>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv, KV* __restrict__ kcache,
+                                                          KV* __restrict__ vcache, const int32_t* __restrict__ pos_p,
+                                                          const float* __restrict__ cs, const float* __restrict__ sn,
+                                                          int heads, int kv_heads, int D, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int rep = heads / kv_heads, kh = h / rep;
+  const int pos = pos_p[0];
+  const int ctx = pos + 1;
+  const int half = D >> 1;
+  float* qs = sm;            // [D] rotated q
+  float* kn = qs + D;        // [D] rotated new k
+  float* sc = kn + D;        // [ctx] scores
+  float* redm = sc + ((ctx + 3) & ~3);  // [8]
+  // rotate q and new k
+  if (tid < half) {
+    const float c = cs[(size_t)pos * half + tid], s = sn[(size_t)pos * half + tid];
+    const float* q = qkv + (size_t)h * D;
+    const float* k = qkv + (size_t)(heads + kh) * D;
+    const float qa = q[tid], qb = q[tid + half], ka = k[tid], kb = k[tid + half];
+    qs[tid] = qa * c - qb * s;
+    qs[tid + half] = qb * c + qa * s;
+    kn[tid] = ka * c - kb * s;
+    kn[tid + half] = kb * c + ka * s;
+  }
+  __syncthreads();
+  const float* vnew = qkv + (size_t)(heads + kv_heads + kh) * D;
+  if (h % rep == 0 && tid < D) {
+    kcache[((size_t)pos * kv_heads + kh) * D + tid] = (KV)kn[tid];
+    vcache[((size_t)pos * kv_heads + kh) * D + tid] = (KV)vnew[tid];
+  }
+  // scores: group of 4 lanes per position, each lane D/4 dims
+  const float scale = 1.0f / sqrtf((float)D);
+  const int sub = tid & 3, dper = D >> 2;
+  float lmax = -INFINITY;
+  for (int t = tid >> 2; t < ctx; t += 64) {
+    float d = 0.f;
+    if (t == pos) {
+      for (int i = 0; i < dper; ++i) d = fmaf(qs[sub * dper + i], (float)(KV)kn[sub * dper + i], d);
+    } else {
+      const KV* kk = kcache + ((size_t)t * kv_heads + kh) * D + sub * dper;
+      for (int i = 0; i < dper; ++i) d = fmaf(qs[sub * dper + i], (float)kk[i], d);
+    }
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d *= scale;
+    if (sub == 0) sc[t] = d;
+    lmax = fmaxf(lmax, d);
+  }
+  lmax = wave_max(lmax);
+  if (lane == 0) redm[wid] = lmax;
+  __syncthreads();
+  const float mx = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+  float lsum = 0.f;
+  for (int t = tid; t < ctx; t += 256) {
+    const float p = __expf(sc[t] - mx);
+    sc[t] = p;
+    lsum += p;
+  }
+  lsum = wave_sum(lsum);
+  if (lane == 0) redm[4 + wid] = lsum;
+  __syncthreads();
+  const float den = redm[4] + redm[5] + redm[6] + redm[7];
+  // out[d] = sum_t p[t] v[t][d]: thread = (t-slice, d); D <= 128 -> 256/D slices
+  const int nsl = 256 / D, sl = tid / D, dd = tid % D;
+  float acc = 0.f;
+  if (sl < nsl) {
+    for (int t = sl; t < ctx; t += nsl) {
+      const float vv = (t == pos) ? (float)(KV)vnew[dd] : (float)vcache[((size_t)t * kv_heads + kh) * D + dd];
+      acc = fmaf(sc[t], vv, acc);
+    }
+  }
+  __syncthreads();
+  float* slab = redm + 8;  // [256] cross-slice reduce buffer
+  slab[tid] = acc;
+  __syncthreads();
+  if (tid < D) {
+    float o = 0.f;
+    for (int s2 = 0; s2 < nsl; ++s2) o += slab[s2 * D + tid];
+    out[(size_t)h * D + tid] = o / den;
+  }
+}
+
+// logits[v] = sum_h xn[h] * W[v][h], W dense fp16/bf16 [vocab, hidden] (lm_head is NOT quantised:
+// utils/config.py:836-837). Final RMSNorm fused in the prologue. One wave per vocab row, 4 rows per WG.
+__global__ __launch_bounds__(256) void lm_head_kernel(const float* __restrict__ hidden_in,
+                                                      const float* __restrict__ norm_w, float eps,
+                                                      const void* __restrict__ W, int w_dtype, int hidden, int vocab,
+                                                      float* __restrict__ logits) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* xs = sm;  // [hidden]
+  __shared__ float part[4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float ss = 0.f;
+  for (int i = tid; i < hidden; i += 256) {
+    const float v = hidden_in[i];
+    xs[i] = v;
+    ss = fmaf(v, v, ss);
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) part[wid] = ss;
+  __syncthreads();
+  const float inv = 1.0f / sqrtf((part[0] + part[1] + part[2] + part[3]) / (float)hidden + eps);
+  for (int i = tid; i < hidden; i += 256) xs[i] = xs[i] * inv * norm_w[i];
+  __syncthreads();
+  const int rows_per_wg = 16;
+  for (int r = wid; r < rows_per_wg; r += 4) {
+    const int v = blockIdx.x * rows_per_wg + r;
+    if (v >= vocab) break;
+    const uint16_t* wr = (const uint16_t*)W + (size_t)v * hidden;
+    float acc = 0.f;
+    for (int k0 = lane * 8; k0 < hidden; k0 += 512) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 raw = __builtin_nontemporal_load((const u32x4*)(wr + k0));
+      const uint32_t rr[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float lo, hi;
+        if (w_dtype == WOQ_BF16) {
+          lo = bf16_bits_to_f32(rr[j] & 0xffff);
+          hi = bf16_bits_to_f32(rr[j] >> 16);
+        } else {
+          lo = f16_bits_to_f32(rr[j] & 0xffff);
+          hi = f16_bits_to_f32(rr[j] >> 16);
+        }
+        acc = fmaf(lo, xs[k0 + 2 * j], acc);
+        acc = fmaf(hi, xs[k0 + 2 * j + 1], acc);
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) logits[v] = acc;
+  }
+}
+
+// greedy: token = argmax(logits) (lowest index on ties, like torch.argmax), pos += 1. One workgroup.
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int vocab,
+                                                      int32_t* __restrict__ token, int32_t* __restrict__ pos) {
+  __shared__ float bv[16];
+  __shared__ int bi[16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int i = tid; i < vocab; i += 1024) {
+    const float v = logits[i];
+    if (v > best || (v == best && i < idx)) {
+      best = v;
+      idx = i;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ov > best || (ov == best && oi < idx)) {
+      best = ov;
+      idx = oi;
+    }
+  }
+  if (lane == 0) {
+    bv[wid] = best;
+    bi[wid] = idx;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < idx)) {
+        best = bv[w];
+        idx = bi[w];
+      }
+    token[0] = idx;
+    pos[0] = pos[0] + 1;
+  }
+}
+
+// ---- host launchers used by the engine ------------------------------------------------------------
+void launch_embed(const void* embed, int dtype, const int32_t* token, int hidden, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(embed_kernel, dim3((hidden + 255) / 256), dim3(256), 0, st, embed, dtype, token, hidden, out);
+}
+
+int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
+                       const float* cs, const float* sn, int heads, int kv_heads, int D, int max_ctx, float* out,
+                       hipStream_t st) {
+  if (D > 256 || (D & 7) || 256 % D != 0) return woq::fail("QBits: attention head_dim must divide 256");
+  const size_t lds = (size_t)(2 * D + ((max_ctx + 3) & ~3) + 8 + 256) * 4;
+  if (lds > 160 * 1024) return woq::fail("QBits: max_ctx too large for the single-pass decode attention");
+  if (kv_dtype == WOQ_F16) {
+    auto k = attn_decode_kernel<_Float16>;
+    static bool once = false;
+    if (!once) {
+      hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      once = true;
+    }
+    hipLaunchKernelGGL(k, dim3(heads), dim3(256), lds, st, qkv, (_Float16*)kcache, (_Float16*)vcache, pos, cs, sn,
+                       heads, kv_heads, D, out);
+  } else {
+    auto k = attn_decode_kernel<__bf16>;
+    static bool once = false;
+    if (!once) {
+      hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      once = true;
+    }
+    hipLaunchKernelGGL(k, dim3(heads), dim3(256), lds, st, qkv, (__bf16*)kcache, (__bf16*)vcache, pos, cs, sn, heads,
+                       kv_heads, D, out);
+  }
+  return 0;
+}
+
+void launch_lm_head(const float* hidden_in, const float* norm_w, float eps, const void* W, int w_dtype, int hidden,
+                    int vocab, float* logits, hipStream_t st) {
+  hipLaunchKernelGGL(lm_head_kernel, dim3((vocab + 15) / 16), dim3(256), (size_t)hidden * 4, st, hidden_in, norm_w,
+                     eps, W, w_dtype, hidden, vocab, logits);
+}
+
+void launch_argmax(const float* logits, int vocab, int32_t* token, int32_t* pos, hipStream_t st) {
+  hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, logits, vocab, token, pos);
+}
+
+}  // namespace woq
+
+using namespace woq;
+
+extern "C" {
+
+int woq_rmsnorm(const void* x_dev, int dtype, const float* weight_dev, float eps, int rows, int d, void* out_dev,
+                int out_dtype, void* stream) {
+  WOQ_TRY
+  WOQ_CHECK(rows >= 0 && d > 0, "QBits: bad rmsnorm shape");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x_dev, dtype, weight_dev, eps, d,
+                     out_dev, out_dtype);
+  WOQ_HIP(hipGetLastError());
+  WOQ_END
+}
+
+int woq_rope(void* x_dev, int dtype, const int32_t* pos_dev, const float* cos_dev, const float* sin_dev, int tokens,
+             int heads, int D, void* stream) {
+  WOQ_TRY
+  WOQ_CHECK((D & 1) == 0, "QBits: rope head_dim must be even");
+  size_t total = (size_t)tokens * heads * (D / 2);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_dev,
+                     dtype, pos_dev, cos_dev, sin_dev, heads, D, total);
+  WOQ_HIP(hipGetLastError());
+  WOQ_END
+}
+
+int woq_silu_mul(const void* gate_dev, const void* up_dev, int dtype, size_t n, void* out_dev, void* stream) {
+  WOQ_TRY
+  if (n == 0) return 0;
+  unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(silu_mul_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gate_dev, up_dev, dtype, n,
+                     out_dev);
+  WOQ_HIP(hipGetLastError());
+  WOQ_END
+}
+
+int woq_gelu(const void* x_dev, int dtype, size_t n, int approximate, void* out_dev, void* stream) {
+  WOQ_TRY
+  if (n == 0) return 0;
+  unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(gelu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x_dev, dtype, n, approximate,
+                     out_dev);
+  WOQ_HIP(hipGetLastError());
+  WOQ_END
+}
+
+}  // extern "C"

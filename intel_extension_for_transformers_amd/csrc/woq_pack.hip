@@ -1,0 +1,290 @@
+// woq_pack.hip — load-time kernels: repack / RTN-quantize / dequantize / extract for the WQH1 blob.
+//
+// Replaces (device-side, gfx950):
+//   qbits.repack_quantized_weight   qbits/qbits.cpp:61-77 -> dispatcher/src/bestla_packq_impl.cpp:20-41
+//   qbits.quantize_to_packed_weight qbits/qbits.cpp:90-100 -> bestla_weightonly_dispatcher.cpp:66-106
+//   qbits.dequantize_packed_weight  qbits/qbits.cpp:102-111 -> bestla_weightonly_dispatcher.cpp:46-64
+//   acquire_packed_weight_info (SCALE_TENSOR / ZP_TENSOR)     bestla_packq_impl.cpp:190-198
+// All HBM-bound byte shuffles; none of them is on the per-token path.
+#include "woq_device.h"
+#include "woq_launch.h"
+
+namespace woq {
+
+__global__ void write_header_kernel(woq_blob_header h, woq_blob_header* dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = h;
+}
+
+// one thread per packed u32 word: gathers 8 int4 values (k .. k+7 of one column) from int8 [K,N]
+__global__ void repack_q_kernel(const int8_t* __restrict__ q, uint32_t* __restrict__ qd, int K, int N,
+                                int tiles_k, size_t n_words) {
+  size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  int s = (int)(w & 3);
+  int lane = (int)((w >> 2) & 63);
+  size_t tile = w >> 8;
+  int kt = (int)(tile % (size_t)tiles_k);
+  int tn = (int)(tile / (size_t)tiles_k);
+  int i = lane & 15, kq = lane >> 4;
+  int n = tn * 16 + i;
+  int k0 = kt * 128 + s * 32 + kq * 8;
+  uint32_t word = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int k = k0 + j;
+    uint32_t u = 8u;  // padding: q = 0
+    if (k < K && n < N) u = (uint32_t)((int)q[(size_t)k * N + n] + 8) & 0xfu;
+    word |= u << (4 * nibble_pos(j));
+  }
+  qd[w] = word;
+}
+
+// one thread per stored scale / zero-point element
+__global__ void repack_scale_kernel(const float* __restrict__ scale, const int8_t* __restrict__ zp,
+                                    woq_blob_header h, uint8_t* __restrict__ blob, size_t n_scale) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_scale) return;
+  int tiles_k = h.Kpad / WOQ_TILE_K;
+  int tn, i, kb;  // kb = first k of the 32-row block (mode 1) or of the group (mode 0)
+  int g;
+  if (h.scale_mode == 0) {
+    i = (int)(idx & 15);
+    g = (int)((idx >> 4) % (size_t)h.n_groups);
+    tn = (int)((idx >> 4) / (size_t)h.n_groups);
+    kb = g * h.group;
+  } else {
+    int s = (int)(idx & 3);
+    i = (int)((idx >> 2) & 15);
+    int kt = (int)((idx >> 6) % (size_t)tiles_k);
+    tn = (int)((idx >> 6) / (size_t)tiles_k);
+    kb = kt * 128 + s * 32;
+    g = kb / h.group;
+    if (g >= h.n_groups) g = h.n_groups - 1;
+  }
+  int n = tn * 16 + i;
+  float sc = 0.f;
+  uint8_t uz = 8;
+  if (n < h.N && kb < h.K) {
+    sc = scale[(size_t)g * h.N + n];
+    if (zp) uz = (uint8_t)(zp[(size_t)g * h.N + n] + 8);
+  }
+  store_f32(blob + h.off_scale, idx, (int)h.scale_type, sc);
+  if (h.off_zp) (blob + h.off_zp)[idx] = uz;
+}
+
+__device__ __forceinline__ void blob_elem(const uint8_t* blob, const woq_blob_header& h, int k, int n, int& u,
+                                          int& uz, float& sc) {
+  int tiles_k = h.Kpad / WOQ_TILE_K;
+  int tn = n >> 4, i = n & 15, kt = k >> 7, r = k & 127;
+  int s = r >> 5, kq = (r & 31) >> 3, j = r & 7;
+  size_t word = (((size_t)tn * tiles_k + kt) * 64 + (size_t)(kq * 16 + i)) * 4 + s;
+  uint32_t w = ((const uint32_t*)(blob + h.off_q))[word];
+  u = (int)((w >> (4 * nibble_pos(j))) & 0xfu);
+  size_t si;
+  if (h.scale_mode == 0) {
+    int g = k / h.group;
+    if (g >= h.n_groups) g = h.n_groups - 1;
+    si = ((size_t)tn * h.n_groups + g) * 16 + i;
+  } else {
+    si = ((((size_t)tn * tiles_k + kt) * 16 + i) << 2) + s;
+  }
+  sc = load_f32(blob + h.off_scale, si, (int)h.scale_type);
+  uz = h.off_zp ? (int)(blob + h.off_zp)[si] : 8;
+}
+
+// w[k][n] = (u - uz) * scale  == (q - zp) * scale, modules.py:264-295
+__global__ void dequant_kernel(const uint8_t* __restrict__ blob, woq_blob_header h, float* __restrict__ out,
+                               int transpose) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)h.K * h.N;
+  if (idx >= total) return;
+  int k, n;
+  if (transpose) {
+    n = (int)(idx / (size_t)h.K);
+    k = (int)(idx % (size_t)h.K);
+  } else {
+    k = (int)(idx / (size_t)h.N);
+    n = (int)(idx % (size_t)h.N);
+  }
+  int u, uz;
+  float sc;
+  blob_elem(blob, h, k, n, u, uz, sc);
+  out[idx] = (float)(u - uz) * sc;
+}
+
+// what = WOQ_ACQ_SCALE_TENSOR -> fp32 [G,N]; WOQ_ACQ_ZP_TENSOR -> int8 [G,N] (signed domain)
+__global__ void extract_kernel(const uint8_t* __restrict__ blob, woq_blob_header h, int what, void* out) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)h.n_groups * h.N;
+  if (idx >= total) return;
+  int g = (int)(idx / (size_t)h.N), n = (int)(idx % (size_t)h.N);
+  int u, uz;
+  float sc;
+  blob_elem(blob, h, g * h.group, n, u, uz, sc);
+  if (what == WOQ_ACQ_SCALE_TENSOR)
+    ((float*)out)[idx] = sc;
+  else
+    ((int8_t*)out)[idx] = (int8_t)(uz - 8);
+}
+
+// RTN: one thread per (group, column). int4 "clip" range. Rounding rule documented in DESIGN.md
+// (parity unpinned: BesTLA's quantiser is not in /root/reference). rintf = round-half-even.
+__global__ void rtn_kernel(const float* __restrict__ w, int transpose, int K, int N, int group, int n_groups,
+                           int asym, int8_t* __restrict__ q, float* __restrict__ scales,
+                           int8_t* __restrict__ zp) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)n_groups * N) return;
+  int g = (int)(idx / (size_t)N), n = (int)(idx % (size_t)N);
+  int k0 = g * group, k1 = min(k0 + group, K);
+  float mx = -INFINITY, mn = INFINITY, amax = 0.f;
+  for (int k = k0; k < k1; ++k) {
+    float v = transpose ? w[(size_t)n * K + k] : w[(size_t)k * N + n];
+    mx = fmaxf(mx, v);
+    mn = fminf(mn, v);
+    amax = fmaxf(amax, fabsf(v));
+  }
+  float s;
+  int z = 0;
+  if (!asym) {
+    s = amax / 7.f;
+    if (s == 0.f) s = 1.f;
+  } else {
+    s = (mx - mn) / 15.f;
+    if (s == 0.f) s = 1.f;
+    z = (int)rintf(-mn / s);
+    z = max(0, min(15, z));
+  }
+  scales[idx] = s;
+  if (asym) zp[idx] = (int8_t)(z - 8);
+  for (int k = k0; k < k1; ++k) {
+    float v = transpose ? w[(size_t)n * K + k] : w[(size_t)k * N + n];
+    int qi;
+    if (!asym) {
+      qi = (int)rintf(v / s);
+      qi = max(-8, min(7, qi));
+    } else {
+      qi = (int)rintf(v / s) + z;
+      qi = max(0, min(15, qi)) - 8;
+    }
+    q[(size_t)k * N + n] = (int8_t)qi;
+  }
+}
+
+}  // namespace woq
+
+using namespace woq;
+
+static size_t n_scale_elems(const woq_blob_header& h) {
+  size_t tiles_n = (size_t)h.Npad / WOQ_TILE_N, tiles_k = (size_t)h.Kpad / WOQ_TILE_K;
+  return h.scale_mode == 0 ? tiles_n * (size_t)h.n_groups * 16u : tiles_n * tiles_k * 64u;
+}
+
+extern "C" {
+
+size_t woq_packed_weight_size(int K, int N, int blocksize, int weight_type, int scale_type, int asym,
+                              int act_shuffle) {
+  woq_blob_header h;
+  if (weight_type != WOQ_W_INT4_CLIP) return 0;
+  if (woq_header_init(&h, K, N, blocksize, (uint32_t)weight_type, (uint32_t)scale_type, WOQ_C_FP32, asym,
+                      act_shuffle) != 0)
+    return 0;
+  return h.total_bytes;
+}
+
+int woq_repack_quantized_weight(const int8_t* qweight_dev, const float* scale_dev, const int8_t* zp_dev,
+                                const int32_t* g_idx_dev, int K, int N, int blocksize, int weight_type,
+                                int scale_type, int compute_type, void* blob_dev, size_t blob_bytes,
+                                void* stream) {
+  WOQ_TRY
+  WOQ_CHECK(weight_type == WOQ_W_INT4_CLIP, "QBits: unsupported weight_type in repack (only int4_clip)");
+  WOQ_CHECK(scale_type >= WOQ_F32 && scale_type <= WOQ_F16, "QBits: unsupported scale_type");
+  woq_blob_header h;
+  WOQ_CHECK(woq_header_init(&h, K, N, blocksize, (uint32_t)weight_type, (uint32_t)scale_type,
+                            (uint32_t)compute_type, zp_dev != nullptr, g_idx_dev != nullptr) == 0,
+            "QBits: unsupported blocksize (must be -1 or a multiple of 32)");
+  WOQ_CHECK(blob_bytes >= h.total_bytes, "QBits: packed-weight buffer too small");
+  WOQ_CHECK(((uintptr_t)blob_dev & 255u) == 0, "QBits: packed-weight buffer must be 256-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  uint8_t* blob = (uint8_t*)blob_dev;
+  hipLaunchKernelGGL(write_header_kernel, dim3(1), dim3(64), 0, st, h, (woq_blob_header*)blob);
+  int tiles_k = h.Kpad / WOQ_TILE_K;
+  size_t n_words = (size_t)(h.Npad / WOQ_TILE_N) * tiles_k * 256u;
+  hipLaunchKernelGGL(repack_q_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, qweight_dev,
+                     (uint32_t*)(blob + h.off_q), K, N, tiles_k, n_words);
+  size_t ns = n_scale_elems(h);
+  hipLaunchKernelGGL(repack_scale_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, scale_dev, zp_dev,
+                     h, blob, ns);
+  if (g_idx_dev)
+    WOQ_HIP(hipMemcpyAsync(blob + h.off_shuffle, g_idx_dev, (size_t)K * 4u, hipMemcpyDeviceToDevice, st));
+  WOQ_HIP(hipGetLastError());
+  WOQ_END
+}
+
+int woq_quantize_to_packed_weight(const float* weight_dev, int transpose, int K, int N, int blocksize,
+                                  int weight_type, int scale_type, int compute_type, int asym, void* blob_dev,
+                                  size_t blob_bytes, void* stream) {
+  WOQ_TRY
+  WOQ_CHECK(weight_type == WOQ_W_INT4_CLIP, "QBits: unsupported weight_type in quantize (only int4_clip)");
+  int group = (blocksize <= 0 || blocksize > K) ? K : blocksize;  // blocksize -1 -> K (dispatcher.cpp:296)
+  int n_groups = (K + group - 1) / group;
+  hipStream_t st = (hipStream_t)stream;
+  int8_t* q = nullptr;
+  float* sc = nullptr;
+  int8_t* zp = nullptr;
+  WOQ_HIP(hipMalloc((void**)&q, (size_t)K * N));
+  WOQ_HIP(hipMalloc((void**)&sc, (size_t)n_groups * N * sizeof(float)));
+  if (asym) WOQ_HIP(hipMalloc((void**)&zp, (size_t)n_groups * N));
+  size_t nt = (size_t)n_groups * N;
+  hipLaunchKernelGGL(rtn_kernel, dim3((unsigned)((nt + 127) / 128)), dim3(128), 0, st, weight_dev, transpose, K, N,
+                     group, n_groups, asym, q, sc, zp);
+  int rc = woq_repack_quantized_weight(q, sc, zp, nullptr, K, N, blocksize, weight_type, scale_type, compute_type,
+                                       blob_dev, blob_bytes, stream);
+  hipError_t e = hipStreamSynchronize(st);
+  hipFree(q);
+  hipFree(sc);
+  if (zp) hipFree(zp);
+  if (rc != 0) return rc;
+  WOQ_HIP(e);
+  WOQ_END
+}
+
+int woq_dequantize_packed_weight(const void* blob_dev, const woq_blob_header* hdr, float* out_dev, int transpose,
+                                 void* stream) {
+  WOQ_TRY
+  WOQ_CHECK(hdr && hdr->magic == WOQ_BLOB_MAGIC, "QBits: not a WQH1 packed weight");
+  size_t total = (size_t)hdr->K * hdr->N;
+  hipLaunchKernelGGL(dequant_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint8_t*)blob_dev, *hdr, out_dev, transpose);
+  WOQ_HIP(hipGetLastError());
+  WOQ_END
+}
+
+int woq_read_header(const void* blob_dev, woq_blob_header* hdr_out, void* stream) {
+  WOQ_TRY
+  WOQ_HIP(hipMemcpyAsync(hdr_out, blob_dev, sizeof(woq_blob_header), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  WOQ_HIP(hipStreamSynchronize((hipStream_t)stream));
+  WOQ_CHECK(hdr_out->magic == WOQ_BLOB_MAGIC, "QBits: not a WQH1 packed weight");
+  WOQ_END
+}
+
+int woq_blob_extract(const void* blob_dev, const woq_blob_header* hdr, int what, void* out_dev, void* stream) {
+  WOQ_TRY
+  WOQ_CHECK(hdr && hdr->magic == WOQ_BLOB_MAGIC, "QBits: not a WQH1 packed weight");
+  hipStream_t st = (hipStream_t)stream;
+  if (what == WOQ_ACQ_G_IDX) {
+    WOQ_CHECK(hdr->off_shuffle != 0, "QBits: not pack g_idx tensor.");
+    WOQ_HIP(hipMemcpyAsync(out_dev, (const uint8_t*)blob_dev + hdr->off_shuffle, (size_t)hdr->K * 4u,
+                           hipMemcpyDeviceToDevice, st));
+  } else if (what == WOQ_ACQ_SCALE_TENSOR || what == WOQ_ACQ_ZP_TENSOR) {
+    if (what == WOQ_ACQ_ZP_TENSOR) WOQ_CHECK(hdr->off_zp != 0, "QBits: not pack zero-point tensor.");
+    size_t total = (size_t)hdr->n_groups * hdr->N;
+    hipLaunchKernelGGL(extract_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const uint8_t*)blob_dev, *hdr, what, out_dev);
+    WOQ_HIP(hipGetLastError());
+  } else {
+    WOQ_FAIL("QBits: unsupported acquire_type");
+  }
+  WOQ_END
+}
+
+}  // extern "C"

@@ -1,0 +1,183 @@
+"""Python handle of the native batch-1 decode engine (csrc/woq_engine.hip).
+
+The engine is the MI355X counterpart of `ipex.optimize_transformers(qmodel, ...)`, the reference's own
+precedent for swapping HF's RMSNorm / RoPE / MLP glue for fused device kernels after `from_pretrained`
+(docs/weightonlyquant.md:199-202, README.md:290): quantised-linear replacement happens at load, the fused
+decode path is an optional post-pass over the same WQH1 blobs. torch is plumbing here (device memory,
+streams); every kernel is in libwoq_hip.so.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib as L
+from .. import qbits
+
+
+def build_rope_tables(max_pos, head_dim, theta=10000.0, device="cuda"):
+    """cos/sin [max_pos, head_dim/2] fp32, HF LlamaRotaryEmbedding's default parameterisation."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    ang = torch.arange(max_pos, dtype=torch.float32)[:, None] * inv_freq[None, :]
+    return ang.cos().contiguous().to(device), ang.sin().contiguous().to(device)
+
+
+def fuse_gate_up(gate, up):
+    """[*, I] x 2 -> [*, 2I] with 16-column tiles interleaved (gate tile t, up tile t, gate tile t+1, ...), the
+    column order the fused SiLU*mul GEMV epilogue expects."""
+    lead = gate.shape[:-1]
+    inter = gate.shape[-1]
+    assert inter % 16 == 0, "intermediate size must be a multiple of 16"
+    g = gate.reshape(*lead, inter // 16, 1, 16)
+    u = up.reshape(*lead, inter // 16, 1, 16)
+    return torch.cat([g, u], dim=-2).reshape(*lead, 2 * inter).contiguous()
+
+
+class WoqDecoderEngine:
+    """Owns the native engine plus the torch tensors whose device memory it points at."""
+
+    def __init__(self, hidden, inter, heads, kv_heads, head_dim, layers, vocab, max_ctx=2048, rms_eps=1e-5,
+                 rope_theta=10000.0, kv_dtype=torch.float16, tp_rank=0, tp_size=1, device=None):
+        L.require_gpu()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.cfg = L.EngineConfig(hidden=hidden, inter=inter, heads=heads, kv_heads=kv_heads, head_dim=head_dim,
+                                  layers=layers, vocab=vocab, max_ctx=max_ctx, rms_eps=rms_eps, rope_theta=rope_theta,
+                                  tp_rank=tp_rank, tp_size=tp_size, kv_dtype=L.torch_dtype_code(kv_dtype))
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(L.lib().woq_engine_create(ctypes.byref(self.cfg), ctypes.byref(self._h)))
+        self.token = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.pos = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.logits = torch.zeros(vocab, dtype=torch.float32, device=self.device)
+        self.hidden = torch.zeros(hidden, dtype=torch.float32, device=self.device)
+        L.check(L.lib().woq_engine_bind_io(self._h, self.token.data_ptr(), self.pos.data_ptr(),
+                                           self.logits.data_ptr(), self.hidden.data_ptr()))
+        self._keep = []  # tensors the engine holds raw pointers to
+        self._allreduce_cb = None
+        self.captured = False
+
+    def __del__(self):
+        try:
+            if self._h:
+                L.lib().woq_engine_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def set_layer(self, idx, qkv_blob, o_blob, gate_up_blob, down_blob, ln1, ln2):
+        ln1 = ln1.to(self.device, torch.float32).contiguous()
+        ln2 = ln2.to(self.device, torch.float32).contiguous()
+        w = L.LayerWeights(qkv_blob=qkv_blob.data_ptr(), o_blob=o_blob.data_ptr(),
+                           gate_up_blob=gate_up_blob.data_ptr(), down_blob=down_blob.data_ptr(),
+                           ln1=ln1.data_ptr(), ln2=ln2.data_ptr(), qkv_hdr=qbits.header_of(qkv_blob),
+                           o_hdr=qbits.header_of(o_blob), gate_up_hdr=qbits.header_of(gate_up_blob),
+                           down_hdr=qbits.header_of(down_blob))
+        L.check(L.lib().woq_engine_set_layer(self._h, idx, ctypes.byref(w)))
+        self._keep += [qkv_blob, o_blob, gate_up_blob, down_blob, ln1, ln2]
+
+    def set_head(self, embed, final_norm, lm_head, cos=None, sin=None):
+        embed = embed.to(self.device).contiguous()
+        lm_head = lm_head.to(self.device).contiguous()
+        final_norm = final_norm.to(self.device, torch.float32).contiguous()
+        if cos is None:
+            cos, sin = build_rope_tables(self.cfg.max_ctx, self.cfg.head_dim, self.cfg.rope_theta, self.device)
+        L.check(L.lib().woq_engine_set_head(self._h, embed.data_ptr(), L.torch_dtype_code(embed.dtype),
+                                            final_norm.data_ptr(), lm_head.data_ptr(),
+                                            L.torch_dtype_code(lm_head.dtype), cos.data_ptr(), sin.data_ptr()))
+        self._keep += [embed, lm_head, final_norm, cos, sin]
+
+    def reset(self, token=0, pos=0):
+        self.token.fill_(int(token))
+        self.pos.fill_(int(pos))
+
+    def step(self, greedy=True):
+        L.check(L.lib().woq_engine_step(self._h, int(greedy), L.stream_ptr()))
+
+    def capture(self, greedy=True):
+        L.check(L.lib().woq_engine_capture(self._h, int(greedy), L.stream_ptr()))
+        self.captured = True
+
+    def replay(self, n=1):
+        L.check(L.lib().woq_engine_replay(self._h, int(n), L.stream_ptr()))
+
+    def phase(self, layer, phase, greedy=True):
+        L.check(L.lib().woq_engine_phase(self._h, int(layer), int(phase), int(greedy), L.stream_ptr()))
+
+    def time_gemv(self, reps=1):
+        ms, by, n = ctypes.c_float(), ctypes.c_double(), ctypes.c_int()
+        L.check(L.lib().woq_engine_time_gemv(self._h, reps, L.stream_ptr(), ctypes.byref(ms), ctypes.byref(by),
+                                             ctypes.byref(n)))
+        return ms.value, by.value, n.value
+
+    # ---- tensor parallel: host-driven collectives between sub-blocks (RCCL via torch.distributed) ----
+    def step_tp(self, group=None, greedy=True):
+        """One token with the row-parallel partial sums all-reduced after o_proj and down_proj.
+        One RCCL all-reduce (sum, fp32 [hidden]) per sub-block — SURVEY.md §8(e)."""
+        import torch.distributed as dist
+
+        for l in range(self.cfg.layers):
+            self.phase(l, 0, greedy)
+            dist.all_reduce(self.hidden, group=group)
+            self.phase(l, 1, greedy)
+            dist.all_reduce(self.hidden, group=group)
+        self.phase(0, 2, greedy)
+
+    def generate(self, prompt_ids, max_new_tokens):
+        """Greedy decode: feed the prompt token by token (batch-1 decode path), then chain steps on device."""
+        out = []
+        self.reset(prompt_ids[0], 0)
+        for i, t in enumerate(prompt_ids):
+            self.token.fill_(int(t))
+            self.pos.fill_(i)
+            last = i == len(prompt_ids) - 1
+            self.step(greedy=last)
+        for _ in range(max_new_tokens):
+            out.append(int(self.token.item()))
+            if len(out) == max_new_tokens:
+                break
+            self.step(greedy=True)
+        return out
+
+
+def synth_llama_weights(engine, hidden, inter, heads, kv_heads, head_dim, layers, vocab, group=128, sym=True,
+                        scale_dtype="fp16", seed=1234, model_dtype=torch.float16):
+    """Synthetic random-init quantised Llama-shaped weights built directly on the device (no checkpoint, no
+    network): int4 values uniform in [-8,7], scales ~ 0.02-ish/7 so dequantised weights look like N(0, 0.02^2),
+    norms 1 + N(0, 0.02^2), embeddings N(0, 0.02^2). Returns the list of blobs (kept alive by the engine)."""
+    dev = engine.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    gs = hidden if group == -1 else group
+
+    def rand_q(k, n):
+        q = torch.randint(-8, 8, (k, n), generator=g, device=dev, dtype=torch.int8)
+        kg = (k + (k if group == -1 else group) - 1) // (k if group == -1 else group)
+        s = (0.5 + torch.rand(kg, n, generator=g, device=dev)) * (0.02 / 4.0)
+        z = None if sym else torch.randint(-8, 8, (kg, n), generator=g, device=dev, dtype=torch.int8)
+        return q, s, z
+
+    def pack(q, s, z):
+        return qbits.repack_quantized_weight(q, s, z if z is not None else torch.empty(0, dtype=torch.int8),
+                                             torch.empty(0, dtype=torch.int32), "int4_clip", scale_dtype, "fp32",
+                                             z is not None, group)
+
+    qkv_n = (heads + 2 * kv_heads) * head_dim
+    for l in range(layers):
+        q, s, z = rand_q(hidden, qkv_n)
+        qkv_blob = pack(q, s, z)
+        q, s, z = rand_q(heads * head_dim, hidden)
+        o_blob = pack(q, s, z)
+        gq, gsc, gz = rand_q(hidden, inter)
+        uq, usc, uz = rand_q(hidden, inter)
+        gu_blob = pack(fuse_gate_up(gq, uq), fuse_gate_up(gsc, usc), None if gz is None else fuse_gate_up(gz, uz))
+        q, s, z = rand_q(inter, hidden)
+        down_blob = pack(q, s, z)
+        ln1 = 1 + 0.02 * torch.randn(hidden, generator=g, device=dev)
+        ln2 = 1 + 0.02 * torch.randn(hidden, generator=g, device=dev)
+        engine.set_layer(l, qkv_blob, o_blob, gu_blob, down_blob, ln1, ln2)
+        del q, s, z, gq, gsc, gz, uq, usc, uz
+    embed = (0.02 * torch.randn(vocab, hidden, generator=g, device=dev)).to(model_dtype)
+    lm_head = (0.02 * torch.randn(vocab, hidden, generator=g, device=dev)).to(model_dtype)
+    norm = 1 + 0.02 * torch.randn(hidden, generator=g, device=dev)
+    engine.set_head(embed, norm, lm_head)
+    _ = gs
+    return engine

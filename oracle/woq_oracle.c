@@ -392,7 +392,7 @@ ORC_API int orc_woq_gemv_stream(const float* x, const uint8_t* blob, const float
           for (int kq = 0; kq < 4; ++kq) {
             uint32_t w = tile[(size_t)(kq * 16 + i) * 4 + s];
             const float* xp = xs + kb + kq * 8;
-            for (int j = 0; j < 8; ++j) part += (float)((int)((w >> (4 * j)) & 0xf) - uz) * xp[j];
+            for (int j = 0; j < 8; ++j) part += (float)((int)((w >> (4 * woq_nibble_pos(j))) & 0xf) - uz) * xp[j];
           }
           acc[i] += part * sc;
         }

@@ -1,0 +1,234 @@
+"""GPU parity: the HIP path (through the C ABI / qbits shim) against the CPU oracle on identical inputs.
+
+Bit-exact for bytes / integers / indices; floating point with the tolerance written at each assert.
+Shapes the oracle finishes in seconds; full-size properties are in test_gpu_fullsize.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import woq_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DT = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+ST = {"fp32": orc.F32, "bf16": orc.BF16, "fp16": orc.F16}
+
+
+@pytest.fixture(scope="module")
+def qbits():
+    from intel_extension_for_transformers_amd import qbits as q
+
+    return q
+
+
+def _mk(K, N, group, asym, shuf, seed=0):
+    rng = np.random.default_rng(seed)
+    q = rng.integers(-8, 8, (K, N), dtype=np.int8)
+    g = K if group == -1 else group
+    G = (K + g - 1) // g
+    s = (rng.random((G, N), dtype=np.float32) + 0.5) * 0.01
+    z = rng.integers(-8, 8, (G, N), dtype=np.int8) if asym else None
+    idx = rng.permutation(K).astype(np.int32) if shuf else None
+    return q, s, z, idx
+
+
+def _gpu_blob(qbits, q, s, z, idx, group, scale_type="fp32"):
+    e8 = torch.empty(0, dtype=torch.int8)
+    e32 = torch.empty(0, dtype=torch.int32)
+    return qbits.repack_quantized_weight(
+        torch.from_numpy(q).cuda(), torch.from_numpy(s).cuda(), e8 if z is None else torch.from_numpy(z).cuda(),
+        e32 if idx is None else torch.from_numpy(idx).cuda(), "int4_clip", scale_type, "fp32", z is not None, group)
+
+
+CASES = [
+    (512, 1024, 128, False, False),  # qbits_ut/test_weightonly.py geometry
+    (512, 1024, 128, True, True),    # qbits_ut/test_packq.py geometry
+    (512, 1024, -1, False, False),
+    (256, 48, 32, True, False),      # scale_mode 1
+    (160, 24, 64, True, False),      # tail group, K/N padding
+    (96, 20, 32, False, False),
+    (16, 8, -1, False, False),
+    (1024, 4096, 128, False, False),
+]
+
+
+@pytest.mark.parametrize("K,N,group,asym,shuf", CASES)
+@pytest.mark.parametrize("scale_type", ["fp32", "fp16", "bf16"])
+def test_repack_blob_bit_exact(qbits, K, N, group, asym, shuf, scale_type):
+    """Device repack == oracle repack, byte for byte (layout transform only, qbits.cpp:61-77)."""
+    q, s, z, idx = _mk(K, N, group, asym, shuf)
+    blob = _gpu_blob(qbits, q, s, z, idx, group, scale_type)
+    ref = orc.repack(q, s, z, idx, group, scale_type=ST[scale_type])
+    got = blob.cpu().numpy().view(np.uint8)
+    assert got.size == ref.size == qbits.get_packed_weight_size(K, N, "int4_clip", scale_type, "fp32", asym, group,
+                                                                shuf)
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("K,N,group,asym,shuf", CASES)
+def test_dequantize_exact(qbits, K, N, group, asym, shuf):
+    """(q - zp) * scale is one fp32 multiply: exact against the oracle, both orientations (qbits.cpp:102-111)."""
+    q, s, z, idx = _mk(K, N, group, asym, shuf, seed=1)
+    blob = _gpu_blob(qbits, q, s, z, idx, group)
+    ref = orc.dequant_raw(q, s, z, K if group == -1 else group)
+    out = torch.zeros(K, N, dtype=torch.float32, device="cuda")
+    qbits.dequantize_packed_weight(blob, out, False, "fp32", "int4_clip", "fp32")
+    assert np.array_equal(out.cpu().numpy(), ref)
+    out_t = torch.zeros(N, K, dtype=torch.float32, device="cuda")
+    qbits.dequantize_packed_weight(blob, out_t, True, "fp32", "int4_clip", "fp32")
+    assert np.array_equal(out_t.cpu().numpy(), ref.T)
+
+
+def test_packed_weight_info_roundtrip(qbits):
+    """qbits_ut/test_packq.py:88-109: size, type strings, act-shuffle flag, g_idx / scale / zp pass-through exact."""
+    K, N, bs = 512, 1024, 128
+    torch.manual_seed(0)
+    raw = torch.randint(-8, 8, [K, N], dtype=torch.int8)
+    g_idx = torch.arange(K // bs, dtype=torch.int).repeat(bs)
+    cvt = torch.from_numpy(orc.convert_idx(g_idx.numpy(), K, bs))
+    zp = torch.randint(-4, 4, [K // bs, N], dtype=torch.int8)
+    scale = torch.rand(K // bs, N, dtype=torch.float)
+    packw = qbits.repack_quantized_weight(raw.cuda(), scale.cuda(), zp.cuda(), cvt.cuda(), "int4_clip", "fp32", "fp32",
+                                          True, bs)
+    assert qbits.acquire_packed_weight_info(packw, 0)[0].item() == packw.numel()
+    assert qbits.acquire_packed_weight_info(packw, 1)[0].item() == bs
+    assert qbits.acquire_packed_weight_info(packw, 2)[0].item() == K
+    assert qbits.acquire_packed_weight_info(packw, 3)[0].item() == N
+    assert qbits.acquire_packed_weight_info(packw, 4)[0].item() == 1
+    assert qbits.acquire_packed_weight_info(packw, 11)[0].item() == 1
+    name = "".join(chr(c) for c in qbits.acquire_packed_weight_info(packw, 6).tolist())
+    assert name == "int4_clip"
+    assert "".join(chr(c) for c in qbits.acquire_packed_weight_info(packw, 7).tolist()) == "fp32"
+    assert "".join(chr(c) for c in qbits.acquire_packed_weight_info(packw, 8).tolist()) == "fp32"
+    assert torch.equal(qbits.acquire_packed_weight_info(packw, 5).cpu(), cvt.to(torch.int32))
+    assert torch.equal(qbits.acquire_packed_weight_info(packw, 9).cpu(), scale)
+    assert torch.equal(qbits.acquire_packed_weight_info(packw, 10).cpu(), zp)
+
+
+@pytest.mark.parametrize("K,N,group,asym,shuf", CASES)
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 7])
+def test_woq_linear_decode_vs_oracle(qbits, K, N, group, asym, shuf, M):
+    """Decode GEMV (M <= 8) vs the parity definition (autograd/functions.py:41-63), fp32 in / fp32 out.
+    Tolerance: |err| <= 2e-5 * sum_k |x_k w_k| bound, stated as 1e-4 * max|ref| + 1e-6 (fp32 accumulation in a
+    different order than the oracle's double sum); the reference's own criterion is allclose(rtol=0.03)."""
+    q, s, z, idx = _mk(K, N, group, asym, shuf, seed=2)
+    blob = _gpu_blob(qbits, q, s, z, idx, group)
+    rng = np.random.default_rng(3)
+    x = (rng.random((M, K), dtype=np.float32) - 0.3)
+    bias = rng.random(N, dtype=np.float32) * 10
+    ref = orc.woq_linear(x, orc.repack(q, s, z, idx, group), bias)
+    out = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    qbits.woq_linear(torch.from_numpy(x).cuda(), blob, torch.from_numpy(bias).cuda(), out, "fp32", "int4_clip", "fp32",
+                     asym)
+    got = out.cpu().numpy()
+    tol = 1e-4 * np.abs(ref - bias).max() + 1e-6
+    assert np.abs(got - ref).max() <= tol
+    assert np.allclose(got, ref, rtol=0.03, atol=tol)
+
+
+@pytest.mark.parametrize("src_dt,dst_dt", [("bf16", "bf16"), ("fp16", "fp16"), ("bf16", "fp32"), ("fp32", "bf16")])
+@pytest.mark.parametrize("M", [1, 4])
+def test_woq_linear_decode_dtypes(qbits, src_dt, dst_dt, M):
+    """src/dst dtype matrix of qbits_ut/test_weightonly.py:40-41 (+fp16). The 16-bit activation is up-cast exactly
+    to fp32 (as modules.py:153 does), so the only extra error is the final store rounding: bf16 2^-8, fp16 2^-11
+    relative, on top of the fp32 tolerance."""
+    K, N, group = 512, 1024, 128
+    q, s, z, idx = _mk(K, N, group, True, False, seed=4)
+    blob = _gpu_blob(qbits, q, s, z, idx, group)
+    xt = (torch.rand(M, K) - 0.3).to(DT[src_dt])
+    x = xt.float().numpy()
+    ref = orc.woq_linear(x, orc.repack(q, s, z, idx, group))
+    out = torch.zeros(M, N, dtype=DT[dst_dt], device="cuda")
+    qbits.woq_linear(xt.cuda(), blob, torch.empty(0), out, "fp32", "int4_clip", "fp32", True)
+    got = out.float().cpu().numpy()
+    store_eps = {"fp32": 0.0, "bf16": 2.0 ** -8, "fp16": 2.0 ** -11}[dst_dt]
+    tol = (1e-4 + store_eps) * np.abs(ref).max() + 1e-6
+    assert np.abs(got - ref).max() <= tol
+
+
+@pytest.mark.parametrize("blocksize,asym", [(128, False), (128, True), (-1, False), (32, True)])
+@pytest.mark.parametrize("add_bias", [True, False])
+def test_reference_unit_test_idiom(qbits, blocksize, asym, add_bias):
+    """qbits_ut/test_weightonly.py:51-88 run against the HIP library: seed 0, uniform [0,1) inputs, m=256 n=1024
+    k=512, quantize_to_packed_weight -> dequantize_packed_weight -> torch.matmul reference,
+    torch.allclose(rtol=0.03), both transpose settings, fp32 and bf16 src/dst."""
+    m, n, k = 256, 1024, 512
+    for transpose in (True, False):
+        for src_dt, dst_dt in (("fp32", "fp32"), ("bf16", "bf16")):
+            torch.manual_seed(0)
+            ref_activation = torch.rand(m, k, dtype=torch.float)
+            tar_activation = ref_activation.clone().to(DT[src_dt])
+            wei_row, wei_col = (n, k) if transpose else (k, n)
+            raw_wei = torch.rand(wei_row, wei_col, dtype=torch.float)
+            compress_wei = qbits.quantize_to_packed_weight(raw_wei.cuda(), transpose, blocksize, "fp32", "int4_clip",
+                                                           "fp32", asym)
+            revert_wei = torch.zeros(wei_row, wei_col, dtype=torch.float, device="cuda")
+            qbits.dequantize_packed_weight(compress_wei, revert_wei, transpose, "fp32", "int4_clip", "fp32")
+            revert_wei = revert_wei.cpu()
+            bias = torch.rand(n, dtype=torch.float) * 10 if add_bias else torch.empty(0)
+            tar_dst = torch.zeros(m, n, dtype=DT[dst_dt], device="cuda")
+            if transpose:
+                revert_wei = torch.transpose(revert_wei, 0, 1)
+            ref_dst = torch.matmul(ref_activation, revert_wei)
+            qbits.woq_linear(tar_activation.cuda(), compress_wei, bias.cuda(), tar_dst, "fp32", "int4_clip", "fp32",
+                             asym)
+            tar = tar_dst.float().cpu()
+            if add_bias:
+                ref_dst += bias
+            assert torch.allclose(tar, ref_dst, rtol=0.03), (transpose, src_dt)
+
+
+def test_rtn_quantizer_matches_oracle(qbits):
+    """Device RTN == oracle RTN bit for bit on the blob (same formula, PARITY UNPINNED vs BesTLA — see DESIGN.md)."""
+    torch.manual_seed(5)
+    w = torch.randn(256, 96)
+    for transpose in (False, True):
+        for group, asym in ((32, False), (128, True), (-1, False)):
+            wt = w.t().contiguous() if transpose else w
+            blob = qbits.quantize_to_packed_weight(wt.cuda(), transpose, group, "fp32", "int4_clip", "fp32", asym)
+            q, s, z = orc.rtn_quantize(wt.numpy(), transpose, group, asym)
+            ref = orc.repack(q, s, z, None, group)
+            assert np.array_equal(blob.cpu().numpy().view(np.uint8), ref)
+
+
+def test_ops_vs_oracle_and_hf_golden(qbits, golden_dir):
+    """RMSNorm / RoPE / SiLU*mul / GeLU kernels vs HF outputs (tests/golden/hf_ops.npz). fp32 tolerance 1e-5."""
+    import os
+
+    g = np.load(os.path.join(golden_dir, "hf_ops.npz"))
+    x = torch.from_numpy(g["rms_x"]).cuda()
+    y = qbits.rmsnorm(x, torch.from_numpy(g["rms_w"]).cuda(), float(g["rms_eps"]))
+    np.testing.assert_allclose(y.cpu().numpy(), g["rms_y"], rtol=1e-5, atol=1e-5)
+    from intel_extension_for_transformers_amd.runtime import build_rope_tables
+
+    q = torch.from_numpy(g["rope_q"][0]).permute(1, 0, 2).contiguous().cuda()  # [tokens, heads, D]
+    pos = torch.from_numpy(g["rope_pos"][0].astype(np.int32)).cuda()
+    cos, sin = build_rope_tables(8192, q.shape[-1], 10000.0, "cuda")
+    qbits.rope(q, pos, cos, sin)
+    np.testing.assert_allclose(q.permute(1, 0, 2).cpu().numpy(), g["rope_qr"][0], rtol=0, atol=2e-5)
+    gate, up = torch.from_numpy(g["silu_gate"]).cuda(), torch.from_numpy(g["silu_up"]).cuda()
+    np.testing.assert_allclose(qbits.silu_mul(gate, up).cpu().numpy(), g["silu_y"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(qbits.gelu(gate, "tanh").cpu().numpy(), g["gelu_new_y"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(qbits.gelu(gate, "erf").cpu().numpy(), g["gelu_y"], rtol=1e-5, atol=1e-5)
+    # 16-bit storage variants: compute in fp32, round once on store
+    yb = qbits.rmsnorm(x.bfloat16(), torch.from_numpy(g["rms_w"]).cuda(), float(g["rms_eps"]))
+    ref = orc.rmsnorm(x.bfloat16().float().cpu().numpy(), g["rms_w"], float(g["rms_eps"]))
+    np.testing.assert_allclose(yb.float().cpu().numpy(), ref, rtol=2.0 ** -7, atol=1e-3)
+
+
+def test_errors_are_runtime_errors(qbits):
+    """Error convention: RuntimeError with a 'QBits:' / 'Qbits:' prefix (dispatcher.cpp:289,368; qbits.cpp:35)."""
+    with pytest.raises(RuntimeError, match="[Qq][Bb]its"):
+        qbits.repack_quantized_weight(torch.zeros(96, 16, dtype=torch.int8).cuda(), torch.ones(6, 16).cuda(),
+                                      torch.empty(0, dtype=torch.int8), torch.empty(0, dtype=torch.int32), "int4_clip",
+                                      "fp32", "fp32", False, 16)
+    blob = qbits.quantize_to_packed_weight(torch.rand(64, 32).cuda(), False, 32, "fp32", "int4_clip", "fp32", False)
+    with pytest.raises(RuntimeError, match="QBits"):
+        qbits.woq_linear(torch.rand(1, 65).cuda(), blob, torch.empty(0), torch.zeros(1, 32).cuda(), "fp32",
+                         "int4_clip", "fp32", False)
+    with pytest.raises(RuntimeError, match="unsupported qbits data type"):
+        qbits.woq_linear(torch.rand(1, 64).double().cuda(), blob, torch.empty(0), torch.zeros(1, 32).cuda(), "fp32",
+                         "int4_clip", "fp32", False)
+    with pytest.raises(RuntimeError, match="[Qq]bits"):
+        qbits.quantize_to_packed_weight(torch.rand(64, 32).cuda(), False, 32, "fp32", "nf4", "fp32", False)
