@@ -99,7 +99,7 @@ def lib():
     L.woq_engine_destroy.restype = None
     L.woq_engine_set_layer.argtypes = [vp, ci, ctypes.POINTER(LayerWeights)]
     L.woq_engine_set_head.argtypes = [vp, vp, ci, vp, vp, ci, vp, vp]
-    for f in ("woq_engine_bind_io", "woq_engine_token_ptr", "woq_engine_pos_ptr", "woq_engine_logits_ptr", "woq_engine_hidden_ptr"):
+    for f in ("woq_engine_token_ptr", "woq_engine_pos_ptr", "woq_engine_logits_ptr", "woq_engine_hidden_ptr"):
         getattr(L, f).restype = vp
         getattr(L, f).argtypes = [vp]
     L.woq_engine_bind_io.argtypes = [vp, vp, vp, vp, vp]

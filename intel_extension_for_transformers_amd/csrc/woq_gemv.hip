@@ -45,7 +45,9 @@ struct GemvArgs {
   const float* residual;  // epilogue: out = residual + acc (fp32, row stride ld_res); may alias out
   int ld_res;
   int epi;  // 0 plain, 1 SiLU(gate)*up over (even, odd) tile pairs (needs CB == 2)
-  int nt;   // 1: non-temporal weight loads
+  int nt;   // reserved (weight loads are always non-temporal)
+  int tpg_is1;          // group == 128
+  unsigned tpg_magic;   // ceil(2^32 / (group / 128)) for the multiply-high division
 };
 
 constexpr int PF = 4;  // weight tiles in flight per wave per column block
@@ -61,48 +63,53 @@ struct ScaleT<1> {
   typedef float4_t type;
 };
 
-template <int SMODE, bool ASYM>
+// 16-bit scale bits -> fp32 without a branch (both conversions are 1-2 VALU ops; select the right one)
+__device__ __forceinline__ float scale16(uint32_t bits, bool is_bf16) {
+  const float a = bf16_bits_to_f32((uint16_t)bits), b = f16_bits_to_f32((uint16_t)bits);
+  return is_bf16 ? a : b;
+}
+
+// Branch-free tile fetch: out-of-range kt is clamped to the last tile and its scale forced to 0, so the
+// instruction stream has no control flow around the loads (hipcc drains vmcnt(0) at every such branch —
+// cdna_hip_programming.md "Three .s-level traps" (c)). S32: scales are fp32 (else 16-bit).
+template <int SMODE, bool ASYM, bool S32>
 __device__ __forceinline__ void load_tile(const GemvArgs& a, int tn, int kt, int lane, u32x4& w,
                                           typename ScaleT<SMODE>::type& sc, typename ScaleT<SMODE>::type& uz) {
   const int i = lane & 15;
-  if (kt >= a.tiles_k) {
-    w = (u32x4){0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u};
-    if constexpr (SMODE == 0) {
-      sc = 0.f;
-      uz = 8.f;
-    } else {
-      sc = (float4_t){0.f, 0.f, 0.f, 0.f};
-      uz = (float4_t){8.f, 8.f, 8.f, 8.f};
-    }
-    return;
-  }
-  const u32x4* p = a.q + ((size_t)tn * a.tiles_k + kt) * 64 + lane;
-  w = a.nt ? __builtin_nontemporal_load(p) : *p;
+  const bool valid = kt < a.tiles_k;
+  const int ktc = valid ? kt : a.tiles_k - 1;
+  const u32x4* p = a.q + ((size_t)tn * a.tiles_k + ktc) * 64 + lane;
+  w = __builtin_nontemporal_load(p);  // streamed once: keep it out of the way of x / scales in L2
+  const bool is_bf16 = a.scale_type == WOQ_BF16;
   if constexpr (SMODE == 0) {
-    int grp = 0;
-    if (a.n_groups > 1) {
-      int tpg = a.group >> 7;
-      grp = tpg == 1 ? kt : kt / tpg;
-      grp = min(grp, a.n_groups - 1);
-    }
-    size_t si = ((size_t)tn * a.n_groups + grp) * 16 + i;
-    sc = load_f32(a.scales, si, a.scale_type);
-    uz = ASYM ? (float)a.zp[si] : 8.f;
+    // group of this K tile = ktc / (group / 128), as a multiply-high (no divide, no branch)
+    int grp = a.tpg_is1 ? ktc : (int)__umulhi((unsigned)ktc, a.tpg_magic);
+    grp = a.n_groups > 1 ? min(grp, a.n_groups - 1) : 0;
+    const size_t si = ((size_t)tn * a.n_groups + grp) * 16 + i;
+    float v;
+    if constexpr (S32)
+      v = ((const float*)a.scales)[si];
+    else
+      v = scale16(((const uint16_t*)a.scales)[si], is_bf16);
+    sc = valid ? v : 0.f;
+    if constexpr (ASYM)
+      uz = (float)a.zp[si];
+    else
+      uz = 8.f;
   } else {
-    size_t si = (((size_t)tn * a.tiles_k + kt) * 16 + i) * 4;
-    if (a.scale_type == WOQ_F32) {
-      sc = *(const float4_t*)((const float*)a.scales + si);
+    const size_t si = (((size_t)tn * a.tiles_k + ktc) * 16 + i) * 4;
+    float4_t v;
+    if constexpr (S32) {
+      v = *(const float4_t*)((const float*)a.scales + si);
     } else {
-      uint2 r = *(const uint2*)((const uint16_t*)a.scales + si);
-      if (a.scale_type == WOQ_BF16)
-        sc = (float4_t){bf16_bits_to_f32(r.x & 0xffff), bf16_bits_to_f32(r.x >> 16), bf16_bits_to_f32(r.y & 0xffff),
-                        bf16_bits_to_f32(r.y >> 16)};
-      else
-        sc = (float4_t){f16_bits_to_f32(r.x & 0xffff), f16_bits_to_f32(r.x >> 16), f16_bits_to_f32(r.y & 0xffff),
-                        f16_bits_to_f32(r.y >> 16)};
+      const uint2 r = *(const uint2*)((const uint16_t*)a.scales + si);
+      v = (float4_t){scale16(r.x & 0xffff, is_bf16), scale16(r.x >> 16, is_bf16), scale16(r.y & 0xffff, is_bf16),
+                     scale16(r.y >> 16, is_bf16)};
     }
-    if (ASYM) {
-      uint32_t z = *(const uint32_t*)(a.zp + si);
+    const float vm = valid ? 1.f : 0.f;
+    sc = v * vm;
+    if constexpr (ASYM) {
+      const uint32_t z = *(const uint32_t*)(a.zp + si);
       uz = (float4_t){(float)(z & 0xff), (float)((z >> 8) & 0xff), (float)((z >> 16) & 0xff), (float)(z >> 24)};
     } else {
       uz = (float4_t){8.f, 8.f, 8.f, 8.f};
@@ -159,7 +166,7 @@ __device__ __forceinline__ void consume_tile(const u32x4& w, const typename Scal
   }
 }
 
-template <int NW, int MT, int CB, int SMODE, bool ASYM>
+template <int NW, int MT, int CB, int SMODE, bool ASYM, bool S32>
 __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int T = NW * 64;
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvArgs a) {
   for (int p = 0; p < PF; ++p)
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
-      load_tile<SMODE, ASYM>(a, tnb * CB + cb, wid + p * NW, lane, wbuf[p][cb], sbuf[p][cb], zbuf[p][cb]);
+      load_tile<SMODE, ASYM, S32>(a, tnb * CB + cb, wid + p * NW, lane, wbuf[p][cb], sbuf[p][cb], zbuf[p][cb]);
 
   // ---- 2. stage activations (fp32) + per-8 sums in LDS, optional fused RMSNorm ----
   const int nchunk = Kpad >> 3;
@@ -286,8 +293,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvArgs a) {
       for (int cb = 0; cb < CB; ++cb) {
         const u32x4 w = wbuf[p][cb];
         const sc_t sc = sbuf[p][cb], uz = zbuf[p][cb];
-        load_tile<SMODE, ASYM>(a, tnb * CB + cb, kt + NW * PF, lane, wbuf[p][cb], sbuf[p][cb], zbuf[p][cb]);
-        if (kt < a.tiles_k) consume_tile<MT, SMODE>(w, sc, uz, kt, kq, xs, xsum, Kpad, tot[cb]);
+        load_tile<SMODE, ASYM, S32>(a, tnb * CB + cb, kt + NW * PF, lane, wbuf[p][cb], sbuf[p][cb], zbuf[p][cb]);
+        // unconditional: a tile past the end was fetched clamped with scale 0 and contributes nothing
+        consume_tile<MT, SMODE>(w, sc, uz, min(kt, a.tiles_k - 1), kq, xs, xsum, Kpad, tot[cb]);
       }
     }
   }
@@ -332,11 +340,11 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvArgs a) {
   }
 }
 
-template <int NW, int MT, int CB, int SMODE, bool ASYM>
+template <int NW, int MT, int CB, int SMODE, bool ASYM, bool S32>
 static int launch_gemv_t(const GemvArgs& a, hipStream_t st) {
   const size_t lds = ((size_t)MT * a.Kpad + (size_t)MT * (a.Kpad >> 3) + (size_t)NW * CB * MT * 16 + NW * MT) * 4;
   if (lds > 160 * 1024) return woq::fail("QBits: activation tile does not fit LDS (K too large for this M tile)");
-  auto kern = gemv_kernel<NW, MT, CB, SMODE, ASYM>;
+  auto kern = gemv_kernel<NW, MT, CB, SMODE, ASYM, S32>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -351,19 +359,25 @@ static int launch_gemv_t(const GemvArgs& a, hipStream_t st) {
 
 template <int NW, int MT, int CB>
 static int launch_gemv_sm(const GemvArgs& a, int smode, bool asym, hipStream_t st) {
-  if (smode == 0)
-    return asym ? launch_gemv_t<NW, MT, CB, 0, true>(a, st) : launch_gemv_t<NW, MT, CB, 0, false>(a, st);
-  return asym ? launch_gemv_t<NW, MT, CB, 1, true>(a, st) : launch_gemv_t<NW, MT, CB, 1, false>(a, st);
+  const bool s32 = a.scale_type == WOQ_F32;
+#define WOQ_GEMV_CASE(SM, AS, S3) \
+  if (smode == SM && asym == AS && s32 == S3) return launch_gemv_t<NW, MT, CB, SM, AS, S3>(a, st);
+  WOQ_GEMV_CASE(0, false, false)
+  WOQ_GEMV_CASE(0, false, true)
+  WOQ_GEMV_CASE(0, true, false)
+  WOQ_GEMV_CASE(0, true, true)
+  WOQ_GEMV_CASE(1, false, false)
+  WOQ_GEMV_CASE(1, false, true)
+  WOQ_GEMV_CASE(1, true, false)
+  WOQ_GEMV_CASE(1, true, true)
+#undef WOQ_GEMV_CASE
+  return woq::fail("QBits: bad GEMV configuration");
 }
 
-// cb: 1 or 2 column tiles per workgroup; mt: rows per workgroup (1, 2 or 4)
+// cb: 1 or 2 column tiles per workgroup (2 only with mt == 1); mt: rows per workgroup (1, 2 or 4)
 int launch_gemv(const GemvArgs& a, int smode, bool asym, int cb, int mt, hipStream_t st) {
   constexpr int NW = 8;
-  if (cb == 2) {
-    if (mt == 1) return launch_gemv_sm<NW, 1, 2>(a, smode, asym, st);
-    if (mt == 2) return launch_gemv_sm<NW, 2, 2>(a, smode, asym, st);
-    return launch_gemv_sm<NW, 4, 2>(a, smode, asym, st);
-  }
+  if (cb == 2) return launch_gemv_sm<NW, 1, 2>(a, smode, asym, st);
   if (mt == 1) return launch_gemv_sm<NW, 1, 1>(a, smode, asym, st);
   if (mt == 2) return launch_gemv_sm<NW, 2, 1>(a, smode, asym, st);
   return launch_gemv_sm<NW, 4, 1>(a, smode, asym, st);
@@ -404,12 +418,18 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
   a.ld_res = ld_res;
   a.epi = epi;
   a.nt = nt;
+  {
+    const unsigned tpg = h.group >= 128 ? (unsigned)(h.group >> 7) : 1u;
+    a.tpg_is1 = tpg <= 1;
+    a.tpg_magic = tpg <= 1 ? 0u : (unsigned)((0x100000000ull + tpg - 1) / tpg);
+  }
   const int tiles_n = h.Npad / WOQ_TILE_N;
   // two column tiles per workgroup once there are enough tiles to keep > 2 workgroups per CU busy,
   // and always for the fused SiLU*mul epilogue (gate/up tile pairs)
   int cb = (epi == 1 || (M == 1 && tiles_n >= 1024)) ? 2 : 1;
   if (epi == 1 && (tiles_n & 1)) return woq::fail("QBits: fused gate/up weight needs an even number of column tiles");
   int mt = M >= 4 ? 4 : (M >= 2 ? 2 : 1);
+  if (cb == 2) mt = 1;
   auto lds_bytes = [&](int mt_) { return ((size_t)mt_ * a.Kpad * 9 / 8 + 8 * 2 * mt_ * 16 + 64) * 4; };
   while (mt > 1 && lds_bytes(mt) > 150 * 1024) mt >>= 1;
   return launch_gemv(a, (int)h.scale_mode, a.zp != nullptr, cb, mt, st);

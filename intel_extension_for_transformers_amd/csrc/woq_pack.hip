@@ -206,6 +206,8 @@ int woq_repack_quantized_weight(const int8_t* qweight_dev, const float* scale_de
   WOQ_CHECK(((uintptr_t)blob_dev & 255u) == 0, "QBits: packed-weight buffer must be 256-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   uint8_t* blob = (uint8_t*)blob_dev;
+  // section padding must be deterministic (blobs are compared / checksummed byte-wise)
+  WOQ_HIP(hipMemsetAsync(blob + h.off_scale, 0, h.total_bytes - h.off_scale, st));
   hipLaunchKernelGGL(write_header_kernel, dim3(1), dim3(64), 0, st, h, (woq_blob_header*)blob);
   int tiles_k = h.Kpad / WOQ_TILE_K;
   size_t n_words = (size_t)(h.Npad / WOQ_TILE_N) * tiles_k * 256u;

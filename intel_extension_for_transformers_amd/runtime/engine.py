@@ -54,6 +54,8 @@ class WoqDecoderEngine:
         self._keep = []  # tensors the engine holds raw pointers to
         self._allreduce_cb = None
         self.captured = False
+        # hipGraph capture is not allowed on the legacy null stream torch uses by default
+        self._stream = torch.cuda.Stream(device=self.device)
 
     def __del__(self):
         try:
@@ -93,11 +95,21 @@ class WoqDecoderEngine:
         L.check(L.lib().woq_engine_step(self._h, int(greedy), L.stream_ptr()))
 
     def capture(self, greedy=True):
-        L.check(L.lib().woq_engine_capture(self._h, int(greedy), L.stream_ptr()))
+        """Capture one token step into a hipGraph (on the engine's own stream)."""
+        cur = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            L.check(L.lib().woq_engine_capture(self._h, int(greedy), L.stream_ptr()))
+        cur.wait_stream(self._stream)
         self.captured = True
 
     def replay(self, n=1):
-        L.check(L.lib().woq_engine_replay(self._h, int(n), L.stream_ptr()))
+        """Replay the captured step n times (greedy chaining stays on the device)."""
+        cur = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            L.check(L.lib().woq_engine_replay(self._h, int(n), L.stream_ptr()))
+        cur.wait_stream(self._stream)
 
     def phase(self, layer, phase, greedy=True):
         L.check(L.lib().woq_engine_phase(self._h, int(layer), int(phase), int(greedy), L.stream_ptr()))

@@ -274,6 +274,11 @@ ORC_API int orc_repack(const int8_t* q, const float* scales, const int8_t* zp, c
       uint8_t u = (uint8_t)((q[(size_t)k * N + n] + 8) & 0xf);
       qd[b] = (uint8_t)((qd[b] & ~(0xfu << shift)) | (u << shift));
     }
+  if (zp) { /* padding zero point = 8 (u = 8 padding nibbles then dequantise to exactly 0) */
+    size_t tiles_n = (size_t)h.Npad / WOQ_TILE_N, tiles_k = (size_t)h.Kpad / WOQ_TILE_K;
+    size_t n_scale = h.scale_mode == 0 ? tiles_n * (size_t)h.n_groups * 16u : tiles_n * tiles_k * 64u;
+    memset(blob + h.off_zp, 8, n_scale);
+  }
   /* scales / zeros: walk every 32-row block so that scale_mode 1 (expanded) is filled too */
   for (int n = 0; n < N; ++n)
     for (int kb = 0; kb < h.Kpad; kb += 32) {
