@@ -387,10 +387,29 @@ int launch_gemv(const GemvArgs& a, int smode, bool asym, int cb, int mt, hipStre
 
 namespace woq {
 
+int gemv_decode_max_rows(int Kpad);
+int launch_gemv_decode(const void* act, int act_dtype, int lda, int M, const void* blob, const woq_blob_header& h,
+                       const float* bias, void* out, int out_dtype, int ldo, const float* norm_w, float eps,
+                       const float* residual, int ld_res, int epi, hipStream_t st);
+
 // Build GemvArgs from a cached blob header and pick (CB, MT). Shared by woq_linear and the engine.
 int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                             const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w,
                             float eps, const float* residual, int ld_res, int epi, int nt, hipStream_t st) {
+  // the per-token path: persistent pipelined MFMA kernel (woq_gemv_decode.hip), up to 8 rows per launch
+  static const bool use_valu = getenv("WOQ_GEMV_VALU") != nullptr;  // A/B switch: the fp32 VALU kernel below
+  const int mr = use_valu ? 0 : gemv_decode_max_rows(h.Kpad);
+  if (mr > 0) {
+    const size_t esz_a = act_dtype == WOQ_F32 ? 4 : 2, esz_o = out_dtype == WOQ_F32 ? 4 : 2;
+    for (int m0 = 0; m0 < M; m0 += mr) {
+      const int mc = M - m0 < mr ? M - m0 : mr;
+      int rc = launch_gemv_decode((const char*)act + (size_t)m0 * lda * esz_a, act_dtype, lda, mc, blob, h, bias,
+                                  (char*)out + (size_t)m0 * ldo * esz_o, out_dtype, ldo, norm_w, eps,
+                                  residual ? residual + (size_t)m0 * ld_res : nullptr, ld_res, epi, st);
+      if (rc) return rc;
+    }
+    return 0;
+  }
   GemvArgs a;
   const uint8_t* b = (const uint8_t*)blob;
   a.q = (const u32x4*)(b + h.off_q);
