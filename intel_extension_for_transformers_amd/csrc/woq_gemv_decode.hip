@@ -58,6 +58,7 @@ struct DecodeArgs {
   int cb_n;        // column tiles per step (1 or 2)
   int n_colsteps;  // ceil(tiles_n / cb_n)
   int upc;         // units (4 K tiles) per column per wave
+  int debug;       // timing experiments only: 1 = no streaming, 3 = no activation staging, 4 = exit at once
 };
 
 constexpr int UT = 4;    // K tiles per unit
@@ -208,8 +209,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_decode_kernel(DecodeArgs a) {
   const int units_per_step = upc * cbn;
   const int my_steps =
       ((int)blockIdx.x < a.n_colsteps) ? (a.n_colsteps - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-  const int total_units = my_steps * units_per_step;
+  const int total_units = a.debug == 1 ? 0 : my_steps * units_per_step;
   const int tiles_n = (a.N + 15) >> 4;
+  if (a.debug == 4) return;
 
   // prefetch pointer (wave-uniform): step index pi, column-in-step pcb, unit-in-column pu
   int pi = 0, pcb = 0, pu = 0, pg = 0;
@@ -255,7 +257,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_decode_kernel(DecodeArgs a) {
 
   // ---- 2. stage the activation rows once per workgroup: (RMSNorm) -> power-of-two scale -> hi/lo fp16 ----
   if (tid < 64) ((uint32_t*)zero_blk)[tid] = 0u;
-  if constexpr (FASTX) {
+  if (a.debug == 3) {
+    if (tid == 0) pow2_s[0] = 1.f;
+  } else if constexpr (FASTX) {
     float ss = 0.f, amax = 0.f;
 #pragma unroll
     for (int j = 0; j < XV; ++j) {
@@ -472,6 +476,7 @@ static int launch_decode_nw(const DecodeArgs& a, int smode, bool asym, bool s32,
 
 static int g_num_cus = 0;
 static int g_decode_wgs_per_cu = 2;
+static int g_debug = 0;  // WOQ_DEBUG_DECODE: 1 = staging only (no column steps), 2 = clamp to one step per WG
 
 // largest M this kernel takes for a given K (LDS budget), 0 if not even one row fits
 int gemv_decode_max_rows(int Kpad) {
@@ -491,6 +496,7 @@ int launch_gemv_decode(const void* act, int act_dtype, int lda, int M, const voi
       return woq::fail("QBits: cannot query the HIP device");
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* s = getenv("WOQ_DECODE_WGS_PER_CU")) g_decode_wgs_per_cu = atoi(s) > 0 ? atoi(s) : 2;
+    if (const char* s = getenv("WOQ_DEBUG_DECODE")) g_debug = atoi(s);
   }
   DecodeArgs a;
   const uint8_t* b = (const uint8_t*)blob;
@@ -530,6 +536,8 @@ int launch_gemv_decode(const void* act, int act_dtype, int lda, int M, const voi
   // sees steps b, b + #CUs, b + 2 #CUs, ... and the per-CU byte count stays within one step of the mean
   const int max_wgs = g_num_cus * g_decode_wgs_per_cu;
   const int grid = a.n_colsteps < max_wgs ? a.n_colsteps : max_wgs;
+  a.debug = g_debug;  // timing experiments only (results are garbage when non-zero)
+  if (g_debug == 2) a.n_colsteps = grid;
   const bool s32 = h.scale_type == WOQ_F32;
   return launch_decode_nw<nw>(a, (int)h.scale_mode, a.zp != nullptr, s32, grid, st);
 }

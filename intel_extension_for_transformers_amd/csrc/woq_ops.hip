@@ -84,60 +84,82 @@ __global__ void embed_kernel(const void* __restrict__ embed, int dtype, const in
   if (i < hidden) out[i] = load_f32(embed, (size_t)token[0] * hidden + i, dtype);
 }
 
-// Single-query attention for one new token, one workgroup (256 threads) per query head.
-//   qkv: fp32 [(heads + 2*kv_heads) * D] un-rotated projections of the new token
-//   RoPE is applied here to q and to the new k; the rotated k and v are appended to the cache
-//   (by the first query head of each kv group) at position pos. kv caches: [max_ctx, kv_heads, D].
-//   out: fp32 [heads * D].
-// Scores live in LDS (ctx <= max_ctx floats). 4 lanes share one cached position (32 dims each).
-template <typename KV>
+// Single-query attention for one new token: one workgroup (4 waves) per query head.
+//   qkv: fp32 [(heads + 2*kv_heads) * HD] un-rotated projections of the new token.
+//   RoPE is applied here to q and to the new k; rotated k and v are appended to the cache (by the first query
+//   head of each kv group) at position pos. kv caches: [max_ctx, kv_heads, HD] (fp16 | bf16). out fp32 [heads*HD].
+// Three vectorised phases over the cached positions t < pos (the new position is taken from LDS, so no
+// workgroup ever reads a cache row another workgroup is writing):
+//   scores : 4 lanes per position (HD/4 dims each, 16-B loads), 16 positions per wave per iteration
+//   softmax: block max / sum over the LDS score row
+//   P.V    : HD/8 lanes per position (one 16-B load each), 4x unrolled, fp32 accumulate
+template <typename KV, int HD>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv, KV* __restrict__ kcache,
                                                           KV* __restrict__ vcache, const int32_t* __restrict__ pos_p,
                                                           const float* __restrict__ cs, const float* __restrict__ sn,
-                                                          int heads, int kv_heads, int D, float* __restrict__ out) {
+                                                          int heads, int kv_heads, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  typedef KV kv8 __attribute__((ext_vector_type(8)));
+  constexpr int half = HD / 2;
+  constexpr int DPL = HD / 4;   // dims per lane in the score phase
+  constexpr int LPR = HD / 8;   // lanes per row in the P.V phase
+  constexpr int GP = 64 / LPR;  // position groups per wave in the P.V phase
   const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int rep = heads / kv_heads, kh = h / rep;
   const int pos = pos_p[0];
-  const int ctx = pos + 1;
-  const int half = D >> 1;
-  float* qs = sm;            // [D] rotated q
-  float* kn = qs + D;        // [D] rotated new k
-  float* sc = kn + D;        // [ctx] scores
-  float* redm = sc + ((ctx + 3) & ~3);  // [8]
-  // rotate q and new k
+  float* qs = sm;                 // [HD] rotated q (pre-scaled by 1/sqrt(HD))
+  float* kn = qs + HD;            // [HD] rotated new k, rounded to the cache dtype
+  float* vn = kn + HD;            // [HD] new v, rounded to the cache dtype
+  float* redm = vn + HD;          // [8]
+  float* slab = redm + 8;         // [4 waves][GP][HD] partial outputs
+  float* sc = slab + 4 * GP * HD; // [pos + 1] scores / probabilities
+  const float scale = 1.0f / sqrtf((float)HD);
   if (tid < half) {
     const float c = cs[(size_t)pos * half + tid], s = sn[(size_t)pos * half + tid];
-    const float* q = qkv + (size_t)h * D;
-    const float* k = qkv + (size_t)(heads + kh) * D;
+    const float* q = qkv + (size_t)h * HD;
+    const float* k = qkv + (size_t)(heads + kh) * HD;
     const float qa = q[tid], qb = q[tid + half], ka = k[tid], kb = k[tid + half];
-    qs[tid] = qa * c - qb * s;
-    qs[tid + half] = qb * c + qa * s;
-    kn[tid] = ka * c - kb * s;
-    kn[tid + half] = kb * c + ka * s;
+    qs[tid] = (qa * c - qb * s) * scale;
+    qs[tid + half] = (qb * c + qa * s) * scale;
+    kn[tid] = (float)(KV)(ka * c - kb * s);
+    kn[tid + half] = (float)(KV)(kb * c + ka * s);
+  } else if (tid >= 128 && tid < 128 + HD) {
+    vn[tid - 128] = (float)(KV)qkv[(size_t)(heads + kv_heads + kh) * HD + (tid - 128)];
   }
   __syncthreads();
-  const float* vnew = qkv + (size_t)(heads + kv_heads + kh) * D;
-  if (h % rep == 0 && tid < D) {
-    kcache[((size_t)pos * kv_heads + kh) * D + tid] = (KV)kn[tid];
-    vcache[((size_t)pos * kv_heads + kh) * D + tid] = (KV)vnew[tid];
+  if (h % rep == 0 && tid < HD) {
+    kcache[((size_t)pos * kv_heads + kh) * HD + tid] = (KV)kn[tid];
+    vcache[((size_t)pos * kv_heads + kh) * HD + tid] = (KV)vn[tid];
   }
-  // scores: group of 4 lanes per position, each lane D/4 dims
-  const float scale = 1.0f / sqrtf((float)D);
-  const int sub = tid & 3, dper = D >> 2;
+  // ---- scores for cached positions ----
+  const int sub = lane & 3;
+  float qreg[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) qreg[i] = qs[sub * DPL + i];
   float lmax = -INFINITY;
-  for (int t = tid >> 2; t < ctx; t += 64) {
+  for (int t0 = wid * 16; t0 < pos; t0 += 64) {
+    const int t = t0 + (lane >> 2);
+    const int tc = min(t, pos - 1);
+    const kv8* kp = (const kv8*)(kcache + ((size_t)tc * kv_heads + kh) * HD + sub * DPL);
+    kv8 kv[DPL / 8];
+#pragma unroll
+    for (int j = 0; j < DPL / 8; ++j) kv[j] = kp[j];
     float d = 0.f;
-    if (t == pos) {
-      for (int i = 0; i < dper; ++i) d = fmaf(qs[sub * dper + i], (float)(KV)kn[sub * dper + i], d);
-    } else {
-      const KV* kk = kcache + ((size_t)t * kv_heads + kh) * D + sub * dper;
-      for (int i = 0; i < dper; ++i) d = fmaf(qs[sub * dper + i], (float)kk[i], d);
-    }
+#pragma unroll
+    for (int j = 0; j < DPL / 8; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d = fmaf(qreg[j * 8 + i], (float)kv[j][i], d);
     d += __shfl_xor(d, 1, 64);
     d += __shfl_xor(d, 2, 64);
-    d *= scale;
-    if (sub == 0) sc[t] = d;
+    if (t < pos) {
+      if (sub == 0) sc[t] = d;
+      lmax = fmaxf(lmax, d);
+    }
+  }
+  if (tid == 0) {  // the new position, from LDS
+    float d = 0.f;
+    for (int i = 0; i < HD; ++i) d = fmaf(qs[i], kn[i], d);
+    sc[pos] = d;
     lmax = fmaxf(lmax, d);
   }
   lmax = wave_max(lmax);
@@ -145,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
   __syncthreads();
   const float mx = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
   float lsum = 0.f;
-  for (int t = tid; t < ctx; t += 256) {
+  for (int t = tid; t <= pos; t += 256) {
     const float p = __expf(sc[t] - mx);
     sc[t] = p;
     lsum += p;
@@ -153,24 +175,42 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
   lsum = wave_sum(lsum);
   if (lane == 0) redm[4 + wid] = lsum;
   __syncthreads();
-  const float den = redm[4] + redm[5] + redm[6] + redm[7];
-  // out[d] = sum_t p[t] v[t][d]: thread = (t-slice, d); D <= 128 -> 256/D slices
-  const int nsl = 256 / D, sl = tid / D, dd = tid % D;
-  float acc = 0.f;
-  if (sl < nsl) {
-    for (int t = sl; t < ctx; t += nsl) {
-      const float vv = (t == pos) ? (float)(KV)vnew[dd] : (float)vcache[((size_t)t * kv_heads + kh) * D + dd];
-      acc = fmaf(sc[t], vv, acc);
+  const float den = (redm[4] + redm[5]) + (redm[6] + redm[7]);
+  // ---- P.V ----
+  const int g = lane / LPR, l8 = lane % LPR;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  constexpr int TSTEP = 4 * GP;  // positions covered by the workgroup per pass
+  for (int t0 = wid * GP + g; t0 < pos; t0 += 4 * TSTEP) {
+    kv8 vv[4];
+    float pp[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * TSTEP;
+      const int tc = min(t, pos - 1);
+      vv[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
+      pp[u] = t < pos ? sc[tc] : 0.f;
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = fmaf(pp[u], (float)vv[u][i], acc[i]);
   }
+  if (wid == 0 && g == 0) {  // the new position
+    const float p = sc[pos];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, vn[l8 * 8 + i], acc[i]);
+  }
+  float* dst = slab + ((size_t)(wid * GP + g)) * HD + l8 * 8;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dst[i] = acc[i];
   __syncthreads();
-  float* slab = redm + 8;  // [256] cross-slice reduce buffer
-  slab[tid] = acc;
-  __syncthreads();
-  if (tid < D) {
+  if (tid < HD) {
     float o = 0.f;
-    for (int s2 = 0; s2 < nsl; ++s2) o += slab[s2 * D + tid];
-    out[(size_t)h * D + tid] = o / den;
+#pragma unroll
+    for (int s2 = 0; s2 < 4 * GP; ++s2) o += slab[s2 * HD + tid];
+    out[(size_t)h * HD + tid] = o / den;
   }
 }
 
@@ -270,32 +310,33 @@ void launch_embed(const void* embed, int dtype, const int32_t* token, int hidden
   hipLaunchKernelGGL(embed_kernel, dim3((hidden + 255) / 256), dim3(256), 0, st, embed, dtype, token, hidden, out);
 }
 
+template <typename KV, int HD>
+static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int32_t* pos, const float* cs,
+                         const float* sn, int heads, int kv_heads, int max_ctx, float* out, hipStream_t st) {
+  constexpr int GP = 64 / (HD / 8);
+  const size_t lds = (size_t)(3 * HD + 8 + 4 * GP * HD + ((max_ctx + 3) & ~3)) * 4;
+  if (lds > 160 * 1024) return woq::fail("QBits: max_ctx too large for the single-pass decode attention");
+  auto k = attn_decode_kernel<KV, HD>;
+  static bool once = false;
+  if (!once) {
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    once = true;
+  }
+  hipLaunchKernelGGL(k, dim3(heads), dim3(256), lds, st, qkv, (KV*)kcache, (KV*)vcache, pos, cs, sn, heads, kv_heads,
+                     out);
+  return 0;
+}
+
 int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
                        const float* cs, const float* sn, int heads, int kv_heads, int D, int max_ctx, float* out,
                        hipStream_t st) {
-  if (D > 256 || (D & 7) || 256 % D != 0) return woq::fail("QBits: attention head_dim must divide 256");
-  const size_t lds = (size_t)(2 * D + ((max_ctx + 3) & ~3) + 8 + 256) * 4;
-  if (lds > 160 * 1024) return woq::fail("QBits: max_ctx too large for the single-pass decode attention");
+  if (D != 64 && D != 128) return woq::fail("QBits: attention head_dim must be 64 or 128");
   if (kv_dtype == WOQ_F16) {
-    auto k = attn_decode_kernel<_Float16>;
-    static bool once = false;
-    if (!once) {
-      hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      once = true;
-    }
-    hipLaunchKernelGGL(k, dim3(heads), dim3(256), lds, st, qkv, (_Float16*)kcache, (_Float16*)vcache, pos, cs, sn,
-                       heads, kv_heads, D, out);
-  } else {
-    auto k = attn_decode_kernel<__bf16>;
-    static bool once = false;
-    if (!once) {
-      hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      once = true;
-    }
-    hipLaunchKernelGGL(k, dim3(heads), dim3(256), lds, st, qkv, (__bf16*)kcache, (__bf16*)vcache, pos, cs, sn, heads,
-                       kv_heads, D, out);
+    if (D == 128) return launch_attn_t<_Float16, 128>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, st);
+    return launch_attn_t<_Float16, 64>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, st);
   }
-  return 0;
+  if (D == 128) return launch_attn_t<__bf16, 128>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, st);
+  return launch_attn_t<__bf16, 64>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, st);
 }
 
 void launch_lm_head(const float* hidden_in, const float* norm_w, float eps, const void* W, int w_dtype, int hidden,
