@@ -388,6 +388,11 @@ int launch_gemv(const GemvArgs& a, int smode, bool asym, int cb, int mt, hipStre
 namespace woq {
 
 int gemv_decode_max_rows(int Kpad);
+int gemv_tile_max_rows(const void* act, int act_dtype, int lda, const woq_blob_header& h, const float* norm_w,
+                       int epi);
+int launch_gemv_tile(const void* act, int act_dtype, int lda, int M, const void* blob, const woq_blob_header& h,
+                     const float* bias, void* out, int out_dtype, int ldo, const float* norm_w, float eps,
+                     const float* residual, int ld_res, int epi, hipStream_t st);
 int launch_gemv_decode(const void* act, int act_dtype, int lda, int M, const void* blob, const woq_blob_header& h,
                        const float* bias, void* out, int out_dtype, int ldo, const float* norm_w, float eps,
                        const float* residual, int ld_res, int epi, hipStream_t st);
@@ -396,9 +401,25 @@ int launch_gemv_decode(const void* act, int act_dtype, int lda, int M, const voi
 int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                             const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w,
                             float eps, const float* residual, int ld_res, int epi, int nt, hipStream_t st) {
-  // the per-token path: persistent pipelined MFMA kernel (woq_gemv_decode.hip), up to 8 rows per launch
-  static const bool use_valu = getenv("WOQ_GEMV_VALU") != nullptr;  // A/B switch: the fp32 VALU kernel below
-  const int mr = use_valu ? 0 : gemv_decode_max_rows(h.Kpad);
+  // A/B switch (timing experiments): WOQ_GEMV_IMPL = tile (default) | persist | valu
+  static const int impl = [] {
+    const char* s = getenv("WOQ_GEMV_IMPL");
+    return !s ? 0 : (s[0] == 'p' ? 1 : (s[0] == 'v' ? 2 : 0));
+  }();
+  // the per-token path: straight-line MFMA tile kernel (woq_gemv_tile.hip), up to 8 rows per launch
+  const int mt_rows = impl == 0 ? gemv_tile_max_rows(act, act_dtype, lda, h, norm_w, epi) : 0;
+  if (mt_rows > 0) {
+    const size_t esz_o = out_dtype == WOQ_F32 ? 4 : 2;
+    for (int m0 = 0; m0 < M; m0 += mt_rows) {
+      const int mc = M - m0 < mt_rows ? M - m0 : mt_rows;
+      int rc = launch_gemv_tile((const char*)act + (size_t)m0 * lda * 4, act_dtype, lda, mc, blob, h, bias,
+                                (char*)out + (size_t)m0 * ldo * esz_o, out_dtype, ldo, norm_w, eps,
+                                residual ? residual + (size_t)m0 * ld_res : nullptr, ld_res, epi, st);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  const int mr = impl == 1 ? gemv_decode_max_rows(h.Kpad) : 0;
   if (mr > 0) {
     const size_t esz_a = act_dtype == WOQ_F32 ? 4 : 2, esz_o = out_dtype == WOQ_F32 ? 4 : 2;
     for (int m0 = 0; m0 < M; m0 += mr) {
