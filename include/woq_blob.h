@@ -8,23 +8,24 @@
  * and re-parses on every call (bestla_weightonly_dispatcher.cpp:335-340).
  * The layout is opaque to callers of the reference too, so it is designed
  * for gfx950, not copied: one 1-KiB "tile" = 16 output columns x 128 K rows
- * is exactly one wave64 `global_load_dwordx4` (64 lanes x 16 B), and the lane
+ * is exactly one wave64 `buffer_load_dwordx4` (64 lanes x 16 B), and the lane
  * <-> (column, k) map inside a tile is the B-operand fragment map of
- * v_mfma_f32_16x16x32_{f16,bf16}, so the same bytes feed the decode GEMV
- * (VALU, wave-shuffle reduce) and the prefill GEMM (MFMA) with no re-layout.
+ * v_mfma_i32_16x16x64_i8 (lane l: column l & 15, 16 consecutive k starting at
+ * (l >> 4) * 16), with every int4 stored as a SIGNED two's-complement nibble, so
+ * that `(w << 4) & 0xf0f0f0f0` and `w & 0xf0f0f0f0` are directly four int8
+ * values 16*q each: three VALU instructions turn 8 weights into MFMA operands.
  *
  * Blob = [256-B header][qdata][scales][zero points][shuffle indices]
  *
  * qdata   : [Npad/16][Kpad/128][64 lanes][4 x u32]
- *           lane l: column i = l & 15, k-quarter kq = l >> 4
- *           u32 #s (0..3), k-offset j (0..7)  <->  k = kt*128 + s*32 + kq*8 + j,  n = tn*16 + i
- *           k-offset j sits at nibble position pos(j) = (j >> 1) | ((j & 1) << 2)  (bits
- *           4*pos..4*pos+3): `w & 0x000f000f` is then (j0 | j1 << 16), `(w >> 4) & ..` (j2, j3),
- *           `(w >> 8)` (j4, j5), `(w >> 12)` (j6, j7) — consecutive-k pairs in one register, the
- *           order an MFMA fragment wants after the int4 -> fp16/bf16 "magic number" conversion.
- *           nibble value u = q + 8, q in [-8,7]  (the reference's signed-nibble
- *           domain, llm/quantization/nn/modules.py:225-227, re-biased to unsigned)
- *           padding (k >= K or n >= N) is u = 8 (q = 0).
+ *           lane l: column i = l & 15, k-sixteenth kq = l >> 4
+ *           u32 #w (0..3): 64-k half h = w >> 1, part p = w & 1; it holds k-offsets j = 8p .. 8p+7 of
+ *               k = kt*128 + h*64 + kq*16 + j,  n = tn*16 + i
+ *           k-offset j = 8p + jj sits in byte c = jj & 3, low nibble for jj < 4, high nibble for jj >= 4
+ *           (bit shift 8*c + 4*(jj >> 2)): the low nibbles of the 4 bytes are j = 8p..8p+3, the high
+ *           nibbles j = 8p+4..8p+7 — B registers 2p and 2p+1 of the MFMA fragment.
+ *           nibble value = q & 0xf, q in [-8,7] (the reference's signed-nibble domain,
+ *           llm/quantization/nn/modules.py:225-227); padding (k >= K or n >= N) is q = 0.
  * scales  : scale_mode 0 (group % 128 == 0, or a single group):
  *               [Npad/16][n_groups][16]            element (tn, g, i)
  *           scale_mode 1 (any other group that is a multiple of 32):
@@ -39,7 +40,7 @@
  *           tensor the caller passed as g_idx (bestla_packq_impl.cpp:37-38,
  *           round-trip pinned by qbits_ut/test_packq.py:100); absent otherwise.
  *
- * Dequantisation: w[k][n] = (u - uz) * scale     (uz = 8 when !asym)
+ * Dequantisation: w[k][n] = (q - (uz - 8)) * scale     (uz = 8 when !asym)
  *   == (q - zp) * scale of modules.py:264-295 / recover_qparms :349-352.
  */
 #ifndef WOQ_BLOB_H_
@@ -53,7 +54,7 @@ extern "C" {
 #endif
 
 #define WOQ_BLOB_MAGIC 0x31485157u /* "WQH1" */
-#define WOQ_BLOB_VERSION 1u
+#define WOQ_BLOB_VERSION 2u
 #define WOQ_HEADER_BYTES 256
 #define WOQ_TILE_N 16
 #define WOQ_TILE_K 128
@@ -114,8 +115,11 @@ enum woq_acquire_type {
   WOQ_ACQ_IS_ASYM = 11
 };
 
-/* nibble position of k-offset j inside a packed u32 (see layout comment) */
-static inline int woq_nibble_pos(int j) { return (j >> 1) | ((j & 1) << 2); }
+/* bit shift of k-offset j (0..15 within a lane's 16-k run of one 64-k half) inside its u32 (#2h + (j >> 3)) */
+static inline int woq_nibble_shift(int j) {
+  int jj = j & 7;
+  return 8 * (jj & 3) + 4 * (jj >> 2);
+}
 
 static inline size_t woq_dtype_size(uint32_t dt) { return dt == WOQ_F32 ? 4u : 2u; }
 static inline size_t woq_round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
@@ -175,16 +179,16 @@ static inline size_t woq_scale_index(const woq_blob_header* h, int k, int n) {
   return ((tn * ((size_t)h->Kpad / WOQ_TILE_K) + kt) * 16u + i) * 4u + s;
 }
 
-/* byte offset (from off_q) and nibble shift of weight element (k, n) */
+/* byte offset (from off_q) and nibble shift (0 | 4) of weight element (k, n) */
 static inline size_t woq_q_byte(const woq_blob_header* h, int k, int n, int* shift) {
   size_t tn = (size_t)n / WOQ_TILE_N, i = (size_t)n % WOQ_TILE_N;
   size_t kt = (size_t)k / WOQ_TILE_K, r = (size_t)k % WOQ_TILE_K;
-  size_t s = r / 32u, kq = (r % 32u) / 8u, j = r % 8u;
+  size_t hh = r / 64u, kq = (r % 64u) / 16u, j = r % 16u;
   size_t lane = kq * 16u + i;
-  size_t word = ((tn * ((size_t)h->Kpad / WOQ_TILE_K) + kt) * 64u + lane) * 4u + s;
-  int pos = woq_nibble_pos((int)j);
-  *shift = (pos & 1) * 4;
-  return word * 4u + (size_t)pos / 2u;
+  size_t word = ((tn * ((size_t)h->Kpad / WOQ_TILE_K) + kt) * 64u + lane) * 4u + hh * 2u + j / 8u;
+  int sh = woq_nibble_shift((int)j);
+  *shift = sh & 4;
+  return word * 4u + (size_t)(sh >> 3);
 }
 
 #ifdef __cplusplus

@@ -36,10 +36,9 @@ __device__ __forceinline__ void store_f32(void* p, size_t i, int dt, float v) {
     ((uint16_t*)p)[i] = f32_to_f16_bits(v);
 }
 
-// position of k-offset j (0..7) inside a packed u32: nibble index pos(j) = (j >> 1) | ((j & 1) << 2).
-// With this interleave `w & 0x000f000f` yields (j0 | j1 << 16), `(w >> 4) & ..` (j2, j3), `(w >> 8)`
-// (j4, j5), `(w >> 12)` (j6, j7): consecutive-k pairs land in one register in MFMA fragment order.
-__host__ __device__ __forceinline__ int nibble_pos(int j) { return (j >> 1) | ((j & 1) << 2); }
+// bit shift of k-offset j (0..15 of a lane's 16-k run in one 64-k half) inside its packed u32 — the device twin of
+// woq_nibble_shift() in include/woq_blob.h: byte j & 3, low nibble for (j & 7) < 4, high nibble otherwise.
+__host__ __device__ __forceinline__ int nibble_shift(int j) { return 8 * (j & 3) + 4 * ((j & 7) >> 2); }
 
 // wave64 sum over the 4 lanes that share a column (lane, lane^16, lane^32, lane^48)
 __device__ __forceinline__ float reduce_kq(float v) {
@@ -47,6 +46,34 @@ __device__ __forceinline__ float reduce_kq(float v) {
   v += __shfl_xor(v, 32, 64);
   return v;
 }
+// wave64 all-reduce without LDS traffic: four DPP butterfly steps leave every 16-lane row uniform
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the four row values are combined through SGPRs.
+// ~10 short instructions instead of six dependent ds_bpermute round trips (~100 cycles each).
+#define WOQ_DPP_F32(v, ctrl) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false))
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += WOQ_DPP_F32(v, 0xB1);
+  v += WOQ_DPP_F32(v, 0x4E);
+  v += WOQ_DPP_F32(v, 0x141);
+  v += WOQ_DPP_F32(v, 0x140);
+  const int b = __builtin_bit_cast(int, v);
+  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) +
+          __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) +
+          __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = fmaxf(v, WOQ_DPP_F32(v, 0xB1));
+  v = fmaxf(v, WOQ_DPP_F32(v, 0x4E));
+  v = fmaxf(v, WOQ_DPP_F32(v, 0x141));
+  v = fmaxf(v, WOQ_DPP_F32(v, 0x140));
+  const int b = __builtin_bit_cast(int, v);
+  return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)),
+                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))),
+               fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)),
+                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48))));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -15,7 +15,9 @@ __global__ void write_header_kernel(woq_blob_header h, woq_blob_header* dst) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *dst = h;
 }
 
-// one thread per packed u32 word: gathers 8 int4 values (k .. k+7 of one column) from int8 [K,N]
+// one thread per packed u32 word: gathers 8 int4 values (8 consecutive k of one column) from int8 [K,N].
+// Word #w of lane (kq, i): 64-k half h = w >> 1, part p = w & 1 -> k = kt*128 + h*64 + kq*16 + 8p + jj,
+// jj in byte jj & 3, low nibble for jj < 4, high nibble otherwise (include/woq_blob.h).
 __global__ void repack_q_kernel(const int8_t* __restrict__ q, uint32_t* __restrict__ qd, int K, int N,
                                 int tiles_k, size_t n_words) {
   size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -27,14 +29,14 @@ __global__ void repack_q_kernel(const int8_t* __restrict__ q, uint32_t* __restri
   int tn = (int)(tile / (size_t)tiles_k);
   int i = lane & 15, kq = lane >> 4;
   int n = tn * 16 + i;
-  int k0 = kt * 128 + s * 32 + kq * 8;
+  int k0 = kt * 128 + (s >> 1) * 64 + kq * 16 + (s & 1) * 8;
   uint32_t word = 0;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    int k = k0 + j;
-    uint32_t u = 8u;  // padding: q = 0
-    if (k < K && n < N) u = (uint32_t)((int)q[(size_t)k * N + n] + 8) & 0xfu;
-    word |= u << (4 * nibble_pos(j));
+  for (int jj = 0; jj < 8; ++jj) {
+    int k = k0 + jj;
+    uint32_t u = 0u;  // padding: q = 0
+    if (k < K && n < N) u = (uint32_t)q[(size_t)k * N + n] & 0xfu;  // two's-complement nibble
+    word |= u << nibble_shift(jj);
   }
   qd[w] = word;
 }
@@ -76,10 +78,11 @@ __device__ __forceinline__ void blob_elem(const uint8_t* blob, const woq_blob_he
                                           int& uz, float& sc) {
   int tiles_k = h.Kpad / WOQ_TILE_K;
   int tn = n >> 4, i = n & 15, kt = k >> 7, r = k & 127;
-  int s = r >> 5, kq = (r & 31) >> 3, j = r & 7;
-  size_t word = (((size_t)tn * tiles_k + kt) * 64 + (size_t)(kq * 16 + i)) * 4 + s;
+  int s = r >> 5, hh = r >> 6, kq = (r & 63) >> 4, j = r & 15;
+  size_t word = (((size_t)tn * tiles_k + kt) * 64 + (size_t)(kq * 16 + i)) * 4 + hh * 2 + (j >> 3);
   uint32_t w = ((const uint32_t*)(blob + h.off_q))[word];
-  u = (int)((w >> (4 * nibble_pos(j))) & 0xfu);
+  int qv = (int)((w >> nibble_shift(j)) & 0xfu);
+  u = (qv & 8) ? qv + 8 - 16 : qv + 8;  // unsigned-domain value u = q + 8
   size_t si;
   if (h.scale_mode == 0) {
     int g = k / h.group;

@@ -265,16 +265,15 @@ ORC_API int orc_repack(const int8_t* q, const float* scales, const int8_t* zp, c
   memset(blob, 0, h.total_bytes);
   memcpy(blob, &h, sizeof(h));
   uint8_t* qd = blob + h.off_q;
-  /* padding nibble = 8 (q = 0) */
-  memset(qd, 0x88, (size_t)(h.Npad / WOQ_TILE_N) * (size_t)(h.Kpad / WOQ_TILE_K) * WOQ_TILE_BYTES);
+  /* padding nibble = 0 (q = 0, signed two's-complement nibbles): the memset above did it */
   for (int k = 0; k < K; ++k)
     for (int n = 0; n < N; ++n) {
       int shift;
       size_t b = woq_q_byte(&h, k, n, &shift);
-      uint8_t u = (uint8_t)((q[(size_t)k * N + n] + 8) & 0xf);
+      uint8_t u = (uint8_t)(q[(size_t)k * N + n] & 0xf); /* two's-complement nibble of q in [-8,7] */
       qd[b] = (uint8_t)((qd[b] & ~(0xfu << shift)) | (u << shift));
     }
-  if (zp) { /* padding zero point = 8 (u = 8 padding nibbles then dequantise to exactly 0) */
+  if (zp) { /* padding zero point: uz = 8 <-> zp = 0 (q = 0 padding nibbles then dequantise to exactly 0) */
     size_t tiles_n = (size_t)h.Npad / WOQ_TILE_N, tiles_k = (size_t)h.Kpad / WOQ_TILE_K;
     size_t n_scale = h.scale_mode == 0 ? tiles_n * (size_t)h.n_groups * 16u : tiles_n * tiles_k * 64u;
     memset(blob + h.off_zp, 8, n_scale);
@@ -312,11 +311,12 @@ ORC_API int orc_dequantize_blob(const uint8_t* blob, float* out, int transpose) 
     for (int n = 0; n < h.N; ++n) {
       int shift;
       size_t b = woq_q_byte(&h, k, n, &shift);
-      int u = (qd[b] >> shift) & 0xf;
+      int qv = (qd[b] >> shift) & 0xf;
+      if (qv & 8) qv -= 16; /* sign-extend the nibble */
       size_t si = woq_scale_index(&h, k, n);
       float s = orc_load_scalar(blob + h.off_scale, si, (int)h.scale_type);
-      int uz = h.off_zp ? (blob + h.off_zp)[si] : 8;
-      float w = (float)(u - uz) * s;
+      int zpv = h.off_zp ? (int)(blob + h.off_zp)[si] - 8 : 0;
+      float w = (float)(qv - zpv) * s;
       if (transpose)
         out[(size_t)n * h.K + k] = w;
       else
@@ -387,17 +387,19 @@ ORC_API int orc_woq_gemv_stream(const float* x, const uint8_t* blob, const float
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     for (int kt = 0; kt < tiles_k; ++kt) {
       const uint32_t* tile = (const uint32_t*)(blob + h.off_q) + ((size_t)tn * tiles_k + kt) * 256u;
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < 4; ++s) { /* 32-row blocks: the finest scale granularity */
         int kb = kt * 128 + s * 32;
         for (int i = 0; i < 16; ++i) {
           size_t si = woq_scale_index(&h, kb, tn * 16 + i);
           float sc = orc_load_scalar(blob + h.off_scale, si, (int)h.scale_type);
-          int uz = h.off_zp ? (blob + h.off_zp)[si] : 8;
+          int zpv = h.off_zp ? (int)(blob + h.off_zp)[si] - 8 : 0;
           float part = 0.f;
-          for (int kq = 0; kq < 4; ++kq) {
-            uint32_t w = tile[(size_t)(kq * 16 + i) * 4 + s];
-            const float* xp = xs + kb + kq * 8;
-            for (int j = 0; j < 8; ++j) part += (float)((int)((w >> (4 * woq_nibble_pos(j))) & 0xf) - uz) * xp[j];
+          for (int r = 0; r < 32; ++r) { /* k = kb + r: half hh, sixteenth kq, offset j (woq_blob.h) */
+            int rr = s * 32 + r, hh = rr / 64, kq = (rr % 64) / 16, j = rr % 16;
+            uint32_t w = tile[(size_t)(kq * 16 + i) * 4 + hh * 2 + j / 8];
+            int qv = (int)((w >> woq_nibble_shift(j)) & 0xf);
+            if (qv & 8) qv -= 16;
+            part += (float)(qv - zpv) * xs[kb + r];
           }
           acc[i] += part * sc;
         }

@@ -12,7 +12,8 @@
 #include <vector>
 
 __device__ unsigned long long* g_probe = nullptr;
-#include "../intel_extension_for_transformers_amd/csrc/woq_gemv_tile.hip"
+int g_probe_flags = 0;  // OR-ed into the kernel flags (experiment switches)
+#include "../intel_extension_for_transformers_amd/csrc/woq_gemv_i8.hip"
 
 namespace woq {
 std::string& last_error_ref() {
@@ -139,6 +140,25 @@ int main(int argc, char** argv) {
     const double us = ms * 1e3 / (reps * nb);
     printf("%-8s K=%5d N=%5d  %6.2f MB  back-to-back %6.2f us/launch  %6.0f GB/s algorithmic\n", s.name, s.K, s.N,
            alg / 1e6, us, alg / us / 1e3);
+
+    // experiment switches (probe build only): what does each stage cost end to end?
+    {
+      const int exps[] = {16, 32, 64, 128, 256, 32 | 128, 32 | 64 | 128, 32 | 64 | 128 | 256};
+      const char* en[] = {"no residual load", "no staging math", "no mfma loop", "no x loads", "no barrier/epilogue",
+                          "no staging, no x", "no staging/x/mfma", "loads only"};
+      for (int e = 0; e < 8; ++e) {
+        g_probe_flags = exps[e];
+        for (int b = 0; b < nb; ++b) launch(b);
+        CK(hipEventRecord(e0, st));
+        for (int r = 0; r < reps; ++r)
+          for (int b = 0; b < nb; ++b) launch(b);
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("         %-22s back-to-back %6.2f us/launch\n", en[e], ms * 1e3 / (reps * nb));
+      }
+      g_probe_flags = 0;
+    }
 
     // load-only twin
     const int tiles_k = h.Kpad / 128, tiles_n = h.Npad / 16;
