@@ -36,9 +36,10 @@
  *           signed-domain zero point handed to repack (range [-8, 7]: the reference's
  *           (zeros - 8) * 16 // 16 on int8 wraps 16 -> -8, modules.py:225-227, pinned by
  *           tests/golden/set_weights_bias.npz); absent when !asym.
- * shuffle : int32[K] activation shuffle indices (x'[j] = x[idx[j]]), exactly the
- *           tensor the caller passed as g_idx (bestla_packq_impl.cpp:37-38,
- *           round-trip pinned by qbits_ut/test_packq.py:100); absent otherwise.
+ * shuffle : int32[K] activation shuffle indices (x'[j] = x[idx[j]]): convert_idx of the
+ *           raw GPTQ g_idx the caller passed (bestla_packq_impl.cpp:37-38; what
+ *           acquire_packed_weight_info(G_IDX) returns, qbits_ut/test_packq.py:98-100);
+ *           absent otherwise.
  *
  * Dequantisation: w[k][n] = (q - (uz - 8)) * scale     (uz = 8 when !asym)
  *   == (q - zp) * scale of modules.py:264-295 / recover_qparms :349-352.

@@ -49,7 +49,9 @@ WOQ_API size_t woq_packed_weight_size(int K, int N, int blocksize, int weight_ty
 
 /* replaces qbits.repack_quantized_weight (qbits.cpp:61-77 -> bestla_packq_impl.cpp:20-41).
  * qweight int8 [K,N] (int4 values, signed domain, modules.py:225-227), scale fp32 [G,N],
- * zp int8 [G,N] or NULL (sym), g_idx int32 [K] shuffle indices or NULL. blob_dev: caller-allocated,
+ * zp int8 [G,N] or NULL (sym), g_idx int32 [K] = GPTQ act-order group id of every K row (each group exactly
+ * `blocksize` rows) or NULL; like BesTLA, repack converts it to activation shuffle indices
+ * (qbits_ut/test_packq.py:22-28,59-64) and the blob keeps those. blob_dev: caller-allocated,
  * woq_packed_weight_size() bytes, 256-B aligned. Layout transform only; device-side. */
 WOQ_API int woq_repack_quantized_weight(const int8_t* qweight_dev, const float* scale_dev, const int8_t* zp_dev,
                                         const int32_t* g_idx_dev, int K, int N, int blocksize, int weight_type,

@@ -41,6 +41,23 @@ __global__ void repack_q_kernel(const int8_t* __restrict__ q, uint32_t* __restri
   qd[w] = word;
 }
 
+// GPTQ g_idx (group id of every K row, act-order) -> activation shuffle indices: position g*blocksize + c holds the
+// c-th row (in increasing row order) whose group is g — the reference's convert_idx (qbits_ut/test_packq.py:22-28),
+// which BesTLA applies inside repack (the test hands repack the raw g_idx and reads the converted one back,
+// test_packq.py:59-64,98-100). One thread per group scans K: O(G*K) reads, load time only.
+__global__ void convert_idx_kernel(const int32_t* __restrict__ g_idx, int K, int blocksize, int n_groups,
+                                   int32_t* __restrict__ out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_groups) return;
+  int c = 0;
+  for (int i = 0; i < K; ++i)
+    if (g_idx[i] == g) {
+      const int p = g * blocksize + c;
+      if (p < K) out[p] = i;
+      ++c;
+    }
+}
+
 // one thread per stored scale / zero-point element
 __global__ void repack_scale_kernel(const float* __restrict__ scale, const int8_t* __restrict__ zp,
                                     woq_blob_header h, uint8_t* __restrict__ blob, size_t n_scale) {
@@ -219,8 +236,11 @@ int woq_repack_quantized_weight(const int8_t* qweight_dev, const float* scale_de
   size_t ns = n_scale_elems(h);
   hipLaunchKernelGGL(repack_scale_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, scale_dev, zp_dev,
                      h, blob, ns);
-  if (g_idx_dev)
-    WOQ_HIP(hipMemcpyAsync(blob + h.off_shuffle, g_idx_dev, (size_t)K * 4u, hipMemcpyDeviceToDevice, st));
+  if (g_idx_dev) {
+    WOQ_HIP(hipMemsetAsync(blob + h.off_shuffle, 0, (size_t)K * 4u, st));
+    hipLaunchKernelGGL(convert_idx_kernel, dim3((unsigned)((h.n_groups + 63) / 64)), dim3(64), 0, st, g_idx_dev, K,
+                       (int)h.group, (int)h.n_groups, (int32_t*)(blob + h.off_shuffle));
+  }
   WOQ_HIP(hipGetLastError());
   WOQ_END
 }

@@ -193,3 +193,62 @@ def synth_llama_weights(engine, hidden, inter, heads, kv_heads, head_dim, layers
     engine.set_head(embed, norm, lm_head)
     _ = gs
     return engine
+
+
+# ---- fused decode engine from a quantised HF model (the `ipex.optimize_transformers` analogue) ---------------------
+def _signed_parts(mod):
+    """QuantizedLinearQBits -> (q int8 [K,N] in [-8,7], scales fp32 [G,N], zp int8 [G,N] signed or None)."""
+    int_w, scales, zeros, g_idx = mod.recover_qparms()
+    if g_idx is not None:
+        raise RuntimeError("QBits: the fused decode engine does not take act-order (g_idx) layers")
+    return (int_w - 8).to(torch.int8), scales, None if zeros is None else (zeros - 8).to(torch.int8)
+
+
+def optimize_transformers(model, max_ctx=2048, kv_dtype=torch.float16):
+    """Post-pass over a model returned by `AutoModelForCausalLM.from_pretrained(..., quantization_config=...)`:
+    builds the native batch-1 decode engine over the SAME quantised weights (q/k/v fused along N, gate/up
+    interleaved per 16-column tile for the fused SiLU*mul epilogue). Mirrors the two-step shape of the reference's
+    Intel-GPU flow, `ipex.optimize_transformers(qmodel, ...)` after `from_pretrained`
+    (docs/weightonlyquant.md:199-202). Llama-class decoders (Llama-2, Mistral: RMSNorm, RoPE, gated SiLU MLP)."""
+    cfg = model.config
+    if getattr(cfg, "model_type", "") not in ("llama", "mistral"):
+        raise RuntimeError("QBits: the fused decode engine covers Llama-class decoders, got %r" % cfg.model_type)
+    layers = model.model.layers
+    first = layers[0].self_attn.q_proj
+    hidden, inter = cfg.hidden_size, cfg.intermediate_size
+    heads = cfg.num_attention_heads
+    kv_heads = getattr(cfg, "num_key_value_heads", heads) or heads
+    head_dim = getattr(cfg, "head_dim", None) or hidden // heads
+    theta = getattr(cfg, "rope_theta", None)
+    if theta is None:
+        theta = (getattr(cfg, "rope_parameters", None) or {}).get("rope_theta", 10000.0)
+    dev = first.weight.device
+    eng = WoqDecoderEngine(hidden, inter, heads, kv_heads, head_dim, len(layers), cfg.vocab_size, max_ctx=max_ctx,
+                           rms_eps=cfg.rms_norm_eps, rope_theta=float(theta), kv_dtype=kv_dtype, device=dev)
+    asym = first.scheme == "asym"
+    group, sdt = first.blocksize, first.scale_dtype
+
+    def pack(q, s, z):
+        return qbits.repack_quantized_weight(q.contiguous(), s.contiguous(),
+                                             z.contiguous() if z is not None else torch.empty(0, dtype=torch.int8),
+                                             torch.empty(0, dtype=torch.int32), "int4_clip", sdt, "fp32", asym, group)
+
+    def cat(parts):
+        return (torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 1),
+                torch.cat([p[2] for p in parts], 1) if asym else None)
+
+    for l, layer in enumerate(layers):
+        at, mlp = layer.self_attn, layer.mlp
+        for m in (at.q_proj, at.k_proj, at.v_proj, at.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj):
+            if m.bias is not None:
+                raise RuntimeError("QBits: the fused decode engine does not take biased projections")
+        qkv = pack(*cat([_signed_parts(at.q_proj), _signed_parts(at.k_proj), _signed_parts(at.v_proj)]))
+        g, u = _signed_parts(mlp.gate_proj), _signed_parts(mlp.up_proj)
+        gu = pack(fuse_gate_up(g[0], u[0]), fuse_gate_up(g[1], u[1]), fuse_gate_up(g[2], u[2]) if asym else None)
+        eng.set_layer(l, qkv, at.o_proj.weight.data, gu, mlp.down_proj.weight.data, layer.input_layernorm.weight,
+                      layer.post_attention_layernorm.weight)
+    head_dtype = kv_dtype
+    eng.set_head(model.model.embed_tokens.weight.detach().to(head_dtype), model.model.norm.weight,
+                 model.lm_head.weight.detach().to(head_dtype))
+    model.woq_engine = eng
+    return eng

@@ -1,0 +1,221 @@
+"""`AutoModelForCausalLM` with the reference's entry points, MI355X backend.
+
+Counterpart of intel_extension_for_transformers/transformers/modeling/modeling_auto.py:
+  from_pretrained   :363-905   load an HF model, quantise its linears per `quantization_config`, return the HF model
+                               with `.quantization_config` set and `.save_pretrained` patched (:896-903)
+  save_low_bit      :209-320   write the quantised model in the INC / optimum tensor format + quantize_config.json
+  load_low_bit      :1311-1990 rebuild from that directory
+What is different by design: the quantised linears run on the GPU (`device_map="cuda"` is the default here, "cpu"
+is rejected — no CPU fallback); `use_neural_speed` is accepted and ignored with a warning (Neural Speed is an x86
+runtime); the loader reads safetensors directly instead of HF's private `_load_pretrained_model`
+(SURVEY.md §7 hard part iv).
+"""
+import json
+import logging
+import os
+import types
+
+import torch
+import transformers
+
+from ..llm.quantization.nn.modules import QuantizedLinearQBits
+from ..llm.quantization.utils import convert_to_quantized_model, pack_weight, replace_linear, unpack_weight
+from ..utils.config import (AutoRoundConfig, AwqConfig, GPTQConfig, ITREXQuantizationConfigMixin, RtnConfig,
+                            TeqConfig)
+
+logger = logging.getLogger(__name__)
+
+QUANT_CONFIG = "quantize_config.json"  # reference utils/utility.py:34
+WEIGHTS_NAME = "model_woq.safetensors"
+_BY_METHOD = {"rtn": RtnConfig, "awq": AwqConfig, "teq": TeqConfig, "gptq": GPTQConfig, "autoround": AutoRoundConfig}
+
+
+def _config_from_dict(d):
+    method = d.get("quant_method", "rtn")
+    method = getattr(method, "value", method)
+    return _BY_METHOD.get(method, RtnConfig).from_dict(d)
+
+
+def save_low_bit(self, save_directory, push_to_hub=False, **kwargs):
+    """reference modeling_auto.py:209-320 (`convert_model_to_public` :190-205 + `recover_export_model` :99-157):
+    every QuantizedLinearQBits is exported as `<name>.qweight / .scales / .qzeros / .g_idx / .bias` in the optimum
+    format that `unpack_weight` (utils.py:82-125) reads back; all other tensors are saved as they are."""
+    if push_to_hub:
+        raise RuntimeError("push_to_hub is not supported (no network)")
+    from safetensors.torch import save_file
+
+    os.makedirs(save_directory, exist_ok=True)
+    tensors = {}
+    quantized = set()
+    for name, mod in self.named_modules():
+        if isinstance(mod, QuantizedLinearQBits):
+            int_w, scales, zeros, g_idx = mod.recover_qparms()
+            qweight, sc16, qzeros = pack_weight(int_w, scales, zeros, bits=mod.bits)
+            tensors[name + ".qweight"] = qweight.cpu().contiguous()
+            tensors[name + ".scales"] = (scales if mod.scale_dtype == "fp32" else sc16).cpu().contiguous()
+            if qzeros is not None:
+                tensors[name + ".qzeros"] = qzeros.cpu().contiguous()
+            if g_idx is not None:
+                tensors[name + ".g_idx"] = g_idx.cpu().contiguous()
+            if mod.bias is not None:
+                tensors[name + ".bias"] = mod.bias.detach().cpu().contiguous()
+            quantized.add(name)
+    seen_ptr = {}
+    for key, t in self.state_dict().items():
+        owner = key.rsplit(".", 1)[0]
+        if owner in quantized:
+            continue
+        t = t.detach()
+        ptr = t.data_ptr()
+        if ptr in seen_ptr and t.numel():  # tied weights (embed / lm_head): store once, record the alias
+            seen_ptr[ptr].append(key)
+            continue
+        seen_ptr[ptr] = [key]
+        tensors[key] = t.cpu().contiguous()
+    aliases = {names[0]: names[1:] for names in seen_ptr.values() if len(names) > 1}
+    save_file(tensors, os.path.join(save_directory, WEIGHTS_NAME),
+              metadata={"format": "pt", "aliases": json.dumps(aliases), "quantized": json.dumps(sorted(quantized))})
+    self.config.save_pretrained(save_directory)
+    qcfg = self.quantization_config
+    qcfg.save_pretrained(save_directory)
+    with open(os.path.join(save_directory, "all_checkpoint_keys.json"), "w") as f:  # modeling_auto.py:289-292
+        json.dump({"all_checkpoint_keys": sorted(tensors.keys())}, f)
+
+
+class _ShellLinear(torch.nn.Module):
+    """Holder of optimum-format tensors between file and repack (the role INC's WeightOnlyLinear shells play in
+    `build_woq_model`, reference modeling_auto.py:160-187)."""
+
+    def __init__(self, in_features, out_features, tensors):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.qweight = tensors["qweight"]
+        self.scales = tensors["scales"]
+        self.qzeros = tensors.get("qzeros")
+        self.g_idx = tensors.get("g_idx")
+        self.bias = tensors.get("bias")
+
+
+def load_low_bit(pretrained_model_name_or_path, device="cuda", **kwargs):
+    """reference modeling_auto.py:1311-1990: config -> empty model -> packed-linear shells -> repack on the device."""
+    from safetensors import safe_open
+
+    d = str(pretrained_model_name_or_path)
+    with open(os.path.join(d, QUANT_CONFIG)) as f:
+        qcfg = _config_from_dict(json.load(f))
+    qcfg.post_init_hip()
+    config = transformers.AutoConfig.from_pretrained(d)
+    with torch.device("meta"):
+        model = transformers.AutoModelForCausalLM.from_config(config)
+    with safe_open(os.path.join(d, WEIGHTS_NAME), framework="pt", device="cpu") as f:
+        meta = f.metadata() or {}
+        tensors = {k: f.get_tensor(k) for k in f.keys()}
+    aliases = json.loads(meta.get("aliases", "{}"))
+    quantized = json.loads(meta.get("quantized", "[]"))
+    for name in quantized:
+        parent_name, _, leaf = name.rpartition(".")
+        parent = model.get_submodule(parent_name) if parent_name else model
+        old = getattr(parent, leaf)
+        if hasattr(old, "nf"):
+            k, n = old.weight.shape[0], old.nf
+        else:
+            k, n = old.in_features, old.out_features
+        parts = {s: tensors[name + "." + s].to(device) for s in ("qweight", "scales", "qzeros", "g_idx", "bias")
+                 if name + "." + s in tensors}
+        parent._modules[leaf] = _ShellLinear(k, n, parts)
+    skip = [n for n, m in model.named_modules()
+            if isinstance(m, torch.nn.Linear) or type(m).__name__ == "Conv1D"]  # whatever was left unquantised
+    replace_linear(model, skip, None, qcfg, device=device)
+    state = {k: v for k, v in tensors.items() if not any(k.startswith(q + ".") for q in quantized)}
+    for first, rest in aliases.items():
+        for r in rest:
+            state[r] = state[first]
+    missing, unexpected = model.load_state_dict(state, strict=False, assign=True)
+    missing = [m for m in missing if not any(m.startswith(q + ".") for q in quantized)]
+    if missing:
+        logger.warning("load_low_bit: tensors not found in the checkpoint: %s", missing[:8])
+    model.tie_weights()
+    _materialise_buffers(model, device)
+    model.to(device)
+    model.eval()
+    return _finish(model, qcfg)
+
+
+def _materialise_buffers(model, device):
+    """Non-persistent buffers (rotary inv_freq ...) are not in the checkpoint: rebuild the modules that own meta
+    buffers from the config."""
+    for name, mod in list(model.named_modules()):
+        if any(b is not None and b.is_meta for b in mod.buffers(recurse=False)):
+            try:
+                fresh = type(mod)(config=model.config)
+            except Exception:
+                fresh = type(mod)(model.config)
+            parent_name, _, leaf = name.rpartition(".")
+            (model.get_submodule(parent_name) if parent_name else model)._modules[leaf] = fresh.to(device)
+
+
+def _finish(model, qcfg):
+    """reference modeling_auto.py:896-903."""
+    qcfg.remove_redundant_parameters()
+    model.quantization_config = qcfg
+    model.config.quantization_config = qcfg.to_dict()
+    model.save_pretrained = types.MethodType(save_low_bit, model)
+    return model
+
+
+class _BaseAutoModelClass:
+    ORIG_MODEL = None
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *model_args, **kwargs):
+        """`from_pretrained(name_or_dir | nn.Module, quantization_config=RtnConfig(...) | load_in_4bit=True,
+        device_map="cuda", use_neural_speed=False, ...)` — reference modeling_auto.py:363-905."""
+        device_map = kwargs.pop("device_map", "cuda")
+        device = "cuda" if device_map in ("auto", "cuda", None) else str(device_map)
+        if device == "cpu":
+            raise RuntimeError("QBits: the MI355X backend has no CPU path; use device_map='cuda'")
+        if kwargs.pop("use_neural_speed", False) or kwargs.pop("use_llm_runtime", False):
+            logger.warning("use_neural_speed is an x86 runtime switch; ignored on the MI355X backend")
+        qcfg = kwargs.pop("quantization_config", None)
+        load_in_4bit = kwargs.pop("load_in_4bit", False)
+        load_in_8bit = kwargs.pop("load_in_8bit", False)
+        kwargs.pop("use_cpu", None)
+        kwargs.pop("use_xpu", None)
+        if load_in_8bit:
+            raise ValueError("Only support quantization to [4] bits on the MI355X path but found 8")
+        if isinstance(pretrained_model_name_or_path, (str, os.PathLike)) and os.path.isfile(
+                os.path.join(str(pretrained_model_name_or_path), QUANT_CONFIG)):
+            return load_low_bit(pretrained_model_name_or_path, device=device)  # :598-657
+        if qcfg is None and load_in_4bit:  # :717-741: load_in_4bit -> RtnConfig(bits=4)
+            qcfg = RtnConfig(bits=4, compute_dtype=kwargs.pop("compute_dtype", None),
+                             weight_dtype=kwargs.pop("weight_dtype", None), scale_dtype=kwargs.pop("scale_dtype", None))
+        if isinstance(pretrained_model_name_or_path, torch.nn.Module):
+            model = pretrained_model_name_or_path
+        else:
+            kwargs.setdefault("torch_dtype", torch.float32)  # quantise from fp32 (utils.py:539-544)
+            kwargs["low_cpu_mem_usage"] = True
+            model = cls.ORIG_MODEL.from_pretrained(pretrained_model_name_or_path, *model_args, **kwargs)
+        if qcfg is None:
+            return model.to(device)
+        if not isinstance(qcfg, ITREXQuantizationConfigMixin):
+            raise ValueError("quantization_config must be one of RtnConfig / AwqConfig / TeqConfig / GPTQConfig / "
+                             "AutoRoundConfig")
+        qcfg.post_init_hip()
+        model = convert_to_quantized_model(model, qcfg, device=device)
+        return _finish(model, qcfg)
+
+    @classmethod
+    def load_low_bit(cls, pretrained_model_name_or_path, *args, **kwargs):
+        return load_low_bit(pretrained_model_name_or_path, **kwargs)
+
+
+class AutoModelForCausalLM(_BaseAutoModelClass):
+    ORIG_MODEL = transformers.AutoModelForCausalLM
+
+
+class AutoModel(_BaseAutoModelClass):
+    ORIG_MODEL = transformers.AutoModel
+
+
+class AutoModelForSeq2SeqLM(_BaseAutoModelClass):
+    ORIG_MODEL = transformers.AutoModelForSeq2SeqLM

@@ -1,0 +1,153 @@
+"""CPU-side checks of the ITREX-compatible Python API (no GPU, no HIP calls): config semantics mirrored from the
+reference's own unit tests, the optimum-format decode against the golden fixtures generated from the reference's
+`unpack_weight`, and the module surface `_replace_linear` relies on."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from intel_extension_for_transformers_amd.transformers import (AwqConfig, GPTQConfig, RtnConfig, TeqConfig,
+                                                                  AutoRoundConfig, WeightOnlyQuantConfig)
+from intel_extension_for_transformers_amd.transformers.llm.quantization import utils as qutils
+
+
+def test_woq_config_diff_dict(tmp_path):
+    """reference tests/CI/test_weight_only.py:93-103."""
+    config = RtnConfig(bits=4, weight_dtype="int4", group_size=32)
+    assert config.to_diff_dict() == {"weight_dtype": "int4"}
+    json.loads(config.to_json_string())
+    config.to_json_file(str(tmp_path / "config.json"))
+    assert json.load(open(tmp_path / "config.json")) == {"weight_dtype": "int4"}
+    assert "RtnConfig" in repr(config)
+
+
+def test_woq_config_post_init_runtime():
+    """reference tests/CI/test_weight_only.py:105-115."""
+    config = RtnConfig(bits=4, weight_dtype="fp4", compute_dtype="int8", scheme="asym", scale_dtype="fp8")
+    config.post_init_runtime()
+    d = config.to_dict()
+    assert (d["weight_dtype"], d["compute_dtype"], d["scheme"], d["scale_dtype"]) == ("fp4_e2m1", "fp32", "sym", "fp32")
+
+
+def test_config_defaults_and_validators():
+    """reference utils/config.py:794-842 defaults; :277-372 post_init_cpu rules."""
+    c = RtnConfig()
+    assert (c.bits, c.group_size, c.sym, c.scheme) == (4, 32, True, "sym")
+    assert c.llm_int8_skip_modules == ["lm_head", "transformer.output_layer", "embed_out"]
+    c.post_init_cpu()
+    assert (c.weight_dtype, c.compute_dtype, c.scale_dtype, c.use_neural_speed) == ("int4_clip", "fp32", "fp32", False)
+    bad = RtnConfig(sym=False, scale_dtype="bf16")
+    with pytest.raises(ValueError):
+        bad.post_init_cpu()  # asym needs fp32 scales on the CPU backend (:360-370)
+    bad.post_init_hip()      # ... but not on the HIP backend
+    with pytest.raises(ValueError):
+        RtnConfig(bits=3).post_init_cpu()
+    with pytest.raises(ValueError):
+        RtnConfig(group_size=48).post_init_hip()
+    with pytest.raises(ValueError):
+        RtnConfig(compute_dtype="fp64").post_init_cpu()
+    assert WeightOnlyQuantConfig is RtnConfig
+    assert AwqConfig().scheme == "asym" and AwqConfig(zero_point=False).scheme == "sym"
+    assert GPTQConfig(desc_act=True).desc_act and GPTQConfig().quant_method.value == "gptq"
+    assert TeqConfig().quant_method.value == "teq" and AutoRoundConfig().group_size == 128
+    assert RtnConfig(compute_dtype=torch.bfloat16).compute_dtype == "bf16"
+
+
+def test_config_roundtrip_and_update(tmp_path):
+    c = GPTQConfig(bits=4, group_size=128, sym=False, desc_act=True)
+    c2 = GPTQConfig.from_dict(c.to_dict())
+    assert c2.to_dict() == c.to_dict()
+    assert c.update(group_size=64, nonsense=1) == {"nonsense": 1} and c.group_size == 64
+    c.save_pretrained(str(tmp_path))
+    saved = json.load(open(tmp_path / "quantize_config.json"))
+    assert saved["quant_method"] == "gptq" and saved["desc_act"] is True
+    c.remove_redundant_parameters()
+    assert not hasattr(c, "tokenizer") and not hasattr(c, "scheme")
+
+
+@pytest.mark.parametrize("tag", ["b4_sym", "b4_asym", "b4_asym_g128", "b8_sym", "b8_asym"])
+def test_unpack_weight_matches_reference_golden(golden_dir, tag):
+    """tests/golden/unpack_weight.npz was produced by running the reference's own unpack_weight
+    (llm/quantization/utils.py:82-125) in the build container (tests/golden/make_golden.py). Bit-exact."""
+    g = np.load(os.path.join(golden_dir, "unpack_weight.npz"))
+    K, N, group, bits, sym = [int(v) for v in g[tag + "_meta"]]
+
+    class Cfg:
+        pass
+
+    Cfg.bits, Cfg.sym = bits, bool(sym)
+    w, s, z = qutils.unpack_weight(torch.from_numpy(g[tag + "_qweight"]), torch.from_numpy(g[tag + "_scales"]),
+                                   torch.from_numpy(g[tag + "_qzeros"]), Cfg)
+    assert np.array_equal(w.numpy().astype(np.int16), g[tag + "_w"])
+    assert np.array_equal(z.numpy().astype(np.int16), g[tag + "_z"])
+
+
+@pytest.mark.parametrize("sym", [True, False])
+def test_pack_unpack_roundtrip(sym):
+    torch.manual_seed(0)
+    K, N, G = 96, 40, 3
+
+    class Cfg:
+        bits = 4
+
+    Cfg.sym = sym
+    w = torch.randint(0, 16, (K, N), dtype=torch.int8)
+    z = torch.randint(1, 17, (G, N), dtype=torch.int8)
+    s = torch.rand(G, N)
+    qw, s16, qz = qutils.pack_weight(w, s, z)
+    assert qw.dtype == torch.int32 and qw.shape == (K // 8, N) and qz.shape == (G, N // 8) and s16.dtype == torch.float16
+    w2, _, z2 = qutils.unpack_weight(qw, s16, qz, Cfg)
+    assert torch.equal(w, w2) and torch.equal(z, z2)
+
+
+@pytest.mark.parametrize("tag", ["rtn_sym", "rtn_asym"])
+def test_signed_nibble_matches_reference_golden(golden_dir, tag):
+    """(t - 8) * 16 // 16 on int8 (modules.py:225-227), including the 16 -> -8 wrap of un-biased zero points."""
+    from intel_extension_for_transformers_amd.transformers.llm.quantization.nn.modules import _signed_nibble
+
+    g = np.load(os.path.join(golden_dir, "set_weights_bias.npz"))
+    out = _signed_nibble(torch.from_numpy(g[tag + "_in_w"].astype(np.int8)))
+    assert np.array_equal(out.numpy().astype(np.int16), g[tag + "_out_w"])
+    if int(g[tag + "_out_asym"]):
+        z = _signed_nibble(torch.from_numpy(g[tag + "_in_z"].astype(np.int8)))
+        assert np.array_equal(z.numpy().astype(np.int16), g[tag + "_out_z"])
+
+
+def test_module_surface_without_gpu():
+    """The class contract `_replace_linear` relies on (reference modules.py:94-111, utils.py:364-366). Constructing
+    the module needs no GPU; running it does, and must fail loudly rather than fall back."""
+    from intel_extension_for_transformers_amd.transformers.llm.quantization.nn.modules import (ParamsQBits,
+                                                                                               QuantizedLinearQBits)
+
+    m = QuantizedLinearQBits(64, 32, bias=True, compute_dtype="fp32", weight_dtype="int4_clip", bits=4,
+                             scale_dtype="fp32", blocksize=32, scheme="sym")
+    assert isinstance(m, torch.nn.Linear) and isinstance(m.weight, ParamsQBits) and m.n_pack == 8
+    for name in ("set_weights_bias", "set_fp_weights_bias", "recover_qparms", "forward"):
+        assert callable(getattr(m, name))
+    m.requires_grad_(False)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 64))
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            m.set_fp_weights_bias(torch.zeros(32, 64))
+
+
+def test_replace_linear_skips_and_requires_gpu():
+    from intel_extension_for_transformers_amd.transformers.llm.quantization.utils import convert_to_quantized_model
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.linear = torch.nn.Linear(32, 2)
+            self.lm_head = torch.nn.Linear(32, 2)
+
+    cfg = RtnConfig(bits=4, group_size=32)
+    cfg.post_init_hip()
+    with pytest.raises(RuntimeError):
+        convert_to_quantized_model(M(), cfg, device="cpu")
+    with pytest.raises(NotImplementedError):
+        g = GPTQConfig()
+        g.post_init_hip()
+        convert_to_quantized_model(M(), g, device="cuda")

@@ -1,0 +1,219 @@
+"""GPU checks of the ITREX-compatible Python API: QuantizedLinearQBits, convert_to_quantized_model,
+AutoModelForCausalLM.from_pretrained / save_low_bit / load_low_bit, and the fused decode-engine post-pass.
+
+Models are tiny random-init HF architectures (no checkpoints, no network), saved to a temp dir so that the
+`from_pretrained(path, quantization_config=...)` route of the reference's own tests
+(tests/CI/test_weight_only.py:159-209) is the one exercised. Reference outputs: the SAME HF architecture in fp32
+torch with every quantised linear's weight replaced by its dequantised weight — the reference's self-consistency
+criterion (qbits_ut/test_weightonly.py:51-88), tolerance stated per assert.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import woq_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiny_llama(kv_heads=4):
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=kv_heads, vocab_size=320, max_position_embeddings=256, rms_norm_eps=1e-5,
+                      tie_word_embeddings=False)
+    return LlamaForCausalLM(cfg).float().eval()
+
+
+def _tiny_gpt2():
+    from transformers import GPT2Config, GPT2LMHeadModel
+
+    torch.manual_seed(0)
+    return GPT2LMHeadModel(GPT2Config(n_embd=128, n_layer=2, n_head=4, vocab_size=300, n_positions=128)).float().eval()
+
+
+def _dequantised_twin(qmodel, fp_model):
+    """fp32 copy of the architecture whose converted linears carry the dequantised weights of `qmodel`."""
+    from intel_extension_for_transformers_amd import qbits
+    from intel_extension_for_transformers_amd.transformers.llm.quantization.nn.modules import QuantizedLinearQBits
+
+    twin = copy.deepcopy(fp_model).cuda()
+    qmods = dict(qmodel.named_modules())
+    n = 0
+    for name, mod in twin.named_modules():
+        qm = qmods.get(name)
+        if isinstance(qm, QuantizedLinearQBits):
+            k, nn_ = qm.in_features, qm.out_features
+            deq = torch.empty(k, nn_, dtype=torch.float32, device="cuda")
+            qbits.dequantize_packed_weight(qm.weight.data, deq, False, "fp32", "int4_clip", qm.scale_dtype)
+            with torch.no_grad():
+                mod.weight.copy_(deq if type(mod).__name__ == "Conv1D" else deq.t())
+            n += 1
+    assert n > 0
+    return twin
+
+
+def test_tiny_linear_int4_module():
+    """reference tests/CI/test_weight_only.py:117-137 (there with int8): M(32 -> 2), with and without bias."""
+    from intel_extension_for_transformers_amd import qbits
+    from intel_extension_for_transformers_amd.transformers import RtnConfig
+    from intel_extension_for_transformers_amd.transformers.llm.quantization.utils import convert_to_quantized_model
+    from intel_extension_for_transformers_amd.transformers.llm.quantization.nn.modules import QuantizedLinearQBits
+
+    class M(torch.nn.Module):
+        def __init__(self, with_bias):
+            super().__init__()
+            self.linear = torch.nn.Linear(32, 2, bias=with_bias)
+
+        def forward(self, x):
+            return self.linear(x)
+
+    torch.manual_seed(0)
+    raw = torch.rand(2, 32)
+    packed = qbits.quantize_to_packed_weight(raw.cuda(), True, 32, "fp32", "int4_clip", "fp32", False)
+    revert = torch.zeros(2, 32, device="cuda")
+    qbits.dequantize_packed_weight(packed, revert, True, "fp32", "int4_clip", "fp32")
+    for bias in (True, False):
+        model = M(bias)
+        with torch.no_grad():
+            model.linear.weight = torch.nn.Parameter(revert.cpu())  # exactly representable -> re-quantises exactly
+        act = torch.rand(1, 32)
+        ref = model(act)
+        cfg = RtnConfig(bits=4, weight_dtype="int4", group_size=32)
+        cfg.post_init_hip()
+        convert_to_quantized_model(model, cfg, device="cuda")
+        assert isinstance(model.linear, QuantizedLinearQBits)
+        out = model(act.cuda()).cpu()
+        assert torch.allclose(ref, out, rtol=0.01, atol=1e-5)  # the reference's own tolerance
+
+
+@pytest.mark.parametrize("method,sym,desc_act", [("rtn", True, False), ("rtn", False, False), ("gptq", False, True),
+                                                 ("gptq", True, False)])
+def test_set_weights_bias_and_recover(method, sym, desc_act):
+    """Checkpoint-side tensors (unsigned int weight, scales, zeros +1-unbiased, GPTQ g_idx) -> blob -> forward vs
+    the oracle on the same tensors (modules.py:195-262), then recover_qparms returns them exactly (:297-392)."""
+    from intel_extension_for_transformers_amd.transformers import GPTQConfig, RtnConfig
+    from intel_extension_for_transformers_amd.transformers.llm.quantization.nn.modules import QuantizedLinearQBits
+
+    K, N, g = 256, 48, 32
+    rng = np.random.default_rng(5)
+    w_u = rng.integers(0, 16, (K, N)).astype(np.int8)
+    s = ((rng.random((K // g, N), dtype=np.float32) + 0.5) * 0.02)
+    z_u = rng.integers(1, 16, (K // g, N)).astype(np.int8)
+    gidx = rng.permutation(np.arange(K, dtype=np.int32) // g).astype(np.int32)
+    cfg = (GPTQConfig(bits=4, group_size=g, sym=sym, desc_act=desc_act) if method == "gptq"
+           else RtnConfig(bits=4, group_size=g, sym=sym))
+    cfg.post_init_hip()
+    m = QuantizedLinearQBits(K, N, True, compute_dtype="fp32", weight_dtype="int4_clip", bits=4, scale_dtype="fp32",
+                             blocksize=g, scheme=cfg.scheme)
+    bias = torch.from_numpy(rng.random(N, dtype=np.float32))
+    m.set_weights_bias(torch.from_numpy(w_u), torch.from_numpy(s), torch.from_numpy(z_u), torch.from_numpy(gidx), cfg,
+                       bias)
+    # oracle on the same tensors: signed domain, rows regrouped by convert_idx when act-order is on
+    q = w_u.astype(np.int16) - 8
+    zp = None if sym else (z_u.astype(np.int16) - 8).astype(np.int8)
+    shuf = None
+    if desc_act:
+        shuf = orc.convert_idx(gidx, K, g)
+        q = q[shuf]
+    blob = orc.repack(q.astype(np.int8), s, zp, shuf, g)
+    x = (rng.random((3, K), dtype=np.float32) - 0.4)
+    ref = orc.woq_linear(x, blob, bias.numpy())
+    got = m(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-6
+    iw, sc, zz, gi = m.recover_qparms()
+    assert np.array_equal(iw.cpu().numpy(), (q + 8).astype(np.int8))
+    assert np.array_equal(sc.cpu().numpy(), s)
+    if sym:
+        assert zz is None
+    else:
+        assert np.array_equal(zz.cpu().numpy(), z_u)
+    if desc_act:
+        assert np.array_equal(gi.cpu().numpy(), shuf.astype(np.int32))
+    else:
+        assert gi is None
+
+
+@pytest.mark.parametrize("group,sym,scale_dtype", [(128, True, "fp16"), (32, False, "fp32")])
+def test_from_pretrained_llama_logits_generate_save_load(tmp_path, group, sym, scale_dtype):
+    """reference tests/CI/test_weight_only.py:159-209: from_pretrained(..., quantization_config) swaps the linears,
+    generate runs, save -> load round trip reproduces the outputs."""
+    from intel_extension_for_transformers_amd.transformers import AutoModelForCausalLM, RtnConfig
+    from intel_extension_for_transformers_amd.transformers.llm.quantization.nn.modules import QuantizedLinearQBits
+
+    fp = _tiny_llama()
+    src = tmp_path / "fp"
+    fp.save_pretrained(str(src))
+    qmodel = AutoModelForCausalLM.from_pretrained(str(src), quantization_config=RtnConfig(
+        bits=4, group_size=group, sym=sym, scale_dtype=scale_dtype), use_neural_speed=False)
+    lin = [m for m in qmodel.modules() if isinstance(m, torch.nn.Linear)]
+    assert sum(isinstance(m, QuantizedLinearQBits) for m in lin) == 2 * 7  # 7 projections per layer
+    assert not isinstance(qmodel.lm_head, QuantizedLinearQBits)            # llm_int8_skip_modules (config.py:836-837)
+    assert qmodel.quantization_config.group_size == group
+    ids = torch.tensor([[5, 17, 200, 3, 77, 140, 9, 31]], device="cuda")
+    with torch.no_grad():
+        logits = qmodel(ids).logits.float()
+        twin = _dequantised_twin(qmodel, fp)
+        ref = twin(ids).logits.float()
+    # same math, fp32 both sides; differences are summation order only
+    assert (logits - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-5
+    out = qmodel.generate(ids, max_new_tokens=8, do_sample=False)
+    ref_out = twin.generate(ids, max_new_tokens=8, do_sample=False)
+    assert torch.equal(out, ref_out)
+    dst = tmp_path / "woq"
+    qmodel.save_pretrained(str(dst))
+    reloaded = AutoModelForCausalLM.from_pretrained(str(dst))
+    with torch.no_grad():
+        again = reloaded(ids).logits.float()
+    assert torch.equal(again, logits)  # identical integers, scales and kernels -> identical bits
+
+
+def test_from_pretrained_gpt2_conv1d(tmp_path):
+    """BASELINE configs[0] plumbing: GPT-2's projections are Conv1D, weight already [K, N]."""
+    from intel_extension_for_transformers_amd.transformers import AutoModelForCausalLM, RtnConfig
+    from intel_extension_for_transformers_amd.transformers.llm.quantization.nn.modules import QuantizedLinearQBits
+
+    fp = _tiny_gpt2()
+    src = tmp_path / "gpt2"
+    fp.save_pretrained(str(src))
+    qmodel = AutoModelForCausalLM.from_pretrained(str(src), load_in_4bit=True)
+    nq = sum(isinstance(m, QuantizedLinearQBits) for m in qmodel.modules())
+    assert nq == 2 * 4  # c_attn, c_proj, mlp.c_fc, mlp.c_proj per block
+    ids = torch.tensor([[1, 2, 3, 4, 5, 6]], device="cuda")
+    with torch.no_grad():
+        logits = qmodel(ids).logits.float()
+        ref = _dequantised_twin(qmodel, fp)(ids).logits.float()
+    assert (logits - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-5
+    out = qmodel.generate(ids, max_new_tokens=6, do_sample=False, pad_token_id=0)
+    assert out.shape == (1, 12)
+
+
+@pytest.mark.parametrize("kv_heads", [4, 2])
+def test_optimize_transformers_engine_matches_hf_path(tmp_path, kv_heads):
+    """The fused decode engine built from the quantised HF model reproduces that model's greedy decode
+    (the HF path runs torch attention / norm kernels around the same int4 linears)."""
+    from intel_extension_for_transformers_amd.runtime.engine import optimize_transformers
+    from intel_extension_for_transformers_amd.transformers import AutoModelForCausalLM, RtnConfig
+
+    fp = _tiny_llama(kv_heads)
+    src = tmp_path / "fp"
+    fp.save_pretrained(str(src))
+    qmodel = AutoModelForCausalLM.from_pretrained(str(src), quantization_config=RtnConfig(bits=4, group_size=128,
+                                                                                          scale_dtype="fp16"))
+    eng = optimize_transformers(qmodel, max_ctx=64, kv_dtype=torch.float16)
+    prompt = [5, 17, 200, 3, 77]
+    ids = torch.tensor([prompt], device="cuda")
+    with torch.no_grad():
+        ref_logits = qmodel(ids).logits[0, -1].float()
+        ref_out = qmodel.generate(ids, max_new_tokens=6, do_sample=False)[0, len(prompt):].tolist()
+    for i, t in enumerate(prompt):
+        eng.token.fill_(t)
+        eng.pos.fill_(i)
+        eng.step(greedy=False)
+    got = eng.logits.float()
+    # fp16 KV cache + fp16 lm_head on the engine side vs fp32 torch: 2e-3 relative on logits
+    assert (got - ref_logits).abs().max().item() <= 2e-3 * ref_logits.abs().max().item() + 1e-4
+    assert eng.generate(prompt, 6) == ref_out

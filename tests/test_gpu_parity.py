@@ -29,8 +29,15 @@ def _mk(K, N, group, asym, shuf, seed=0):
     G = (K + g - 1) // g
     s = (rng.random((G, N), dtype=np.float32) + 0.5) * 0.01
     z = rng.integers(-8, 8, (G, N), dtype=np.int8) if asym else None
-    idx = rng.permutation(K).astype(np.int32) if shuf else None
+    # raw GPTQ g_idx: group id of every K row, each group exactly g rows, in act-order (shuffled) positions —
+    # what the reference hands to repack_quantized_weight (qbits_ut/test_packq.py:59-64)
+    idx = rng.permutation(np.arange(K, dtype=np.int32) // g).astype(np.int32) if shuf else None
     return q, s, z, idx
+
+
+def _cvt(idx, K, group):
+    """raw g_idx -> activation shuffle indices (the reference's convert_idx, test_packq.py:22-28), for the oracle."""
+    return None if idx is None else orc.convert_idx(idx, K, K if group == -1 else group)
 
 
 def _gpu_blob(qbits, q, s, z, idx, group, scale_type="fp32"):
@@ -59,7 +66,7 @@ def test_repack_blob_bit_exact(qbits, K, N, group, asym, shuf, scale_type):
     """Device repack == oracle repack, byte for byte (layout transform only, qbits.cpp:61-77)."""
     q, s, z, idx = _mk(K, N, group, asym, shuf)
     blob = _gpu_blob(qbits, q, s, z, idx, group, scale_type)
-    ref = orc.repack(q, s, z, idx, group, scale_type=ST[scale_type])
+    ref = orc.repack(q, s, z, _cvt(idx, K, group), group, scale_type=ST[scale_type])
     got = blob.cpu().numpy().view(np.uint8)
     assert got.size == ref.size == qbits.get_packed_weight_size(K, N, "int4_clip", scale_type, "fp32", asym, group,
                                                                 shuf)
@@ -89,8 +96,8 @@ def test_packed_weight_info_roundtrip(qbits):
     cvt = torch.from_numpy(orc.convert_idx(g_idx.numpy(), K, bs))
     zp = torch.randint(-4, 4, [K // bs, N], dtype=torch.int8)
     scale = torch.rand(K // bs, N, dtype=torch.float)
-    packw = qbits.repack_quantized_weight(raw.cuda(), scale.cuda(), zp.cuda(), cvt.cuda(), "int4_clip", "fp32", "fp32",
-                                          True, bs)
+    packw = qbits.repack_quantized_weight(raw.cuda(), scale.cuda(), zp.cuda(), g_idx.cuda(), "int4_clip", "fp32",
+                                          "fp32", True, bs)
     assert qbits.acquire_packed_weight_info(packw, 0)[0].item() == packw.numel()
     assert qbits.acquire_packed_weight_info(packw, 1)[0].item() == bs
     assert qbits.acquire_packed_weight_info(packw, 2)[0].item() == K
@@ -117,7 +124,7 @@ def test_woq_linear_decode_vs_oracle(qbits, K, N, group, asym, shuf, M):
     rng = np.random.default_rng(3)
     x = (rng.random((M, K), dtype=np.float32) - 0.3)
     bias = rng.random(N, dtype=np.float32) * 10
-    ref = orc.woq_linear(x, orc.repack(q, s, z, idx, group), bias)
+    ref = orc.woq_linear(x, orc.repack(q, s, z, _cvt(idx, K, group), group), bias)
     out = torch.zeros(M, N, dtype=torch.float32, device="cuda")
     qbits.woq_linear(torch.from_numpy(x).cuda(), blob, torch.from_numpy(bias).cuda(), out, "fp32", "int4_clip", "fp32",
                      asym)
@@ -138,7 +145,7 @@ def test_woq_linear_decode_dtypes(qbits, src_dt, dst_dt, M):
     blob = _gpu_blob(qbits, q, s, z, idx, group)
     xt = (torch.rand(M, K) - 0.3).to(DT[src_dt])
     x = xt.float().numpy()
-    ref = orc.woq_linear(x, orc.repack(q, s, z, idx, group))
+    ref = orc.woq_linear(x, orc.repack(q, s, z, _cvt(idx, K, group), group))
     out = torch.zeros(M, N, dtype=DT[dst_dt], device="cuda")
     qbits.woq_linear(xt.cuda(), blob, torch.empty(0), out, "fp32", "int4_clip", "fp32", True)
     got = out.float().cpu().numpy()
