@@ -1,0 +1,110 @@
+"""Tensor-parallel sharding of the int4 decoder for one node of MI355X GPUs (one process per GPU, RCCL over xGMI).
+
+The reference never combines weight-only quantisation with tensor parallelism (its multi-device inference is
+DeepSpeed AutoTP over HCCL / oneCCL on fp models, neural_chat/models/model_utils.py:238-311),
+so this is new, but the plan is the textbook one and the only exchange step is the one the maths requires:
+  * q / k / v and gate / up are COLUMN-parallel: split N (whole heads; quantisation groups run along K, untouched);
+  * o_proj and down_proj are ROW-parallel: split K at multiples of the group size, so every rank owns whole groups;
+    each rank produces a partial [hidden] sum and ONE all-reduce (sum) follows each of the two — 2 per layer, 16 KB
+    at batch 1 for the 70B shape (latency-bound, far below what the 7 x ~153 GB/s xGMI links carry);
+  * lm_head is vocab-sharded; logits are all-gathered (greedy could reduce (max, argmax) pairs instead).
+The host logic here is pure tensor slicing (numpy or torch) and is exercised on CPU with gloo at world size 2
+(tests/test_tp_gloo.py); the device path (`TPDecoder`) feeds the shards to the same WoqDecoderEngine kernels.
+"""
+import numpy as np
+
+
+def _slice(a, sl, axis):
+    if a is None:
+        return None
+    idx = [slice(None)] * a.ndim
+    idx[axis] = sl
+    return a[tuple(idx)]
+
+
+def shard_columns(q, scales, zp, rank, world):
+    """Column-parallel: q [K,N], scales/zp [G,N] -> the rank's N slice. N must divide evenly."""
+    n = q.shape[1]
+    if n % world:
+        raise ValueError("QBits: N=%d is not divisible by the tensor-parallel degree %d" % (n, world))
+    sl = slice(rank * n // world, (rank + 1) * n // world)
+    return _slice(q, sl, 1), _slice(scales, sl, 1), _slice(zp, sl, 1)
+
+
+def shard_rows(q, scales, zp, rank, world, group):
+    """Row-parallel: the rank's K slice; the cut must fall on a group boundary so that groups stay whole
+    (70B: 8192/8 = 8*128, 28672/8 = 28*128; 7B g32/g128 all divide)."""
+    k = q.shape[0]
+    g = k if group in (-1, 0) or group >= k else group
+    if k % world or (k // world) % g:
+        raise ValueError("QBits: K=%d cannot be row-sharded %d ways on group-%d boundaries" % (k, world, g))
+    ks = slice(rank * k // world, (rank + 1) * k // world)
+    gs = slice(rank * (k // g) // world, (rank + 1) * (k // g) // world)
+    return _slice(q, ks, 0), _slice(scales, gs, 0), _slice(zp, gs, 0)
+
+
+def shard_heads(q, scales, zp, rank, world, heads, head_dim):
+    """q/k/v projection [K, heads*head_dim] -> the rank's whole heads."""
+    if heads % world:
+        raise ValueError("QBits: %d heads are not divisible by the tensor-parallel degree %d" % (heads, world))
+    per = heads // world * head_dim
+    sl = slice(rank * per, (rank + 1) * per)
+    return _slice(q, sl, 1), _slice(scales, sl, 1), _slice(zp, sl, 1)
+
+
+def shard_llama_layer(parts, rank, world, heads, kv_heads, head_dim, group):
+    """parts: dict name -> (q, scales, zp) for q,k,v,o,gate,up,down of ONE decoder layer (full size).
+    Returns the same dict for `rank`. kv_heads < world would need KV replication: rejected."""
+    if kv_heads % world:
+        raise ValueError("QBits: %d KV heads cannot be split %d ways (replication is not implemented)"
+                         % (kv_heads, world))
+    out = {}
+    out["q"] = shard_heads(*parts["q"], rank, world, heads, head_dim)
+    out["k"] = shard_heads(*parts["k"], rank, world, kv_heads, head_dim)
+    out["v"] = shard_heads(*parts["v"], rank, world, kv_heads, head_dim)
+    out["o"] = shard_rows(*parts["o"], rank, world, group)
+    out["gate"] = shard_columns(*parts["gate"], rank, world)
+    out["up"] = shard_columns(*parts["up"], rank, world)
+    out["down"] = shard_rows(*parts["down"], rank, world, group)
+    return out
+
+
+def shard_vocab(lm_head, rank, world):
+    """lm_head [vocab, hidden] -> the rank's vocab rows (padded split: the last rank may hold fewer)."""
+    v = lm_head.shape[0]
+    per = (v + world - 1) // world
+    return lm_head[rank * per:min(v, (rank + 1) * per)]
+
+
+def gather_logits(local_logits, vocab, group=None):
+    """All-gather of the vocab-sharded logits (torch.distributed; backend "nccl" = RCCL on the GPUs, gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    per = (vocab + world - 1) // world
+    buf = torch.zeros(per, dtype=local_logits.dtype, device=local_logits.device)
+    buf[:local_logits.numel()] = local_logits
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf, group=group)
+    return torch.cat(parts)[:vocab]
+
+
+class TPDecoder:
+    """One rank of a tensor-parallel decoder: a WoqDecoderEngine over this rank's shards; `step()` issues the
+    engine's sub-blocks and the two RCCL all-reduces per layer between them (engine.step_tp)."""
+
+    def __init__(self, engine, vocab, group=None):
+        self.engine, self.vocab, self.group = engine, vocab, group
+
+    def step(self, greedy=True):
+        import torch
+
+        e = self.engine
+        e.step_tp(self.group, greedy=False)  # logits of this rank's vocab shard
+        logits = gather_logits(e.logits[:e.cfg.vocab], self.vocab, self.group)
+        if greedy:
+            nxt = torch.argmax(logits).to(torch.int32)
+            e.token.fill_(int(nxt))  # every rank computes the same argmax from the same gathered logits
+            e.pos.add_(1)
+        return logits
