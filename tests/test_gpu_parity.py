@@ -239,3 +239,32 @@ def test_errors_are_runtime_errors(qbits):
                          "int4_clip", "fp32", False)
     with pytest.raises(RuntimeError, match="[Qq]bits"):
         qbits.quantize_to_packed_weight(torch.rand(64, 32).cuda(), False, 32, "fp32", "nf4", "fp32", False)
+
+
+@pytest.mark.parametrize("K,N,group,asym", [(512, 1024, 128, False), (512, 1024, 128, True), (256, 48, 32, True),
+                                            (160, 24, 64, True), (384, 200, -1, False), (1024, 4096, 256, False)])
+@pytest.mark.parametrize("M", [9, 130, 256])
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_woq_linear_prefill_gemm_vs_oracle(qbits, K, N, group, asym, M, compute):
+    """MFMA GEMM path (M > 8, csrc/woq_gemm.hip) vs the parity definition, ragged M / N / K included.
+    compute_dtype fp32: two fp16 planes per activation (hi + lo, block floating point per row and K step) ->
+    fp32-class, stated bound 2e-5 * sum|x||w| expressed as 1e-4 * max|ref| + 1e-5. compute_dtype bf16: one plane,
+    activation rounded to fp16 (2^-11 relative): stated bound 2e-3 * max|ref| (the reference's own criterion for
+    reduced-precision compute is allclose(rtol=0.03), qbits_ut/test_weightonly.py:88)."""
+    q, s, z, idx = _mk(K, N, group, asym, False, seed=7)
+    e8, e32 = torch.empty(0, dtype=torch.int8), torch.empty(0, dtype=torch.int32)
+    blob = qbits.repack_quantized_weight(torch.from_numpy(q).cuda(), torch.from_numpy(s).cuda(),
+                                         e8 if z is None else torch.from_numpy(z).cuda(), e32, "int4_clip", "fp32",
+                                         compute, z is not None, group)
+    rng = np.random.default_rng(8)
+    x = (rng.random((M, K), dtype=np.float32) - 0.3) * np.exp(rng.normal(0, 2, (M, 1))).astype(np.float32)
+    bias = rng.random(N, dtype=np.float32)
+    ref = orc.woq_linear(x, orc.repack(q, s, z, None, group), bias)
+    out = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    qbits.woq_linear(torch.from_numpy(x).cuda(), blob, torch.from_numpy(bias).cuda(), out, compute, "int4_clip",
+                     "fp32", asym)
+    got = out.cpu().numpy()
+    # per-row bound: rows differ in magnitude by e^2-ish factors on purpose (block floating point is per row)
+    scale = np.abs(ref - bias).max(axis=1, keepdims=True)
+    rel = 1e-4 if compute == "fp32" else 2e-3
+    assert (np.abs(got - ref) <= rel * scale + 1e-5).all()
