@@ -141,6 +141,16 @@ int main(int argc, char** argv) {
     printf("%-8s K=%5d N=%5d  %6.2f MB  back-to-back %6.2f us/launch  %6.0f GB/s algorithmic\n", s.name, s.K, s.N,
            alg / 1e6, us, alg / us / 1e3);
 
+    // same launch on ONE blob over and over: weights resident in L2 / Infinity Cache (what a perfect warm-up buys)
+    {
+      for (int r = 0; r < 20; ++r) launch(0);
+      CK(hipEventRecord(e0, st));
+      for (int r = 0; r < 200; ++r) launch(0);
+      CK(hipEventRecord(e1, st));
+      CK(hipStreamSynchronize(st));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("         cache-resident weights back-to-back %6.2f us/launch\n", ms * 1e3 / 200);
+    }
     // experiment switches (probe build only): what does each stage cost end to end?
     {
       const int exps[] = {16, 32, 64, 128, 256, 32 | 128, 32 | 64 | 128, 32 | 64 | 128 | 256};
