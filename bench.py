@@ -13,7 +13,7 @@ rank runs an independent replica on its own GPU, no data-path collective; value 
 time ("weak" scaling). Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     : dominant kernel = the int4 decode GEMV (woq::gemv_decode_kernel). achieved = algorithmic bytes per
+  roofline     : dominant kernel = the int4 decode GEMV (woq::gemv_tile_kernel, csrc/woq_gemv_i8.hip). achieved = algorithmic bytes per
                  launch (int4 payload + fp16 scales, SURVEY.md §8(d): 3 339 190 272 B / 128 launches per token)
                  / average launch duration measured with HIP event pairs on the launch stream. peak = 8000 GB/s.
                  traffic = HBM bytes per launch from the rocprofv3 --pmc pass (profiles/*_pmc_traffic.json), or null.
@@ -184,7 +184,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int4 weights x fp32 activations (fp16 hi/lo split on MFMA), fp32 accumulate",
+            "dtype": "int4 weights x fp32 activations as 3 x int8 fixed-point limbs on i8 MFMA (exact int32 tile sums), fp32 across tiles",
             "data": "synthetic (random-init int4 weights of the Llama-2-7B shape, random prompt ids)",
             "config": {
                 "workload": "Llama-2-7B int4 sym group_size=128 fp16 scales, batch=1 greedy decode, prompt %d, "
@@ -198,7 +198,7 @@ def main():
             "hbm_frac_of_peak_end_to_end": qbytes * (tok_s / world) / 1e9 / HBM_PEAK_GBPS,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "woq::gemv_decode_kernel (int4 GEMV, M=1)",
+                "kernel": "woq::gemv_tile_kernel (int4 GEMV, M=1, csrc/woq_gemv_i8.hip)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",

@@ -504,7 +504,11 @@ static int launch_tile_sm(const TileLaunch& a, int smode, bool asym, bool s32, h
 // geometry pick: nw waves x tpw tiles cover tiles_k (8 tiles = 8 KiB per wave per column tile; 4 for short K so
 // that a workgroup still has a few waves). Returns false when this kernel does not take the shape (K > 16384).
 static bool tile_geometry(int tiles_k, int cb, int smode, int& nw, int& tpw) {
-  tpw = (tiles_k > 16 && !(cb == 2 && smode == 1)) ? 8 : 4;  // per-32 scales x 2 column tiles: register budget
+  static const int force4 = [] {  // WOQ_TILE_TPW4=<max tiles_k>: 4 tiles per wave up to that K (timing experiments)
+    const char* s = getenv("WOQ_TILE_TPW4");
+    return s ? atoi(s) : 0;
+  }();
+  tpw = (tiles_k > 16 && !(cb == 2 && smode == 1) && tiles_k > force4) ? 8 : 4;  // per-32 scales x 2 column tiles: register budget
   nw = (tiles_k + tpw - 1) / tpw;
   return nw <= (cb * tpw > 8 ? 8 : 16);  // the kernel's __launch_bounds__
 }

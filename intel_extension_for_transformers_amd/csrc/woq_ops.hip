@@ -114,6 +114,25 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
   float* slab = redm + 8;         // [4 waves][GP][HD] partial outputs
   float* sc = slab + 4 * GP * HD; // [pos + 1] scores / probabilities
   const float scale = 1.0f / sqrtf((float)HD);
+  // The cache rows of the first score / P.V iteration depend only on `pos`: fetch them now, so that their HBM
+  // latency runs under the q/k/v read, the RoPE and the first barrier instead of after them.
+  const int sub = lane & 3;
+  const int g = lane / LPR, l8 = lane % LPR;
+  constexpr int TSTEP = 4 * GP;  // positions covered by the workgroup per P.V pass
+  const int plast = max(pos - 1, 0);
+  kv8 kpre[DPL / 8];
+  {
+    const int tc = min(wid * 16 + (lane >> 2), plast);
+    const kv8* kp = (const kv8*)(kcache + ((size_t)tc * kv_heads + kh) * HD + sub * DPL);
+#pragma unroll
+    for (int j = 0; j < DPL / 8; ++j) kpre[j] = kp[j];
+  }
+  kv8 vpre[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int tc = min(wid * GP + g + u * TSTEP, plast);
+    vpre[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
+  }
   if (tid < half) {
     const float c = cs[(size_t)pos * half + tid], s = sn[(size_t)pos * half + tid];
     const float* q = qkv + (size_t)h * HD;
@@ -132,18 +151,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     vcache[((size_t)pos * kv_heads + kh) * HD + tid] = (KV)vn[tid];
   }
   // ---- scores for cached positions ----
-  const int sub = lane & 3;
   float qreg[DPL];
 #pragma unroll
   for (int i = 0; i < DPL; ++i) qreg[i] = qs[sub * DPL + i];
   float lmax = -INFINITY;
-  for (int t0 = wid * 16; t0 < pos; t0 += 64) {
+  auto score = [&](int t0, const kv8 (&kv)[DPL / 8]) {
     const int t = t0 + (lane >> 2);
-    const int tc = min(t, pos - 1);
-    const kv8* kp = (const kv8*)(kcache + ((size_t)tc * kv_heads + kh) * HD + sub * DPL);
-    kv8 kv[DPL / 8];
-#pragma unroll
-    for (int j = 0; j < DPL / 8; ++j) kv[j] = kp[j];
     float d = 0.f;
 #pragma unroll
     for (int j = 0; j < DPL / 8; ++j)
@@ -155,6 +168,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
       if (sub == 0) sc[t] = d;
       lmax = fmaxf(lmax, d);
     }
+  };
+  if (wid * 16 < pos) score(wid * 16, kpre);
+  for (int t0 = wid * 16 + 64; t0 < pos; t0 += 64) {
+    const int tc = min(t0 + (lane >> 2), pos - 1);
+    const kv8* kp = (const kv8*)(kcache + ((size_t)tc * kv_heads + kh) * HD + sub * DPL);
+    kv8 kv[DPL / 8];
+#pragma unroll
+    for (int j = 0; j < DPL / 8; ++j) kv[j] = kp[j];
+    score(t0, kv);
   }
   if (tid == 0) {  // the new position, from LDS
     float d = 0.f;
@@ -177,25 +199,27 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
   __syncthreads();
   const float den = (redm[4] + redm[5]) + (redm[6] + redm[7]);
   // ---- P.V ----
-  const int g = lane / LPR, l8 = lane % LPR;
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  constexpr int TSTEP = 4 * GP;  // positions covered by the workgroup per pass
-  for (int t0 = wid * GP + g; t0 < pos; t0 += 4 * TSTEP) {
-    kv8 vv[4];
-    float pp[4];
+  auto pv = [&](int t0, const kv8 (&vv)[4]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int t = t0 + u * TSTEP;
-      const int tc = min(t, pos - 1);
-      vv[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
-      pp[u] = t < pos ? sc[tc] : 0.f;
+      const float p = t < pos ? sc[min(t, pos - 1)] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, (float)vv[u][i], acc[i]);
     }
+  };
+  if (wid * GP + g < pos) pv(wid * GP + g, vpre);
+  for (int t0 = wid * GP + g + 4 * TSTEP; t0 < pos; t0 += 4 * TSTEP) {
+    kv8 vv[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = fmaf(pp[u], (float)vv[u][i], acc[i]);
+    for (int u = 0; u < 4; ++u) {
+      const int tc = min(t0 + u * TSTEP, pos - 1);
+      vv[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
+    }
+    pv(t0, vv);
   }
   if (wid == 0 && g == 0) {  // the new position
     const float p = sc[pos];
