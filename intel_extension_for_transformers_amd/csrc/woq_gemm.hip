@@ -14,7 +14,9 @@
 //    exactly. The contraction order inside an MFMA is free as long as A and B agree, so the MFMA for 64-k half h,
 //    part p takes lane (column i, sixteenth kq)'s k = kq*16 + 8p + {0,2,4,6,1,3,5,7} — exactly the order the four
 //    and/shift extractions of blob word #(2h+p) produce — and the A tile is stored in LDS in that same order;
-//  * A: the 128 x 128 activation tile is converted to fp16 in block floating point: per (row, K step) a power-of-two
+//  * A: a pack pass (act_pack_kernel, one read of the activations) converts them ONCE to fp16 planes in block
+//    floating point — the GEMM workgroups of all N/128 column blocks then re-read 2 B (4 B with the lo plane) per
+//    element from L2 instead of converting 4-B values again each: per (row, K step) a power-of-two
 //    scale from the row segment's max keeps |x| in fp16 range (exact scaling), hi = fp16(x 2^-e); with
 //    compute_dtype fp32 a second plane lo = fp16(x 2^-e - hi) is contracted as well (two MFMAs per fragment pair,
 //    ~2^-21 relative on the activation); with compute_dtype bf16 / fp16 / int8 only hi (2^-11), like the reference's
@@ -23,8 +25,8 @@
 //    scales (any multiple of 128) and the block exponents never touch the fp16 operands;
 //  * group-32 scales: a 64-k MFMA mixes two groups, so each is issued per group with the other group's A lanes
 //    reading a zero block (2x the MFMAs; exact).
-// One LDS buffer, two workgroups per CU overlap each other's staging and arithmetic. First version: correct and
-// matrix-pipe-bound by construction, not yet tuned (no XCD-aware tile order, no double buffering inside a workgroup).
+// The A tile of step k+1 is fetched into registers before the MFMAs of step k and written to the other LDS buffer
+// after them: one barrier per K step. Not yet tuned further (no XCD-aware tile order, B through VGPRs only).
 #include "woq_device.h"
 #include "woq_launch.h"
 
@@ -45,6 +47,10 @@ struct GemmArgs {
   int K, N, tiles_k, tiles_n, n_groups, group, scale_type;
   const void* x;
   int x_dtype, lda, M;
+  const _Float16* a_hi;  // packed planes [M][Kpad] (fragment order inside every 8-group), block floating point
+  const _Float16* a_lo;
+  const float* a_rs;     // [M][tiles_k] 2^e of every (row, K step)
+  int Kpad;
   void* out;
   int out_dtype, ldo;
   const float* bias;
@@ -53,10 +59,9 @@ struct GemmArgs {
 constexpr int GBM = 128, GBN = 128, GKS = 128;
 constexpr int GRS = GKS + 8;  // LDS row stride in halves (+16 B: conflict-free ds_read_b128 across rows)
 
-// LDS: [zero row GRS halves][A hi 128 x GRS][A lo 128 x GRS (NPASS == 2)][row scales 128 f32]
-__host__ __device__ constexpr size_t gemm_lds_bytes(int npass) {
-  return (size_t)GRS * 2 + (size_t)npass * GBM * GRS * 2 + GBM * 4;
-}
+// LDS: [zero row GRS halves] + 2 buffers of {A hi 128 x GRS, A lo 128 x GRS (NPASS == 2), row scales 128 f32}
+__host__ __device__ constexpr size_t gemm_buf_bytes(int npass) { return (size_t)npass * GBM * GRS * 2 + GBM * 4; }
+__host__ __device__ constexpr size_t gemm_lds_bytes(int npass) { return (size_t)GRS * 2 + 2 * gemm_buf_bytes(npass); }
 
 // order in which the nibble extraction delivers a word's 8 k-offsets: element e of a fragment <-> k-offset GPERM[e]
 __device__ __forceinline__ int gperm(int e) { return (e < 4) ? 2 * e : 2 * (e - 4) + 1; }
@@ -71,13 +76,64 @@ __device__ __forceinline__ h8 gdq8(uint32_t w, h2 c) {
   return __builtin_bit_cast(h8, (u32x4){o0, o1, o2, o3});
 }
 
-template <int NPASS, int SMODE, bool ASYM>
-__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs a) {
+// Activation pack pass: [M, K] (fp32 | bf16 | fp16) -> fp16 plane(s) [M][Kpad] + per-(row, K step) scales.
+// 16 lanes per row segment of 128 k (8 consecutive k = one fragment group each), row max by four DPP steps.
+template <int NPASS>
+__global__ __launch_bounds__(256) void act_pack_kernel(const void* __restrict__ x, int x_dtype, int lda, int M, int K,
+                                                       int Kpad, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                       float* __restrict__ rs) {
+  const int tid = threadIdx.x;
+  const int g8 = tid & 15;
+  const int tiles_k = Kpad / 128;
+  const size_t seg = (size_t)blockIdx.x * 16 + (tid >> 4);  // (row, K step) segment index
+  if (seg >= (size_t)M * tiles_k) return;
+  const int r = (int)(seg / tiles_k), kt = (int)(seg % tiles_k);
+  const int k0 = kt * 128 + g8 * 8;
+  const size_t base = (size_t)r * lda;
+  float v[8];
+  if (x_dtype == WOQ_F32 && k0 + 8 <= K && ((lda | (int)(((uintptr_t)x) >> 2)) & 3) == 0) {
+    const float4_t lo4 = *(const float4_t*)((const float*)x + base + k0);
+    const float4_t hi4 = *(const float4_t*)((const float*)x + base + k0 + 4);
+    v[0] = lo4.x, v[1] = lo4.y, v[2] = lo4.z, v[3] = lo4.w, v[4] = hi4.x, v[5] = hi4.y, v[6] = hi4.z, v[7] = hi4.w;
+  } else if (x_dtype != WOQ_F32 && k0 + 8 <= K && ((lda | (int)(((uintptr_t)x) >> 1)) & 7) == 0) {
+    const u32x4 raw = *(const u32x4*)((const uint16_t*)x + base + k0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint16_t bits = (uint16_t)(raw[j >> 1] >> (16 * (j & 1)));
+      v[j] = x_dtype == WOQ_BF16 ? bf16_bits_to_f32(bits) : f16_bits_to_f32(bits);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = k0 + j < K ? load_f32(x, base + k0 + j, x_dtype) : 0.f;
+  }
+  float amax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
+  amax = fmaxf(amax, WOQ_DPP_F32(amax, 0xB1));
+  amax = fmaxf(amax, WOQ_DPP_F32(amax, 0x4E));
+  amax = fmaxf(amax, WOQ_DPP_F32(amax, 0x141));
+  amax = fmaxf(amax, WOQ_DPP_F32(amax, 0x140));  // every lane of the 16-lane row now holds the segment max
+  int e = 0;
+  if (amax > 0.f && amax < INFINITY) e = max(-100, min(100, __builtin_amdgcn_frexp_expf(amax) - 14));
+  const float p2 = ldexpf(1.f, -e);  // |x| 2^-e < 2^14
+  if (g8 == 0) rs[seg] = ldexpf(1.f, e);
+  h8 hh, ll;
+#pragma unroll
+  for (int e8 = 0; e8 < 8; ++e8) {
+    const float xs = v[gperm(e8)] * p2;
+    const _Float16 hv = (_Float16)xs;
+    hh[e8] = hv;
+    ll[e8] = (_Float16)(xs - (float)hv);
+  }
+  *(h8*)(hi + (size_t)r * Kpad + k0) = hh;
+  if constexpr (NPASS == 2) *(h8*)(lo + (size_t)r * Kpad + k0) = ll;
+}
+
+template <int NPASS, int SMODE, bool ASYM, bool S32>
+__global__ __launch_bounds__(256, 1) void gemm_mfma_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm_raw[];
   _Float16* zrow = (_Float16*)gsm_raw;
-  _Float16* a_hi = zrow + GRS;
-  _Float16* a_lo = a_hi + (NPASS == 2 ? GBM * GRS : 0);
-  float* rsc = (float*)(a_hi + (size_t)NPASS * GBM * GRS);
+  unsigned char* bufs = gsm_raw + GRS * 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, kq = lane >> 4;
@@ -91,11 +147,43 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs a) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) tot[rt][c] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
-  for (int kt = 0; kt < a.tiles_k; ++kt) {
-    // ---- B tiles of this wave, issued before the staging so they fly meanwhile ----
-    u32x4 wv[2];
-    float wsc[2][4];
-    float wz[2][4];
+  // A-tile mover: 16 lanes per row (one 16-B fragment group each), 8 passes of 32 rows... 4 waves x 4 rows x 8 passes
+  const int mv_g8 = tid & 15, mv_r = tid >> 4;  // row within a pass of 16 rows
+  u32x4 ph[GBM / 16], pl[GBM / 16];
+  float prs = 0.f;
+  auto fetch_a = [&](int kt) {  // global -> registers
+#pragma unroll
+    for (int pass = 0; pass < GBM / 16; ++pass) {
+      const int r = min(row0 + pass * 16 + mv_r, a.M - 1);
+      const size_t off = (size_t)r * a.Kpad + kt * 128 + mv_g8 * 8;
+      ph[pass] = *(const u32x4*)(a.a_hi + off);
+      if constexpr (NPASS == 2) pl[pass] = *(const u32x4*)(a.a_lo + off);
+    }
+    if (tid < GBM) prs = a.a_rs[(size_t)min(row0 + tid, a.M - 1) * a.tiles_k + kt];
+  };
+  auto store_a = [&](int buf) {  // registers -> LDS buffer
+    _Float16* dh = (_Float16*)(bufs + (size_t)buf * gemm_buf_bytes(NPASS));
+    _Float16* dl = dh + GBM * GRS;
+    float* dr = (float*)(dh + (size_t)NPASS * GBM * GRS);
+#pragma unroll
+    for (int pass = 0; pass < GBM / 16; ++pass) {
+      *(u32x4*)(dh + (size_t)(pass * 16 + mv_r) * GRS + mv_g8 * 8) = ph[pass];
+      if constexpr (NPASS == 2) *(u32x4*)(dl + (size_t)(pass * 16 + mv_r) * GRS + mv_g8 * 8) = pl[pass];
+    }
+    if (tid < GBM) dr[tid] = prs;
+  };
+  // scale fetch without a branch around the load (a dtype switch there makes hipcc wait vmcnt(0) per load)
+  const bool sc_bf = a.scale_type == WOQ_BF16;
+  auto ldsc = [&](size_t si) -> float {
+    if constexpr (S32) {
+      return ((const float*)a.scales)[si];
+    } else {
+      const uint16_t bits = ((const uint16_t*)a.scales)[si];
+      const float fb = bf16_bits_to_f32(bits), fh = f16_bits_to_f32(bits);
+      return sc_bf ? fb : fh;
+    }
+  };
+  auto fetch_b = [&](int kt, u32x4 (&wv)[2], float (&wsc)[2][4], float (&wz)[2][4]) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int tn = min(ct0 + c, a.tiles_n - 1);
@@ -104,73 +192,33 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs a) {
         int g = (kt * 128) / a.group;
         g = g >= a.n_groups ? a.n_groups - 1 : g;
         const size_t si = ((size_t)tn * a.n_groups + g) * 16 + i16;
-        wsc[c][0] = load_f32(a.scales, si, a.scale_type);
+        wsc[c][0] = ldsc(si);
         wz[c][0] = ASYM ? (float)((int)a.zp[si] - 8) : 0.f;
       } else {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const size_t si = ((((size_t)tn * a.tiles_k + kt) * 16 + i16) << 2) + s;
-          wsc[c][s] = load_f32(a.scales, si, a.scale_type);
+          wsc[c][s] = ldsc(si);
           wz[c][s] = ASYM ? (float)((int)a.zp[si] - 8) : 0.f;
         }
       }
     }
-    __syncthreads();  // everyone is done reading the previous A tile
+  };
+  u32x4 wv[2], wvn[2];
+  float wsc[2][4], wz[2][4], wscn[2][4], wzn[2][4];
+  fetch_a(0);
+  fetch_b(0, wv, wsc, wz);
+  store_a(0);
+  __syncthreads();
 
-    // ---- stage A: 16 lanes per row (8 consecutive k = one fragment group each), 16 rows per pass, 8 passes:
-    //      fully used 512-B row segments on the load side, one ds_write_b128 per lane and plane on the LDS side,
-    //      row max over the 16 lanes by four DPP steps; block floating point per (row, K step) ----
-    {
-      const int g8 = tid & 15;                 // fragment group (8 consecutive k) within the K step
-      const int k0 = kt * 128 + g8 * 8;
-#pragma unroll 2
-      for (int pass = 0; pass < GBM / 16; ++pass) {
-        const int r = pass * 16 + (tid >> 4);
-        const bool ok = row0 + r < a.M;
-        const size_t base = (size_t)(row0 + (ok ? r : 0)) * a.lda;
-        float v[8];
-        if (a.x_dtype == WOQ_F32 && k0 + 8 <= a.K && ((a.lda | (int)(((uintptr_t)a.x) >> 2)) & 3) == 0) {
-          const float4_t lo4 = *(const float4_t*)((const float*)a.x + base + k0);
-          const float4_t hi4 = *(const float4_t*)((const float*)a.x + base + k0 + 4);
-          v[0] = lo4.x, v[1] = lo4.y, v[2] = lo4.z, v[3] = lo4.w, v[4] = hi4.x, v[5] = hi4.y, v[6] = hi4.z, v[7] = hi4.w;
-        } else if (a.x_dtype != WOQ_F32 && k0 + 8 <= a.K && ((a.lda | (int)(((uintptr_t)a.x) >> 1)) & 7) == 0) {
-          const u32x4 raw = *(const u32x4*)((const uint16_t*)a.x + base + k0);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const uint16_t bits = (uint16_t)(raw[j >> 1] >> (16 * (j & 1)));
-            v[j] = a.x_dtype == WOQ_BF16 ? bf16_bits_to_f32(bits) : f16_bits_to_f32(bits);
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = k0 + j < a.K ? load_f32(a.x, base + k0 + j, a.x_dtype) : 0.f;
-        }
-        float amax = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          v[j] = ok ? v[j] : 0.f;
-          amax = fmaxf(amax, fabsf(v[j]));
-        }
-        amax = fmaxf(amax, WOQ_DPP_F32(amax, 0xB1));
-        amax = fmaxf(amax, WOQ_DPP_F32(amax, 0x4E));
-        amax = fmaxf(amax, WOQ_DPP_F32(amax, 0x141));
-        amax = fmaxf(amax, WOQ_DPP_F32(amax, 0x140));  // every lane of the 16-lane row now holds the row max
-        int e = 0;
-        if (amax > 0.f && amax < INFINITY) e = max(-100, min(100, __builtin_amdgcn_frexp_expf(amax) - 14));
-        const float p2 = ldexpf(1.f, -e);  // |x| 2^-e < 2^14
-        if (g8 == 0) rsc[r] = ldexpf(1.f, e);
-        h8 hh, ll;
-#pragma unroll
-        for (int e8 = 0; e8 < 8; ++e8) {
-          const float x = v[gperm(e8)] * p2;
-          const _Float16 hv = (_Float16)x;
-          hh[e8] = hv;
-          ll[e8] = (_Float16)(x - (float)hv);
-        }
-        *(h8*)(a_hi + (size_t)r * GRS + g8 * 8) = hh;
-        if constexpr (NPASS == 2) *(h8*)(a_lo + (size_t)r * GRS + g8 * 8) = ll;
-      }
-    }
-    __syncthreads();
+  for (int kt = 0; kt < a.tiles_k; ++kt) {
+    const int cur = kt & 1;
+    const _Float16* a_hi = (const _Float16*)(bufs + (size_t)cur * gemm_buf_bytes(NPASS));
+    const _Float16* a_lo = a_hi + GBM * GRS;
+    const float* rsc = (const float*)(a_hi + (size_t)NPASS * GBM * GRS);
+    const int ktn = min(kt + 1, a.tiles_k - 1);
+    fetch_a(ktn);  // next step's operands fly during this step's MFMAs
+    fetch_b(ktn, wvn, wscn, wzn);
 
     // ---- contraction of this K step ----
     if constexpr (SMODE == 0) {
@@ -179,27 +227,40 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs a) {
       for (int rt = 0; rt < 8; ++rt)
 #pragma unroll
         for (int c = 0; c < 2; ++c) acc[rt][c] = (float4_t){0.f, 0.f, 0.f, 0.f};
+      // A fragments of blob word #hp are read one word AHEAD of their MFMAs (a lone wave per SIMD has nobody to hide
+      // the ~130-cycle ds_read latency behind)
+      h8 afh[2][8], afl[2][8];
+      auto read_a = [&](int hp, h8 (&dh)[8], h8 (&dl)[8]) {
+        const int koff = (hp >> 1) * 64 + kq * 16 + (hp & 1) * 8;
+#pragma unroll
+        for (int rt = 0; rt < 8; ++rt) {
+          dh[rt] = *(const h8*)(a_hi + (size_t)(rt * 16 + i16) * GRS + koff);
+          if constexpr (NPASS == 2) dl[rt] = *(const h8*)(a_lo + (size_t)(rt * 16 + i16) * GRS + koff);
+        }
+      };
+      read_a(0, afh[0], afl[0]);
 #pragma unroll
       for (int hp = 0; hp < 4; ++hp) {  // (half h, part p) = blob word #hp
+        if (hp < 3) read_a(hp + 1, afh[(hp + 1) & 1], afl[(hp + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD: hipcc otherwise sinks each next to its first use
         h8 bfr[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const _Float16 cz = (_Float16)(-(1032.f + wz[c][0]));
           bfr[c] = gdq8(wv[c][hp], (h2){cz, cz});
         }
-        const int koff = (hp >> 1) * 64 + kq * 16 + (hp & 1) * 8;
 #pragma unroll
         for (int rt = 0; rt < 8; ++rt) {
-          const h8 ah = *(const h8*)(a_hi + (size_t)(rt * 16 + i16) * GRS + koff);
 #pragma unroll
-          for (int c = 0; c < 2; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bfr[c], acc[rt][c], 0, 0, 0);
+          for (int c = 0; c < 2; ++c)
+            acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afh[hp & 1][rt], bfr[c], acc[rt][c], 0, 0, 0);
           if constexpr (NPASS == 2) {
-            const h8 al = *(const h8*)(a_lo + (size_t)(rt * 16 + i16) * GRS + koff);
 #pragma unroll
             for (int c = 0; c < 2; ++c)
-              acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bfr[c], acc[rt][c], 0, 0, 0);
+              acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afl[hp & 1][rt], bfr[c], acc[rt][c], 0, 0, 0);
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int rt = 0; rt < 8; ++rt) {
@@ -253,27 +314,47 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs a) {
         }
       }
     }
-  }
-
-  // ---- epilogue: + bias, store. D: lane (column i16, rows 4*kq + j) of every 16 x 16 fragment ----
+    store_a(cur ^ 1);
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const int n = (ct0 + c) * 16 + i16;
-    if (ct0 + c >= a.tiles_n || n >= a.N) continue;
-    const float b = a.bias ? a.bias[n] : 0.f;
-#pragma unroll
-    for (int rt = 0; rt < 8; ++rt)
+    for (int c = 0; c < 2; ++c) {
+      wv[c] = wvn[c];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int m = row0 + rt * 16 + kq * 4 + j;
-        if (m < a.M) store_f32(a.out, (size_t)m * a.ldo + n, a.out_dtype, tot[rt][c][j] + b);
+        wsc[c][j] = wscn[c][j];
+        wz[c][j] = wzn[c][j];
       }
+    }
+    __syncthreads();
   }
+
+  // ---- epilogue: + bias, store. D: lane (column i16, rows 4*kq + j) of every 16 x 16 fragment. The output-type switch
+  //      sits OUTSIDE the store loops: a per-element switch makes hipcc wait vmcnt(0) after every store ----
+  auto store_all = [&](auto put) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int n = (ct0 + c) * 16 + i16;
+      if (ct0 + c >= a.tiles_n || n >= a.N) continue;
+      const float bsv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int m = row0 + rt * 16 + kq * 4 + j;
+          if (m < a.M) put((size_t)m * a.ldo + n, tot[rt][c][j] + bsv);
+        }
+    }
+  };
+  if (a.out_dtype == WOQ_F32)
+    store_all([&](size_t i, float v) { ((float*)a.out)[i] = v; });
+  else if (a.out_dtype == WOQ_BF16)
+    store_all([&](size_t i, float v) { ((uint16_t*)a.out)[i] = f32_to_bf16_bits(v); });
+  else
+    store_all([&](size_t i, float v) { ((uint16_t*)a.out)[i] = f32_to_f16_bits(v); });
 }
 
-template <int NPASS, int SMODE, bool ASYM>
-static int launch_gemm_t(const GemmArgs& a, hipStream_t st) {
-  auto kern = gemm_mfma_kernel<NPASS, SMODE, ASYM>;
+template <int NPASS, int SMODE, bool ASYM, bool S32>
+static int launch_gemm_t(GemmArgs& a, hipStream_t st) {
+  auto kern = gemm_mfma_kernel<NPASS, SMODE, ASYM, S32>;
   const size_t lds = gemm_lds_bytes(NPASS);
   static bool attr_set = false;
   if (!attr_set) {
@@ -281,8 +362,23 @@ static int launch_gemm_t(const GemmArgs& a, hipStream_t st) {
     if (e != hipSuccess) return woq::fail(std::string("QBits: hipFuncSetAttribute: ") + hipGetErrorString(e));
     attr_set = true;
   }
+  // stream-ordered scratch for the packed activation planes (the reference allocates its A-side workspace per call
+  // too when none was registered, bestla_weightonly_dispatcher.cpp:108-118,179)
+  const size_t plane = (size_t)a.M * a.Kpad * sizeof(_Float16);
+  const size_t rs_bytes = (size_t)a.M * a.tiles_k * sizeof(float);
+  const size_t total = (size_t)NPASS * plane + rs_bytes;
+  unsigned char* ws = nullptr;
+  hipError_t e = hipMallocAsync((void**)&ws, total, st);
+  if (e != hipSuccess) return woq::fail(std::string("QBits: workspace allocation failed: ") + hipGetErrorString(e));
+  a.a_hi = (const _Float16*)ws;
+  a.a_lo = (const _Float16*)(ws + (NPASS == 2 ? plane : 0));
+  a.a_rs = (const float*)(ws + (size_t)NPASS * plane);
+  const size_t segs = (size_t)a.M * a.tiles_k;
+  hipLaunchKernelGGL(act_pack_kernel<NPASS>, dim3((unsigned)((segs + 15) / 16)), dim3(256), 0, st, a.x, a.x_dtype, a.lda,
+                     a.M, a.K, a.Kpad, (_Float16*)a.a_hi, (_Float16*)a.a_lo, (float*)a.a_rs);
   const dim3 grid((unsigned)((a.tiles_n * 16 + GBN - 1) / GBN), (unsigned)((a.M + GBM - 1) / GBM));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+  hipFreeAsync(ws, st);
   return 0;
 }
 
@@ -310,6 +406,7 @@ int launch_gemm_mfma(const void* act, int act_dtype, int lda, const void* blob, 
   a.x_dtype = act_dtype;
   a.lda = lda;
   a.M = M;
+  a.Kpad = h.Kpad;
   a.out = out;
   a.out_dtype = out_dtype;
   a.ldo = ldo;
@@ -317,8 +414,10 @@ int launch_gemm_mfma(const void* act, int act_dtype, int lda, const void* blob, 
   const bool two = h.compute_type == WOQ_C_FP32;
   const bool asym = a.zp != nullptr;
   const int sm = (int)h.scale_mode;
-#define WOQ_GEMM_CASE(NP, SM, AS) \
-  if (two == (NP == 2) && sm == SM && asym == AS) return launch_gemm_t<NP, SM, AS>(a, st);
+  const bool s32 = h.scale_type == WOQ_F32;
+#define WOQ_GEMM_CASE(NP, SM, AS)                                                          \
+  if (two == (NP == 2) && sm == SM && asym == AS)                                           \
+    return s32 ? launch_gemm_t<NP, SM, AS, true>(a, st) : launch_gemm_t<NP, SM, AS, false>(a, st);
   WOQ_GEMM_CASE(1, 0, false)
   WOQ_GEMM_CASE(1, 0, true)
   WOQ_GEMM_CASE(1, 1, false)
