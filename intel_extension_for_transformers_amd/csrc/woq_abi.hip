@@ -3,7 +3,8 @@
 // woq_linear replaces qbits.woq_linear (qbits/qbits.cpp:113-140) and the string-driven template
 // selection under it (bestla_weightonly_dispatcher.cpp:230-382: parse_launcher / parse_store /
 // parse_activation / parse_weight / parse_gemm_core). Here the "dispatcher" is a few integer
-// compares on the cached header: M <= 8 -> decode GEMV, else the MFMA GEMM.
+// compares on the cached header: M <= 8 -> decode GEMV, else an MFMA GEMM (exact two-plane kernel for compute_dtype
+// fp32, fp16-operand kernel for the reduced-precision compute modes).
 #include "woq_device.h"
 #include "woq_launch.h"
 
@@ -19,6 +20,9 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
                             float eps, const float* residual, int ld_res, int epi, int nt, hipStream_t st);
 int launch_gemm_mfma(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                      const float* bias, void* out, int out_dtype, int ldo, int M, hipStream_t st);
+int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
+                    const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w, float eps,
+                    void* ws, hipStream_t st);
 }  // namespace woq
 
 using namespace woq;
@@ -43,7 +47,11 @@ int woq_linear(const void* act_dev, int act_dtype, int lda, const void* blob_dev
   if (M <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (M <= 8 || hdr->off_shuffle != 0)
+  static const bool gemm_as_gemv = getenv("WOQ_GEMM_AS_GEMV") != nullptr;  // A/B switch for tests
+  if (M > 8 && hdr->compute_type != WOQ_C_FP32 && !gemm_as_gemv)  // reduced-precision compute modes: fp16-operand MFMA GEMM
+    rc = launch_gemm_f16(act_dev, act_dtype, lda, blob_dev, *hdr, bias_dev, out_dev, out_dtype, ldo, M, nullptr, 0.f,
+                         nullptr, st);
+  else if (M <= 8 || hdr->off_shuffle != 0)
     rc = launch_gemv_from_header(act_dev, act_dtype, lda, blob_dev, *hdr, bias_dev, out_dev, out_dtype, ldo, M,
                                  nullptr, 0.f, nullptr, 0, 0, 1, st);
   else

@@ -1,0 +1,547 @@
+// woq_gemm_f16.hip — prefill-side int4 weight x activation GEMM for the reduced-precision compute modes
+// (compute_dtype bf16 / fp16 / int8 in the blob header), M > 8.
+//
+// Replaces the arithmetic behind qbits.woq_linear at large M for those modes: qbits.cpp:113-140 ->
+// bestla_weightonly_dispatcher.cpp:150-178, where the reference's HCoreRowNAmxbf16 core rounds BOTH operands to
+// bf16 (8-bit significand) before the AMX tile product. Parity definition: autograd/functions.py:41-63 at the
+// reference's own tolerance for these modes (qbits_ut/test_weightonly.py:82-88, rtol 0.03).
+//
+// compute_dtype fp32 keeps the exact two-plane kernel of woq_gemm.hip. Here both operands are fp16 (11-bit
+// significand, 8x tighter than the reference's bf16 operands) and every scale that can be is folded into them, so
+// the K loop is nothing but loads, a short dequantisation and MFMAs — v_mfma_f32_16x16x32_f16 accumulating ONE
+// fp32 fragment set over all of K:
+//  * A: a pack pass turns the activations into fp16 with one power-of-two scale PER ROW (exact scaling; elements
+//    below rowmax * 2^-28 go subnormal — far under the 2^-9 relative steps of a bf16 activation), optionally gathers
+//    the GPTQ act-order shuffle and applies RMSNorm on the way, and writes them as [M/128][K/128] tiles of
+//    128 rows x 16 chunks x 8 halves = 32 KiB in exactly the image the workgroup wants in LDS: chunk c of row r sits
+//    in 16-byte slot c ^ (r & 15) (every 16-lane ds_read_b128 group then covers all 64 banks), k inside a chunk in the
+//    nibble-extraction order {0,2,4,6,1,3,5,7}. The GEMM moves a tile with 32 LDS-DMA instructions
+//    (global_load_lds_dwordx4, lane-linear destination) — no staging registers, no ds_write pass;
+//  * B: each wave loads ITS two 1-KiB blob tiles per K step straight to VGPRs. (w ^ 0x88888888) makes the signed
+//    nibbles unsigned u; (x & 0x000f000f) | 0x64006400 = fp16 (1024 + u) pairs and (x & 0x00f000f0) | 0x54005400 =
+//    fp16 (64 + u) pairs (the nibble sits 4 bits up, where 64.0's ulp is 1/16) — one v_pk_add_f16 of -(base + zp)
+//    gives q - zp exactly, one v_pk_mul_f16 by the group's RELATIVE scale r = s / 2^E[col] <= 1 finishes the operand:
+//    14 VALU per 8 x 16 fragment, each fragment feeding 8 MFMAs. Group-32 scales cost nothing extra: the lane
+//    quarter kq of the MFMA for 64-k half h holds k in [64h + 16kq, 64h + 16kq + 16), i.e. group 2h + (kq >> 1), so a
+//    lane simply carries its own group's r and zero point;
+//  * epilogue: acc * 2^e[row] * 2^E[col] + bias, adjacent columns paired through DPP so stores are 4 (16-bit out)
+//    or 8 bytes wide.
+// Workgroup 128 x 128 (4 waves, wave w = all rows x columns [32w, 32w+32) -> 8 x 2 fragments = 64 accumulator VGPRs),
+// two LDS buffers of 32 KiB, two workgroups per CU. Workgroup ids are laid out XCD-aware: the 64 workgroups that
+// share an XCD's L2 at a time form an 8 x 8 super-tile (8 A row blocks x 8 B column blocks re-used 8x each).
+#include <type_traits>
+
+#include "woq_device.h"
+#include "woq_launch.h"
+
+namespace woq {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+struct GemmF16Args {
+  const u32x4* q;
+  const void* scales;
+  const uint8_t* zp;
+  int K, N, tiles_k, tiles_n, n_groups, group, scale_type;
+  const _Float16* ap;  // packed activation tiles [mb][kt][128][16 slots][8]
+  const float* rs;     // [Mpad] 2^e per row
+  const float* cs;     // [Npad] 2^E per column
+  int M, nb_m, nb_n, sup_n, n_sup;
+  void* out;
+  int out_dtype, ldo;
+  const float* bias;
+};
+
+constexpr int FBM = 128, FBN = 128;
+constexpr int FTILE_BYTES = 128 * 128 * 2;
+
+__device__ __forceinline__ int fperm(int e) { return (e < 4) ? 2 * e : 2 * (e - 4) + 1; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// pack pass. Blocks [0, Mpad): one workgroup per activation row (row max / sum of squares, then convert and store).
+// Blocks [Mpad, ...): one thread per weight column -> 2^E[col] >= max |scale| of the column.
+// ---------------------------------------------------------------------------------------------------------------
+struct PackF16Args {
+  const void* x;
+  int x_dtype, lda, M, Mpad, K, Kpad;
+  const int32_t* shuffle;  // GPTQ act-order gather (converted g_idx) or null
+  const float* norm_w;     // RMSNorm weight or null
+  float eps;
+  _Float16* ap;
+  float* rs;
+  // column-scale part
+  const void* scales;
+  int scale_type, scale_mode, n_groups, tiles_k, Npad, row_blocks;
+  float* cs;
+};
+
+// MODE 0: fp32 rows, 16-B aligned; 1: bf16 / fp16 rows, 16-B aligned; 2: anything (shuffle, ragged alignment).
+// Modes 0 / 1 keep the row in registers (one HBM read) when it fits PACK_MAXI chunks per thread, every load issued
+// before the first use; the chunk index is clamped instead of branched on so the loads stay one batch.
+constexpr int PACK_MAXI = 8;
+
+template <int MODE>
+__device__ __forceinline__ void pack_load8(const PackF16Args& a, size_t base, int k0, float (&v)[8]) {
+  if constexpr (MODE == 0) {
+    const float4_t lo4 = *(const float4_t*)((const float*)a.x + base + k0);
+    const float4_t hi4 = *(const float4_t*)((const float*)a.x + base + k0 + 4);
+    v[0] = lo4.x, v[1] = lo4.y, v[2] = lo4.z, v[3] = lo4.w, v[4] = hi4.x, v[5] = hi4.y, v[6] = hi4.z, v[7] = hi4.w;
+  } else if constexpr (MODE == 1) {
+    const u32x4 raw = *(const u32x4*)((const uint16_t*)a.x + base + k0);
+    const bool bf = a.x_dtype == WOQ_BF16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint16_t bits = (uint16_t)(raw[j >> 1] >> (16 * (j & 1)));
+      const float fb = bf16_bits_to_f32(bits), fh = f16_bits_to_f32(bits);
+      v[j] = bf ? fb : fh;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      v[j] = k0 + j < a.K ? load_f32(a.x, base + (a.shuffle ? a.shuffle[k0 + j] : k0 + j), a.x_dtype) : 0.f;
+  }
+}
+
+template <int MODE, bool CACHED>
+__device__ __forceinline__ void pack_row(const PackF16Args& a, int r, float* red) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int mb = r >> 7, rl = r & 127;
+  const int chunks = a.Kpad >> 3;
+  const int full = a.K >> 3;  // chunks that lie wholly inside K (modes 0 / 1 load only those)
+  const size_t tile_halves = (size_t)128 * 128;
+  _Float16* dst_row = a.ap + (size_t)mb * (a.Kpad >> 7) * tile_halves + (size_t)rl * 128;
+  const size_t base = (size_t)r * a.lda;
+  const bool norm = a.norm_w != nullptr;
+  constexpr int NI = CACHED ? PACK_MAXI : 1;
+  float v[NI][8];
+  float amax = 0.f, ss = 0.f;
+  auto fetch = [&](int c, bool valid, float (&d)[8]) {
+    if constexpr (MODE == 2) {
+      pack_load8<2>(a, base, c << 3, d);
+      if (!valid) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = 0.f;
+      }
+    } else {
+      const bool in = valid && c < full;
+      pack_load8<MODE>(a, base, min(c, max(full - 1, 0)) << 3, d);
+      if (!in) {  // K tail chunk (K % 8 != 0 never reaches modes 0 / 1 with a partial chunk) or K padding
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = 0.f;
+      }
+    }
+    if (norm) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ss = fmaf(d[j], d[j], ss);
+        d[j] *= a.norm_w[min(c * 8 + j, a.K - 1)];
+      }
+    }
+  };
+  if constexpr (CACHED) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) fetch(min(tid + 256 * i, chunks - 1), tid + 256 * i < chunks, v[i]);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[i][j]));
+    }
+  } else {
+    for (int c = tid; c < chunks; c += 256) {
+      fetch(c, true, v[0]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[0][j]));
+    }
+  }
+  // block reduction (4 waves)
+  amax = wave_max_dpp(amax);
+  ss = wave_sum_dpp(ss);
+  if (lane == 0) {
+    red[wid] = amax;
+    red[4 + wid] = ss;
+  }
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  ss = (red[4] + red[5]) + (red[6] + red[7]);
+  float nf = 1.f;
+  if (norm) nf = rsqrtf(ss / (float)a.K + a.eps);
+  amax *= nf;
+  int e = 0;
+  if (amax > 0.f && amax < INFINITY) e = max(-100, min(100, __builtin_amdgcn_frexp_expf(amax) - 14));
+  const float p2 = ldexpf(1.f, -e) * nf;  // |x| nf 2^-e < 2^14
+  if (tid == 0) a.rs[r] = ldexpf(1.f, e);
+  auto emit = [&](int c, const float (&d)[8]) {
+    h8 hh;
+#pragma unroll
+    for (int e8 = 0; e8 < 8; ++e8) hh[e8] = (_Float16)(d[fperm(e8)] * p2);
+    *(h8*)(dst_row + (size_t)(c >> 4) * tile_halves + (size_t)(((c & 15) ^ (rl & 15)) << 3)) = hh;
+  };
+  if constexpr (CACHED) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (tid + 256 * i < chunks) emit(tid + 256 * i, v[i]);
+  } else {
+    for (int c = tid; c < chunks; c += 256) {  // second sweep: the row is L2-resident now
+      fetch(c, true, v[0]);
+      emit(c, v[0]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_f16_kernel(PackF16Args a) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= a.row_blocks) {  // ---- column scales ----
+    const int n = ((int)blockIdx.x - a.row_blocks) * 256 + tid;
+    if (n >= a.Npad) return;
+    const int tn = n >> 4, i16 = n & 15;
+    float mx = 0.f;
+    if (a.scale_mode == 0) {
+      for (int g = 0; g < a.n_groups; ++g)
+        mx = fmaxf(mx, fabsf(load_f32(a.scales, ((size_t)tn * a.n_groups + g) * 16 + i16, a.scale_type)));
+    } else {
+      for (int kt = 0; kt < a.tiles_k; ++kt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          mx = fmaxf(mx, fabsf(load_f32(a.scales, ((((size_t)tn * a.tiles_k + kt) * 16 + i16) << 2) + s, a.scale_type)));
+    }
+    int e = 0;
+    if (mx > 0.f && mx < INFINITY) e = max(-120, min(120, __builtin_amdgcn_frexp_expf(mx)));  // mx < 2^e
+    a.cs[n] = ldexpf(1.f, e);
+    return;
+  }
+  const int r = (int)blockIdx.x;
+  if (r >= a.M) {  // padding rows of the last row block: zeros
+    const int mb = r >> 7, rl = r & 127;
+    const size_t tile_halves = (size_t)128 * 128;
+    _Float16* dst_row = a.ap + (size_t)mb * (a.Kpad >> 7) * tile_halves + (size_t)rl * 128;
+    for (int c = tid; c < (a.Kpad >> 3); c += 256)
+      *(u32x4*)(dst_row + (size_t)(c >> 4) * tile_halves + (size_t)(((c & 15) ^ (rl & 15)) << 3)) = (u32x4){0, 0, 0, 0};
+    if (tid == 0) a.rs[r] = 0.f;
+    return;
+  }
+  const int esz = a.x_dtype == WOQ_F32 ? 4 : 2;
+  const bool vec_ok = a.shuffle == nullptr && (((uintptr_t)a.x) & 15) == 0 && (((size_t)a.lda * esz) & 15) == 0 &&
+                      (a.K & 7) == 0;
+  const bool cached = (a.Kpad >> 3) <= PACK_MAXI * 256;
+  if (vec_ok && cached) {
+    if (a.x_dtype == WOQ_F32)
+      pack_row<0, true>(a, r, red);
+    else
+      pack_row<1, true>(a, r, red);
+  } else if (vec_ok) {
+    if (a.x_dtype == WOQ_F32)
+      pack_row<0, false>(a, r, red);
+    else
+      pack_row<1, false>(a, r, red);
+  } else {
+    pack_row<2, false>(a, r, red);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GEMM
+// ---------------------------------------------------------------------------------------------------------------
+template <int SMODE, bool S32>
+struct BRegs {  // one K step of one wave's weight operand, as loaded
+  u32x4 wv[2];
+  typename std::conditional<S32, float, uint32_t>::type sc[2][SMODE == 0 ? 1 : 2];
+  uint32_t zp[2][SMODE == 0 ? 1 : 2];
+};
+
+// 8 signed nibbles of one blob word -> 8 fp16 (q - zp) * r, order {0,2,4,6,1,3,5,7}
+__device__ __forceinline__ h8 dq8s(uint32_t w, h2 nlo, h2 nhi, h2 r) {
+  const uint32_t x = w ^ 0x88888888u, y = x >> 8;
+  const h2 f0 = (__builtin_bit_cast(h2, (x & 0x000f000fu) | 0x64006400u) + nlo) * r;
+  const h2 f1 = (__builtin_bit_cast(h2, (x & 0x00f000f0u) | 0x54005400u) + nhi) * r;
+  const h2 f2 = (__builtin_bit_cast(h2, (y & 0x000f000fu) | 0x64006400u) + nlo) * r;
+  const h2 f3 = (__builtin_bit_cast(h2, (y & 0x00f000f0u) | 0x54005400u) + nhi) * r;
+  return __builtin_bit_cast(h8, (u32x4){__builtin_bit_cast(uint32_t, f0), __builtin_bit_cast(uint32_t, f1),
+                                        __builtin_bit_cast(uint32_t, f2), __builtin_bit_cast(uint32_t, f3)});
+}
+
+template <int SMODE, bool ASYM, bool S32>
+__global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(GemmF16Args a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char fsm[];  // 2 x 32 KiB A tiles
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, kq = lane >> 4;
+
+  // XCD-aware placement: workgroup ids go round-robin over the 8 XCDs; each XCD walks its own sequence of
+  // 8 x 8 super-tiles, 64 consecutive local ids per super-tile
+  const int bid = (int)blockIdx.x;
+  const int sup = ((bid >> 3) >> 6) * 8 + (bid & 7), within = (bid >> 3) & 63;
+  if (sup >= a.n_sup) return;
+  const int mb = (sup / a.sup_n) * 8 + (within >> 3), nb = (sup % a.sup_n) * 8 + (within & 7);
+  if (mb >= a.nb_m || nb >= a.nb_n) return;
+  const int row0 = mb * FBM;
+  const int ct0 = nb * (FBN / 16) + wid * 2;  // this wave's first column tile
+
+  float4_t acc[8][2];
+#pragma unroll
+  for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[rt][c] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+  // ---- operand movers ----
+  const _Float16* a_tiles = a.ap + (size_t)mb * a.tiles_k * (FTILE_BYTES / 2);
+  auto issue_a = [&](int kt, int buf) {  // 8 LDS-DMA pieces of 1 KiB per wave
+    const _Float16* src = a_tiles + (size_t)kt * (FTILE_BYTES / 2) + (size_t)wid * 4096 + lane * 8;
+    unsigned char* dst = fsm + buf * FTILE_BYTES + wid * 8192;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 512),
+                                       (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+  };
+  int tnc[2];
+  float icol[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    tnc[c] = min(ct0 + c, a.tiles_n - 1);
+    icol[c] = 1.f / a.cs[tnc[c] * 16 + i16];  // exact: a power of two
+  }
+  const int lane_s = kq >> 1;  // group-32: which 32-k group of a 64-k half this lane quarter belongs to
+  auto load_b = [&](int kt, BRegs<SMODE, S32>& b) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      b.wv[c] = a.q[((size_t)tnc[c] * a.tiles_k + kt) * 64 + lane];
+      if constexpr (SMODE == 0) {
+        int g = (kt * 128) / a.group;
+        g = g >= a.n_groups ? a.n_groups - 1 : g;
+        const size_t si = ((size_t)tnc[c] * a.n_groups + g) * 16 + i16;
+        if constexpr (S32)
+          b.sc[c][0] = ((const float*)a.scales)[si];
+        else
+          b.sc[c][0] = ((const uint16_t*)a.scales)[si];
+        if constexpr (ASYM) b.zp[c][0] = a.zp[si];
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const size_t si = ((((size_t)tnc[c] * a.tiles_k + kt) * 16 + i16) << 2) + 2 * h + lane_s;
+          if constexpr (S32)
+            b.sc[c][h] = ((const float*)a.scales)[si];
+          else
+            b.sc[c][h] = ((const uint16_t*)a.scales)[si];
+          if constexpr (ASYM) b.zp[c][h] = a.zp[si];
+        }
+      }
+    }
+  };
+  const bool sc_bf = a.scale_type == WOQ_BF16;
+  // A fragment of (64-k half h, part p) for row tile rt: chunk h*8 + kq*2 + p of row rt*16 + i16, slot = chunk ^ i16
+  int a_off[4];
+#pragma unroll
+  for (int hp = 0; hp < 4; ++hp) a_off[hp] = i16 * 256 + ((((hp >> 1) * 8 + kq * 2 + (hp & 1)) ^ i16) << 4);
+
+  auto compute = [&](int buf, const BRegs<SMODE, S32>& b) {
+    const unsigned char* at = fsm + buf * FTILE_BYTES;
+    constexpr int NS = SMODE == 0 ? 1 : 2;
+    h2 r2[2][NS], nlo[2][NS], nhi[2][NS];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        float sv;
+        if constexpr (S32) {
+          sv = b.sc[c][s];
+        } else {
+          const float fb = bf16_bits_to_f32((uint16_t)b.sc[c][s]), fh = f16_bits_to_f32((uint16_t)b.sc[c][s]);
+          sv = sc_bf ? fb : fh;
+        }
+        const _Float16 rr = (_Float16)(sv * icol[c]);
+        r2[c][s] = (h2){rr, rr};
+        const float uz = ASYM ? (float)(b.zp[c][s] & 0xff) : 8.f;
+        const _Float16 l = (_Float16)(-(1024.f + uz)), hgh = (_Float16)(-(64.f + uz));
+        nlo[c][s] = (h2){l, l};
+        nhi[c][s] = (h2){hgh, hgh};
+      }
+    // (an explicit one-word read-ahead of the A fragments, pinned with sched_barrier, measured the same throughput at
+    // +40 VGPRs: with two workgroups per CU the other workgroup's waves already cover the ds_read latency)
+#pragma unroll
+    for (int hp = 0; hp < 4; ++hp) {
+      const int s = SMODE == 0 ? 0 : (hp >> 1);
+      h8 bfr[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) bfr[c] = dq8s(b.wv[c][hp], nlo[c][s], nhi[c][s], r2[c][s]);
+#pragma unroll
+      for (int rt = 0; rt < 8; ++rt) {
+        const h8 af = *(const h8*)(at + rt * 4096 + a_off[hp]);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr[c], acc[rt][c], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- K loop, two steps per trip (ping-pong register sets and LDS buffers; no register copies) ----
+  BRegs<SMODE, S32> b0, b1;
+  issue_a(0, 0);
+  load_b(0, b0);
+  const int last = a.tiles_k - 1;
+  for (int kt = 0; kt < a.tiles_k; kt += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt has landed
+    __syncthreads();                                   // everyone's has; everyone is done reading the other buffer
+    issue_a(min(kt + 1, last), 1);
+    load_b(min(kt + 1, last), b1);
+    __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks these loads below the MFMAs, next to their first use
+    compute(0, b0);
+    if (kt + 1 >= a.tiles_k) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    issue_a(min(kt + 2, last), 0);
+    load_b(min(kt + 2, last), b0);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1, b1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still be writing LDS when the workgroup retires
+
+  // ---- epilogue. D: lane (column i16, rows 4*kq + j) of every 16 x 16 fragment ----
+  const bool odd = (i16 & 1) != 0;
+  const bool pair_ok = (a.ldo & 1) == 0 && (a.N & 1) == 0 &&
+                       (((uintptr_t)a.out) & (a.out_dtype == WOQ_F32 ? 7 : 3)) == 0;
+  auto store_all = [&](auto put1, auto put2) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int n = (ct0 + c) * 16 + i16;
+      const bool live = ct0 + c < a.tiles_n && n < a.N;
+      const float csv = live ? a.cs[n] : 0.f;
+      const float bsv = (live && a.bias) ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int rt = 0; rt < 8; ++rt) {
+        const int mrow = row0 + rt * 16 + kq * 4;
+        const float4_t rsv = *(const float4_t*)(a.rs + mrow);  // rs is padded to the row block
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[rt][c][j], rsv[j] * csv, bsv);
+        if (pair_ok) {
+          // even lanes keep rows 0,1 of (col, col+1); odd lanes rows 2,3 of (col-1, col)
+          const float t0 = WOQ_DPP_F32(odd ? v[0] : v[2], 0xB1), t1 = WOQ_DPP_F32(odd ? v[1] : v[3], 0xB1);
+          if (live) {
+            const int m0 = mrow + (odd ? 2 : 0);
+            const int nn = n & ~1;
+            if (m0 < a.M) put2((size_t)m0 * a.ldo + nn, odd ? t0 : v[0], odd ? v[2] : t0);
+            if (m0 + 1 < a.M) put2((size_t)(m0 + 1) * a.ldo + nn, odd ? t1 : v[1], odd ? v[3] : t1);
+          }
+        } else if (live) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (mrow + j < a.M) put1((size_t)(mrow + j) * a.ldo + n, v[j]);
+        }
+      }
+    }
+  };
+  if (a.out_dtype == WOQ_F32)
+    store_all([&](size_t i, float v) { ((float*)a.out)[i] = v; },
+              [&](size_t i, float x, float y) { *(float2*)((float*)a.out + i) = make_float2(x, y); });
+  else if (a.out_dtype == WOQ_BF16)
+    store_all([&](size_t i, float v) { ((uint16_t*)a.out)[i] = f32_to_bf16_bits(v); },
+              [&](size_t i, float x, float y) {
+                *(uint32_t*)((uint16_t*)a.out + i) = (uint32_t)f32_to_bf16_bits(x) | ((uint32_t)f32_to_bf16_bits(y) << 16);
+              });
+  else
+    store_all([&](size_t i, float v) { ((uint16_t*)a.out)[i] = f32_to_f16_bits(v); },
+              [&](size_t i, float x, float y) {
+                *(uint32_t*)((uint16_t*)a.out + i) = (uint32_t)f32_to_f16_bits(x) | ((uint32_t)f32_to_f16_bits(y) << 16);
+              });
+}
+
+template <int SMODE, bool ASYM, bool S32>
+static int launch_f16_t(GemmF16Args& a, hipStream_t st) {
+  auto kern = gemm_f16s_kernel<SMODE, ASYM, S32>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FTILE_BYTES);
+    if (e != hipSuccess) return woq::fail(std::string("QBits: hipFuncSetAttribute: ") + hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int n_sup8 = (a.n_sup + 7) / 8;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(n_sup8 * 8 * 64)), dim3(256), 2 * FTILE_BYTES, st, a);
+  return 0;
+}
+
+// Workspace bytes for an [M, K] x [K, N] call (activation tiles + row scales + column scales).
+size_t gemm_f16_workspace_bytes(int M, int Kpad, int Npad) {
+  const size_t Mpad = ((size_t)M + FBM - 1) / FBM * FBM;
+  return Mpad * Kpad * sizeof(_Float16) + Mpad * sizeof(float) + (size_t)Npad * sizeof(float);
+}
+
+// out[M,N] = act[M,K] . W_deq (+ bias) with fp16 operands. `ws` = caller workspace of gemm_f16_workspace_bytes or
+// null (stream-ordered allocation per call, like the reference's per-call amalloc,
+// bestla_weightonly_dispatcher.cpp:108-118,179). norm_w/eps: RMSNorm fused into the pack pass (null = none).
+int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
+                    const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w, float eps,
+                    void* ws, hipStream_t st) {
+  GemmF16Args a;
+  const uint8_t* b = (const uint8_t*)blob;
+  a.q = (const u32x4*)(b + h.off_q);
+  a.scales = b + h.off_scale;
+  a.zp = h.off_zp ? b + h.off_zp : nullptr;
+  a.K = h.K;
+  a.N = h.N;
+  a.tiles_k = h.Kpad / WOQ_TILE_K;
+  a.tiles_n = h.Npad / WOQ_TILE_N;
+  a.n_groups = h.n_groups;
+  a.group = h.group;
+  a.scale_type = (int)h.scale_type;
+  a.M = M;
+  a.nb_m = (M + FBM - 1) / FBM;
+  a.nb_n = (a.tiles_n * 16 + FBN - 1) / FBN;
+  const int sup_m = (a.nb_m + 7) / 8;
+  a.sup_n = (a.nb_n + 7) / 8;
+  a.n_sup = sup_m * a.sup_n;
+  a.out = out;
+  a.out_dtype = out_dtype;
+  a.ldo = ldo;
+  a.bias = bias;
+  const size_t Mpad = (size_t)a.nb_m * FBM;
+  const size_t total = gemm_f16_workspace_bytes(M, h.Kpad, h.Npad);
+  unsigned char* w = (unsigned char*)ws;
+  const bool own = w == nullptr;
+  if (own) {
+    hipError_t e = hipMallocAsync((void**)&w, total, st);
+    if (e != hipSuccess) return woq::fail(std::string("QBits: workspace allocation failed: ") + hipGetErrorString(e));
+  }
+  a.ap = (const _Float16*)w;
+  a.rs = (const float*)(w + Mpad * h.Kpad * sizeof(_Float16));
+  a.cs = a.rs + Mpad;
+
+  PackF16Args p;
+  p.x = act;
+  p.x_dtype = act_dtype;
+  p.lda = lda;
+  p.M = M;
+  p.Mpad = (int)Mpad;
+  p.K = h.K;
+  p.Kpad = h.Kpad;
+  p.shuffle = h.off_shuffle ? (const int32_t*)(b + h.off_shuffle) : nullptr;
+  p.norm_w = norm_w;
+  p.eps = eps;
+  p.ap = (_Float16*)a.ap;
+  p.rs = (float*)a.rs;
+  p.scales = a.scales;
+  p.scale_type = a.scale_type;
+  p.scale_mode = (int)h.scale_mode;
+  p.n_groups = h.n_groups;
+  p.tiles_k = a.tiles_k;
+  p.Npad = h.Npad;
+  p.row_blocks = (int)Mpad;
+  p.cs = (float*)a.cs;
+  hipLaunchKernelGGL(pack_f16_kernel, dim3((unsigned)(p.row_blocks + (h.Npad + 255) / 256)), dim3(256), 0, st, p);
+
+  const bool asym = a.zp != nullptr;
+  const int sm = (int)h.scale_mode;
+  const bool s32 = h.scale_type == WOQ_F32;
+  int rc = 1;
+#define WOQ_F16_CASE(SM, AS)                                                                   \
+  if (sm == SM && asym == AS) rc = s32 ? launch_f16_t<SM, AS, true>(a, st) : launch_f16_t<SM, AS, false>(a, st);
+  WOQ_F16_CASE(0, false)
+  WOQ_F16_CASE(0, true)
+  WOQ_F16_CASE(1, false)
+  WOQ_F16_CASE(1, true)
+#undef WOQ_F16_CASE
+  if (own) hipFreeAsync(w, st);
+  return rc;
+}
+
+}  // namespace woq

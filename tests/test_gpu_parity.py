@@ -268,3 +268,60 @@ def test_woq_linear_prefill_gemm_vs_oracle(qbits, K, N, group, asym, M, compute)
     scale = np.abs(ref - bias).max(axis=1, keepdims=True)
     rel = 1e-4 if compute == "fp32" else 2e-3
     assert (np.abs(got - ref) <= rel * scale + 1e-5).all()
+
+
+@pytest.mark.parametrize("act_dt,out_dt,scale_type", [("bf16", "bf16", "fp16"), ("fp16", "fp16", "bf16"),
+                                                      ("fp32", "bf16", "fp32"), ("bf16", "fp32", "fp16")])
+@pytest.mark.parametrize("K,N,group,asym,shuf", [(512, 1024, 128, False, False), (512, 1024, 128, True, True),
+                                                 (256, 48, 32, True, False), (160, 24, 64, True, False),
+                                                 (2048, 272, 32, False, True)])
+def test_woq_linear_prefill_f16_operand_variants(qbits, K, N, group, asym, shuf, act_dt, out_dt, scale_type):
+    """fp16-operand MFMA GEMM (compute_dtype bf16, csrc/woq_gemm_f16.hip): activation / output / scale dtypes, the
+    GPTQ act-order gather done in the pack pass, K / N / M tails. Bound: operands carry 11-bit significands
+    (2^-12 relative per product, the reference's bf16 cores 2^-9) -> 2e-3 * rowmax|ref| as in the test above, plus
+    the output type's own rounding (bf16 2^-9, fp16 2^-11 of the value)."""
+    M = 200
+    q, s, z, idx = _mk(K, N, group, asym, shuf, seed=11)
+    e8, e32 = torch.empty(0, dtype=torch.int8), torch.empty(0, dtype=torch.int32)
+    blob = qbits.repack_quantized_weight(torch.from_numpy(q).cuda(), torch.from_numpy(s).cuda(),
+                                         e8 if z is None else torch.from_numpy(z).cuda(),
+                                         e32 if idx is None else torch.from_numpy(idx).cuda(), "int4_clip", scale_type,
+                                         "bf16", z is not None, group)
+    rng = np.random.default_rng(12)
+    x32 = (rng.random((M, K), dtype=np.float32) - 0.4) * np.exp(rng.normal(0, 1.5, (M, 1))).astype(np.float32)
+    xt = torch.from_numpy(x32).to(DT[act_dt])
+    x_used = xt.float().numpy()  # what the kernel is given, exactly
+    s_used = torch.from_numpy(s).to(DT[scale_type]).float().numpy()
+    ref = orc.woq_linear(x_used, orc.repack(q, s_used, z, _cvt(idx, K, group), group), None)
+    out = torch.zeros(M, N, dtype=DT[out_dt], device="cuda")
+    qbits.woq_linear(xt.cuda(), blob, torch.empty(0), out, "bf16", "int4_clip", scale_type, asym)
+    got = out.float().cpu().numpy()
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    out_eps = {"fp32": 0.0, "bf16": 2.0 ** -8, "fp16": 2.0 ** -10}[out_dt]
+    assert (np.abs(got - ref) <= 2e-3 * scale + out_eps * np.abs(ref) + 1e-5).all()
+
+
+def test_woq_linear_prefill_f16_strided_rows(qbits):
+    """lda / ldo larger than K / N and not 16-byte multiples: the generic pack path and the scalar-store epilogue."""
+    K, N, M, group = 384, 100, 70, 128
+    q, s, z, idx = _mk(K, N, group, False, False, seed=13)
+    blob = qbits.repack_quantized_weight(torch.from_numpy(q).cuda(), torch.from_numpy(s).cuda(),
+                                         torch.empty(0, dtype=torch.int8), torch.empty(0, dtype=torch.int32),
+                                         "int4_clip", "fp32", "bf16", False, group)
+    rng = np.random.default_rng(14)
+    xbig = torch.from_numpy(rng.standard_normal((M, K + 3), dtype=np.float32)).cuda()
+    obig = torch.full((M, N + 1), 7.0, device="cuda")
+    x, out = xbig[:, :K], obig[:, :N]
+    import ctypes
+
+    from intel_extension_for_transformers_amd import _lib as L
+
+    hdr = qbits.header_of(blob)
+    L.check(L.lib().woq_linear(ctypes.c_void_p(x.data_ptr()), L.torch_dtype_code(x.dtype), x.stride(0),
+                               ctypes.c_void_p(blob.data_ptr()), ctypes.byref(hdr), None,
+                               ctypes.c_void_p(out.data_ptr()), L.torch_dtype_code(out.dtype), out.stride(0), M,
+                               L.stream_ptr()))
+    ref = orc.woq_linear(x.cpu().numpy().copy(), orc.repack(q, s, None, None, group), None)
+    got = out.cpu().numpy()
+    assert (np.abs(got - ref) <= 2e-3 * np.abs(ref).max(axis=1, keepdims=True) + 1e-5).all()
+    assert (obig[:, N].cpu().numpy() == 7.0).all()  # the column past N is untouched

@@ -15,7 +15,8 @@ def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
     group, asym = (int(sys.argv[2]), True) if len(sys.argv) > 2 else (128, False)
     res = []
-    for compute in ("bf16", "fp32"):
+    computes = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("bf16", "fp32")
+    for compute in computes:
         for name, K, N in (("qkv", 4096, 12288), ("o", 4096, 4096), ("gate_up", 4096, 22016), ("down", 11008, 4096)):
             g = torch.Generator(device="cuda").manual_seed(0)
             q = torch.randint(-8, 8, (K, N), generator=g, device="cuda", dtype=torch.int8)
