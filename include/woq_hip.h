@@ -118,7 +118,7 @@ typedef struct woq_engine_config {
   float rms_eps, rope_theta;
   int32_t tp_rank, tp_size; /* tensor parallel: heads/inter are PER-RANK sizes when tp_size > 1 */
   int32_t kv_dtype;         /* WOQ_F16 | WOQ_BF16 */
-  int32_t reserved[3];
+  int32_t reserved[3];      /* [0] = max_batch: sequences the KV cache holds for woq_engine_prefill (0 / 1 = one) */
 } woq_engine_config;
 
 typedef struct woq_layer_weights {
@@ -150,6 +150,17 @@ WOQ_API void* woq_engine_hidden_ptr(woq_engine* e); /* fp32[hidden] residual str
 /* one decode step: embed(token) -> layers -> final norm -> lm_head -> logits; if greedy != 0 also
  * argmax -> token_ptr and pos_ptr += 1, so steps can be chained with no host round trip. */
 WOQ_API int woq_engine_step(woq_engine* e, int greedy, void* stream);
+/* prompt pass (what HF's first generate() forward does with the reference's linears at M = batch * T rows,
+ * nn/modules.py:140-169): n_seq sequences x T new tokens each, tokens int32 [n_seq][T] on the device, at positions
+ * start_pos .. start_pos + T - 1 (each sequence's cache must already hold [0, start_pos): chunked prefill = calls
+ * with growing start_pos). Fills the KV caches; the last position's logits of every sequence go to
+ * woq_engine_prefill_logits_ptr() (fp32 [n_seq][vocab]); sequence 0's also to logits_ptr / hidden_ptr, with
+ * pos_ptr = start_pos + T - 1, and if greedy != 0 token_ptr = argmax and pos_ptr = start_pos + T so that
+ * woq_engine_step continues sequence 0. Linears run on the fp16-operand MFMA GEMM whatever the blobs' compute_type;
+ * q/k/v, attention output and MLP activations are fp16 between kernels, the residual stream fp32. */
+WOQ_API int woq_engine_prefill(woq_engine* e, const int32_t* tokens_dev, int n_seq, int T, int start_pos, int greedy,
+                               void* stream);
+WOQ_API void* woq_engine_prefill_logits_ptr(woq_engine* e);
 /* capture one step into a hipGraph and replay it `n` times (greedy chaining). */
 WOQ_API int woq_engine_capture(woq_engine* e, int greedy, void* stream);
 WOQ_API int woq_engine_replay(woq_engine* e, int n, void* stream);

@@ -22,7 +22,7 @@ int launch_gemm_mfma(const void* act, int act_dtype, int lda, const void* blob, 
                      const float* bias, void* out, int out_dtype, int ldo, int M, hipStream_t st);
 int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                     const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w, float eps,
-                    void* ws, hipStream_t st);
+                    const float* residual, int ld_res, int epi, void* ws, hipStream_t st);
 }  // namespace woq
 
 using namespace woq;
@@ -50,7 +50,7 @@ int woq_linear(const void* act_dev, int act_dtype, int lda, const void* blob_dev
   static const bool gemm_as_gemv = getenv("WOQ_GEMM_AS_GEMV") != nullptr;  // A/B switch for tests
   if (M > 8 && hdr->compute_type != WOQ_C_FP32 && !gemm_as_gemv)  // reduced-precision compute modes: fp16-operand MFMA GEMM
     rc = launch_gemm_f16(act_dev, act_dtype, lda, blob_dev, *hdr, bias_dev, out_dev, out_dtype, ldo, M, nullptr, 0.f,
-                         nullptr, st);
+                         nullptr, 0, 0, nullptr, st);
   else if (M <= 8 || hdr->off_shuffle != 0)
     rc = launch_gemv_from_header(act_dev, act_dtype, lda, blob_dev, *hdr, bias_dev, out_dev, out_dtype, ldo, M,
                                  nullptr, 0.f, nullptr, 0, 0, 1, st);

@@ -12,6 +12,7 @@
 // swapping HF's norm/rope/MLP for device kernels after from_pretrained (docs/weightonlyquant.md:199-202).
 // Residual stream and the GEMV I/O stay fp32 (the reference up-casts every activation to fp32 at the
 // qbits boundary, modules.py:152-154); the KV cache is fp16/bf16.
+#include <algorithm>
 #include <vector>
 
 #include "woq_device.h"
@@ -28,6 +29,20 @@ int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtyp
 void launch_lm_head(const float* hidden_in, const float* norm_w, float eps, const void* W, int w_dtype, int hidden,
                     int vocab, float* logits, hipStream_t st);
 void launch_argmax(const float* logits, int vocab, int32_t* token, int32_t* pos, hipStream_t st);
+// prompt pass (woq_gemm_f16.hip, woq_prefill.hip)
+size_t gemm_f16_workspace_bytes(int M, int Kpad, int Npad);
+int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
+                    const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w, float eps,
+                    const float* residual, int ld_res, int epi, void* ws, hipStream_t st);
+void launch_embed_rows(const void* embed, int dtype, const int32_t* tokens, int M, int hidden, float* out,
+                       hipStream_t st);
+int launch_rope_append(_Float16* qkv, int n_seq, int T, int start, int heads, int kv_heads, int HD, const float* cs,
+                       const float* sn, void* kcache, void* vcache, int kv_dtype, size_t seq_stride_elems,
+                       hipStream_t st);
+int launch_attn_prefill(const _Float16* qkv, int n_seq, int T, int start, int heads, int kv_heads, int HD,
+                        const void* kcache, const void* vcache, int kv_dtype, size_t seq_stride_elems, _Float16* out,
+                        hipStream_t st);
+void launch_gather_last(const float* h, int n_seq, int T, int hidden, float* dst, hipStream_t st);
 }  // namespace woq
 
 struct woq_engine {
@@ -56,6 +71,16 @@ struct woq_engine {
   void* allreduce_user = nullptr;
   int nt = 1;
   std::vector<void*> owned;  // everything hipMalloc'ed by create()
+  // prompt pass: [n_seq * T] rows at a time; buffers grow on demand (never inside a captured graph)
+  int max_batch = 1;
+  size_t pf_rows = 0, pf_ws_bytes = 0;
+  float* pf_h = nullptr;        // fp32 residual stream [rows][hidden]
+  _Float16* pf_qkv = nullptr;   // fp16 [rows][(heads + 2 kv_heads) * head_dim]
+  _Float16* pf_attn = nullptr;  // fp16 [rows][heads * head_dim]
+  _Float16* pf_act = nullptr;   // fp16 [rows][inter]
+  void* pf_ws = nullptr;        // GEMM pack workspace
+  float* pf_last = nullptr;     // fp32 [max_batch][hidden]
+  float* pf_logits = nullptr;   // fp32 [max_batch][vocab]
 };
 
 using namespace woq;
@@ -109,7 +134,103 @@ static int engine_step_impl(woq_engine* e, int greedy, hipStream_t st) {
   return engine_head(e, greedy, st);
 }
 
+// ---- prompt pass -------------------------------------------------------------------------------------------------
+// HF runs the prompt as ONE forward over [batch, T] (generation's first step); the reference's qbits linears then see
+// M = batch * T rows (nn/modules.py:140-169). Same here: every linear is one MFMA GEMM over all rows
+// (woq_gemm_f16.hip: RMSNorm fused into the activation pack pass, residual add / SiLU*mul fused into the epilogue),
+// attention is one launch per layer over the KV cache (woq_prefill.hip). 6 launches + 4 pack passes per layer.
+static int engine_prefill_reserve(woq_engine* e, size_t rows) {
+  const woq_engine_config& c = e->cfg;
+  const woq_layer_weights& w = e->layers[0];
+  int kpad = 0, npad = 0;
+  for (const woq_blob_header* h : {&w.qkv_hdr, &w.o_hdr, &w.gate_up_hdr, &w.down_hdr}) {
+    kpad = std::max(kpad, (int)h->Kpad);
+    npad = std::max(npad, (int)h->Npad);
+  }
+  const size_t ws = gemm_f16_workspace_bytes((int)rows, kpad, npad);
+  if (rows <= e->pf_rows && ws <= e->pf_ws_bytes) return 0;
+  WOQ_HIP(hipDeviceSynchronize());
+  for (void* p : {(void*)e->pf_h, (void*)e->pf_qkv, (void*)e->pf_attn, (void*)e->pf_act, e->pf_ws})
+    if (p) WOQ_HIP(hipFree(p));
+  e->pf_h = nullptr, e->pf_qkv = nullptr, e->pf_attn = nullptr, e->pf_act = nullptr, e->pf_ws = nullptr;
+  e->pf_rows = 0;
+  const size_t qkv_n = (size_t)(c.heads + 2 * c.kv_heads) * c.head_dim;
+  WOQ_HIP(hipMalloc((void**)&e->pf_h, rows * c.hidden * 4));
+  WOQ_HIP(hipMalloc((void**)&e->pf_qkv, rows * qkv_n * 2));
+  WOQ_HIP(hipMalloc((void**)&e->pf_attn, rows * (size_t)c.heads * c.head_dim * 2));
+  WOQ_HIP(hipMalloc((void**)&e->pf_act, rows * (size_t)c.inter * 2));
+  WOQ_HIP(hipMalloc((void**)&e->pf_ws, ws));
+  e->pf_rows = rows;
+  e->pf_ws_bytes = ws;
+  return 0;
+}
+
+static int engine_prefill_impl(woq_engine* e, const int32_t* tokens, int n_seq, int T, int start, int greedy,
+                               hipStream_t st) {
+  const woq_engine_config& c = e->cfg;
+  const int M = n_seq * T;
+  const int qkv_n = (c.heads + 2 * c.kv_heads) * c.head_dim;
+  const size_t seq_stride = e->kv_layer_bytes / 2 * c.layers;  // cache elements between two sequences
+  int rc = engine_prefill_reserve(e, (size_t)M);
+  if (rc) return rc;
+  launch_embed_rows(e->embed, e->embed_dtype, tokens, M, c.hidden, e->pf_h, st);
+  const float* res = (c.tp_size <= 1 || c.tp_rank == 0) ? e->pf_h : nullptr;
+  for (int l = 0; l < c.layers; ++l) {
+    const woq_layer_weights& w = e->layers[l];
+    uint8_t* kc = e->kcache + (size_t)l * e->kv_layer_bytes;
+    uint8_t* vc = e->vcache + (size_t)l * e->kv_layer_bytes;
+    if ((rc = launch_gemm_f16(e->pf_h, WOQ_F32, c.hidden, w.qkv_blob, w.qkv_hdr, nullptr, e->pf_qkv, WOQ_F16, qkv_n, M,
+                              w.ln1, c.rms_eps, nullptr, 0, 0, e->pf_ws, st)) != 0)
+      return rc;
+    if ((rc = launch_rope_append(e->pf_qkv, n_seq, T, start, c.heads, c.kv_heads, c.head_dim, e->cs, e->sn, kc, vc,
+                                 c.kv_dtype, seq_stride, st)) != 0)
+      return rc;
+    if ((rc = launch_attn_prefill(e->pf_qkv, n_seq, T, start, c.heads, c.kv_heads, c.head_dim, kc, vc, c.kv_dtype,
+                                  seq_stride, e->pf_attn, st)) != 0)
+      return rc;
+    if ((rc = launch_gemm_f16(e->pf_attn, WOQ_F16, c.heads * c.head_dim, w.o_blob, w.o_hdr, nullptr, e->pf_h, WOQ_F32,
+                              c.hidden, M, nullptr, 0.f, res, c.hidden, 0, e->pf_ws, st)) != 0)
+      return rc;
+    if (e->allreduce && e->allreduce(e->allreduce_user, e->pf_h, (size_t)M * c.hidden, st) != 0)
+      return woq::fail("QBits: tensor-parallel all-reduce callback failed");
+    if ((rc = launch_gemm_f16(e->pf_h, WOQ_F32, c.hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, e->pf_act, WOQ_F16,
+                              c.inter, M, w.ln2, c.rms_eps, nullptr, 0, 1, e->pf_ws, st)) != 0)
+      return rc;
+    if ((rc = launch_gemm_f16(e->pf_act, WOQ_F16, c.inter, w.down_blob, w.down_hdr, nullptr, e->pf_h, WOQ_F32,
+                              c.hidden, M, nullptr, 0.f, res, c.hidden, 0, e->pf_ws, st)) != 0)
+      return rc;
+    if (e->allreduce && e->allreduce(e->allreduce_user, e->pf_h, (size_t)M * c.hidden, st) != 0)
+      return woq::fail("QBits: tensor-parallel all-reduce callback failed");
+  }
+  // logits of every sequence's last position; sequence 0 also lands in the decode step's buffers
+  launch_gather_last(e->pf_h, n_seq, T, c.hidden, e->pf_last, st);
+  for (int s = 0; s < n_seq; ++s)
+    launch_lm_head(e->pf_last + (size_t)s * c.hidden, e->final_norm, c.rms_eps, e->lm_head, e->lm_dtype, c.hidden,
+                   c.vocab, e->pf_logits + (size_t)s * c.vocab, st);
+  WOQ_HIP(hipMemcpyAsync(e->hidden, e->pf_last, (size_t)c.hidden * 4, hipMemcpyDeviceToDevice, st));
+  WOQ_HIP(hipMemcpyAsync(e->logits, e->pf_logits, (size_t)c.vocab * 4, hipMemcpyDeviceToDevice, st));
+  WOQ_HIP(hipMemsetD32Async((hipDeviceptr_t)e->pos, start + T - 1, 1, st));
+  if (greedy) launch_argmax(e->logits, c.vocab, e->token, e->pos, st);  // token <- argmax, pos <- start + T
+  return 0;
+}
+
 extern "C" {
+
+int woq_engine_prefill(woq_engine* e, const int32_t* tokens_dev, int n_seq, int T, int start_pos, int greedy,
+                       void* stream) {
+  WOQ_TRY
+  WOQ_CHECK(e && e->embed && e->lm_head, "QBits: engine head not set");
+  WOQ_CHECK(tokens_dev && n_seq >= 1 && T >= 1 && start_pos >= 0, "QBits: bad prefill arguments");
+  WOQ_CHECK(n_seq <= e->max_batch, "QBits: prefill batch exceeds the engine's max_batch");
+  WOQ_CHECK(start_pos + T <= e->cfg.max_ctx, "QBits: prefill runs past max_ctx");
+  WOQ_CHECK((long long)n_seq * T < (1ll << 31), "QBits: prefill row count overflows");
+  int rc = engine_prefill_impl(e, tokens_dev, n_seq, T, start_pos, greedy, (hipStream_t)stream);
+  if (rc) return rc;
+  WOQ_HIP(hipGetLastError());
+  WOQ_END
+}
+
+void* woq_engine_prefill_logits_ptr(woq_engine* e) { return e ? e->pf_logits : nullptr; }
 
 int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
   WOQ_TRY
@@ -130,11 +251,17 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
   WOQ_HIP(hipMemset(e->token, 0, 4));
   WOQ_HIP(hipMemset(e->pos, 0, 4));
   e->kv_layer_bytes = (size_t)cfg->max_ctx * cfg->kv_heads * cfg->head_dim * 2;
-  WOQ_HIP(hipMalloc((void**)&e->kcache, e->kv_layer_bytes * cfg->layers));
-  WOQ_HIP(hipMalloc((void**)&e->vcache, e->kv_layer_bytes * cfg->layers));
-  WOQ_HIP(hipMemset(e->kcache, 0, e->kv_layer_bytes * cfg->layers));
-  WOQ_HIP(hipMemset(e->vcache, 0, e->kv_layer_bytes * cfg->layers));
-  e->owned = {e->hidden, e->qkv, e->attn, e->act, e->logits, e->token, e->pos, e->kcache, e->vcache};
+  // KV cache [sequence][layer][position][kv head][d]; sequence 0 is the one the decode step continues
+  e->max_batch = cfg->reserved[0] > 1 ? cfg->reserved[0] : 1;
+  const size_t kv_total = e->kv_layer_bytes * cfg->layers * e->max_batch;
+  WOQ_HIP(hipMalloc((void**)&e->kcache, kv_total));
+  WOQ_HIP(hipMalloc((void**)&e->vcache, kv_total));
+  WOQ_HIP(hipMemset(e->kcache, 0, kv_total));
+  WOQ_HIP(hipMemset(e->vcache, 0, kv_total));
+  WOQ_HIP(hipMalloc((void**)&e->pf_last, (size_t)e->max_batch * cfg->hidden * 4));
+  WOQ_HIP(hipMalloc((void**)&e->pf_logits, (size_t)e->max_batch * cfg->vocab * 4));
+  e->owned = {e->hidden, e->qkv, e->attn, e->act, e->logits, e->token, e->pos, e->kcache, e->vcache, e->pf_last,
+              e->pf_logits};
   *out = e;
   WOQ_END
 }
@@ -144,6 +271,8 @@ void woq_engine_destroy(woq_engine* e) {
   if (e->exec) hipGraphExecDestroy(e->exec);
   if (e->graph) hipGraphDestroy(e->graph);
   for (void* p : e->owned) hipFree(p);
+  for (void* p : {(void*)e->pf_h, (void*)e->pf_qkv, (void*)e->pf_attn, (void*)e->pf_act, e->pf_ws})
+    if (p) hipFree(p);
   delete e;
 }
 

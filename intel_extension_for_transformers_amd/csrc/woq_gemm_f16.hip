@@ -52,6 +52,9 @@ struct GemmF16Args {
   void* out;
   int out_dtype, ldo;
   const float* bias;
+  const float* residual;  // fp32 [M][ld_res] added in the epilogue (may alias `out`), or null
+  int ld_res;
+  int epi;                // 0 plain; 1 SiLU(gate) * up over interleaved gate / up column tiles -> N/2 output columns
 };
 
 constexpr int FBM = 128, FBN = 128;
@@ -398,39 +401,64 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(GemmF16Args a) {
 
   // ---- epilogue. D: lane (column i16, rows 4*kq + j) of every 16 x 16 fragment ----
   const bool odd = (i16 & 1) != 0;
-  const bool pair_ok = (a.ldo & 1) == 0 && (a.N & 1) == 0 &&
-                       (((uintptr_t)a.out) & (a.out_dtype == WOQ_F32 ? 7 : 3)) == 0;
+  const bool silu = a.epi == 1;
+  const int n_out = silu ? (a.N >> 1) : a.N;
+  const bool pair_ok = (a.ldo & 1) == 0 && (n_out & 1) == 0 && (a.ld_res & 1) == 0 &&
+                       (((uintptr_t)a.out) & (a.out_dtype == WOQ_F32 ? 7 : 3)) == 0 && (((uintptr_t)a.residual) & 7) == 0;
   auto store_all = [&](auto put1, auto put2) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const int n = (ct0 + c) * 16 + i16;
-      const bool live = ct0 + c < a.tiles_n && n < a.N;
-      const float csv = live ? a.cs[n] : 0.f;
-      const float bsv = (live && a.bias) ? a.bias[n] : 0.f;
+      if (silu && c == 1) continue;  // the up tile was consumed together with its gate tile
+      const int n_in = (ct0 + c) * 16 + i16;                       // weight column
+      const int n = silu ? (ct0 >> 1) * 16 + i16 : n_in;           // output column
+      const bool live = ct0 + c < a.tiles_n && n_in < a.N && n < n_out;
+      const float csv = live ? a.cs[n_in] : 0.f;
+      const float csu = (silu && live) ? a.cs[n_in + 16] : 0.f;
+      const float bsv = (live && a.bias) ? a.bias[n_in] : 0.f;
+      const float bsu = (silu && live && a.bias) ? a.bias[n_in + 16] : 0.f;
 #pragma unroll
       for (int rt = 0; rt < 8; ++rt) {
         const int mrow = row0 + rt * 16 + kq * 4;
         const float4_t rsv = *(const float4_t*)(a.rs + mrow);  // rs is padded to the row block
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[rt][c][j], rsv[j] * csv, bsv);
+        for (int j = 0; j < 4; ++j) {
+          v[j] = fmaf(acc[rt][c][j], rsv[j] * csv, bsv);
+          if (silu) {
+            const float u = fmaf(acc[rt][1][j], rsv[j] * csu, bsu);
+            v[j] = v[j] / (1.f + __expf(-v[j])) * u;
+          }
+        }
         if (pair_ok) {
           // even lanes keep rows 0,1 of (col, col+1); odd lanes rows 2,3 of (col-1, col)
           const float t0 = WOQ_DPP_F32(odd ? v[0] : v[2], 0xB1), t1 = WOQ_DPP_F32(odd ? v[1] : v[3], 0xB1);
           if (live) {
             const int m0 = mrow + (odd ? 2 : 0);
             const int nn = n & ~1;
-            if (m0 < a.M) put2((size_t)m0 * a.ldo + nn, odd ? t0 : v[0], odd ? v[2] : t0);
-            if (m0 + 1 < a.M) put2((size_t)(m0 + 1) * a.ldo + nn, odd ? t1 : v[1], odd ? v[3] : t1);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              if (m0 + u >= a.M) continue;
+              float x = odd ? (u ? t1 : t0) : v[u], y = odd ? v[2 + u] : (u ? t1 : t0);
+              if (a.residual) {
+                const float2 rr = *(const float2*)(a.residual + (size_t)(m0 + u) * a.ld_res + nn);
+                x += rr.x;
+                y += rr.y;
+              }
+              put2((size_t)(m0 + u) * a.ldo + nn, x, y);
+            }
           }
         } else if (live) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (mrow + j < a.M) put1((size_t)(mrow + j) * a.ldo + n, v[j]);
+            if (mrow + j < a.M)
+              put1((size_t)(mrow + j) * a.ldo + n,
+                   v[j] + (a.residual ? a.residual[(size_t)(mrow + j) * a.ld_res + n] : 0.f));
         }
       }
     }
   };
+  // fp16 stores saturate instead of overflowing to inf (the engine keeps q / k / v / MLP activations in fp16)
+  auto h16 = [](float v) { return f32_to_f16_bits(fminf(fmaxf(v, -65504.f), 65504.f)); };
   if (a.out_dtype == WOQ_F32)
     store_all([&](size_t i, float v) { ((float*)a.out)[i] = v; },
               [&](size_t i, float x, float y) { *(float2*)((float*)a.out + i) = make_float2(x, y); });
@@ -440,9 +468,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(GemmF16Args a) {
                 *(uint32_t*)((uint16_t*)a.out + i) = (uint32_t)f32_to_bf16_bits(x) | ((uint32_t)f32_to_bf16_bits(y) << 16);
               });
   else
-    store_all([&](size_t i, float v) { ((uint16_t*)a.out)[i] = f32_to_f16_bits(v); },
+    store_all([&](size_t i, float v) { ((uint16_t*)a.out)[i] = h16(v); },
               [&](size_t i, float x, float y) {
-                *(uint32_t*)((uint16_t*)a.out + i) = (uint32_t)f32_to_f16_bits(x) | ((uint32_t)f32_to_f16_bits(y) << 16);
+                *(uint32_t*)((uint16_t*)a.out + i) = (uint32_t)h16(x) | ((uint32_t)h16(y) << 16);
               });
 }
 
@@ -468,10 +496,13 @@ size_t gemm_f16_workspace_bytes(int M, int Kpad, int Npad) {
 
 // out[M,N] = act[M,K] . W_deq (+ bias) with fp16 operands. `ws` = caller workspace of gemm_f16_workspace_bytes or
 // null (stream-ordered allocation per call, like the reference's per-call amalloc,
-// bestla_weightonly_dispatcher.cpp:108-118,179). norm_w/eps: RMSNorm fused into the pack pass (null = none).
+// bestla_weightonly_dispatcher.cpp:108-118,179). norm_w/eps: RMSNorm fused into the pack pass (null = none);
+// residual / epi: see GemmF16Args.
 int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                     const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w, float eps,
-                    void* ws, hipStream_t st) {
+                    const float* residual, int ld_res, int epi, void* ws, hipStream_t st) {
+  if (epi == 1 && (((h.Npad / WOQ_TILE_N) & 1) != 0 || (h.N & 31) != 0))
+    return woq::fail("QBits: the SiLU*mul epilogue needs whole gate / up column-tile pairs");
   GemmF16Args a;
   const uint8_t* b = (const uint8_t*)blob;
   a.q = (const u32x4*)(b + h.off_q);
@@ -494,6 +525,9 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   a.out_dtype = out_dtype;
   a.ldo = ldo;
   a.bias = bias;
+  a.residual = residual;
+  a.ld_res = ld_res;
+  a.epi = epi;
   const size_t Mpad = (size_t)a.nb_m * FBM;
   const size_t total = gemm_f16_workspace_bytes(M, h.Kpad, h.Npad);
   unsigned char* w = (unsigned char*)ws;

@@ -1,0 +1,336 @@
+// woq_prefill.hip — the non-linear kernels of the prompt (prefill) pass of the decode engine: token embedding
+// for a batch of rows, RoPE + KV-cache append, causal attention over the cache on the matrix cores, last-row gather.
+//
+// What they replace: stock HF module forwards the reference runs as PyTorch CPU ops around its
+// qbits linears during `model.generate`'s first forward — LlamaRotaryEmbedding / apply_rotary_pos_emb (rotate_half
+// form), the KV cache `torch.cat`, and LlamaAttention's softmax(QK^T / sqrt(d) + causal mask) V. The linears of the
+// same pass are woq_gemm_f16.hip.
+//
+// Attention (attn_prefill_kernel): one workgroup = 128 query rows of one head of one sequence, 4 waves x 32 rows;
+// the K / V rows of the sequence's cache — positions [0, start + row], i.e. earlier chunks and this chunk alike —
+// stream through LDS in tiles of 64 positions:
+//  * S^T = K Q^T per 16-position tile (v_mfma_f32_16x16x32_f16, A = K fragment read from a row-major LDS tile in a
+//    16-B-slot XOR swizzle, B = Q^T fragments held in registers): the result leaves query i16 in lane i16 with
+//    positions 4*kq + j — which IS the B-operand shape of the next product, so probabilities never touch LDS;
+//  * online softmax in the exp2 domain, fp32, per query = per lane column (two cross-quarter shuffles per tile);
+//  * O^T = V^T P^T: A = V^T fragment = two ds_read_b64 from a TRANSPOSED V tile ([d][position], written with a
+//    4 x 8 register transpose and a quad-chunk XOR swizzle so both the writes and the reads are conflict-free),
+//    B = the packed fp16 probabilities; the output again has query i16 in lane i16, so the running rescale is a
+//    plain per-lane multiply.
+// Tiles entirely above a wave's causal diagonal are skipped by that wave; the workgroups with the most tiles are
+// scheduled first. fp32 accumulation throughout; Q, K, V, P enter the MFMAs as fp16.
+#include "woq_device.h"
+#include "woq_launch.h"
+
+namespace woq {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// ---- KV element codecs: cache dtype <-> fp16 lanes -------------------------------------------------------------
+// 8 consecutive cache elements -> 8 fp16
+template <int KVD>
+__device__ __forceinline__ h8 kv_load8(const void* base, size_t elem) {
+  if constexpr (KVD == WOQ_F16) {
+    return *(const h8*)((const _Float16*)base + elem);
+  } else {
+    const u32x4 raw = *(const u32x4*)((const uint16_t*)base + elem);
+    h8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (_Float16)bf16_bits_to_f32((uint16_t)(raw[j >> 1] >> (16 * (j & 1))));
+    return r;
+  }
+}
+template <int KVD>
+__device__ __forceinline__ void kv_store(void* base, size_t elem, float v) {
+  if constexpr (KVD == WOQ_F16)
+    ((_Float16*)base)[elem] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+  else
+    ((uint16_t*)base)[elem] = f32_to_bf16_bits(v);
+}
+
+// ---- embedding rows: h[m][:] = embed[token[m]][:] (fp32 residual stream) ----------------------------------------
+__global__ __launch_bounds__(256) void embed_rows_kernel(const void* __restrict__ embed, int dtype,
+                                                         const int32_t* __restrict__ tokens, int hidden,
+                                                         float* __restrict__ out) {
+  const int m = blockIdx.x;
+  const size_t src = (size_t)tokens[m] * hidden;
+  for (int i = threadIdx.x; i < hidden; i += 256) out[(size_t)m * hidden + i] = load_f32(embed, src + i, dtype);
+}
+
+// ---- RoPE (HF rotate_half form) on q and k, KV append ------------------------------------------------------------
+// qkv fp16 [M][(heads + 2 kv_heads) * HD]: q rotated in place; k rotated -> K cache; v -> V cache.
+// Row m = sequence m / T, position start + m % T. One wave per (row, head slot).
+template <int KVD>
+__global__ __launch_bounds__(256) void rope_append_kernel(_Float16* __restrict__ qkv, int T, int start, int heads,
+                                                          int kv_heads, int HD, const float* __restrict__ cs,
+                                                          const float* __restrict__ sn, void* __restrict__ kcache,
+                                                          void* __restrict__ vcache, size_t seq_stride_elems) {
+  const int m = blockIdx.x, lane = threadIdx.x & 63;
+  const int slot = (int)blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int nslots = heads + 2 * kv_heads;
+  if (slot >= nslots) return;
+  const int seq = m / T, pos = start + m % T;
+  const int half = HD >> 1;
+  _Float16* x = qkv + (size_t)m * nslots * HD + (size_t)slot * HD;
+  if (slot < heads + kv_heads) {
+    for (int i = lane; i < half; i += 64) {
+      const float c = cs[(size_t)pos * half + i], s = sn[(size_t)pos * half + i];
+      const float a = (float)x[i], b = (float)x[i + half];
+      const float ra = a * c - b * s, rb = b * c + a * s;
+      if (slot < heads) {
+        x[i] = (_Float16)fminf(fmaxf(ra, -65504.f), 65504.f);
+        x[i + half] = (_Float16)fminf(fmaxf(rb, -65504.f), 65504.f);
+      } else {
+        const size_t e = (size_t)seq * seq_stride_elems + ((size_t)pos * kv_heads + (slot - heads)) * HD;
+        kv_store<KVD>(kcache, e + i, ra);
+        kv_store<KVD>(kcache, e + i + half, rb);
+      }
+    }
+  } else {
+    const size_t e = (size_t)seq * seq_stride_elems + ((size_t)pos * kv_heads + (slot - heads - kv_heads)) * HD;
+    for (int i = lane; i < HD; i += 64) kv_store<KVD>(vcache, e + i, (float)x[i]);
+  }
+}
+
+// ---- causal attention over the cache -----------------------------------------------------------------------------
+constexpr int AQB = 128;  // query rows per workgroup
+constexpr int AKT = 64;   // cache positions per tile
+constexpr int AVRB = 144; // bytes per V^T row: 64 positions x 2 B + 16 pad (conflict-free ds_read_b64, see header)
+
+template <int HD>
+__host__ __device__ constexpr int attn_lds_bytes() { return AKT * HD * 2 + HD * AVRB; }
+
+template <int KVD, int HD>
+__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const _Float16* __restrict__ qkv, int T, int start,
+                                                              int heads, int kv_heads, const void* __restrict__ kcache,
+                                                              const void* __restrict__ vcache, size_t seq_stride_elems,
+                                                              _Float16* __restrict__ out, int n_qblocks) {
+  constexpr int CPR = HD / 8;   // 16-B chunks per K row
+  constexpr int DC = HD / 32;   // 32-wide d chunks of the QK^T contraction
+  constexpr int DT = HD / 16;   // 16-wide d tiles of the output
+  constexpr int KRB = HD * 2;   // K tile row bytes
+  extern __shared__ __attribute__((aligned(16))) unsigned char asm_raw[];
+  unsigned char* ks = asm_raw;                // [64][HD] fp16, chunk slot swizzled
+  unsigned char* vs = asm_raw + AKT * KRB;    // [HD][AVRB]: V^T
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int qb = n_qblocks - 1 - (int)blockIdx.x;  // longest workgroups first
+  const int h = blockIdx.y, seq = blockIdx.z;
+  const int kh = h / (heads / kv_heads);
+  const int nslots = heads + 2 * kv_heads;
+  const int q0 = qb * AQB + wid * 32;  // this wave's first query row (within the chunk)
+  const size_t row_elems = (size_t)nslots * HD;
+  const size_t cache0 = (size_t)seq * seq_stride_elems + (size_t)kh * HD;
+  const size_t cache_row = (size_t)kv_heads * HD;
+  const int kv_len = start + min(qb * AQB + AQB, T);  // positions this workgroup may look at
+  const int n_tiles = (kv_len + AKT - 1) / AKT;
+  const float sc = 1.44269504088896f / sqrtf((float)HD);  // softmax scale in the exp2 domain
+
+  // Q^T fragments: lane (query i16 of row tile rt, quarter kq) holds d = 32c + 8kq .. +8
+  h8 qf[2][DC];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int qr = min(q0 + rt * 16 + i16, T - 1);
+    const _Float16* qp = qkv + ((size_t)seq * T + qr) * row_elems + (size_t)h * HD;
+#pragma unroll
+    for (int c = 0; c < DC; ++c) qf[rt][c] = *(const h8*)(qp + c * 32 + kq * 8);
+  }
+  float4_t o[DT][2];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) o[dt][rt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY}, l_part[2] = {0.f, 0.f};
+
+  // ---- tile movers. K: thread -> rows tid/CPR + (256/CPR) i, chunk tid % CPR. V: thread -> 4 positions x 8 d ----
+  constexpr int KPT = AKT * CPR / 256;  // K vectors per thread
+  constexpr int KRS = 256 / CPR;        // K row step between a thread's vectors
+  const int k_row = tid / CPR, k_chunk = tid % CPR;
+  const int v_g = (tid / CPR), v_c = tid % CPR;  // position quad (0..15 live), d chunk
+  const bool v_live = v_g < 16;
+  h8 kreg[KPT], vreg[4];
+  auto fetch = [&](int tile) {
+    const int t0 = tile * AKT;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int t = min(t0 + k_row + i * KRS, kv_len - 1);
+      kreg[i] = kv_load8<KVD>(kcache, cache0 + (size_t)t * cache_row + k_chunk * 8);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = min(t0 + min(v_g, 15) * 4 + r, kv_len - 1);
+      vreg[r] = kv_load8<KVD>(vcache, cache0 + (size_t)t * cache_row + v_c * 8);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int row = k_row + i * KRS;
+      const int f = HD == 128 ? (row & 15) : ((row >> 1) & 7);
+      *(h8*)(ks + row * KRB + ((k_chunk ^ f) << 4)) = kreg[i];
+    }
+    if (v_live) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {  // d = 8 v_c + i: positions 4 v_g .. +3
+        const h4 col = {vreg[0][i], vreg[1][i], vreg[2][i], vreg[3][i]};
+        *(h4*)(vs + (v_c * 8 + i) * AVRB + ((v_g ^ (v_c & 15)) << 3)) = col;
+      }
+    }
+  };
+
+  fetch(0);
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    __syncthreads();  // everyone is done with the previous tile
+    stage();
+    __syncthreads();
+    if (tile + 1 < n_tiles) fetch(tile + 1);  // flies under this tile's MFMAs
+    const int t0 = tile * AKT;
+    if (t0 > start + q0 + 31) continue;  // wholly above this wave's diagonal (wave-uniform)
+
+    // ---- S^T = K Q^T ----
+    float4_t s[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) s[a][rt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+      const int row = a * 16 + i16;
+      const int f = HD == 128 ? (row & 15) : ((row >> 1) & 7);
+#pragma unroll
+      for (int c = 0; c < DC; ++c) {
+        const h8 kf = *(const h8*)(ks + row * KRB + (((c * 4 + kq) ^ f) << 4));
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) s[a][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[rt][c], s[a][rt], 0, 0, 0);
+      }
+    }
+    // ---- causal mask + online softmax (query = lane column i16, positions 16a + 4kq + j) ----
+    const bool diag = t0 + AKT - 1 > start + q0;  // some position of the tile may exceed some query of the wave
+    h8 pb[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int qpos = start + q0 + rt * 16 + i16;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (diag && t0 + a * 16 + kq * 4 + j > qpos) s[a][rt][j] = -INFINITY;
+          mx = fmaxf(mx, s[a][rt][j]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[rt], mx * sc);
+      const float m_use = m_new == -INFINITY ? 0.f : m_new;  // a row with nothing visible yet: keep exp2 finite
+      const float alpha = exp2f(m_run[rt] - m_use);
+      m_run[rt] = m_new;
+      float ps = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float p = exp2f(fmaf(s[a][rt][j], sc, -m_use));
+          ps += p;
+          pb[a >> 1][rt][(a & 1) * 4 + j] = (_Float16)p;
+        }
+      l_part[rt] = fmaf(l_part[rt], alpha, ps);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[dt][rt] *= alpha;
+    }
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d = dt * 16 + i16;
+        const int sw = (d >> 3) & 15;
+        const unsigned char* vrow = vs + d * AVRB;
+        const u32x2 lo = *(const u32x2*)(vrow + (((8 * b + kq) ^ sw) << 3));
+        const u32x2 hi = *(const u32x2*)(vrow + (((8 * b + 4 + kq) ^ sw) << 3));
+        const h8 vf = __builtin_bit_cast(h8, (u32x4){lo.x, lo.y, hi.x, hi.y});
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) o[dt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[b][rt], o[dt][rt], 0, 0, 0);
+      }
+  }
+  // ---- finish: divide by the row sums, store fp16 [M][heads * HD] ----
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    float l = l_part[rt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    const int qr = q0 + rt * 16 + i16;
+    if (qr < T) {
+      _Float16* op = out + ((size_t)seq * T + qr) * ((size_t)heads * HD) + (size_t)h * HD + kq * 4;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const float4_t v = o[dt][rt] * inv;
+        *(h4*)(op + dt * 16) = (h4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+      }
+    }
+  }
+}
+
+// last row of every sequence -> dst fp32 [n_seq][hidden]
+__global__ __launch_bounds__(256) void gather_last_kernel(const float* __restrict__ h, int T, int hidden,
+                                                          float* __restrict__ dst) {
+  const int seq = blockIdx.x;
+  const float* src = h + ((size_t)seq * T + (T - 1)) * hidden;
+  for (int i = threadIdx.x; i < hidden; i += 256) dst[(size_t)seq * hidden + i] = src[i];
+}
+
+// ---- host launchers ---------------------------------------------------------------------------------------------
+void launch_embed_rows(const void* embed, int dtype, const int32_t* tokens, int M, int hidden, float* out,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(embed_rows_kernel, dim3(M), dim3(256), 0, st, embed, dtype, tokens, hidden, out);
+}
+
+int launch_rope_append(_Float16* qkv, int n_seq, int T, int start, int heads, int kv_heads, int HD, const float* cs,
+                       const float* sn, void* kcache, void* vcache, int kv_dtype, size_t seq_stride_elems,
+                       hipStream_t st) {
+  const dim3 grid((unsigned)(n_seq * T), (unsigned)((heads + 2 * kv_heads + 3) / 4));
+  if (kv_dtype == WOQ_F16)
+    hipLaunchKernelGGL(rope_append_kernel<WOQ_F16>, grid, dim3(256), 0, st, qkv, T, start, heads, kv_heads, HD, cs, sn,
+                       kcache, vcache, seq_stride_elems);
+  else if (kv_dtype == WOQ_BF16)
+    hipLaunchKernelGGL(rope_append_kernel<WOQ_BF16>, grid, dim3(256), 0, st, qkv, T, start, heads, kv_heads, HD, cs,
+                       sn, kcache, vcache, seq_stride_elems);
+  else
+    return woq::fail("QBits: unsupported KV cache dtype");
+  return 0;
+}
+
+template <int KVD, int HD>
+static int launch_attn_prefill_t(const _Float16* qkv, int n_seq, int T, int start, int heads, int kv_heads,
+                                 const void* kcache, const void* vcache, size_t seq_stride_elems, _Float16* out,
+                                 hipStream_t st) {
+  auto k = attn_prefill_kernel<KVD, HD>;
+  const int nqb = (T + AQB - 1) / AQB;
+  hipLaunchKernelGGL(k, dim3((unsigned)nqb, (unsigned)heads, (unsigned)n_seq), dim3(256), attn_lds_bytes<HD>(), st, qkv,
+                     T, start, heads, kv_heads, kcache, vcache, seq_stride_elems, out, nqb);
+  return 0;
+}
+
+int launch_attn_prefill(const _Float16* qkv, int n_seq, int T, int start, int heads, int kv_heads, int HD,
+                        const void* kcache, const void* vcache, int kv_dtype, size_t seq_stride_elems, _Float16* out,
+                        hipStream_t st) {
+  if (HD != 64 && HD != 128) return woq::fail("QBits: attention head_dim must be 64 or 128");
+#define WOQ_ATTN_CASE(KVD)                                                                                          \
+  if (kv_dtype == KVD)                                                                                              \
+    return HD == 128 ? launch_attn_prefill_t<KVD, 128>(qkv, n_seq, T, start, heads, kv_heads, kcache, vcache,       \
+                                                       seq_stride_elems, out, st)                                  \
+                     : launch_attn_prefill_t<KVD, 64>(qkv, n_seq, T, start, heads, kv_heads, kcache, vcache,        \
+                                                      seq_stride_elems, out, st);
+  WOQ_ATTN_CASE(WOQ_F16)
+  WOQ_ATTN_CASE(WOQ_BF16)
+#undef WOQ_ATTN_CASE
+  return woq::fail("QBits: unsupported KV cache dtype");
+}
+
+void launch_gather_last(const float* h, int n_seq, int T, int hidden, float* dst, hipStream_t st) {
+  hipLaunchKernelGGL(gather_last_kernel, dim3(n_seq), dim3(256), 0, st, h, T, hidden, dst);
+}
+
+}  // namespace woq

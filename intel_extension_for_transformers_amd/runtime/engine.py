@@ -36,12 +36,14 @@ class WoqDecoderEngine:
     """Owns the native engine plus the torch tensors whose device memory it points at."""
 
     def __init__(self, hidden, inter, heads, kv_heads, head_dim, layers, vocab, max_ctx=2048, rms_eps=1e-5,
-                 rope_theta=10000.0, kv_dtype=torch.float16, tp_rank=0, tp_size=1, device=None):
+                 rope_theta=10000.0, kv_dtype=torch.float16, tp_rank=0, tp_size=1, device=None, max_batch=1):
         L.require_gpu()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.cfg = L.EngineConfig(hidden=hidden, inter=inter, heads=heads, kv_heads=kv_heads, head_dim=head_dim,
                                   layers=layers, vocab=vocab, max_ctx=max_ctx, rms_eps=rms_eps, rope_theta=rope_theta,
                                   tp_rank=tp_rank, tp_size=tp_size, kv_dtype=L.torch_dtype_code(kv_dtype))
+        self.cfg.reserved[0] = int(max_batch)
+        self.max_batch = int(max_batch)
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             L.check(L.lib().woq_engine_create(ctypes.byref(self.cfg), ctypes.byref(self._h)))
@@ -133,21 +135,45 @@ class WoqDecoderEngine:
             dist.all_reduce(self.hidden, group=group)
         self.phase(0, 2, greedy)
 
-    def generate(self, prompt_ids, max_new_tokens):
-        """Greedy decode: feed the prompt token by token (batch-1 decode path), then chain steps on device."""
+    def prefill(self, tokens, start_pos=0, greedy=True):
+        """Prompt pass: `tokens` int [T] or [n_seq, T] at positions start_pos.. of each sequence's KV cache (all
+        linears as MFMA GEMMs over n_seq*T rows, causal attention over the cache). Returns the last-position logits
+        fp32 [n_seq, vocab] (a view of engine memory, valid until the next prefill). Sequence 0 is the one
+        step()/replay() continue: with greedy its next token and position are already in place."""
+        t = torch.as_tensor(tokens, dtype=torch.int32, device=self.device)
+        if t.dim() == 1:
+            t = t.unsqueeze(0)
+        t = t.contiguous()
+        n_seq, T = t.shape
+        L.check(L.lib().woq_engine_prefill(self._h, t.data_ptr(), int(n_seq), int(T), int(start_pos), int(greedy),
+                                           L.stream_ptr()))
+        ptr = L.lib().woq_engine_prefill_logits_ptr(self._h)
+        return _device_view(ptr, (n_seq, self.cfg.vocab), self.device)
+
+    def generate(self, prompt_ids, max_new_tokens, chunk=2048):
+        """Greedy decode: the prompt goes through the prefill pass in chunks of `chunk` tokens, then steps are
+        chained on the device."""
         out = []
-        self.reset(prompt_ids[0], 0)
-        for i, t in enumerate(prompt_ids):
-            self.token.fill_(int(t))
-            self.pos.fill_(i)
-            last = i == len(prompt_ids) - 1
-            self.step(greedy=last)
+        ids = [int(t) for t in prompt_ids]
+        for s0 in range(0, len(ids), chunk):
+            self.prefill(ids[s0:s0 + chunk], start_pos=s0, greedy=True)
         for _ in range(max_new_tokens):
             out.append(int(self.token.item()))
             if len(out) == max_new_tokens:
                 break
             self.step(greedy=True)
         return out
+
+
+def _device_view(ptr, shape, device):
+    """fp32 torch view of engine-owned device memory (no copy) through the CUDA array interface."""
+
+    class _Raw:
+        pass
+
+    raw = _Raw()
+    raw.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(raw, device=device)
 
 
 def synth_llama_weights(engine, hidden, inter, heads, kv_heads, head_dim, layers, vocab, group=128, sym=True,
