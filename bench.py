@@ -79,6 +79,33 @@ def cpu_baseline(eng, cfg, budget_s=12.0):
     }
 
 
+def prefill_measure(eng, cfg, n_seq, T, reps=2):
+    """Prompt pass of the same model (north_star: MFMA utilisation on the prefill side): n_seq x T synthetic tokens
+    through all layers (int4 x fp16-operand MFMA GEMMs + causal attention), after the decode timing. Not `value`."""
+    import torch
+
+    g = torch.Generator().manual_seed(4321)
+    toks = torch.randint(0, cfg["vocab"], (n_seq, T), generator=g).cuda()
+    eng.prefill(toks)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.prefill(toks)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    h, i, hd = cfg["hidden"], cfg["inter"], cfg["head_dim"]
+    params = cfg["layers"] * (h * (cfg["heads"] + 2 * cfg["kv_heads"]) * hd + cfg["heads"] * hd * h + 3 * h * i)
+    lin = 2.0 * params * n_seq * T
+    att = cfg["layers"] * n_seq * 4.0 * cfg["heads"] * hd * T * (T + 1) / 2
+    return {
+        "workload": "prompt pass, %d x %d tokens, same int4 g128 weights, fp16-operand MFMA GEMMs + causal attention, "
+                    "lm_head on the last positions" % (n_seq, T),
+        "tokens_per_s": n_seq * T / dt, "ms": dt * 1e3,
+        "achieved_tflops": (lin + att) / dt / 1e12, "linear_tflops": lin / dt / 1e12,
+        "peak_tflops": 2500.0, "mfma_frac": (lin + att) / dt / 1e12 / 2500.0,
+    }
+
+
 def read_traffic():
     """HBM bytes per dominant-kernel launch from the committed PMC pass (None if there is none)."""
     pdir = os.path.join(ROOT, "profiles")
@@ -103,6 +130,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--prompt", type=int, default=32, help="positions already in the KV cache when timing starts")
     ap.add_argument("--layers", type=int, default=LLAMA2_7B["layers"])
+    ap.add_argument("--prefill-seqs", type=int, default=4, help="sequences in the prompt-pass measurement (0 = skip)")
+    ap.add_argument("--prefill-len", type=int, default=2048, help="tokens per sequence in the prompt-pass measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
@@ -126,8 +155,10 @@ def main():
 
     cfg = dict(LLAMA2_7B, layers=args.layers)
     max_ctx = 1 << max(9, (args.prompt + args.warmup + args.steps + 8).bit_length())
+    if args.prefill_seqs > 0:
+        max_ctx = max(max_ctx, args.prefill_len)
     eng = WoqDecoderEngine(cfg["hidden"], cfg["inter"], cfg["heads"], cfg["kv_heads"], cfg["head_dim"], cfg["layers"],
-                           cfg["vocab"], max_ctx=max_ctx)
+                           cfg["vocab"], max_ctx=max_ctx, max_batch=max(1, args.prefill_seqs))
     synth_llama_weights(eng, cfg["hidden"], cfg["inter"], cfg["heads"], cfg["kv_heads"], cfg["head_dim"],
                         cfg["layers"], cfg["vocab"], group=128, sym=True, scale_dtype="fp16", seed=1234 + rank)
 
@@ -209,6 +240,8 @@ def main():
                 "launches_per_token": n_launch,
             },
         }
+        if args.prefill_seqs > 0:
+            out["prefill"] = prefill_measure(eng, cfg, args.prefill_seqs, args.prefill_len)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(eng, cfg)
         print(json.dumps(out), flush=True)

@@ -107,8 +107,9 @@ __device__ __forceinline__ void pack_load8(const PackF16Args& a, size_t base, in
   }
 }
 
-template <int MODE, bool CACHED>
+template <int MODE, int NC>  // NC > 0: row cached in registers, NC chunks per thread; 0: two sweeps
 __device__ __forceinline__ void pack_row(const PackF16Args& a, int r, float* red) {
+  constexpr bool CACHED = NC > 0;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int mb = r >> 7, rl = r & 127;
   const int chunks = a.Kpad >> 3;
@@ -117,7 +118,7 @@ __device__ __forceinline__ void pack_row(const PackF16Args& a, int r, float* red
   _Float16* dst_row = a.ap + (size_t)mb * (a.Kpad >> 7) * tile_halves + (size_t)rl * 128;
   const size_t base = (size_t)r * a.lda;
   const bool norm = a.norm_w != nullptr;
-  constexpr int NI = CACHED ? PACK_MAXI : 1;
+  constexpr int NI = CACHED ? NC : 1;
   float v[NI][8];
   float amax = 0.f, ss = 0.f;
   auto fetch = [&](int c, bool valid, float (&d)[8]) {
@@ -136,10 +137,18 @@ __device__ __forceinline__ void pack_row(const PackF16Args& a, int r, float* red
       }
     }
     if (norm) {
+      float g[8];
+      if (MODE != 2 && c < full) {  // K % 8 == 0 here: whole chunk inside the weight vector
+        const float4_t g0 = *(const float4_t*)(a.norm_w + c * 8), g1 = *(const float4_t*)(a.norm_w + c * 8 + 4);
+        g[0] = g0.x, g[1] = g0.y, g[2] = g0.z, g[3] = g0.w, g[4] = g1.x, g[5] = g1.y, g[6] = g1.z, g[7] = g1.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = a.norm_w[min(c * 8 + j, a.K - 1)];
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         ss = fmaf(d[j], d[j], ss);
-        d[j] *= a.norm_w[min(c * 8 + j, a.K - 1)];
+        d[j] *= g[j];
       }
     }
   };
@@ -228,19 +237,27 @@ __global__ __launch_bounds__(256) void pack_f16_kernel(PackF16Args a) {
   const int esz = a.x_dtype == WOQ_F32 ? 4 : 2;
   const bool vec_ok = a.shuffle == nullptr && (((uintptr_t)a.x) & 15) == 0 && (((size_t)a.lda * esz) & 15) == 0 &&
                       (a.K & 7) == 0;
-  const bool cached = (a.Kpad >> 3) <= PACK_MAXI * 256;
-  if (vec_ok && cached) {
-    if (a.x_dtype == WOQ_F32)
-      pack_row<0, true>(a, r, red);
+  const int per_thread = ((a.Kpad >> 3) + 255) >> 8;  // chunks per thread
+  if (!vec_ok) {
+    pack_row<2, 0>(a, r, red);
+  } else if (a.x_dtype == WOQ_F32) {
+    if (per_thread <= 2)
+      pack_row<0, 2>(a, r, red);
+    else if (per_thread <= 4)
+      pack_row<0, 4>(a, r, red);
+    else if (per_thread <= PACK_MAXI)
+      pack_row<0, PACK_MAXI>(a, r, red);
     else
-      pack_row<1, true>(a, r, red);
-  } else if (vec_ok) {
-    if (a.x_dtype == WOQ_F32)
-      pack_row<0, false>(a, r, red);
-    else
-      pack_row<1, false>(a, r, red);
+      pack_row<0, 0>(a, r, red);
   } else {
-    pack_row<2, false>(a, r, red);
+    if (per_thread <= 2)
+      pack_row<1, 2>(a, r, red);
+    else if (per_thread <= 4)
+      pack_row<1, 4>(a, r, red);
+    else if (per_thread <= PACK_MAXI)
+      pack_row<1, PACK_MAXI>(a, r, red);
+    else
+      pack_row<1, 0>(a, r, red);
   }
 }
 

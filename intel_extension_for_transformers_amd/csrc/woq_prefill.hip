@@ -62,36 +62,68 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const void* __restrict_
 
 // ---- RoPE (HF rotate_half form) on q and k, KV append ------------------------------------------------------------
 // qkv fp16 [M][(heads + 2 kv_heads) * HD]: q rotated in place; k rotated -> K cache; v -> V cache.
-// Row m = sequence m / T, position start + m % T. One wave per (row, head slot).
+// Row m = sequence m / T, position start + m % T. One thread = 8 consecutive d of the first half of one head slot
+// (and their partners in the second half): 16-byte loads and stores throughout.
 template <int KVD>
-__global__ __launch_bounds__(256) void rope_append_kernel(_Float16* __restrict__ qkv, int T, int start, int heads,
-                                                          int kv_heads, int HD, const float* __restrict__ cs,
-                                                          const float* __restrict__ sn, void* __restrict__ kcache,
-                                                          void* __restrict__ vcache, size_t seq_stride_elems) {
-  const int m = blockIdx.x, lane = threadIdx.x & 63;
-  const int slot = (int)blockIdx.y * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void kv_store8(void* base, size_t elem, const float (&v)[8]) {
+  u32x4 w;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t lo, hi;
+    if constexpr (KVD == WOQ_F16) {
+      lo = f32_to_f16_bits(fminf(fmaxf(v[2 * j], -65504.f), 65504.f));
+      hi = f32_to_f16_bits(fminf(fmaxf(v[2 * j + 1], -65504.f), 65504.f));
+    } else {
+      lo = f32_to_bf16_bits(v[2 * j]);
+      hi = f32_to_bf16_bits(v[2 * j + 1]);
+    }
+    w[j] = lo | (hi << 16);
+  }
+  *(u32x4*)((uint16_t*)base + elem) = w;
+}
+
+template <int KVD>
+__global__ __launch_bounds__(256) void rope_append_kernel(_Float16* __restrict__ qkv, int M, int T, int start,
+                                                          int heads, int kv_heads, int HD,
+                                                          const float* __restrict__ cs, const float* __restrict__ sn,
+                                                          void* __restrict__ kcache, void* __restrict__ vcache,
+                                                          size_t seq_stride_elems) {
+  const int half = HD >> 1, cph = half >> 3;  // 8-element chunks per half head
   const int nslots = heads + 2 * kv_heads;
-  if (slot >= nslots) return;
+  const size_t per_row = (size_t)nslots * cph;
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (size_t)M * per_row) return;
+  const int m = (int)(gid / per_row);
+  const int rem = (int)(gid % per_row);
+  const int slot = rem / cph, c8 = (rem % cph) * 8;
   const int seq = m / T, pos = start + m % T;
-  const int half = HD >> 1;
   _Float16* x = qkv + (size_t)m * nslots * HD + (size_t)slot * HD;
+  const h8 xa = *(const h8*)(x + c8), xb = *(const h8*)(x + c8 + half);
+  float ra[8], rb[8];
   if (slot < heads + kv_heads) {
-    for (int i = lane; i < half; i += 64) {
-      const float c = cs[(size_t)pos * half + i], s = sn[(size_t)pos * half + i];
-      const float a = (float)x[i], b = (float)x[i + half];
-      const float ra = a * c - b * s, rb = b * c + a * s;
-      if (slot < heads) {
-        x[i] = (_Float16)fminf(fmaxf(ra, -65504.f), 65504.f);
-        x[i + half] = (_Float16)fminf(fmaxf(rb, -65504.f), 65504.f);
-      } else {
-        const size_t e = (size_t)seq * seq_stride_elems + ((size_t)pos * kv_heads + (slot - heads)) * HD;
-        kv_store<KVD>(kcache, e + i, ra);
-        kv_store<KVD>(kcache, e + i + half, rb);
-      }
+    const float4_t c0 = *(const float4_t*)(cs + (size_t)pos * half + c8), c1 = *(const float4_t*)(cs + (size_t)pos * half + c8 + 4);
+    const float4_t s0 = *(const float4_t*)(sn + (size_t)pos * half + c8), s1 = *(const float4_t*)(sn + (size_t)pos * half + c8 + 4);
+    const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float a = (float)xa[j], b = (float)xb[j];
+      ra[j] = a * cc[j] - b * ss[j];
+      rb[j] = b * cc[j] + a * ss[j];
     }
   } else {
-    const size_t e = (size_t)seq * seq_stride_elems + ((size_t)pos * kv_heads + (slot - heads - kv_heads)) * HD;
-    for (int i = lane; i < HD; i += 64) kv_store<KVD>(vcache, e + i, (float)x[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ra[j] = (float)xa[j], rb[j] = (float)xb[j];
+  }
+  if (slot < heads) {
+    kv_store8<WOQ_F16>(x, c8, ra);
+    kv_store8<WOQ_F16>(x, c8 + half, rb);
+  } else {
+    const int kh = slot < heads + kv_heads ? slot - heads : slot - heads - kv_heads;
+    void* cache = slot < heads + kv_heads ? kcache : vcache;
+    const size_t e = (size_t)seq * seq_stride_elems + ((size_t)pos * kv_heads + kh) * HD;
+    kv_store8<KVD>(cache, e + c8, ra);
+    kv_store8<KVD>(cache, e + c8 + half, rb);
   }
 }
 
@@ -290,12 +322,15 @@ void launch_embed_rows(const void* embed, int dtype, const int32_t* tokens, int 
 int launch_rope_append(_Float16* qkv, int n_seq, int T, int start, int heads, int kv_heads, int HD, const float* cs,
                        const float* sn, void* kcache, void* vcache, int kv_dtype, size_t seq_stride_elems,
                        hipStream_t st) {
-  const dim3 grid((unsigned)(n_seq * T), (unsigned)((heads + 2 * kv_heads + 3) / 4));
+  if ((HD & 15) != 0) return woq::fail("QBits: head_dim must be a multiple of 16");
+  const int M = n_seq * T;
+  const size_t threads = (size_t)M * (heads + 2 * kv_heads) * (HD / 16);
+  const dim3 grid((unsigned)((threads + 255) / 256));
   if (kv_dtype == WOQ_F16)
-    hipLaunchKernelGGL(rope_append_kernel<WOQ_F16>, grid, dim3(256), 0, st, qkv, T, start, heads, kv_heads, HD, cs, sn,
-                       kcache, vcache, seq_stride_elems);
+    hipLaunchKernelGGL(rope_append_kernel<WOQ_F16>, grid, dim3(256), 0, st, qkv, M, T, start, heads, kv_heads, HD, cs,
+                       sn, kcache, vcache, seq_stride_elems);
   else if (kv_dtype == WOQ_BF16)
-    hipLaunchKernelGGL(rope_append_kernel<WOQ_BF16>, grid, dim3(256), 0, st, qkv, T, start, heads, kv_heads, HD, cs,
+    hipLaunchKernelGGL(rope_append_kernel<WOQ_BF16>, grid, dim3(256), 0, st, qkv, M, T, start, heads, kv_heads, HD, cs,
                        sn, kcache, vcache, seq_stride_elems);
   else
     return woq::fail("QBits: unsupported KV cache dtype");
