@@ -63,7 +63,8 @@ extern "C" {
 
 /* element types crossing the ABI (reference: qbits.cpp:31-37 allows fp32|bf16; fp16 added
  * because north_star asks for bf16/fp16 activations) */
-enum woq_dtype { WOQ_F32 = 0, WOQ_BF16 = 1, WOQ_F16 = 2 };
+enum woq_dtype { WOQ_F32 = 0, WOQ_BF16 = 1, WOQ_F16 = 2,
+                 WOQ_FP8_E4M3 = 3 /* OCP e4m3fn; KV-cache storage only (woq_engine_config.kv_dtype) */ };
 
 /* weight types (reference strings: bestla_weightonly_dispatcher.hpp:62-70) */
 enum woq_weight_type { WOQ_W_INT4_CLIP = 0, WOQ_W_INT8 = 1 };
@@ -122,7 +123,7 @@ static inline int woq_nibble_shift(int j) {
   return 8 * (jj & 3) + 4 * (jj >> 2);
 }
 
-static inline size_t woq_dtype_size(uint32_t dt) { return dt == WOQ_F32 ? 4u : 2u; }
+static inline size_t woq_dtype_size(uint32_t dt) { return dt == WOQ_F32 ? 4u : (dt == WOQ_FP8_E4M3 ? 1u : 2u); }
 static inline size_t woq_round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
 /* Fill every derived field of a header from (K, N, group, types, flags).

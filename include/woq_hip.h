@@ -117,7 +117,7 @@ typedef struct woq_engine_config {
   int32_t hidden, inter, heads, kv_heads, head_dim, layers, vocab, max_ctx;
   float rms_eps, rope_theta;
   int32_t tp_rank, tp_size; /* tensor parallel: heads/inter are PER-RANK sizes when tp_size > 1 */
-  int32_t kv_dtype;         /* WOQ_F16 | WOQ_BF16 */
+  int32_t kv_dtype;         /* WOQ_F16 | WOQ_BF16 | WOQ_FP8_E4M3 (unscaled e4m3fn, saturating at +-448) */
   int32_t reserved[3];      /* [0] = max_batch: sequences the KV cache holds for woq_engine_prefill (0 / 1 = one) */
 } woq_engine_config;
 
@@ -161,6 +161,9 @@ WOQ_API int woq_engine_step(woq_engine* e, int greedy, void* stream);
 WOQ_API int woq_engine_prefill(woq_engine* e, const int32_t* tokens_dev, int n_seq, int T, int start_pos, int greedy,
                                void* stream);
 WOQ_API void* woq_engine_prefill_logits_ptr(woq_engine* e);
+/* KV cache base pointers (which: 0 = K, 1 = V), layout [sequence][layer][position][kv_head][head_dim] in kv_dtype:
+ * inspection / tests, and the seam for an external cache manager. */
+WOQ_API void* woq_engine_kv_cache_ptr(woq_engine* e, int which);
 /* capture one step into a hipGraph and replay it `n` times (greedy chaining). */
 WOQ_API int woq_engine_capture(woq_engine* e, int greedy, void* stream);
 WOQ_API int woq_engine_replay(woq_engine* e, int n, void* stream);

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwoq_hip.so")
 
-F32, BF16, F16 = 0, 1, 2
+F32, BF16, F16, FP8_E4M3 = 0, 1, 2, 3
 W_INT4_CLIP, W_INT8 = 0, 1
 C_FP32, C_BF16, C_INT8, C_FP16 = 0, 1, 2, 3
 HEADER_BYTES = 256
@@ -64,7 +64,7 @@ EXPORTS = [
     "woq_engine_create", "woq_engine_destroy", "woq_engine_set_layer", "woq_engine_set_head",
     "woq_engine_bind_io", "woq_engine_token_ptr", "woq_engine_pos_ptr", "woq_engine_logits_ptr", "woq_engine_hidden_ptr",
     "woq_engine_step", "woq_engine_capture", "woq_engine_replay", "woq_engine_set_allreduce", "woq_engine_phase",
-    "woq_engine_time_gemv", "woq_engine_prefill", "woq_engine_prefill_logits_ptr",
+    "woq_engine_time_gemv", "woq_engine_prefill", "woq_engine_prefill_logits_ptr", "woq_engine_kv_cache_ptr",
 ]
 
 _lib = None
@@ -111,6 +111,8 @@ def lib():
     L.woq_engine_prefill.argtypes = [vp, vp, ci, ci, ci, ci, vp]
     L.woq_engine_prefill_logits_ptr.restype = vp
     L.woq_engine_prefill_logits_ptr.argtypes = [vp]
+    L.woq_engine_kv_cache_ptr.restype = vp
+    L.woq_engine_kv_cache_ptr.argtypes = [vp, ci]
     L.woq_engine_time_gemv.argtypes = [vp, ci, vp, ctypes.POINTER(cf), ctypes.POINTER(ctypes.c_double),
                                        ctypes.POINTER(ci)]
     _lib = L

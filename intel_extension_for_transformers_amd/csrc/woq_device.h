@@ -85,4 +85,34 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+
+// ---- OCP e4m3fn (KV-cache storage). Conversions saturate at +-448 (the format has no infinity). ----
+__device__ __forceinline__ uint32_t f32x2_to_fp8x2(float a, float b) {
+  a = fminf(fmaxf(a, -448.f), 448.f);
+  b = fminf(fmaxf(b, -448.f), 448.f);
+  return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
+}
+struct Fp8 {  // one cache element
+  uint8_t b;
+  __device__ Fp8() = default;
+  __device__ explicit Fp8(float f) : b((uint8_t)(f32x2_to_fp8x2(f, 0.f) & 0xffu)) {}
+  __device__ explicit operator float() const { return __builtin_amdgcn_cvt_f32_fp8((int)b, 0); }
+};
+struct __attribute__((aligned(8))) Fp8x8 {  // eight consecutive cache elements
+  uint32_t lo, hi;
+  __device__ Fp8 operator[](int i) const {
+    Fp8 r;
+    r.b = (uint8_t)(((i < 4 ? lo : hi) >> (8 * (i & 3))) & 0xffu);
+    return r;
+  }
+};
+template <typename KV>
+struct KvVec8 {
+  typedef KV type __attribute__((ext_vector_type(8)));
+};
+template <>
+struct KvVec8<Fp8> {
+  typedef Fp8x8 type;
+};
+
 }  // namespace woq

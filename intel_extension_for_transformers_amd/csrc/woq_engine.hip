@@ -170,7 +170,7 @@ static int engine_prefill_impl(woq_engine* e, const int32_t* tokens, int n_seq, 
   const woq_engine_config& c = e->cfg;
   const int M = n_seq * T;
   const int qkv_n = (c.heads + 2 * c.kv_heads) * c.head_dim;
-  const size_t seq_stride = e->kv_layer_bytes / 2 * c.layers;  // cache elements between two sequences
+  const size_t seq_stride = e->kv_layer_bytes / woq_dtype_size((uint32_t)c.kv_dtype) * c.layers;  // elements between sequences
   int rc = engine_prefill_reserve(e, (size_t)M);
   if (rc) return rc;
   launch_embed_rows(e->embed, e->embed_dtype, tokens, M, c.hidden, e->pf_h, st);
@@ -231,12 +231,14 @@ int woq_engine_prefill(woq_engine* e, const int32_t* tokens_dev, int n_seq, int 
 }
 
 void* woq_engine_prefill_logits_ptr(woq_engine* e) { return e ? e->pf_logits : nullptr; }
+void* woq_engine_kv_cache_ptr(woq_engine* e, int which) { return e ? (which ? e->vcache : e->kcache) : nullptr; }
 
 int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
   WOQ_TRY
   WOQ_CHECK(cfg && out, "QBits: null engine config");
   WOQ_CHECK(cfg->heads % cfg->kv_heads == 0, "QBits: heads must be a multiple of kv_heads");
-  WOQ_CHECK(cfg->kv_dtype == WOQ_F16 || cfg->kv_dtype == WOQ_BF16, "QBits: kv_dtype must be fp16 or bf16");
+  WOQ_CHECK(cfg->kv_dtype == WOQ_F16 || cfg->kv_dtype == WOQ_BF16 || cfg->kv_dtype == WOQ_FP8_E4M3,
+            "QBits: kv_dtype must be fp16, bf16 or fp8_e4m3");
   woq_engine* e = new woq_engine();
   e->cfg = *cfg;
   e->layers.resize(cfg->layers);
@@ -250,7 +252,7 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
   WOQ_HIP(hipMalloc((void**)&e->pos, 4));
   WOQ_HIP(hipMemset(e->token, 0, 4));
   WOQ_HIP(hipMemset(e->pos, 0, 4));
-  e->kv_layer_bytes = (size_t)cfg->max_ctx * cfg->kv_heads * cfg->head_dim * 2;
+  e->kv_layer_bytes = (size_t)cfg->max_ctx * cfg->kv_heads * cfg->head_dim * woq_dtype_size((uint32_t)cfg->kv_dtype);
   // KV cache [sequence][layer][position][kv head][d]; sequence 0 is the one the decode step continues
   e->max_batch = cfg->reserved[0] > 1 ? cfg->reserved[0] : 1;
   const size_t kv_total = e->kv_layer_bytes * cfg->layers * e->max_batch;

@@ -87,7 +87,7 @@ __global__ void embed_kernel(const void* __restrict__ embed, int dtype, const in
 // Single-query attention for one new token: one workgroup (4 waves) per query head.
 //   qkv: fp32 [(heads + 2*kv_heads) * HD] un-rotated projections of the new token.
 //   RoPE is applied here to q and to the new k; rotated k and v are appended to the cache (by the first query
-//   head of each kv group) at position pos. kv caches: [max_ctx, kv_heads, HD] (fp16 | bf16). out fp32 [heads*HD].
+//   head of each kv group) at position pos. kv caches: [max_ctx, kv_heads, HD] (fp16 | bf16 | e4m3). out fp32 [heads*HD].
 // Three vectorised phases over the cached positions t < pos (the new position is taken from LDS, so no
 // workgroup ever reads a cache row another workgroup is writing):
 //   scores : 4 lanes per position (HD/4 dims each, 16-B loads), 16 positions per wave per iteration
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
                                                           const float* __restrict__ cs, const float* __restrict__ sn,
                                                           int heads, int kv_heads, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  typedef KV kv8 __attribute__((ext_vector_type(8)));
+  typedef typename KvVec8<KV>::type kv8;
   constexpr int half = HD / 2;
   constexpr int DPL = HD / 4;   // dims per lane in the score phase
   constexpr int LPR = HD / 8;   // lanes per row in the P.V phase
@@ -358,6 +358,10 @@ int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtyp
   if (kv_dtype == WOQ_F16) {
     if (D == 128) return launch_attn_t<_Float16, 128>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, st);
     return launch_attn_t<_Float16, 64>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, st);
+  }
+  if (kv_dtype == WOQ_FP8_E4M3) {
+    if (D == 128) return launch_attn_t<Fp8, 128>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, st);
+    return launch_attn_t<Fp8, 64>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, st);
   }
   if (D == 128) return launch_attn_t<__bf16, 128>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, st);
   return launch_attn_t<__bf16, 64>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, st);

@@ -35,6 +35,17 @@ template <int KVD>
 __device__ __forceinline__ h8 kv_load8(const void* base, size_t elem) {
   if constexpr (KVD == WOQ_F16) {
     return *(const h8*)((const _Float16*)base + elem);
+  } else if constexpr (KVD == WOQ_FP8_E4M3) {
+    const u32x2 raw = *(const u32x2*)((const uint8_t*)base + elem);
+    h8 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t w = j < 2 ? raw.x : raw.y;
+      const auto f = (j & 1) ? __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true) : __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);
+      r[2 * j] = (_Float16)f[0];
+      r[2 * j + 1] = (_Float16)f[1];
+    }
+    return r;
   } else {
     const u32x4 raw = *(const u32x4*)((const uint16_t*)base + elem);
     h8 r;
@@ -43,14 +54,6 @@ __device__ __forceinline__ h8 kv_load8(const void* base, size_t elem) {
     return r;
   }
 }
-template <int KVD>
-__device__ __forceinline__ void kv_store(void* base, size_t elem, float v) {
-  if constexpr (KVD == WOQ_F16)
-    ((_Float16*)base)[elem] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
-  else
-    ((uint16_t*)base)[elem] = f32_to_bf16_bits(v);
-}
-
 // ---- embedding rows: h[m][:] = embed[token[m]][:] (fp32 residual stream) ----------------------------------------
 __global__ __launch_bounds__(256) void embed_rows_kernel(const void* __restrict__ embed, int dtype,
                                                          const int32_t* __restrict__ tokens, int hidden,
@@ -66,6 +69,13 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const void* __restrict_
 // (and their partners in the second half): 16-byte loads and stores throughout.
 template <int KVD>
 __device__ __forceinline__ void kv_store8(void* base, size_t elem, const float (&v)[8]) {
+  if constexpr (KVD == WOQ_FP8_E4M3) {
+    u32x2 w8;
+    w8.x = f32x2_to_fp8x2(v[0], v[1]) | (f32x2_to_fp8x2(v[2], v[3]) << 16);
+    w8.y = f32x2_to_fp8x2(v[4], v[5]) | (f32x2_to_fp8x2(v[6], v[7]) << 16);
+    *(u32x2*)((uint8_t*)base + elem) = w8;
+    return;
+  }
   u32x4 w;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -332,6 +342,9 @@ int launch_rope_append(_Float16* qkv, int n_seq, int T, int start, int heads, in
   else if (kv_dtype == WOQ_BF16)
     hipLaunchKernelGGL(rope_append_kernel<WOQ_BF16>, grid, dim3(256), 0, st, qkv, M, T, start, heads, kv_heads, HD, cs,
                        sn, kcache, vcache, seq_stride_elems);
+  else if (kv_dtype == WOQ_FP8_E4M3)
+    hipLaunchKernelGGL(rope_append_kernel<WOQ_FP8_E4M3>, grid, dim3(256), 0, st, qkv, M, T, start, heads, kv_heads, HD,
+                       cs, sn, kcache, vcache, seq_stride_elems);
   else
     return woq::fail("QBits: unsupported KV cache dtype");
   return 0;
@@ -360,6 +373,7 @@ int launch_attn_prefill(const _Float16* qkv, int n_seq, int T, int start, int he
                                                       seq_stride_elems, out, st);
   WOQ_ATTN_CASE(WOQ_F16)
   WOQ_ATTN_CASE(WOQ_BF16)
+  WOQ_ATTN_CASE(WOQ_FP8_E4M3)
 #undef WOQ_ATTN_CASE
   return woq::fail("QBits: unsupported KV cache dtype");
 }

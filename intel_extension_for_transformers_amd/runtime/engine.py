@@ -32,6 +32,13 @@ def fuse_gate_up(gate, up):
     return torch.cat([g, u], dim=-2).reshape(*lead, 2 * inter).contiguous()
 
 
+def _kv_code(dt):
+    """KV-cache storage dtype -> ABI code: fp16 / bf16, or fp8 (torch.float8_e4m3fn or the string "fp8_e4m3")."""
+    if dt in ("fp8", "fp8_e4m3") or dt == getattr(torch, "float8_e4m3fn", None):
+        return L.FP8_E4M3
+    return L.torch_dtype_code(dt)
+
+
 class WoqDecoderEngine:
     """Owns the native engine plus the torch tensors whose device memory it points at."""
 
@@ -41,7 +48,8 @@ class WoqDecoderEngine:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.cfg = L.EngineConfig(hidden=hidden, inter=inter, heads=heads, kv_heads=kv_heads, head_dim=head_dim,
                                   layers=layers, vocab=vocab, max_ctx=max_ctx, rms_eps=rms_eps, rope_theta=rope_theta,
-                                  tp_rank=tp_rank, tp_size=tp_size, kv_dtype=L.torch_dtype_code(kv_dtype))
+                                  tp_rank=tp_rank, tp_size=tp_size, kv_dtype=_kv_code(kv_dtype))
+        self.kv_dtype = kv_dtype
         self.cfg.reserved[0] = int(max_batch)
         self.max_batch = int(max_batch)
         self._h = ctypes.c_void_p()
@@ -150,6 +158,17 @@ class WoqDecoderEngine:
         ptr = L.lib().woq_engine_prefill_logits_ptr(self._h)
         return _device_view(ptr, (n_seq, self.cfg.vocab), self.device)
 
+    def kv_cache(self, which="k"):
+        """The engine's K or V cache as a torch view [max_batch, layers, max_ctx, kv_heads, head_dim] (no copy)."""
+        c = self.cfg
+        shape = (self.max_batch, c.layers, c.max_ctx, c.kv_heads, c.head_dim)
+        ptr = L.lib().woq_engine_kv_cache_ptr(self._h, 0 if which == "k" else 1)
+        code = c.kv_dtype
+        if code == L.FP8_E4M3:
+            return _device_view(ptr, shape, self.device, "|u1").view(torch.float8_e4m3fn)
+        t = _device_view(ptr, shape, self.device, "<f2")
+        return t if code == L.F16 else t.view(torch.bfloat16)
+
     def generate(self, prompt_ids, max_new_tokens, chunk=2048):
         """Greedy decode: the prompt goes through the prefill pass in chunks of `chunk` tokens, then steps are
         chained on the device."""
@@ -165,14 +184,14 @@ class WoqDecoderEngine:
         return out
 
 
-def _device_view(ptr, shape, device):
-    """fp32 torch view of engine-owned device memory (no copy) through the CUDA array interface."""
+def _device_view(ptr, shape, device, typestr="<f4"):
+    """torch view of engine-owned device memory (no copy) through the CUDA array interface."""
 
     class _Raw:
         pass
 
     raw = _Raw()
-    raw.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+    raw.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
     return torch.as_tensor(raw, device=device)
 
 

@@ -199,3 +199,37 @@ def test_prefill_argument_checks():
         eng.prefill(list(range(60)), start_pos=10)
     with pytest.raises(RuntimeError, match="max_batch"):
         eng.prefill(np.zeros((2, 4), dtype=np.int64))
+
+
+def test_fp8_kv_cache_prefill_and_decode():
+    """kv_dtype fp8_e4m3 (BASELINE configs[4]): the cache holds OCP e4m3fn bytes of the same K / V the fp16 engine
+    holds (3-bit significand: |diff| <= 2^-4 |x| + smallest subnormal step), no NaN codes, and both the prompt pass
+    and the decode step read it back: logits stay within 6e-2 * max|logit| of the fp16-cache engine on a
+    150-token prompt and 3 decode steps."""
+    T = 150
+    rng = np.random.default_rng(9)
+    prompt = rng.integers(0, 384, T).tolist()
+    e16, _, cfg = _tiny(128, False, "fp16", seed=7, max_ctx=256, head_dim=128)
+    e8, _, _ = _tiny(128, False, "fp16", seed=7, max_ctx=256, head_dim=128, kv_dtype=torch.float8_e4m3fn)
+    l16 = e16.prefill(prompt)[0].cpu().numpy().copy()
+    l8 = e8.prefill(prompt)[0].cpu().numpy().copy()
+    for which in ("k", "v"):
+        # layer 0 only: deeper layers see hidden states that already differ through layer 0's fp8 attention
+        c16 = e16.kv_cache(which)[0, :1, :T].float().cpu().numpy()
+        raw = e8.kv_cache(which)[0, :1, :T]
+        bits = raw.view(torch.uint8).cpu().numpy()
+        assert ((bits & 0x7f) != 0x7f).all()  # e4m3fn NaN codes never appear
+        c8 = raw.float().cpu().numpy()
+        assert (np.abs(c8 - c16) <= 2.0 ** -4 * np.abs(c16) + 2.0 ** -9).all()
+    assert np.abs(l8 - l16).max() <= 6e-2 * np.abs(l16).max()
+    for _ in range(3):
+        e16.token.copy_(e8.token)  # same continuation token on both engines
+        e16.step(greedy=True)
+        e8.step(greedy=True)
+        a, b = e16.logits.cpu().numpy(), e8.logits.cpu().numpy()
+        assert np.abs(a - b).max() <= 6e-2 * np.abs(a).max()
+        e16.token.copy_(e8.token)
+    # the decode step's own append wrote e4m3 too
+    k8 = e8.kv_cache("k")[0, :1, T:T + 3].float().cpu().numpy()
+    k16 = e16.kv_cache("k")[0, :1, T:T + 3].float().cpu().numpy()
+    assert (np.abs(k8 - k16) <= 2.0 ** -4 * np.abs(k16) + 2.0 ** -9).all()
