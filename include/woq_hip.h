@@ -118,7 +118,9 @@ typedef struct woq_engine_config {
   float rms_eps, rope_theta;
   int32_t tp_rank, tp_size; /* tensor parallel: heads/inter are PER-RANK sizes when tp_size > 1 */
   int32_t kv_dtype;         /* WOQ_F16 | WOQ_BF16 | WOQ_FP8_E4M3 (unscaled e4m3fn, saturating at +-448) */
-  int32_t reserved[3];      /* [0] = max_batch: sequences the KV cache holds for woq_engine_prefill (0 / 1 = one) */
+  int32_t reserved[3];      /* [0] = max_batch: sequences the KV cache holds for woq_engine_prefill (0 / 1 = one);
+                             * [1] = attn_splits: context slices per head in the decode attention (0 = automatic:
+                             *       1 up to max_ctx 4096, else 256 / heads clamped to [2, 16]) */
 } woq_engine_config;
 
 typedef struct woq_layer_weights {

@@ -25,7 +25,7 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
 void launch_embed(const void* embed, int dtype, const int32_t* token, int hidden, float* out, hipStream_t st);
 int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
                        const float* cs, const float* sn, int heads, int kv_heads, int D, int max_ctx, float* out,
-                       hipStream_t st);
+                       int splits, float* part, hipStream_t st);
 void launch_lm_head(const float* hidden_in, const float* norm_w, float eps, const void* W, int w_dtype, int hidden,
                     int vocab, float* logits, hipStream_t st);
 void launch_argmax(const float* logits, int vocab, int32_t* token, int32_t* pos, hipStream_t st);
@@ -72,6 +72,8 @@ struct woq_engine {
   int nt = 1;
   std::vector<void*> owned;  // everything hipMalloc'ed by create()
   // prompt pass: [n_seq * T] rows at a time; buffers grow on demand (never inside a captured graph)
+  int attn_splits = 1;          // decode attention: context slices per head (long contexts)
+  float* attn_part = nullptr;   // fp32 [heads][attn_splits][head_dim + 2] partials
   int max_batch = 1;
   size_t pf_rows = 0, pf_ws_bytes = 0;
   float* pf_h = nullptr;        // fp32 residual stream [rows][hidden]
@@ -92,7 +94,8 @@ static int engine_attn_block(woq_engine* e, int l, hipStream_t st) {
                                    w.qkv_hdr.N, 1, w.ln1, c.rms_eps, nullptr, 0, 0, e->nt, st);
   if (rc) return rc;
   rc = launch_attn_decode(e->qkv, e->kcache + (size_t)l * e->kv_layer_bytes, e->vcache + (size_t)l * e->kv_layer_bytes,
-                          c.kv_dtype, e->pos, e->cs, e->sn, c.heads, c.kv_heads, c.head_dim, c.max_ctx, e->attn, st);
+                          c.kv_dtype, e->pos, e->cs, e->sn, c.heads, c.kv_heads, c.head_dim, c.max_ctx, e->attn,
+                          e->attn_splits, e->attn_part, st);
   if (rc) return rc;
   // row-parallel o_proj: rank 0 carries the residual so that the sum over ranks adds it exactly once
   const float* res = (c.tp_size <= 1 || c.tp_rank == 0) ? e->hidden : nullptr;
@@ -260,10 +263,15 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
   WOQ_HIP(hipMalloc((void**)&e->vcache, kv_total));
   WOQ_HIP(hipMemset(e->kcache, 0, kv_total));
   WOQ_HIP(hipMemset(e->vcache, 0, kv_total));
+  // decode attention slices: reserved[1] if given, else enough to fill the chip once the context is long
+  e->attn_splits = cfg->reserved[1] > 0 ? cfg->reserved[1]
+                   : (cfg->max_ctx > 4096 ? std::max(2, std::min(16, 256 / std::max(1, (int)cfg->heads))) : 1);
+  WOQ_CHECK(e->attn_splits <= 64, "QBits: attn_splits must be <= 64");
+  WOQ_HIP(hipMalloc((void**)&e->attn_part, (size_t)cfg->heads * e->attn_splits * (cfg->head_dim + 2) * 4));
   WOQ_HIP(hipMalloc((void**)&e->pf_last, (size_t)e->max_batch * cfg->hidden * 4));
   WOQ_HIP(hipMalloc((void**)&e->pf_logits, (size_t)e->max_batch * cfg->vocab * 4));
   e->owned = {e->hidden, e->qkv, e->attn, e->act, e->logits, e->token, e->pos, e->kcache, e->vcache, e->pf_last,
-              e->pf_logits};
+              e->pf_logits, e->attn_part};
   *out = e;
   WOQ_END
 }

@@ -93,7 +93,11 @@ __global__ void embed_kernel(const void* __restrict__ embed, int dtype, const in
 //   scores : 4 lanes per position (HD/4 dims each, 16-B loads), 16 positions per wave per iteration
 //   softmax: block max / sum over the LDS score row
 //   P.V    : HD/8 lanes per position (one 16-B load each), 4x unrolled, fp32 accumulate
-template <typename KV, int HD>
+// SPLIT (long contexts, flash-decoding style): gridDim.y workgroups per head, each over its own slice of the cached
+// positions (the last slice also takes the new position) -> un-normalised partial (o[HD], max, sum) per (head,
+// slice) in `out`; attn_combine_kernel merges them. A lone workgroup per head streams the cache at one CU's
+// ~10 B/clk, which is why contexts beyond a few thousand positions need the slices.
+template <typename KV, int HD, bool SPLIT>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv, KV* __restrict__ kcache,
                                                           KV* __restrict__ vcache, const int32_t* __restrict__ pos_p,
                                                           const float* __restrict__ cs, const float* __restrict__ sn,
@@ -106,7 +110,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
   constexpr int GP = 64 / LPR;  // position groups per wave in the P.V phase
   const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int rep = heads / kv_heads, kh = h / rep;
-  const int pos = pos_p[0];
+  const int apos = pos_p[0];  // absolute position of the new token = number of cached positions
+  int t_lo = 0, pos = apos;   // this workgroup's cached slice is [t_lo, t_lo + pos)
+  bool incl_new = true;
+  if constexpr (SPLIT) {
+    const int ns = (int)gridDim.y, sp = (int)blockIdx.y;
+    const int chunk = (((apos + ns - 1) / ns) + 63) & ~63;
+    t_lo = min(sp * chunk, apos);
+    pos = min(apos - t_lo, chunk);
+    incl_new = sp == ns - 1;
+    kcache += (size_t)t_lo * kv_heads * HD;
+    vcache += (size_t)t_lo * kv_heads * HD;
+  }
+  const int npos_abs = apos - t_lo;  // row of the new position relative to the re-based cache pointers
   float* qs = sm;                 // [HD] rotated q (pre-scaled by 1/sqrt(HD))
   float* kn = qs + HD;            // [HD] rotated new k, rounded to the cache dtype
   float* vn = kn + HD;            // [HD] new v, rounded to the cache dtype
@@ -134,7 +150,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     vpre[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
   }
   if (tid < half) {
-    const float c = cs[(size_t)pos * half + tid], s = sn[(size_t)pos * half + tid];
+    const float c = cs[(size_t)apos * half + tid], s = sn[(size_t)apos * half + tid];
     const float* q = qkv + (size_t)h * HD;
     const float* k = qkv + (size_t)(heads + kh) * HD;
     const float qa = q[tid], qb = q[tid + half], ka = k[tid], kb = k[tid + half];
@@ -146,9 +162,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     vn[tid - 128] = (float)(KV)qkv[(size_t)(heads + kv_heads + kh) * HD + (tid - 128)];
   }
   __syncthreads();
-  if (h % rep == 0 && tid < HD) {
-    kcache[((size_t)pos * kv_heads + kh) * HD + tid] = (KV)kn[tid];
-    vcache[((size_t)pos * kv_heads + kh) * HD + tid] = (KV)vn[tid];
+  if (h % rep == 0 && tid < HD && incl_new) {
+    kcache[((size_t)npos_abs * kv_heads + kh) * HD + tid] = (KV)kn[tid];
+    vcache[((size_t)npos_abs * kv_heads + kh) * HD + tid] = (KV)vn[tid];
   }
   // ---- scores for cached positions ----
   float qreg[DPL];
@@ -178,7 +194,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     for (int j = 0; j < DPL / 8; ++j) kv[j] = kp[j];
     score(t0, kv);
   }
-  if (tid == 0) {  // the new position, from LDS
+  if (tid == 0 && incl_new) {  // the new position, from LDS
     float d = 0.f;
     for (int i = 0; i < HD; ++i) d = fmaf(qs[i], kn[i], d);
     sc[pos] = d;
@@ -189,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
   __syncthreads();
   const float mx = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
   float lsum = 0.f;
-  for (int t = tid; t <= pos; t += 256) {
+  for (int t = tid; t < pos + (incl_new ? 1 : 0); t += 256) {
     const float p = __expf(sc[t] - mx);
     sc[t] = p;
     lsum += p;
@@ -221,7 +237,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     }
     pv(t0, vv);
   }
-  if (wid == 0 && g == 0) {  // the new position
+  if (wid == 0 && g == 0 && incl_new) {  // the new position
     const float p = sc[pos];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, vn[l8 * 8 + i], acc[i]);
@@ -234,9 +250,37 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     float o = 0.f;
 #pragma unroll
     for (int s2 = 0; s2 < 4 * GP; ++s2) o += slab[s2 * HD + tid];
-    out[(size_t)h * HD + tid] = o / den;
+    if constexpr (SPLIT) {
+      float* part = out + ((size_t)h * gridDim.y + blockIdx.y) * (HD + 2);
+      part[tid] = o;
+      if (tid == 0) {
+        part[HD] = mx;
+        part[HD + 1] = den;
+      }
+    } else {
+      out[(size_t)h * HD + tid] = o / den;
+    }
   }
 }
+
+// merge the slices of attn_decode_kernel<SPLIT>: out[h][d] = sum_s o_s[d] e^(m_s - m) / sum_s l_s e^(m_s - m)
+template <int HD>
+__global__ __launch_bounds__(HD) void attn_combine_kernel(const float* __restrict__ part, int ns,
+                                                         float* __restrict__ out) {
+  const int h = blockIdx.x, d = threadIdx.x;
+  const float* p = part + (size_t)h * ns * (HD + 2);
+  float m = -INFINITY;
+  for (int s = 0; s < ns; ++s) m = fmaxf(m, p[(size_t)s * (HD + 2) + HD]);
+  float l = 0.f, o = 0.f;
+  for (int s = 0; s < ns; ++s) {
+    const float ms = p[(size_t)s * (HD + 2) + HD];
+    const float w = ms == -INFINITY ? 0.f : __expf(ms - m);
+    l = fmaf(p[(size_t)s * (HD + 2) + HD + 1], w, l);
+    o = fmaf(p[(size_t)s * (HD + 2) + d], w, o);
+  }
+  out[(size_t)h * HD + d] = o / l;
+}
+
 
 // logits[v] = sum_h xn[h] * W[v][h], W dense fp16/bf16 [vocab, hidden] (lm_head is NOT quantised:
 // utils/config.py:836-837). Final RMSNorm fused in the prologue. One wave per vocab row, 4 rows per WG.
@@ -336,11 +380,25 @@ void launch_embed(const void* embed, int dtype, const int32_t* token, int hidden
 
 template <typename KV, int HD>
 static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int32_t* pos, const float* cs,
-                         const float* sn, int heads, int kv_heads, int max_ctx, float* out, hipStream_t st) {
+                         const float* sn, int heads, int kv_heads, int max_ctx, float* out, int splits, float* part,
+                         hipStream_t st) {
   constexpr int GP = 64 / (HD / 8);
-  const size_t lds = (size_t)(3 * HD + 8 + 4 * GP * HD + ((max_ctx + 3) & ~3)) * 4;
-  if (lds > 160 * 1024) return woq::fail("QBits: max_ctx too large for the single-pass decode attention");
-  auto k = attn_decode_kernel<KV, HD>;
+  const int span = splits > 1 ? ((((max_ctx + splits - 1) / splits) + 63) & ~63) + 64 : max_ctx;
+  const size_t lds = (size_t)(3 * HD + 8 + 4 * GP * HD + ((span + 4) & ~3)) * 4;
+  if (lds > 160 * 1024) return woq::fail("QBits: max_ctx too large for the decode attention (raise attn_splits)");
+  if (splits > 1) {
+    auto k = attn_decode_kernel<KV, HD, true>;
+    static bool once = false;
+    if (!once) {
+      hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      once = true;
+    }
+    hipLaunchKernelGGL(k, dim3(heads, splits), dim3(256), lds, st, qkv, (KV*)kcache, (KV*)vcache, pos, cs, sn, heads,
+                       kv_heads, part);
+    hipLaunchKernelGGL(attn_combine_kernel<HD>, dim3(heads), dim3(HD), 0, st, part, splits, out);
+    return 0;
+  }
+  auto k = attn_decode_kernel<KV, HD, false>;
   static bool once = false;
   if (!once) {
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -351,20 +409,21 @@ static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int
   return 0;
 }
 
+// splits <= 1: one workgroup per head (short contexts); else `splits` slices per head + a combine launch, partials in
+// `part` (fp32 [heads][splits][D + 2]).
 int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
                        const float* cs, const float* sn, int heads, int kv_heads, int D, int max_ctx, float* out,
-                       hipStream_t st) {
+                       int splits, float* part, hipStream_t st) {
   if (D != 64 && D != 128) return woq::fail("QBits: attention head_dim must be 64 or 128");
-  if (kv_dtype == WOQ_F16) {
-    if (D == 128) return launch_attn_t<_Float16, 128>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, st);
-    return launch_attn_t<_Float16, 64>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, st);
-  }
-  if (kv_dtype == WOQ_FP8_E4M3) {
-    if (D == 128) return launch_attn_t<Fp8, 128>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, st);
-    return launch_attn_t<Fp8, 64>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, st);
-  }
-  if (D == 128) return launch_attn_t<__bf16, 128>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, st);
-  return launch_attn_t<__bf16, 64>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, st);
+#define WOQ_ATTN_DEC(T)                                                                                              \
+  return D == 128 ? launch_attn_t<T, 128>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, splits,   \
+                                          part, st)                                                                 \
+                  : launch_attn_t<T, 64>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, splits,    \
+                                         part, st);
+  if (kv_dtype == WOQ_F16) { WOQ_ATTN_DEC(_Float16) }
+  if (kv_dtype == WOQ_FP8_E4M3) { WOQ_ATTN_DEC(Fp8) }
+  WOQ_ATTN_DEC(__bf16)
+#undef WOQ_ATTN_DEC
 }
 
 void launch_lm_head(const float* hidden_in, const float* norm_w, float eps, const void* W, int w_dtype, int hidden,

@@ -43,7 +43,8 @@ class WoqDecoderEngine:
     """Owns the native engine plus the torch tensors whose device memory it points at."""
 
     def __init__(self, hidden, inter, heads, kv_heads, head_dim, layers, vocab, max_ctx=2048, rms_eps=1e-5,
-                 rope_theta=10000.0, kv_dtype=torch.float16, tp_rank=0, tp_size=1, device=None, max_batch=1):
+                 rope_theta=10000.0, kv_dtype=torch.float16, tp_rank=0, tp_size=1, device=None, max_batch=1,
+                 attn_splits=0):
         L.require_gpu()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.cfg = L.EngineConfig(hidden=hidden, inter=inter, heads=heads, kv_heads=kv_heads, head_dim=head_dim,
@@ -51,6 +52,7 @@ class WoqDecoderEngine:
                                   tp_rank=tp_rank, tp_size=tp_size, kv_dtype=_kv_code(kv_dtype))
         self.kv_dtype = kv_dtype
         self.cfg.reserved[0] = int(max_batch)
+        self.cfg.reserved[1] = int(attn_splits)
         self.max_batch = int(max_batch)
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
