@@ -120,7 +120,7 @@ typedef struct woq_engine_config {
   int32_t kv_dtype;         /* WOQ_F16 | WOQ_BF16 | WOQ_FP8_E4M3 (unscaled e4m3fn, saturating at +-448) */
   int32_t reserved[3];      /* [0] = max_batch: sequences the KV cache holds for woq_engine_prefill (0 / 1 = one);
                              * [1] = attn_splits: context slices per head in the decode attention (0 = automatic:
-                             *       1 up to max_ctx 4096, else 256 / heads clamped to [2, 16]) */
+                             *       1 up to max_ctx 4096, else 1024 / heads clamped to [2, 32]) */
 } woq_engine_config;
 
 typedef struct woq_layer_weights {
@@ -163,6 +163,11 @@ WOQ_API int woq_engine_step(woq_engine* e, int greedy, void* stream);
 WOQ_API int woq_engine_prefill(woq_engine* e, const int32_t* tokens_dev, int n_seq, int T, int start_pos, int greedy,
                                void* stream);
 WOQ_API void* woq_engine_prefill_logits_ptr(woq_engine* e);
+/* decode attention regime: 1 = one workgroup per head (fastest up to a few hundred cached positions), n > 1 = n
+ * context slices per head + a combine launch (long contexts). Takes effect at the next step / capture; a graph
+ * captured earlier keeps the regime it was captured with. */
+WOQ_API int woq_engine_set_attn_splits(woq_engine* e, int splits);
+WOQ_API int woq_engine_attn_splits(woq_engine* e);
 /* KV cache base pointers (which: 0 = K, 1 = V), layout [sequence][layer][position][kv_head][head_dim] in kv_dtype:
  * inspection / tests, and the seam for an external cache manager. */
 WOQ_API void* woq_engine_kv_cache_ptr(woq_engine* e, int which);

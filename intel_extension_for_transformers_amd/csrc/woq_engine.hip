@@ -234,6 +234,13 @@ int woq_engine_prefill(woq_engine* e, const int32_t* tokens_dev, int n_seq, int 
 }
 
 void* woq_engine_prefill_logits_ptr(woq_engine* e) { return e ? e->pf_logits : nullptr; }
+int woq_engine_set_attn_splits(woq_engine* e, int splits) {
+  WOQ_TRY
+  WOQ_CHECK(e && splits >= 1 && splits <= 64, "QBits: attn_splits must be in [1, 64]");
+  e->attn_splits = splits;  // takes effect at the next step / capture (a captured graph keeps its own)
+  WOQ_END
+}
+int woq_engine_attn_splits(woq_engine* e) { return e ? e->attn_splits : 0; }
 void* woq_engine_kv_cache_ptr(woq_engine* e, int which) { return e ? (which ? e->vcache : e->kcache) : nullptr; }
 
 int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
@@ -265,9 +272,9 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
   WOQ_HIP(hipMemset(e->vcache, 0, kv_total));
   // decode attention slices: reserved[1] if given, else enough to fill the chip once the context is long
   e->attn_splits = cfg->reserved[1] > 0 ? cfg->reserved[1]
-                   : (cfg->max_ctx > 4096 ? std::max(2, std::min(16, 256 / std::max(1, (int)cfg->heads))) : 1);
+                   : (cfg->max_ctx > 4096 ? std::max(2, std::min(32, 1024 / std::max(1, (int)cfg->heads))) : 1);
   WOQ_CHECK(e->attn_splits <= 64, "QBits: attn_splits must be <= 64");
-  WOQ_HIP(hipMalloc((void**)&e->attn_part, (size_t)cfg->heads * e->attn_splits * (cfg->head_dim + 2) * 4));
+  WOQ_HIP(hipMalloc((void**)&e->attn_part, (size_t)cfg->heads * 64 * (cfg->head_dim + 2) * 4));  // room for 64 slices
   WOQ_HIP(hipMalloc((void**)&e->pf_last, (size_t)e->max_batch * cfg->hidden * 4));
   WOQ_HIP(hipMalloc((void**)&e->pf_logits, (size_t)e->max_batch * cfg->vocab * 4));
   e->owned = {e->hidden, e->qkv, e->attn, e->act, e->logits, e->token, e->pos, e->kcache, e->vcache, e->pf_last,

@@ -108,7 +108,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
   constexpr int DPL = HD / 4;   // dims per lane in the score phase
   constexpr int LPR = HD / 8;   // lanes per row in the P.V phase
   constexpr int GP = 64 / LPR;  // position groups per wave in the P.V phase
-  const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // workgroup ids go round-robin over the 8 XCDs: give every XCD a run of consecutive heads, so that the query heads
+  // sharing a kv head (GQA) share an L2 instead of pulling the same cache rows into several
+  const int bx = (int)blockIdx.x;
+  const int h = (heads & 7) == 0 ? (bx & 7) * (heads >> 3) + (bx >> 3) : bx;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int rep = heads / kv_heads, kh = h / rep;
   const int apos = pos_p[0];  // absolute position of the new token = number of cached positions
   int t_lo = 0, pos = apos;   // this workgroup's cached slice is [t_lo, t_lo + pos)
@@ -186,13 +190,26 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     }
   };
   if (wid * 16 < pos) score(wid * 16, kpre);
-  for (int t0 = wid * 16 + 64; t0 < pos; t0 += 64) {
-    const int tc = min(t0 + (lane >> 2), pos - 1);
-    const kv8* kp = (const kv8*)(kcache + ((size_t)tc * kv_heads + kh) * HD + sub * DPL);
-    kv8 kv[DPL / 8];
+  {
+    // rows of iteration i+1 are in flight while iteration i is scored (a lone dependent load per iteration would
+    // expose the full HBM latency every 64 positions)
+    auto kload = [&](int t0, kv8 (&kv)[DPL / 8]) {
+      const int tc = min(t0 + (lane >> 2), max(pos - 1, 0));
+      const kv8* kp = (const kv8*)(kcache + ((size_t)tc * kv_heads + kh) * HD + sub * DPL);
 #pragma unroll
-    for (int j = 0; j < DPL / 8; ++j) kv[j] = kp[j];
-    score(t0, kv);
+      for (int j = 0; j < DPL / 8; ++j) kv[j] = kp[j];
+    };
+    kv8 ka[DPL / 8], kb[DPL / 8];
+    int t0 = wid * 16 + 64;
+    if (t0 < pos) kload(t0, ka);
+    for (; t0 < pos; t0 += 128) {
+      if (t0 + 64 < pos) kload(t0 + 64, kb);
+      score(t0, ka);
+      if (t0 + 64 < pos) {
+        if (t0 + 128 < pos) kload(t0 + 128, ka);
+        score(t0 + 64, kb);
+      }
+    }
   }
   if (tid == 0 && incl_new) {  // the new position, from LDS
     float d = 0.f;
@@ -228,14 +245,25 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     }
   };
   if (wid * GP + g < pos) pv(wid * GP + g, vpre);
-  for (int t0 = wid * GP + g + 4 * TSTEP; t0 < pos; t0 += 4 * TSTEP) {
-    kv8 vv[4];
+  {
+    auto vload = [&](int t0, kv8 (&vv)[4]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int tc = min(t0 + u * TSTEP, pos - 1);
-      vv[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
+      for (int u = 0; u < 4; ++u) {
+        const int tc = min(t0 + u * TSTEP, max(pos - 1, 0));
+        vv[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
+      }
+    };
+    kv8 va[4], vb[4];
+    int t0 = wid * GP + g + 4 * TSTEP;
+    if (t0 < pos) vload(t0, va);
+    for (; t0 < pos; t0 += 8 * TSTEP) {
+      if (t0 + 4 * TSTEP < pos) vload(t0 + 4 * TSTEP, vb);
+      pv(t0, va);
+      if (t0 + 4 * TSTEP < pos) {
+        if (t0 + 8 * TSTEP < pos) vload(t0 + 8 * TSTEP, va);
+        pv(t0 + 4 * TSTEP, vb);
+      }
     }
-    pv(t0, vv);
   }
   if (wid == 0 && g == 0 && incl_new) {  // the new position
     const float p = sc[pos];

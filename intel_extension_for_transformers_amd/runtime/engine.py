@@ -160,6 +160,23 @@ class WoqDecoderEngine:
         ptr = L.lib().woq_engine_prefill_logits_ptr(self._h)
         return _device_view(ptr, (n_seq, self.cfg.vocab), self.device)
 
+    # ---- decode attention regime -----------------------------------------------------------------------------
+    LONG_CTX = 512  # cached positions beyond which the sliced decode attention wins over one workgroup per head
+
+    def set_attn_splits(self, n):
+        """1 = one workgroup per head, n > 1 = n context slices per head + combine. Invalidates a captured graph."""
+        if int(n) != L.lib().woq_engine_attn_splits(self._h):
+            L.check(L.lib().woq_engine_set_attn_splits(self._h, int(n)))
+            self.captured = False
+
+    def tune_attn_for(self, positions):
+        """Pick the regime for a context of `positions` cached tokens (host-side hint: the position lives on the
+        device): slices = enough workgroups to fill the chip, each at least 64 positions."""
+        if positions <= self.LONG_CTX:
+            self.set_attn_splits(1)
+        else:
+            self.set_attn_splits(max(2, min(32, 1024 // max(1, self.cfg.heads), positions // 64)))
+
     def kv_cache(self, which="k"):
         """The engine's K or V cache as a torch view [max_batch, layers, max_ctx, kv_heads, head_dim] (no copy)."""
         c = self.cfg
@@ -178,6 +195,7 @@ class WoqDecoderEngine:
         ids = [int(t) for t in prompt_ids]
         for s0 in range(0, len(ids), chunk):
             self.prefill(ids[s0:s0 + chunk], start_pos=s0, greedy=True)
+        self.tune_attn_for(len(ids) + max_new_tokens)
         for _ in range(max_new_tokens):
             out.append(int(self.token.item()))
             if len(out) == max_new_tokens:
