@@ -312,7 +312,7 @@ def optimize_transformers(model, max_ctx=2048, kv_dtype=torch.float16):
         gu = pack(fuse_gate_up(g[0], u[0]), fuse_gate_up(g[1], u[1]), fuse_gate_up(g[2], u[2]) if asym else None)
         eng.set_layer(l, qkv, at.o_proj.weight.data, gu, mlp.down_proj.weight.data, layer.input_layernorm.weight,
                       layer.post_attention_layernorm.weight)
-    head_dtype = kv_dtype
+    head_dtype = kv_dtype if kv_dtype in (torch.float16, torch.bfloat16) else torch.float16  # fp8 is cache-only
     eng.set_head(model.model.embed_tokens.weight.detach().to(head_dtype), model.model.norm.weight,
                  model.lm_head.weight.detach().to(head_dtype))
     model.woq_engine = eng

@@ -1,7 +1,7 @@
 """`intel_extension_for_transformers.transformers` surface for the int4 weight-only path, MI355X backend
 (reference exports: transformers/__init__.py:28-42)."""
-from .utils.config import (AutoRoundConfig, AwqConfig, GPTQConfig, RtnConfig, TeqConfig,  # noqa: F401
-                           WeightOnlyQuantConfig)
+from .utils.config import (AutoRoundConfig, AwqConfig, GPTQConfig, MixedPrecisionConfig, RtnConfig,  # noqa: F401
+                           TeqConfig, WeightOnlyQuantConfig)
 
 
 def __getattr__(name):  # the model classes import torch + HF transformers: load them on first use
@@ -13,4 +13,4 @@ def __getattr__(name):  # the model classes import torch + HF transformers: load
 
 
 __all__ = ["AutoModelForCausalLM", "AutoModel", "AutoModelForSeq2SeqLM", "RtnConfig", "AwqConfig", "TeqConfig",
-           "GPTQConfig", "AutoRoundConfig", "WeightOnlyQuantConfig"]
+           "GPTQConfig", "AutoRoundConfig", "WeightOnlyQuantConfig", "MixedPrecisionConfig"]

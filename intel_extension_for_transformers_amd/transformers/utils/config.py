@@ -256,6 +256,14 @@ class ITREXQuantizationConfigMixin(_HFBase):
 _TAIL = (("use_ggml", False), ("use_quant", True), ("use_neural_speed", False))
 
 
+class MixedPrecisionConfig:
+    """Reference transformers/utils/config.py:59-66: no weight quantisation, just the model dtype. NeuralChat's
+    default `optimization_config` (neural_chat/config.py:509-510)."""
+
+    def __init__(self, dtype="bfloat16"):
+        self.dtype = dtype
+
+
 class RtnConfig(ITREXQuantizationConfigMixin):
     """Round-to-nearest (config.py:794-842). Defaults: bits 4, group_size 32, sym."""
 

@@ -151,3 +151,41 @@ def test_replace_linear_skips_and_requires_gpu():
         g = GPTQConfig()
         g.post_init_hip()
         convert_to_quantized_model(M(), g, device="cuda")
+
+
+# ---- NeuralChat serving seam: configuration surface (no GPU needed) ----------------------------------------------
+def test_neural_chat_config_surface():
+    """Field names / defaults of the reference's neural_chat/config.py for the fields this path reads
+    (GenerationConfig :400-423, PipelineConfig :466-517) and the optimisation-config type check (:511-515)."""
+    from intel_extension_for_transformers_amd.neural_chat import GenerationConfig, PipelineConfig
+    from intel_extension_for_transformers_amd.transformers import MixedPrecisionConfig, RtnConfig
+
+    g = GenerationConfig()
+    assert (g.temperature, g.top_k, g.top_p, g.repetition_penalty, g.num_beams, g.max_new_tokens, g.do_sample,
+            g.return_stats, g.format_version) == (0.1, 40, 0.75, 1.1, 1, 256, True, False, "v2")
+    p = PipelineConfig(device="cuda")
+    assert p.model_name_or_path == "Intel/neural-chat-7b-v3-1"
+    assert isinstance(p.optimization_config, MixedPrecisionConfig) and p.optimization_config.dtype == "float16"
+    q = PipelineConfig(model_name_or_path="meta-llama/Llama-2-7b-chat-hf", device="cuda",
+                       optimization_config=RtnConfig(bits=4, group_size=128))
+    assert q.optimization_config.bits == 4 and q.loading_config.use_cache
+    with pytest.raises(AssertionError, match="optimization_config"):
+        PipelineConfig(device="cuda", optimization_config=object())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        PipelineConfig(device="auto")  # this container has no GPU: the backend refuses instead of picking "cpu"
+
+
+def test_neural_chat_prompt_templates():
+    from intel_extension_for_transformers_amd.neural_chat.prompts import get_conv_template
+
+    c = get_conv_template("neural-chat-7b-v3")
+    c.append_message(c.roles[0], "Tell me about MI355X.")
+    c.append_message(c.roles[1], None)
+    p = c.get_prompt()
+    assert p.startswith("### System:\n- You are a helpful assistant chatbot trained by Intel.")
+    assert p.endswith("### User:\nTell me about MI355X.\n### Assistant:\n")
+    c = get_conv_template("llama-2")
+    c.append_message(c.roles[0], "hi")
+    c.append_message(c.roles[1], None)
+    assert c.get_prompt() == "[INST] hi [/INST]"
+    assert get_conv_template("llama-2").messages == []  # templates are copied, not shared

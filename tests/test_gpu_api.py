@@ -217,3 +217,51 @@ def test_optimize_transformers_engine_matches_hf_path(tmp_path, kv_heads):
     # fp16 KV cache + fp16 lm_head on the engine side vs fp32 torch: 2e-3 relative on logits
     assert (got - ref_logits).abs().max().item() <= 2e-3 * ref_logits.abs().max().item() + 1e-4
     assert eng.generate(prompt, 6) == ref_out
+
+
+def _tiny_tokenizer(path, vocab_size):
+    """Word-level tokenizer over w0..wN (no network): enough for build_chatbot's tokenizer.from_pretrained."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+
+    vocab = {"<unk>": 0, "<s>": 1, "</s>": 2}
+    for i in range(3, vocab_size):
+        vocab["w%d" % i] = i
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tk.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    fast = PreTrainedTokenizerFast(tokenizer_object=tk, unk_token="<unk>", bos_token="<s>", eos_token="</s>")
+    fast.save_pretrained(str(path))
+
+
+def test_neural_chat_build_chatbot_predict_and_stream(tmp_path):
+    """SURVEY §8(f)3 / north_star: PipelineConfig(optimization_config=RtnConfig) -> build_chatbot -> predict /
+    predict_stream. Greedy requests ride the fused engine (prompt pass + graph-replayed decode); the streamed pieces
+    concatenate to predict()'s text and match the HF module path's greedy continuation; sampling requests take the
+    model.generate + TextIteratorStreamer route; return_stats appends the reference's stats table."""
+    from intel_extension_for_transformers_amd.neural_chat import GenerationConfig, PipelineConfig, build_chatbot
+    from intel_extension_for_transformers_amd.transformers import RtnConfig
+
+    d = tmp_path / "tiny-llama-chat"
+    fp = _tiny_llama()
+    fp.generation_config.eos_token_id = None  # random-init model: never stop early
+    fp.save_pretrained(str(d))
+    _tiny_tokenizer(d, fp.config.vocab_size)
+    bot = build_chatbot(PipelineConfig(model_name_or_path=str(d), device="cuda",
+                                       optimization_config=RtnConfig(bits=4, group_size=128, scale_dtype="fp16")))
+    assert type(bot).__name__ == "LlamaModel" and bot.engine is not None
+    q = "w5 w17 w200 w3 w77"
+    cfg = GenerationConfig(max_new_tokens=8, do_sample=False, repetition_penalty=1.0)
+    text = bot.predict(q, config=cfg)
+    pieces = list(bot.predict_stream(q, config=cfg))
+    assert "".join(pieces) == text and len(text.split()) == 8
+    # the module path (HF generate over the QuantizedLinearQBits model) gives the same greedy continuation
+    bot_engine, bot.engine = bot.engine, None
+    try:
+        assert bot.predict(q, config=cfg) == text
+    finally:
+        bot.engine = bot_engine
+    # sampling -> HF generate + streamer thread; stats block in the v2 table format
+    scfg = GenerationConfig(max_new_tokens=5, do_sample=True, temperature=0.7, return_stats=True)
+    out = list(bot.predict_stream(q, config=scfg))
+    joined = "".join(out)
+    assert "| Key" in joined and "msecond_per_token" in joined and "input_token_len" in joined
