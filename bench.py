@@ -15,7 +15,8 @@ time ("weak" scaling). Rank 0 prints ONE JSON line.
 Extra objects in the line:
   roofline     : dominant kernel = the int4 decode GEMV (woq::gemv_tile_kernel, csrc/woq_gemv_i8.hip). achieved = algorithmic bytes per
                  launch (int4 payload + fp16 scales, SURVEY.md §8(d): 3 339 190 272 B / 128 launches per token)
-                 / average launch duration measured with HIP event pairs on the launch stream. peak = 8000 GB/s.
+                 / average launch duration: HIP events on the launch stream around passes of all 128 GEMV launches back to back
+                 (boundaries between launches included, no per-launch event overhead). peak = 8000 GB/s.
                  traffic = HBM bytes per launch from the rocprofv3 --pmc pass (profiles/*_pmc_traffic.json), or null.
   cpu_baseline : the oracle's streaming int4 GEMV (oracle/woq_oracle.c orc_woq_gemv_stream, kind "port": the
                  reference's BesTLA kernels are not buildable here) timed on this host's cores over ONE decoder
@@ -200,7 +201,7 @@ def main():
 
     if rank == 0:
         qbytes = algorithmic_bytes_per_token(cfg)
-        # dominant kernel, timed alone with HIP event pairs on the launch stream
+        # dominant kernel, timed alone: HIP events on the launch stream around 4 passes of the 128 launches
         ms, by, n_launch = eng.time_gemv(reps=4)
         us_per_launch = ms * 1e3 / (4 * n_launch)
         achieved = (by / n_launch) / (us_per_launch * 1e-6) / 1e9

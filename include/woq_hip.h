@@ -183,8 +183,9 @@ WOQ_API int woq_engine_set_allreduce(woq_engine* e, woq_allreduce_fn fn, void* u
  * between them: phase 0 = embed + attention block up to o_proj partial, 1 = MLP block up to
  * down partial, 2 = head. layer ignored for phase 2. */
 WOQ_API int woq_engine_phase(woq_engine* e, int layer, int phase, int greedy, void* stream);
-/* time the dominant kernel (int4 GEMV) alone over all layers with HIP events on `stream`:
- * runs `reps` passes over every layer's 4 GEMVs, returns total ms and the algorithmic bytes of one pass. */
+/* time the dominant kernel (int4 GEMV) alone over all layers with HIP events on `stream`: `reps` passes over every
+ * layer's 4 GEMVs launched back to back, one event pair around each pass; returns total ms, the algorithmic bytes of
+ * one pass and its launch count (average launch duration = total_ms / (reps * launches_per_pass)). */
 WOQ_API int woq_engine_time_gemv(woq_engine* e, int reps, void* stream, float* total_ms, double* bytes_per_pass,
                                  int* launches_per_pass);
 

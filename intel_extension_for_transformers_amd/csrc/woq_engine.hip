@@ -421,8 +421,11 @@ int woq_engine_time_gemv(woq_engine* e, int reps, void* stream, float* total_ms,
   const woq_engine_config& c = e->cfg;
   const int per_layer = 4;
   const int n_launch = c.layers * per_layer;
-  std::vector<hipEvent_t> ev((size_t)n_launch * 2);
-  for (auto& x : ev) WOQ_HIP(hipEventCreate(&x));
+  // ONE event pair around each pass of n_launch back-to-back launches: the average launch duration then contains
+  // the kernel boundaries a token really pays, but not the ~1-2 us a per-launch event record adds to each interval
+  hipEvent_t ev0, ev1;
+  WOQ_HIP(hipEventCreate(&ev0));
+  WOQ_HIP(hipEventCreate(&ev1));
   double bytes = 0;
   for (int l = 0; l < c.layers; ++l) {
     const woq_layer_weights& w = e->layers[l];
@@ -436,43 +439,31 @@ int woq_engine_time_gemv(woq_engine* e, int reps, void* stream, float* total_ms,
   }
   double ms = 0;
   for (int r = 0; r < reps; ++r) {
-    int k = 0;
+    WOQ_HIP(hipEventRecord(ev0, st));
     for (int l = 0; l < c.layers; ++l) {
       const woq_layer_weights& w = e->layers[l];
       int rc;
-      WOQ_HIP(hipEventRecord(ev[2 * k], st));
       rc = launch_gemv_from_header(e->hidden, WOQ_F32, c.hidden, w.qkv_blob, w.qkv_hdr, nullptr, e->qkv, WOQ_F32,
                                    w.qkv_hdr.N, 1, w.ln1, c.rms_eps, nullptr, 0, 0, e->nt, st);
-      WOQ_HIP(hipEventRecord(ev[2 * k + 1], st));
-      ++k;
       if (rc) return rc;
-      WOQ_HIP(hipEventRecord(ev[2 * k], st));
       rc = launch_gemv_from_header(e->attn, WOQ_F32, c.heads * c.head_dim, w.o_blob, w.o_hdr, nullptr, e->qkv,
                                    WOQ_F32, c.hidden, 1, nullptr, 0.f, nullptr, 0, 0, e->nt, st);
-      WOQ_HIP(hipEventRecord(ev[2 * k + 1], st));
-      ++k;
       if (rc) return rc;
-      WOQ_HIP(hipEventRecord(ev[2 * k], st));
       rc = launch_gemv_from_header(e->hidden, WOQ_F32, c.hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, e->act,
                                    WOQ_F32, c.inter, 1, w.ln2, c.rms_eps, nullptr, 0, 1, e->nt, st);
-      WOQ_HIP(hipEventRecord(ev[2 * k + 1], st));
-      ++k;
       if (rc) return rc;
-      WOQ_HIP(hipEventRecord(ev[2 * k], st));
       rc = launch_gemv_from_header(e->act, WOQ_F32, c.inter, w.down_blob, w.down_hdr, nullptr, e->qkv, WOQ_F32,
                                    c.hidden, 1, nullptr, 0.f, nullptr, 0, 0, e->nt, st);
-      WOQ_HIP(hipEventRecord(ev[2 * k + 1], st));
-      ++k;
       if (rc) return rc;
     }
+    WOQ_HIP(hipEventRecord(ev1, st));
     WOQ_HIP(hipStreamSynchronize(st));
-    for (int i = 0; i < n_launch; ++i) {
-      float t = 0.f;
-      WOQ_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
-      ms += t;
-    }
+    float t = 0.f;
+    WOQ_HIP(hipEventElapsedTime(&t, ev0, ev1));
+    ms += t;
   }
-  for (auto& x : ev) hipEventDestroy(x);
+  hipEventDestroy(ev0);
+  hipEventDestroy(ev1);
   *total_ms = (float)ms;
   *bytes_per_pass = bytes;
   *launches_per_pass = n_launch;
