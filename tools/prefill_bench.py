@@ -13,7 +13,10 @@ from intel_extension_for_transformers_amd import qbits  # noqa: E402
 
 def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    # args: M [group [computes [asym 0/1]]] — a group without the 4th argument means asymmetric (configs[2])
     group, asym = (int(sys.argv[2]), True) if len(sys.argv) > 2 else (128, False)
+    if len(sys.argv) > 4:
+        asym = bool(int(sys.argv[4]))
     res = []
     computes = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("bf16", "fp32")
     for compute in computes:
