@@ -277,11 +277,13 @@ struct BRegs {  // one K step of one wave's weight operand, as loaded
 
 // 8 signed nibbles of one blob word -> 8 fp16 (q - zp) * r, order {0,2,4,6,1,3,5,7}
 __device__ __forceinline__ h8 dq8s(uint32_t w, h2 nlo, h2 nhi, h2 r) {
-  const uint32_t x = w ^ 0x88888888u, y = x >> 8;
-  const h2 f0 = (__builtin_bit_cast(h2, (x & 0x000f000fu) | 0x64006400u) + nlo) * r;
-  const h2 f1 = (__builtin_bit_cast(h2, (x & 0x00f000f0u) | 0x54005400u) + nhi) * r;
-  const h2 f2 = (__builtin_bit_cast(h2, (y & 0x000f000fu) | 0x64006400u) + nlo) * r;
-  const h2 f3 = (__builtin_bit_cast(h2, (y & 0x00f000f0u) | 0x54005400u) + nhi) * r;
+  // ((w ^ 0x88888888) & mask) | magic == (w & mask) ^ (magic | (mask & 0x88888888)): the nibble bits and the magic
+  // bits do not overlap, so the sign flip, the mask and the magic are ONE three-input bit op per nibble pair
+  const uint32_t y = w >> 8;
+  const h2 f0 = (__builtin_bit_cast(h2, (w & 0x000f000fu) ^ 0x64086408u) + nlo) * r;
+  const h2 f1 = (__builtin_bit_cast(h2, (w & 0x00f000f0u) ^ 0x54805480u) + nhi) * r;
+  const h2 f2 = (__builtin_bit_cast(h2, (y & 0x000f000fu) ^ 0x64086408u) + nlo) * r;
+  const h2 f3 = (__builtin_bit_cast(h2, (y & 0x00f000f0u) ^ 0x54805480u) + nhi) * r;
   return __builtin_bit_cast(h8, (u32x4){__builtin_bit_cast(uint32_t, f0), __builtin_bit_cast(uint32_t, f1),
                                         __builtin_bit_cast(uint32_t, f2), __builtin_bit_cast(uint32_t, f3)});
 }
@@ -314,10 +316,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(GemmF16Args a) {
   auto issue_a = [&](int kt, int buf) {  // 8 LDS-DMA pieces of 1 KiB per wave
     const _Float16* src = a_tiles + (size_t)kt * (FTILE_BYTES / 2) + (size_t)wid * 4096 + lane * 8;
     unsigned char* dst = fsm + buf * FTILE_BYTES + wid * 8192;
+    // the instruction offset advances the global AND the LDS address: four 1-KiB pieces per address / M0 setup
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 512),
-                                       (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+    for (int j = 0; j < 8; j += 4) {
+      const __attribute__((address_space(1))) void* g = (const __attribute__((address_space(1))) void*)(src + j * 512);
+      __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(dst + j * 1024);
+      __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+      __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+      __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
+    }
   };
   int tnc[2];
   float icol[2];
