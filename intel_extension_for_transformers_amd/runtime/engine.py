@@ -188,6 +188,29 @@ class WoqDecoderEngine:
         t = _device_view(ptr, shape, self.device, "<f2")
         return t if code == L.F16 else t.view(torch.bfloat16)
 
+    # ---- tensor parallel through the engine's all-reduce seam (woq_engine_set_allreduce) --------------------------
+    def bind_allreduce(self, group=None):
+        """Let the NATIVE step / prompt pass call back into torch.distributed after o_proj and down_proj: the
+        callback wraps the engine's fp32 buffer as a tensor view and issues `dist.all_reduce` (backend "nccl" = RCCL
+        over xGMI) on the current stream. Needed for `prefill` under TP (the host-driven `step_tp` splits only the
+        decode step); not graph-capturable."""
+        import torch.distributed as dist
+
+        def _cb(_user, buf, count, _stream):
+            try:
+                dist.all_reduce(_device_view(buf, (int(count),), self.device), group=group)
+                return 0
+            except Exception:  # pragma: no cover - surfaces as "all-reduce callback failed" from the C side
+                return 1
+
+        self._allreduce_cb = L.ALLREDUCE_FN(_cb)  # keep the ctypes thunk alive
+        L.check(L.lib().woq_engine_set_allreduce(self._h, self._allreduce_cb, None))
+        self.captured = False
+
+    def unbind_allreduce(self):
+        L.check(L.lib().woq_engine_set_allreduce(self._h, ctypes.cast(None, L.ALLREDUCE_FN), None))
+        self._allreduce_cb = None
+
     def generate(self, prompt_ids, max_new_tokens, chunk=2048):
         """Greedy decode: the prompt goes through the prefill pass in chunks of `chunk` tokens, then steps are
         chained on the device."""

@@ -97,6 +97,20 @@ class TPDecoder:
     def __init__(self, engine, vocab, group=None):
         self.engine, self.vocab, self.group = engine, vocab, group
 
+    def prefill(self, tokens, start_pos=0):
+        """Prompt pass over this rank's shards: the engine's native prefill with the all-reduce seam bound to the
+        process group (sum of the row-parallel partials after o_proj / down_proj, [rows, hidden] fp32 each), then
+        the vocab-sharded last-position logits all-gathered. Returns logits [n_seq, vocab]."""
+        import torch
+
+        e = self.engine
+        e.bind_allreduce(self.group)
+        try:
+            local = e.prefill(tokens, start_pos=start_pos, greedy=False)
+        finally:
+            e.unbind_allreduce()
+        return torch.stack([gather_logits(row[:e.cfg.vocab], self.vocab, self.group) for row in local])
+
     def step(self, greedy=True):
         import torch
 

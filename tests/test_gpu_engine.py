@@ -261,3 +261,36 @@ def test_decode_attention_context_slices_vs_oracle(head_dim, splits):
         ref = oracle.forward_token(nxt, 200 + j)
         nxt = int(ref.argmax())
         assert int(eng.token.item()) == nxt
+
+
+def test_tp_seam_world_size_one_rccl():
+    """The tensor-parallel plumbing on a real device with a one-rank RCCL group: TPDecoder.prefill (native prompt pass
+    + all-reduce callback into torch.distributed + vocab all-gather) and TPDecoder.step (host-driven sub-blocks +
+    all-reduces) must reproduce the single-GPU engine — a sum over one rank is the identity, so any difference is a
+    plumbing bug (wrong buffer, count, stream or ordering)."""
+    import os
+
+    import torch.distributed as dist
+
+    from intel_extension_for_transformers_amd.runtime.tp import TPDecoder
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        eng, oracle, cfg = _tiny(128, False, "fp16", seed=5, max_ctx=256)
+        ref_eng, _, _ = _tiny(128, False, "fp16", seed=5, max_ctx=256)
+        prompt = np.random.default_rng(1).integers(0, cfg["vocab"], 70).tolist()
+        want = ref_eng.prefill(prompt, greedy=True)[0].cpu().numpy().copy()
+        tp = TPDecoder(eng, cfg["vocab"])
+        got = tp.prefill(prompt)[0].cpu().numpy()
+        assert np.array_equal(got, want)
+        eng.token.fill_(int(want.argmax()))
+        eng.pos.fill_(len(prompt))
+        for _ in range(3):
+            lg = tp.step(greedy=True).cpu().numpy()
+            ref_eng.step(greedy=True)
+            assert np.array_equal(lg, ref_eng.logits.cpu().numpy())
+            assert int(eng.token.item()) == int(ref_eng.token.item())
+    finally:
+        dist.destroy_process_group()

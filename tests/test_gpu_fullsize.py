@@ -115,3 +115,34 @@ def test_fullsize_engine_is_deterministic_and_graph_equals_eager():
     l1, t1 = run(True)
     assert torch.equal(l0, l1) and t0 == t1
     assert torch.isfinite(l0).all()
+
+
+def test_llama70b_tp8_rank_shard_shapes():
+    """BASELINE configs[3]: the per-rank shapes of Llama-2-70B at TP = 8 (hidden 8192, 8 q heads / 1 kv head per
+    rank, inter 3584 per rank, vocab shard 4000) on ONE device, 2 layers, synthetic weights: the decode GEMV
+    geometry (K = 8192 -> 64 k-tiles, qkv N = 1280, row-parallel o / down with K = 1024 / 3584) and the prompt-pass
+    GEMMs must agree with each other — prefill of a prompt vs token-by-token decode of the same prompt, last-position
+    logits within the prompt-pass tolerance (1e-2 relative), then identical greedy continuation lengths. Rank 0 of a
+    one-rank group: the partial sums are the full sums, so this checks kernels and shapes, not collectives."""
+    from intel_extension_for_transformers_amd.runtime.engine import WoqDecoderEngine, synth_llama_weights
+
+    dims = dict(hidden=8192, inter=3584, heads=8, kv_heads=1, head_dim=128, layers=2, vocab=4000)
+
+    def make():
+        e = WoqDecoderEngine(dims["hidden"], dims["inter"], dims["heads"], dims["kv_heads"], dims["head_dim"],
+                             dims["layers"], dims["vocab"], max_ctx=256)
+        synth_llama_weights(e, dims["hidden"], dims["inter"], dims["heads"], dims["kv_heads"], dims["head_dim"],
+                            dims["layers"], dims["vocab"], group=128, sym=True, scale_dtype="fp16", seed=77)
+        return e
+
+    g = torch.Generator().manual_seed(3)
+    prompt = torch.randint(0, dims["vocab"], (140,), generator=g).tolist()
+    a, b = make(), make()
+    la = a.prefill(prompt, greedy=False)[0].float().cpu()
+    for i, t in enumerate(prompt):
+        b.token.fill_(t)
+        b.pos.fill_(i)
+        b.step(greedy=False)
+    lb = b.logits.float().cpu()
+    assert torch.isfinite(la).all() and torch.isfinite(lb).all()
+    assert (la - lb).abs().max().item() <= 1e-2 * lb.abs().max().item() + 1e-3
