@@ -169,6 +169,30 @@ static inline int woq_header_init(woq_blob_header* h, int K, int N, int group, u
   return 0;
 }
 
+/* int8 weights (WOQ_W_INT8; reference weight type "int8", bestla_weightonly_dispatcher.hpp:62) are stored as a
+ * COMPOSITE of two complete int4 blobs, because
+ *     q8 - zp8 = 16 (hi - zhi) + (lo - zlo),   hi = q8 >> 4 (arithmetic), lo = (q8 & 15) - 8,
+ *                                              zhi = zp8 >> 4,            zlo = (zp8 & 15) - 8
+ * holds exactly with all four terms in the int4 range [-8, 7]: (q8 - zp8) * s = (hi - zhi) * 16s + (lo - zlo) * s,
+ * i.e. an int8 linear is the sum of two int4 linears on the same activations — computed by the SAME exact kernels,
+ * the second launch adding the first's fp32 result. Layout: [256-B outer header][HI int4 blob: scales 16s, zero
+ * points zhi when asym][LO int4 blob: scales s, zero points zlo, always asym]. Outer header: weight_type INT8, the
+ * usual geometry, off_q = offset of the HI blob, off_scale = offset of the LO blob, off_zp / off_shuffle = non-zero
+ * (offset of the LO blob's section) when asymmetric / act-shuffled. Same bytes per weight as a flat int8 layout. */
+static inline int woq_int8_headers(woq_blob_header* outer, woq_blob_header* hi, woq_blob_header* lo, int K, int N,
+                                   int group, uint32_t scale_type, uint32_t compute_type, int asym, int act_shuffle) {
+  if (woq_header_init(hi, K, N, group, 0u /* int4_clip */, scale_type, compute_type, asym, act_shuffle) != 0) return -1;
+  if (woq_header_init(lo, K, N, group, 0u, scale_type, compute_type, 1, act_shuffle) != 0) return -1;
+  *outer = *hi;
+  outer->weight_type = 1u; /* WOQ_W_INT8 */
+  outer->off_q = WOQ_HEADER_BYTES;
+  outer->off_scale = WOQ_HEADER_BYTES + hi->total_bytes;
+  outer->off_zp = asym ? outer->off_scale + lo->off_zp : 0;
+  outer->off_shuffle = act_shuffle ? outer->off_scale + lo->off_shuffle : 0;
+  outer->total_bytes = WOQ_HEADER_BYTES + hi->total_bytes + lo->total_bytes;
+  return 0;
+}
+
 /* index of the scale / zero-point element for (column n, row k) */
 static inline size_t woq_scale_index(const woq_blob_header* h, int k, int n) {
   size_t tn = (size_t)n / WOQ_TILE_N, i = (size_t)n % WOQ_TILE_N;

@@ -15,7 +15,7 @@ W_INT4_CLIP, W_INT8 = 0, 1
 C_FP32, C_BF16, C_INT8, C_FP16 = 0, 1, 2, 3
 HEADER_BYTES = 256
 
-WEIGHT_TYPES = {"int4_clip": W_INT4_CLIP, "int4": W_INT4_CLIP}
+WEIGHT_TYPES = {"int4_clip": W_INT4_CLIP, "int4": W_INT4_CLIP, "int8": W_INT8}
 SCALE_TYPES = {"fp32": F32, "bf16": BF16, "fp16": F16}
 COMPUTE_TYPES = {"fp32": C_FP32, "bf16": C_BF16, "int8": C_INT8, "fp16": C_FP16}
 SCALE_NAMES = {v: k for k, v in SCALE_TYPES.items()}

@@ -19,7 +19,8 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
                             const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w,
                             float eps, const float* residual, int ld_res, int epi, int nt, hipStream_t st);
 int launch_gemm_mfma(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
-                     const float* bias, void* out, int out_dtype, int ldo, int M, hipStream_t st);
+                     const float* bias, void* out, int out_dtype, int ldo, int M, const float* residual, int ld_res,
+                     hipStream_t st);
 int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                     const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w, float eps,
                     const float* residual, int ld_res, int epi, void* ws, hipStream_t st);
@@ -37,6 +38,20 @@ int woq_device_count(void) {
   return n;
 }
 
+// one int4 blob: M <= 8 -> decode GEMV, else an MFMA GEMM by compute type. `residual` (fp32 [M][ld_res]) is added.
+static int linear_int4(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
+                       const float* bias, void* out, int out_dtype, int ldo, int M, const float* residual, int ld_res,
+                       hipStream_t st) {
+  static const bool gemm_as_gemv = getenv("WOQ_GEMM_AS_GEMV") != nullptr;  // A/B switch for tests
+  if (M > 8 && h.compute_type != WOQ_C_FP32 && !gemm_as_gemv)  // reduced-precision compute modes: fp16-operand MFMA GEMM
+    return launch_gemm_f16(act, act_dtype, lda, blob, h, bias, out, out_dtype, ldo, M, nullptr, 0.f, residual, ld_res, 0,
+                           nullptr, st);
+  if (M <= 8 || h.off_shuffle != 0)
+    return launch_gemv_from_header(act, act_dtype, lda, blob, h, bias, out, out_dtype, ldo, M, nullptr, 0.f, residual,
+                                   ld_res, 0, 1, st);
+  return launch_gemm_mfma(act, act_dtype, lda, blob, h, bias, out, out_dtype, ldo, M, residual, ld_res, st);
+}
+
 int woq_linear(const void* act_dev, int act_dtype, int lda, const void* blob_dev, const woq_blob_header* hdr,
                const float* bias_dev, void* out_dev, int out_dtype, int ldo, int M, void* stream) {
   WOQ_TRY
@@ -47,15 +62,23 @@ int woq_linear(const void* act_dev, int act_dtype, int lda, const void* blob_dev
   if (M <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  static const bool gemm_as_gemv = getenv("WOQ_GEMM_AS_GEMV") != nullptr;  // A/B switch for tests
-  if (M > 8 && hdr->compute_type != WOQ_C_FP32 && !gemm_as_gemv)  // reduced-precision compute modes: fp16-operand MFMA GEMM
-    rc = launch_gemm_f16(act_dev, act_dtype, lda, blob_dev, *hdr, bias_dev, out_dev, out_dtype, ldo, M, nullptr, 0.f,
-                         nullptr, 0, 0, nullptr, st);
-  else if (M <= 8 || hdr->off_shuffle != 0)
-    rc = launch_gemv_from_header(act_dev, act_dtype, lda, blob_dev, *hdr, bias_dev, out_dev, out_dtype, ldo, M,
-                                 nullptr, 0.f, nullptr, 0, 0, 1, st);
-  else
-    rc = launch_gemm_mfma(act_dev, act_dtype, lda, blob_dev, *hdr, bias_dev, out_dev, out_dtype, ldo, M, st);
+  if (hdr->weight_type == WOQ_W_INT8) {
+    // (q8 - zp8) s = (hi - zhi) 16s + (lo - zlo) s: two int4 linears on the same activations (woq_blob.h); the
+    // first goes to an fp32 scratch, the second adds it (and the bias) and stores the caller's dtype
+    woq_blob_header o, hi, lo;
+    WOQ_CHECK(woq_int8_headers(&o, &hi, &lo, hdr->K, hdr->N, hdr->group, hdr->scale_type, hdr->compute_type,
+                               hdr->off_zp != 0, hdr->off_shuffle != 0) == 0, "QBits: corrupt int8 header");
+    float* tmp = nullptr;
+    WOQ_HIP(hipMallocAsync((void**)&tmp, (size_t)M * hdr->N * sizeof(float), st));
+    rc = linear_int4(act_dev, act_dtype, lda, (const uint8_t*)blob_dev + hdr->off_q, hi, nullptr, tmp, WOQ_F32,
+                     hdr->N, M, nullptr, 0, st);
+    if (rc == 0)
+      rc = linear_int4(act_dev, act_dtype, lda, (const uint8_t*)blob_dev + hdr->off_scale, lo, bias_dev, out_dev,
+                       out_dtype, ldo, M, tmp, hdr->N, st);
+    hipFreeAsync(tmp, st);
+  } else {
+    rc = linear_int4(act_dev, act_dtype, lda, blob_dev, *hdr, bias_dev, out_dev, out_dtype, ldo, M, nullptr, 0, st);
+  }
   if (rc != 0) return rc;
   WOQ_HIP(hipGetLastError());
   WOQ_END

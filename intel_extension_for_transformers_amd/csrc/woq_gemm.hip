@@ -54,6 +54,8 @@ struct GemmArgs {
   void* out;
   int out_dtype, ldo;
   const float* bias;
+  const float* residual;  // fp32 [M][ld_res] added in the epilogue, or null
+  int ld_res;
 };
 
 constexpr int GBM = 128, GBN = 128, GKS = 128;
@@ -340,7 +342,8 @@ __global__ __launch_bounds__(256, 1) void gemm_mfma_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int m = row0 + rt * 16 + kq * 4 + j;
-          if (m < a.M) put((size_t)m * a.ldo + n, tot[rt][c][j] + bsv);
+          if (m < a.M)
+            put((size_t)m * a.ldo + n, tot[rt][c][j] + bsv + (a.residual ? a.residual[(size_t)m * a.ld_res + n] : 0.f));
         }
     }
   };
@@ -385,11 +388,12 @@ static int launch_gemm_t(GemmArgs& a, hipStream_t st) {
 // out[M,N] = act[M,K] . W_deq (+ bias) for M above the small-M kernels' range. compute_type (blob header):
 // fp32 -> two fp16 planes (hi + lo) per activation, anything else -> one.
 int launch_gemm_mfma(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
-                     const float* bias, void* out, int out_dtype, int ldo, int M, hipStream_t st) {
+                     const float* bias, void* out, int out_dtype, int ldo, int M, const float* residual, int ld_res,
+                     hipStream_t st) {
   static const bool force_gemv = getenv("WOQ_GEMM_AS_GEMV") != nullptr;  // A/B switch for tests
   if (force_gemv || h.off_shuffle != 0 || (h.scale_mode == 0 && h.n_groups > 1 && (h.group % WOQ_TILE_K) != 0))
-    return launch_gemv_from_header(act, act_dtype, lda, blob, h, bias, out, out_dtype, ldo, M, nullptr, 0.f, nullptr,
-                                   0, 0, 0, st);
+    return launch_gemv_from_header(act, act_dtype, lda, blob, h, bias, out, out_dtype, ldo, M, nullptr, 0.f, residual,
+                                   ld_res, 0, 0, st);
   GemmArgs a;
   const uint8_t* b = (const uint8_t*)blob;
   a.q = (const u32x4*)(b + h.off_q);
@@ -411,6 +415,8 @@ int launch_gemm_mfma(const void* act, int act_dtype, int lda, const void* blob, 
   a.out_dtype = out_dtype;
   a.ldo = ldo;
   a.bias = bias;
+  a.residual = residual;
+  a.ld_res = ld_res;
   const bool two = h.compute_type == WOQ_C_FP32;
   const bool asym = a.zp != nullptr;
   const int sm = (int)h.scale_mode;

@@ -114,7 +114,7 @@ __device__ __forceinline__ void blob_elem(const uint8_t* blob, const woq_blob_he
 
 // w[k][n] = (u - uz) * scale  == (q - zp) * scale, modules.py:264-295
 __global__ void dequant_kernel(const uint8_t* __restrict__ blob, woq_blob_header h, float* __restrict__ out,
-                               int transpose) {
+                               int transpose, int accumulate) {
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)h.K * h.N;
   if (idx >= total) return;
@@ -129,7 +129,41 @@ __global__ void dequant_kernel(const uint8_t* __restrict__ blob, woq_blob_header
   int u, uz;
   float sc;
   blob_elem(blob, h, k, n, u, uz, sc);
-  out[idx] = (float)(u - uz) * sc;
+  const float v = (float)(u - uz) * sc;
+  out[idx] = accumulate ? out[idx] + v : v;
+}
+
+// ---- int8 composite (include/woq_blob.h woq_int8_headers): split q8 / zp8 / scale into the two int4 operands ----
+__global__ void split_int8_kernel(const int8_t* __restrict__ q8, size_t n, int8_t* __restrict__ hi,
+                                  int8_t* __restrict__ lo) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int v = q8[idx];
+  hi[idx] = (int8_t)(v >> 4);
+  lo[idx] = (int8_t)((v & 15) - 8);
+}
+__global__ void split_int8_params_kernel(const float* __restrict__ sc, const int8_t* __restrict__ zp8, size_t n,
+                                         float* __restrict__ sc_hi, int8_t* __restrict__ zp_hi,
+                                         int8_t* __restrict__ zp_lo) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  sc_hi[idx] = 16.f * sc[idx];
+  const int z = zp8 ? (int)zp8[idx] : 0;
+  if (zp_hi) zp_hi[idx] = (int8_t)(z >> 4);
+  zp_lo[idx] = (int8_t)((z & 15) - 8);
+}
+// zp8 [G, N] back from the two blobs: 16 zhi + zlo + 8
+__global__ void extract_int8_zp_kernel(const uint8_t* __restrict__ bhi, woq_blob_header hh,
+                                       const uint8_t* __restrict__ blo, woq_blob_header hl, int8_t* out) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)hl.n_groups * hl.N;
+  if (idx >= total) return;
+  int g = (int)(idx / (size_t)hl.N), n = (int)(idx % (size_t)hl.N);
+  int u, uzh = 8, uzl;
+  float sc;
+  if (hh.off_zp) blob_elem(bhi, hh, g * hh.group, n, u, uzh, sc);
+  blob_elem(blo, hl, g * hl.group, n, u, uzl, sc);
+  out[idx] = (int8_t)(16 * (uzh - 8) + (uzl - 8) + 8);
 }
 
 // what = WOQ_ACQ_SCALE_TENSOR -> fp32 [G,N]; WOQ_ACQ_ZP_TENSOR -> int8 [G,N] (signed domain)
@@ -147,11 +181,12 @@ __global__ void extract_kernel(const uint8_t* __restrict__ blob, woq_blob_header
     ((int8_t*)out)[idx] = (int8_t)(uz - 8);
 }
 
-// RTN: one thread per (group, column). int4 "clip" range. Rounding rule documented in DESIGN.md
+// RTN: one thread per (group, column). int4 "clip" range (bits = 4) or int8 (bits = 8). Rounding rule documented in DESIGN.md
 // (parity unpinned: BesTLA's quantiser is not in /root/reference). rintf = round-half-even.
 __global__ void rtn_kernel(const float* __restrict__ w, int transpose, int K, int N, int group, int n_groups,
-                           int asym, int8_t* __restrict__ q, float* __restrict__ scales,
+                           int asym, int bits, int8_t* __restrict__ q, float* __restrict__ scales,
                            int8_t* __restrict__ zp) {
+  const int qmax = (1 << (bits - 1)) - 1, levels = (1 << bits) - 1, off = 1 << (bits - 1);  // 7 / 15 / 8 or 127 / 255 / 128
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)n_groups * N) return;
   int g = (int)(idx / (size_t)N), n = (int)(idx % (size_t)N);
@@ -166,25 +201,25 @@ __global__ void rtn_kernel(const float* __restrict__ w, int transpose, int K, in
   float s;
   int z = 0;
   if (!asym) {
-    s = amax / 7.f;
+    s = amax / (float)qmax;
     if (s == 0.f) s = 1.f;
   } else {
-    s = (mx - mn) / 15.f;
+    s = (mx - mn) / (float)levels;
     if (s == 0.f) s = 1.f;
     z = (int)rintf(-mn / s);
-    z = max(0, min(15, z));
+    z = max(0, min(levels, z));
   }
   scales[idx] = s;
-  if (asym) zp[idx] = (int8_t)(z - 8);
+  if (asym) zp[idx] = (int8_t)(z - off);
   for (int k = k0; k < k1; ++k) {
     float v = transpose ? w[(size_t)n * K + k] : w[(size_t)k * N + n];
     int qi;
     if (!asym) {
       qi = (int)rintf(v / s);
-      qi = max(-8, min(7, qi));
+      qi = max(-off, min(qmax, qi));
     } else {
       qi = (int)rintf(v / s) + z;
-      qi = max(0, min(15, qi)) - 8;
+      qi = max(0, min(levels, qi)) - off;
     }
     q[(size_t)k * N + n] = (int8_t)qi;
   }
@@ -203,7 +238,11 @@ extern "C" {
 
 size_t woq_packed_weight_size(int K, int N, int blocksize, int weight_type, int scale_type, int asym,
                               int act_shuffle) {
-  woq_blob_header h;
+  woq_blob_header h, hi, lo;
+  if (weight_type == WOQ_W_INT8)
+    return woq_int8_headers(&h, &hi, &lo, K, N, blocksize, (uint32_t)scale_type, WOQ_C_FP32, asym, act_shuffle) == 0
+               ? h.total_bytes
+               : 0;
   if (weight_type != WOQ_W_INT4_CLIP) return 0;
   if (woq_header_init(&h, K, N, blocksize, (uint32_t)weight_type, (uint32_t)scale_type, WOQ_C_FP32, asym,
                       act_shuffle) != 0)
@@ -211,36 +250,68 @@ size_t woq_packed_weight_size(int K, int N, int blocksize, int weight_type, int 
   return h.total_bytes;
 }
 
-int woq_repack_quantized_weight(const int8_t* qweight_dev, const float* scale_dev, const int8_t* zp_dev,
-                                const int32_t* g_idx_dev, int K, int N, int blocksize, int weight_type,
-                                int scale_type, int compute_type, void* blob_dev, size_t blob_bytes,
-                                void* stream) {
-  WOQ_TRY
-  WOQ_CHECK(weight_type == WOQ_W_INT4_CLIP, "QBits: unsupported weight_type in repack (only int4_clip)");
-  WOQ_CHECK(scale_type >= WOQ_F32 && scale_type <= WOQ_F16, "QBits: unsupported scale_type");
-  woq_blob_header h;
-  WOQ_CHECK(woq_header_init(&h, K, N, blocksize, (uint32_t)weight_type, (uint32_t)scale_type,
-                            (uint32_t)compute_type, zp_dev != nullptr, g_idx_dev != nullptr) == 0,
-            "QBits: unsupported blocksize (must be -1 or a multiple of 32)");
-  WOQ_CHECK(blob_bytes >= h.total_bytes, "QBits: packed-weight buffer too small");
-  WOQ_CHECK(((uintptr_t)blob_dev & 255u) == 0, "QBits: packed-weight buffer must be 256-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
-  uint8_t* blob = (uint8_t*)blob_dev;
+// one int4 blob at `blob` from signed int4 values / fp32 scales / signed zero points / raw g_idx
+static int repack_int4(const int8_t* qweight_dev, const float* scale_dev, const int8_t* zp_dev,
+                       const int32_t* g_idx_dev, const woq_blob_header& h, uint8_t* blob, hipStream_t st) {
   // section padding must be deterministic (blobs are compared / checksummed byte-wise)
   WOQ_HIP(hipMemsetAsync(blob + h.off_scale, 0, h.total_bytes - h.off_scale, st));
   hipLaunchKernelGGL(write_header_kernel, dim3(1), dim3(64), 0, st, h, (woq_blob_header*)blob);
   int tiles_k = h.Kpad / WOQ_TILE_K;
   size_t n_words = (size_t)(h.Npad / WOQ_TILE_N) * tiles_k * 256u;
   hipLaunchKernelGGL(repack_q_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, qweight_dev,
-                     (uint32_t*)(blob + h.off_q), K, N, tiles_k, n_words);
+                     (uint32_t*)(blob + h.off_q), (int)h.K, (int)h.N, tiles_k, n_words);
   size_t ns = n_scale_elems(h);
   hipLaunchKernelGGL(repack_scale_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, scale_dev, zp_dev,
                      h, blob, ns);
   if (g_idx_dev) {
-    WOQ_HIP(hipMemsetAsync(blob + h.off_shuffle, 0, (size_t)K * 4u, st));
-    hipLaunchKernelGGL(convert_idx_kernel, dim3((unsigned)((h.n_groups + 63) / 64)), dim3(64), 0, st, g_idx_dev, K,
-                       (int)h.group, (int)h.n_groups, (int32_t*)(blob + h.off_shuffle));
+    WOQ_HIP(hipMemsetAsync(blob + h.off_shuffle, 0, (size_t)h.K * 4u, st));
+    hipLaunchKernelGGL(convert_idx_kernel, dim3((unsigned)((h.n_groups + 63) / 64)), dim3(64), 0, st, g_idx_dev,
+                       (int)h.K, (int)h.group, (int)h.n_groups, (int32_t*)(blob + h.off_shuffle));
   }
+  return 0;
+}
+
+int woq_repack_quantized_weight(const int8_t* qweight_dev, const float* scale_dev, const int8_t* zp_dev,
+                                const int32_t* g_idx_dev, int K, int N, int blocksize, int weight_type,
+                                int scale_type, int compute_type, void* blob_dev, size_t blob_bytes,
+                                void* stream) {
+  WOQ_TRY
+  WOQ_CHECK(weight_type == WOQ_W_INT4_CLIP || weight_type == WOQ_W_INT8,
+            "QBits: unsupported weight_type in repack (int4_clip | int8)");
+  WOQ_CHECK(scale_type >= WOQ_F32 && scale_type <= WOQ_F16, "QBits: unsupported scale_type");
+  WOQ_CHECK(((uintptr_t)blob_dev & 255u) == 0, "QBits: packed-weight buffer must be 256-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  uint8_t* blob = (uint8_t*)blob_dev;
+  if (weight_type == WOQ_W_INT8) {
+    woq_blob_header h, hi, lo;
+    WOQ_CHECK(woq_int8_headers(&h, &hi, &lo, K, N, blocksize, (uint32_t)scale_type, (uint32_t)compute_type,
+                               zp_dev != nullptr, g_idx_dev != nullptr) == 0,
+              "QBits: unsupported blocksize (must be -1 or a multiple of 32)");
+    WOQ_CHECK(blob_bytes >= h.total_bytes, "QBits: packed-weight buffer too small");
+    const size_t kn = (size_t)K * N, gn = (size_t)h.n_groups * N;
+    int8_t* tmp = nullptr;  // q_hi [kn] | q_lo [kn] | zp_hi [gn] | zp_lo [gn] | sc_hi fp32 [gn]
+    WOQ_HIP(hipMallocAsync((void**)&tmp, 2 * kn + 2 * gn + 4 * gn + 16, st));
+    int8_t *q_hi = tmp, *q_lo = tmp + kn, *z_hi = tmp + 2 * kn, *z_lo = z_hi + gn;
+    float* s_hi = (float*)(((uintptr_t)(z_lo + gn) + 15) & ~(uintptr_t)15);
+    hipLaunchKernelGGL(split_int8_kernel, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, st, qweight_dev, kn, q_hi,
+                       q_lo);
+    hipLaunchKernelGGL(split_int8_params_kernel, dim3((unsigned)((gn + 255) / 256)), dim3(256), 0, st, scale_dev,
+                       zp_dev, gn, s_hi, zp_dev ? z_hi : nullptr, z_lo);
+    hipLaunchKernelGGL(write_header_kernel, dim3(1), dim3(64), 0, st, h, (woq_blob_header*)blob);
+    int rc = repack_int4(q_hi, s_hi, zp_dev ? z_hi : nullptr, g_idx_dev, hi, blob + h.off_q, st);
+    if (rc == 0) rc = repack_int4(q_lo, scale_dev, z_lo, g_idx_dev, lo, blob + h.off_scale, st);
+    hipFreeAsync(tmp, st);
+    if (rc) return rc;
+    WOQ_HIP(hipGetLastError());
+    return 0;
+  }
+  woq_blob_header h;
+  WOQ_CHECK(woq_header_init(&h, K, N, blocksize, (uint32_t)weight_type, (uint32_t)scale_type,
+                            (uint32_t)compute_type, zp_dev != nullptr, g_idx_dev != nullptr) == 0,
+            "QBits: unsupported blocksize (must be -1 or a multiple of 32)");
+  WOQ_CHECK(blob_bytes >= h.total_bytes, "QBits: packed-weight buffer too small");
+  int rc = repack_int4(qweight_dev, scale_dev, zp_dev, g_idx_dev, h, blob, st);
+  if (rc) return rc;
   WOQ_HIP(hipGetLastError());
   WOQ_END
 }
@@ -249,7 +320,8 @@ int woq_quantize_to_packed_weight(const float* weight_dev, int transpose, int K,
                                   int weight_type, int scale_type, int compute_type, int asym, void* blob_dev,
                                   size_t blob_bytes, void* stream) {
   WOQ_TRY
-  WOQ_CHECK(weight_type == WOQ_W_INT4_CLIP, "QBits: unsupported weight_type in quantize (only int4_clip)");
+  WOQ_CHECK(weight_type == WOQ_W_INT4_CLIP || weight_type == WOQ_W_INT8,
+            "QBits: unsupported weight_type in quantize (int4_clip | int8)");
   int group = (blocksize <= 0 || blocksize > K) ? K : blocksize;  // blocksize -1 -> K (dispatcher.cpp:296)
   int n_groups = (K + group - 1) / group;
   hipStream_t st = (hipStream_t)stream;
@@ -261,7 +333,7 @@ int woq_quantize_to_packed_weight(const float* weight_dev, int transpose, int K,
   if (asym) WOQ_HIP(hipMalloc((void**)&zp, (size_t)n_groups * N));
   size_t nt = (size_t)n_groups * N;
   hipLaunchKernelGGL(rtn_kernel, dim3((unsigned)((nt + 127) / 128)), dim3(128), 0, st, weight_dev, transpose, K, N,
-                     group, n_groups, asym, q, sc, zp);
+                     group, n_groups, asym, weight_type == WOQ_W_INT8 ? 8 : 4, q, sc, zp);
   int rc = woq_repack_quantized_weight(q, sc, zp, nullptr, K, N, blocksize, weight_type, scale_type, compute_type,
                                        blob_dev, blob_bytes, stream);
   hipError_t e = hipStreamSynchronize(st);
@@ -278,8 +350,19 @@ int woq_dequantize_packed_weight(const void* blob_dev, const woq_blob_header* hd
   WOQ_TRY
   WOQ_CHECK(hdr && hdr->magic == WOQ_BLOB_MAGIC, "QBits: not a WQH1 packed weight");
   size_t total = (size_t)hdr->K * hdr->N;
+  if (hdr->weight_type == WOQ_W_INT8) {  // (hi - zhi) * 16s + (lo - zlo) * s, two fp32 terms
+    woq_blob_header o, hi, lo;
+    WOQ_CHECK(woq_int8_headers(&o, &hi, &lo, hdr->K, hdr->N, hdr->group, hdr->scale_type, hdr->compute_type,
+                               hdr->off_zp != 0, hdr->off_shuffle != 0) == 0, "QBits: corrupt int8 header");
+    hipLaunchKernelGGL(dequant_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)blob_dev + hdr->off_q, hi, out_dev, transpose, 0);
+    hipLaunchKernelGGL(dequant_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)blob_dev + hdr->off_scale, lo, out_dev, transpose, 1);
+    WOQ_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(dequant_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint8_t*)blob_dev, *hdr, out_dev, transpose);
+                     (const uint8_t*)blob_dev, *hdr, out_dev, transpose, 0);
   WOQ_HIP(hipGetLastError());
   WOQ_END
 }
@@ -296,6 +379,29 @@ int woq_blob_extract(const void* blob_dev, const woq_blob_header* hdr, int what,
   WOQ_TRY
   WOQ_CHECK(hdr && hdr->magic == WOQ_BLOB_MAGIC, "QBits: not a WQH1 packed weight");
   hipStream_t st = (hipStream_t)stream;
+  if (hdr->weight_type == WOQ_W_INT8) {
+    woq_blob_header o, hi, lo;
+    WOQ_CHECK(woq_int8_headers(&o, &hi, &lo, hdr->K, hdr->N, hdr->group, hdr->scale_type, hdr->compute_type,
+                               hdr->off_zp != 0, hdr->off_shuffle != 0) == 0, "QBits: corrupt int8 header");
+    const uint8_t* bhi = (const uint8_t*)blob_dev + hdr->off_q;
+    const uint8_t* blo = (const uint8_t*)blob_dev + hdr->off_scale;
+    size_t total = (size_t)hdr->n_groups * hdr->N;
+    if (what == WOQ_ACQ_G_IDX) {
+      WOQ_CHECK(hdr->off_shuffle != 0, "QBits: not pack g_idx tensor.");
+      WOQ_HIP(hipMemcpyAsync(out_dev, blo + lo.off_shuffle, (size_t)hdr->K * 4u, hipMemcpyDeviceToDevice, st));
+    } else if (what == WOQ_ACQ_SCALE_TENSOR) {
+      hipLaunchKernelGGL(extract_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, blo, lo, what,
+                         out_dev);
+    } else if (what == WOQ_ACQ_ZP_TENSOR) {
+      WOQ_CHECK(hdr->off_zp != 0, "QBits: not pack zero-point tensor.");
+      hipLaunchKernelGGL(extract_int8_zp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, bhi, hi, blo,
+                         lo, (int8_t*)out_dev);
+    } else {
+      WOQ_FAIL("QBits: unsupported acquire_type");
+    }
+    WOQ_HIP(hipGetLastError());
+    return 0;
+  }
   if (what == WOQ_ACQ_G_IDX) {
     WOQ_CHECK(hdr->off_shuffle != 0, "QBits: not pack g_idx tensor.");
     WOQ_HIP(hipMemcpyAsync(out_dev, (const uint8_t*)blob_dev + hdr->off_shuffle, (size_t)hdr->K * 4u,

@@ -30,7 +30,7 @@ def _blocksize_ok(k, blocksize):
 def _wtype(weight_type):
     if weight_type not in L.WEIGHT_TYPES:
         # reference text: bestla_packq_impl.cpp "unsupported bestla packq config"
-        raise RuntimeError("Qbits: unsupported bestla packq config, weight_type: %s (MI355X path: int4_clip)"
+        raise RuntimeError("Qbits: unsupported bestla packq config, weight_type: %s (MI355X path: int4_clip, int8)"
                            % weight_type)
     return L.WEIGHT_TYPES[weight_type]
 
@@ -75,7 +75,8 @@ def get_packed_weight_size(k, n, weight_type, scale_type, compute_type, asym, bl
 
 
 def repack_quantized_weight(qweight, scale, zp, g_idx, weight_type, scale_type, compute_type, asym, blocksize):
-    """qbits.cpp:61-77: int8 [K,N] (signed int4 values) + fp32 scales [G,N] + int8 zp [G,N] + int32 g_idx -> blob.
+    """qbits.cpp:61-77: int8 [K,N] (signed int4 values, or full int8 for weight_type "int8") + fp32 scales [G,N] +
+    int8 zp [G,N] + int32 g_idx -> blob.
     Empty `zp` / `g_idx` tensors mean "absent", as in the reference (qbits.cpp:67, modules.py:233-237)."""
     L.require_gpu()
     dev = qweight.device if qweight.is_cuda else torch.device("cuda", torch.cuda.current_device())

@@ -158,6 +158,8 @@ class QuantizedLinearQBits(torch.nn.Linear):
         q = torch.round(deq / safe)
         if zeros is not None:
             q = q + zeros[rows].float()
+        if self.bits == 8:  # the reference un-biases only 4-bit integers (:349-352); int8 stays signed
+            return q.clamp_(-128, 127).to(torch.int8), scales, zeros, g_idx
         int_weight = (q + 8).clamp_(0, 15).to(torch.int8)  # back to the unsigned domain (recover_qparms :349-352)
         return int_weight, scales, (zeros + 8 if zeros is not None else None), g_idx
 

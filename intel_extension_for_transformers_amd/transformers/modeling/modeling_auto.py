@@ -50,6 +50,9 @@ def save_low_bit(self, save_directory, push_to_hub=False, **kwargs):
     for name, mod in self.named_modules():
         if isinstance(mod, QuantizedLinearQBits):
             int_w, scales, zeros, g_idx = mod.recover_qparms()
+            if mod.bits == 8:  # on disk 8-bit values live in the unsigned domain, q + 128 (utils.py:103-124 undoes it)
+                int_w = int_w.to(torch.int16) + 128
+                zeros = None if zeros is None else zeros.to(torch.int16) + 128
             qweight, sc16, qzeros = pack_weight(int_w, scales, zeros, bits=mod.bits)
             tensors[name + ".qweight"] = qweight.cpu().contiguous()
             tensors[name + ".scales"] = (scales if mod.scale_dtype == "fp32" else sc16).cpu().contiguous()
@@ -181,13 +184,11 @@ class _BaseAutoModelClass:
         load_in_8bit = kwargs.pop("load_in_8bit", False)
         kwargs.pop("use_cpu", None)
         kwargs.pop("use_xpu", None)
-        if load_in_8bit:
-            raise ValueError("Only support quantization to [4] bits on the MI355X path but found 8")
         if isinstance(pretrained_model_name_or_path, (str, os.PathLike)) and os.path.isfile(
                 os.path.join(str(pretrained_model_name_or_path), QUANT_CONFIG)):
             return load_low_bit(pretrained_model_name_or_path, device=device)  # :598-657
-        if qcfg is None and load_in_4bit:  # :717-741: load_in_4bit -> RtnConfig(bits=4)
-            qcfg = RtnConfig(bits=4, compute_dtype=kwargs.pop("compute_dtype", None),
+        if qcfg is None and (load_in_4bit or load_in_8bit):  # :717-741: load_in_{4,8}bit -> RtnConfig(bits=4 | 8)
+            qcfg = RtnConfig(bits=4 if load_in_4bit else 8, compute_dtype=kwargs.pop("compute_dtype", None),
                              weight_dtype=kwargs.pop("weight_dtype", None), scale_dtype=kwargs.pop("scale_dtype", None))
         if isinstance(pretrained_model_name_or_path, torch.nn.Module):
             model = pretrained_model_name_or_path

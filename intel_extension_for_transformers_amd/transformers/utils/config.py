@@ -169,21 +169,28 @@ class ITREXQuantizationConfigMixin(_HFBase):
 
     def post_init_hip(self):
         """MI355X validator (the device branch the reference lacks, utils.py:355-360 raises for anything but
-        cpu/xpu). int4 weights; fp32 | bf16 | fp16 scales; any group size that is -1 or a multiple of 32;
-        sym or asym with any scale type (the HIP kernels apply zero points exactly)."""
+        cpu/xpu). int4 (bits = 4) or int8 (bits = 8) weights — the reference's `bits in {4, 8}` (config.py:277-372);
+        fp32 | bf16 | fp16 scales; any group size that is -1 or a multiple of 32; sym or asym with any scale type
+        (the HIP kernels apply zero points exactly)."""
         if self.compute_dtype is None:
             self.compute_dtype = "fp32"
         elif self.compute_dtype not in ("fp32", "bf16", "fp16", "int8"):
             raise ValueError("compute_dtype must be 'fp32', 'bf16', 'fp16' or 'int8'.")
         if self.bits is None:
             self.bits = 4
-        elif self.bits != 4:
-            raise ValueError("Only support quantization to [4] bits on the MI355X path but found %s" % self.bits)
-        if self.weight_dtype in (None, "int4", "int4_fullrange"):
+        elif self.bits not in (4, 8):
+            raise ValueError("Only support quantization to [4, 8] bits but found %s" % self.bits)
+        if self.bits == 8:
+            if self.weight_dtype in (None, "int8"):
+                self.weight_dtype = "int8"
+            else:
+                raise ValueError("weight_dtype must be 'int8' for bits=8 on the MI355X path, got %s"
+                                 % self.weight_dtype)
+        elif self.weight_dtype in (None, "int4", "int4_fullrange"):
             self.weight_dtype = "int4_clip"
         elif self.weight_dtype != "int4_clip":
-            raise ValueError("weight_dtype must be 'int4' / 'int4_clip' on the MI355X path, got %s"
-                             % self.weight_dtype)
+            raise ValueError("weight_dtype must be 'int4' / 'int4_clip' (bits=4) or 'int8' (bits=8) on the MI355X "
+                             "path, got %s" % self.weight_dtype)
         if self.scale_dtype is None:
             self.scale_dtype = "fp32"
         elif self.scale_dtype not in ("fp32", "bf16", "fp16"):

@@ -123,6 +123,72 @@ def repack(q, scales, zp=None, shuffle=None, group=-1, scale_type=F32, compute_t
     return blob
 
 
+# ---- int8 weights: composite of two int4 blobs (include/woq_blob.h woq_int8_headers) -------------------------------
+W_INT4, W_INT8 = 0, 1
+
+
+def split_int8(q8, scales, zp8):
+    """q8 - zp8 = 16 (hi - zhi) + (lo - zlo) with every term in [-8, 7]; scales 16 s / s."""
+    q8 = np.asarray(q8, np.int8).astype(np.int32)
+    hi, lo = (q8 >> 4).astype(np.int8), ((q8 & 15) - 8).astype(np.int8)
+    s = np.asarray(scales, np.float32)
+    z = np.zeros(s.shape, np.int32) if zp8 is None else np.asarray(zp8, np.int8).astype(np.int32)
+    zhi = None if zp8 is None else (z >> 4).astype(np.int8)
+    zlo = ((z & 15) - 8).astype(np.int8)
+    return (hi, (16.0 * s).astype(np.float32), zhi), (lo, s, zlo)
+
+
+def repack_int8(q8, scales, zp8=None, shuffle=None, group=-1, scale_type=F32, compute_type=0):
+    """int8 [K, N] + fp32 scales [G, N] + int8 zp [G, N] -> composite blob (outer header + HI blob + LO blob)."""
+    (hi, shi, zhi), (lo, slo, zlo) = split_int8(q8, scales, zp8)
+    bhi = repack(hi, shi, zhi, shuffle, group, scale_type, compute_type)
+    blo = repack(lo, slo, zlo, shuffle, group, scale_type, compute_type)
+    outer = bhi[:HEADER_BYTES].copy()
+    lo_h = header(blo)
+    outer.view(np.uint32)[10] = W_INT8
+    u64 = outer.view(np.uint64)
+    u64[8] = HEADER_BYTES
+    u64[9] = HEADER_BYTES + bhi.size
+    u64[10] = HEADER_BYTES + bhi.size + lo_h["off_zp"] if zp8 is not None else 0
+    u64[11] = HEADER_BYTES + bhi.size + lo_h["off_shuffle"] if shuffle is not None else 0
+    u64[1] = HEADER_BYTES + bhi.size + blo.size
+    return np.concatenate([outer, bhi, blo])
+
+
+def _int8_parts(blob):
+    h = header(blob)
+    return blob[h["off_q"]:h["off_scale"]], blob[h["off_scale"]:h["total_bytes"]]
+
+
+def rtn_quantize_int8(w, transpose, group, asym):
+    """8-bit form of the (parity-unpinned) RTN rule of woq_oracle.c, in fp32 arithmetic like the device kernel:
+    sym s = max|w| / 127, q = clip(rne(w / s), -128, 127); asym s = (max - min) / 255, z = clip(rne(-min / s), 0, 255),
+    q = clip(rne(w / s) + z, 0, 255) - 128, zp = z - 128."""
+    w = np.asarray(w, np.float32)
+    w = w.T if transpose else w
+    K, N = w.shape
+    g = K if group in (-1, 0) or group > K else group
+    G = (K + g - 1) // g
+    q = np.empty((K, N), np.int8)
+    s = np.empty((G, N), np.float32)
+    z = np.empty((G, N), np.int8) if asym else None
+    for gi in range(G):
+        blk = w[gi * g:min(K, (gi + 1) * g)]
+        if not asym:
+            sc = (np.abs(blk).max(0) / np.float32(127)).astype(np.float32)
+            sc[sc == 0] = 1
+            q[gi * g:gi * g + blk.shape[0]] = np.clip(np.rint(blk / sc), -128, 127).astype(np.int8)
+        else:
+            mx, mn = blk.max(0), blk.min(0)
+            sc = ((mx - mn) / np.float32(255)).astype(np.float32)
+            sc[sc == 0] = 1
+            zz = np.clip(np.rint(-mn / sc), 0, 255).astype(np.int32)
+            q[gi * g:gi * g + blk.shape[0]] = (np.clip(np.rint(blk / sc).astype(np.int32) + zz, 0, 255) - 128).astype(np.int8)
+            z[gi] = (zz - 128).astype(np.int8)
+        s[gi] = sc
+    return q, s, z
+
+
 def header(blob):
     """Parse the WQH1 header (include/woq_blob.h) into a dict."""
     h = np.frombuffer(np.ascontiguousarray(blob[:HEADER_BYTES]).tobytes(), dtype=np.uint8)
@@ -140,6 +206,9 @@ def dequantize_blob(blob, transpose=False):
     """reference: qbits.cpp:102-111."""
     blob = _c(blob, np.uint8)
     h = header(blob)
+    if h["weight_type"] == W_INT8:  # (hi - zhi) * 16s + (lo - zlo) * s, the two fp32 terms added in this order
+        bhi, blo = _int8_parts(blob)
+        return dequantize_blob(bhi, transpose) + dequantize_blob(blo, transpose)
     out = np.empty((h["N"], h["K"]) if transpose else (h["K"], h["N"]), np.float32)
     rc = lib().orc_dequantize_blob(_p(blob), _p(out), int(transpose))
     if rc != 0:
@@ -171,6 +240,18 @@ def woq_linear(x, blob, bias=None, out_dtype=F32):
     blob = _c(blob, np.uint8)
     bias = _c(bias, np.float32)
     h = header(blob)
+    if h["weight_type"] == W_INT8:  # dequantise -> fp32 matmul -> + bias on the composite's dequantised weight
+        w = dequantize_blob(blob).astype(np.float64)
+        xs = x if not h["off_shuffle"] else x[:, np.frombuffer(
+            blob[h["off_shuffle"]:h["off_shuffle"] + 4 * h["K"]].tobytes(), np.int32)]
+        y = (xs.astype(np.float64) @ w).astype(np.float32)
+        if bias is not None:
+            y = y + bias
+        if out_dtype == BF16:
+            return bf16_round(y)
+        if out_dtype == F16:
+            return y.astype(np.float16).astype(np.float32)
+        return y
     M = x.shape[0]
     out = np.empty((M, h["N"]), np.float32 if out_dtype == F32 else np.uint16)
     rc = lib().orc_woq_linear(_p(x), x.shape[1], _p(blob), _p(bias), _p(out), out_dtype, h["N"], M)

@@ -189,3 +189,27 @@ def test_neural_chat_prompt_templates():
     c.append_message(c.roles[1], None)
     assert c.get_prompt() == "[INST] hi [/INST]"
     assert get_conv_template("llama-2").messages == []  # templates are copied, not shared
+
+
+@pytest.mark.parametrize("sym", [True, False])
+def test_pack_unpack_weight_8bit_roundtrip(sym):
+    """On-disk 8-bit convention of reference utils.py:82-125: values stored in the unsigned domain (q + 128), zeros
+    as zp - 1; unpack returns signed int8. pack_weight (the save path) inverts it for what save_low_bit feeds it."""
+    import types
+
+    import torch
+
+    from intel_extension_for_transformers_amd.transformers.llm.quantization.utils import pack_weight, unpack_weight
+
+    g = torch.Generator().manual_seed(0)
+    K, N, G = 64, 20, 2
+    q = torch.randint(-128, 128, (K, N), generator=g, dtype=torch.int16)
+    z = None if sym else torch.randint(-127, 128, (G, N), generator=g, dtype=torch.int16)
+    s = torch.rand(G, N, generator=g) + 0.5
+    qweight, _, qzeros = pack_weight(q + 128, s, None if z is None else z + 128, bits=8)
+    assert qweight.shape == (K // 4, N) and qweight.dtype == torch.int32
+    cfg = types.SimpleNamespace(bits=8, sym=sym)
+    w, _, zeros = unpack_weight(qweight, s, qzeros, cfg)
+    assert w.dtype == torch.int8 and torch.equal(w.to(torch.int16), q)
+    if not sym:
+        assert torch.equal(zeros.to(torch.int16), z)

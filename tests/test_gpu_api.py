@@ -265,3 +265,49 @@ def test_neural_chat_build_chatbot_predict_and_stream(tmp_path):
     out = list(bot.predict_stream(q, config=scfg))
     joined = "".join(out)
     assert "| Key" in joined and "msecond_per_token" in joined and "input_token_len" in joined
+
+
+def test_from_pretrained_bits8_int8_weights(tmp_path):
+    """`bits in {4, 8}` (reference utils/config.py:277-372): RtnConfig(bits=8) / load_in_8bit -> int8 weights on the
+    module path; logits against the dequantised fp32 twin; save_low_bit -> load_low_bit round trip."""
+    from intel_extension_for_transformers_amd.transformers import AutoModelForCausalLM, RtnConfig
+
+    fp = _tiny_llama()
+    src = tmp_path / "fp"
+    fp.save_pretrained(str(src))
+    qmodel = AutoModelForCausalLM.from_pretrained(str(src), quantization_config=RtnConfig(bits=8, group_size=64))
+    assert qmodel.quantization_config.weight_dtype == "int8"
+    twin = _dequantised_twin8(qmodel, fp)
+    ids = torch.tensor([[5, 17, 200, 3, 77, 12]], device="cuda")
+    with torch.no_grad():
+        a = qmodel(ids).logits.float()
+        b = twin(ids).logits.float()
+    assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-5
+    # 8-bit RTN of N(0, 0.02) weights is close to the fp model itself
+    with torch.no_grad():
+        c = fp.cuda()(ids).logits.float()
+    assert (a - c).abs().max().item() <= 3e-2 * c.abs().max().item()
+    out = tmp_path / "q8"
+    qmodel.save_pretrained(str(out))
+    again = AutoModelForCausalLM.from_pretrained(str(out))
+    with torch.no_grad():
+        d = again(ids).logits.float()
+    assert (a - d).abs().max().item() <= 1e-5 * a.abs().max().item() + 1e-6
+    m2 = AutoModelForCausalLM.from_pretrained(str(src), load_in_8bit=True)
+    assert m2.quantization_config.bits == 8
+
+
+def _dequantised_twin8(qmodel, fp_model):
+    from intel_extension_for_transformers_amd import qbits
+    from intel_extension_for_transformers_amd.transformers.llm.quantization.nn.modules import QuantizedLinearQBits
+
+    twin = copy.deepcopy(fp_model).cuda()
+    qmods = dict(qmodel.named_modules())
+    for name, mod in twin.named_modules():
+        qm = qmods.get(name)
+        if isinstance(qm, QuantizedLinearQBits):
+            deq = torch.empty(qm.in_features, qm.out_features, dtype=torch.float32, device="cuda")
+            qbits.dequantize_packed_weight(qm.weight.data, deq, False, "fp32", "int8", qm.scale_dtype)
+            with torch.no_grad():
+                mod.weight.copy_(deq.t())
+    return twin

@@ -325,3 +325,90 @@ def test_woq_linear_prefill_f16_strided_rows(qbits):
     got = out.cpu().numpy()
     assert (np.abs(got - ref) <= 2e-3 * np.abs(ref).max(axis=1, keepdims=True) + 1e-5).all()
     assert (obig[:, N].cpu().numpy() == 7.0).all()  # the column past N is untouched
+
+
+# ---- int8 weights (reference weight type "int8", bits = 8): composite of two int4 blobs ---------------------------
+def _mk8(K, N, group, asym, shuf, seed=0):
+    rng = np.random.default_rng(seed)
+    q = rng.integers(-128, 128, (K, N), dtype=np.int8)
+    g = K if group == -1 else group
+    G = (K + g - 1) // g
+    s = (rng.random((G, N), dtype=np.float32) + 0.5) * 0.001
+    z = rng.integers(-128, 128, (G, N), dtype=np.int8) if asym else None
+    idx = rng.permutation(np.arange(K, dtype=np.int32) // g).astype(np.int32) if shuf else None
+    return q, s, z, idx
+
+
+def _gpu_blob8(qbits, q, s, z, idx, group, scale_type="fp32", compute="fp32"):
+    e8, e32 = torch.empty(0, dtype=torch.int8), torch.empty(0, dtype=torch.int32)
+    return qbits.repack_quantized_weight(torch.from_numpy(q).cuda(), torch.from_numpy(s).cuda(),
+                                         e8 if z is None else torch.from_numpy(z).cuda(),
+                                         e32 if idx is None else torch.from_numpy(idx).cuda(), "int8", scale_type,
+                                         compute, z is not None, group)
+
+
+INT8_CASES = [(512, 1024, 128, False, False), (512, 1024, 128, True, True), (256, 48, 32, True, False),
+              (160, 24, 64, False, False), (512, 64, -1, True, False)]
+
+
+@pytest.mark.parametrize("K,N,group,asym,shuf", INT8_CASES)
+@pytest.mark.parametrize("scale_type", ["fp32", "bf16"])
+def test_int8_blob_bytes_dequant_and_info(qbits, K, N, group, asym, shuf, scale_type):
+    """The int8 composite blob is byte-identical to the oracle's (split q8 / zp8 / scale exactly, then two int4
+    repacks); dequantisation equals the oracle's two-term fp32 sum bit for bit and the one-multiply definition
+    (q8 - zp8) * s to 2 ulp; acquire_packed_weight_info hands the original scale / zero-point tensors back."""
+    q, s, z, idx = _mk8(K, N, group, asym, shuf, seed=21)
+    blob = _gpu_blob8(qbits, q, s, z, idx, group, scale_type)
+    ref = orc.repack_int8(q, s, z, _cvt(idx, K, group), group, scale_type=ST[scale_type])
+    got = blob.cpu().numpy().view(np.uint8)
+    assert got.size == ref.size == qbits.get_packed_weight_size(K, N, "int8", scale_type, "fp32", asym, group, shuf)
+    assert np.array_equal(got, ref)
+    deq = torch.empty(K, N, dtype=torch.float32, device="cuda")
+    qbits.dequantize_packed_weight(blob, deq, False, "fp32", "int8", scale_type)
+    want = orc.dequantize_blob(ref)
+    assert np.array_equal(deq.cpu().numpy(), want)
+    g = K if group == -1 else group
+    s_used = torch.from_numpy(s).to(DT[scale_type]).float().numpy()
+    zz = np.zeros_like(s_used) if z is None else z.astype(np.float32)
+    plain = (q.astype(np.float32) - np.repeat(zz, g, 0)[:K]) * np.repeat(s_used, g, 0)[:K]
+    assert np.abs(want - plain).max() <= 2.5e-7 * np.abs(plain).max()
+    assert "".join(chr(c) for c in qbits.acquire_packed_weight_info(blob, 6).tolist()) == "int8"
+    assert np.array_equal(qbits.acquire_packed_weight_info(blob, 9).cpu().numpy(), s_used)
+    if asym:
+        assert np.array_equal(qbits.acquire_packed_weight_info(blob, 10).cpu().numpy(), z)
+
+
+@pytest.mark.parametrize("K,N,group,asym,shuf", INT8_CASES)
+@pytest.mark.parametrize("M,compute", [(1, "fp32"), (4, "fp32"), (40, "fp32"), (200, "bf16")])
+def test_int8_woq_linear_vs_oracle(qbits, K, N, group, asym, shuf, M, compute):
+    """woq_linear on int8 weights = two int4 launches (HI into an fp32 scratch, LO adds it + bias): decode GEMV,
+    fp32-compute GEMM and fp16-operand GEMM routes against dequantise -> matmul -> + bias of the oracle. Bounds as for
+    the int4 routes they reuse (fp32-class 1e-4 of the row's |x||w| scale; 2e-3 for the reduced-precision mode)."""
+    q, s, z, idx = _mk8(K, N, group, asym, shuf, seed=22)
+    blob = _gpu_blob8(qbits, q, s, z, idx, group, "fp32", compute)
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    bias = rng.random(N, dtype=np.float32)
+    ref = orc.woq_linear(x, orc.repack_int8(q, s, z, _cvt(idx, K, group), group), bias)
+    out = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    qbits.woq_linear(torch.from_numpy(x).cuda(), blob, torch.from_numpy(bias).cuda(), out, compute, "int8", "fp32", asym)
+    got = out.cpu().numpy()
+    # cancellation-aware scale: sum |x| |w| per row/column is what the error is relative to
+    w = np.abs(orc.dequantize_blob(orc.repack_int8(q, s, z, None, group)))
+    mag = np.abs(x) @ w if idx is None else np.abs(x)[:, _cvt(idx, K, group)] @ w
+    rel = 2e-6 if compute == "fp32" else 2e-3
+    assert (np.abs(got - ref) <= rel * mag + 1e-5).all()
+
+
+def test_int8_quantize_to_packed_weight_roundtrip(qbits):
+    """qbits.quantize_to_packed_weight(weight_type="int8") == the 8-bit RTN rule + repack of the oracle (rounding
+    rule parity-unpinned), sym and asym, nn.Linear layout."""
+    rng = np.random.default_rng(24)
+    w = (rng.standard_normal((96, 256)) * 0.05).astype(np.float32)  # [N, K]
+    for asym in (False, True):
+        blob = qbits.quantize_to_packed_weight(torch.from_numpy(w).cuda(), True, 64, "fp32", "int8", "fp32", asym)
+        q, s, z = orc.rtn_quantize_int8(w, True, 64, asym)
+        assert np.array_equal(blob.cpu().numpy().view(np.uint8), orc.repack_int8(q, s, z, None, 64))
+        deq = torch.empty(96, 256, dtype=torch.float32, device="cuda")
+        qbits.dequantize_packed_weight(blob, deq, True, "fp32", "int8", "fp32")
+        assert np.abs(deq.cpu().numpy() - w).max() <= 0.51 * s.max()  # within half a quantisation step
