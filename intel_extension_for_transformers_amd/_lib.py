@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwoq_hip.so")
+LIB_PATH = os.environ.get("WOQ_HIP_LIB") or os.path.join(_HERE, "libwoq_hip.so")  # env: A/B builds in development
 
 F32, BF16, F16, FP8_E4M3 = 0, 1, 2, 3
 W_INT4_CLIP, W_INT8 = 0, 1

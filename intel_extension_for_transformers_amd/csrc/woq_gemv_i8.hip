@@ -67,6 +67,16 @@ extern __device__ unsigned long long* g_probe;
 #define WOQ_STAMP(k)
 #endif
 
+// weight-tile loads issued before the activation staging (the rest follow one per consumed tile, or right after the
+// staging with WOQ_REST_EARLY). Measured on the Llama-2-7B decode (tokens/s): 4 -> 721, 8 -> 729, 16 = everything up
+// front -> 740, 8 + rest-early -> 744 (= 16 for every projection but gate/up), 4 + rest-early -> 719: the earlier
+// the whole wave's loads are queued the better, even when the CU's miss queue makes the wave wait at issue.
+#ifndef WOQ_PF
+#define WOQ_PF 16
+#endif
+#ifndef WOQ_REST_EARLY
+#define WOQ_REST_EARLY 0
+#endif
 namespace woq {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_tile_kernel(
     }
   }
   WOQ_STAMP(2);
-  constexpr int PF = 4;
+  constexpr int PF = WOQ_PF;
   rsrc_t rq[CB];
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb)
@@ -286,6 +296,10 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_tile_kernel(
   // the strip, zero and ones blocks are wave-private and LDS executes one wave's accesses in order: no barrier
   __builtin_amdgcn_wave_barrier();
   WOQ_STAMP(4);
+  if constexpr (WOQ_REST_EARLY) {
+#pragma unroll
+    for (int i = PF; i < CB * TPW; ++i) issue_w(i);
+  }
 
   // ---- 3. inner products, tiles in arrival order ----
   // A rows: MFMA row r = lane & 15 -> activation row r >> 2, part r & 3 (limb 0..2 | ones). D: lane group kq
@@ -335,7 +349,7 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_tile_kernel(
       }
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) {
-        if (t * CB + cb + PF < CB * TPW) issue_w(t * CB + cb + PF);
+        if (!WOQ_REST_EARLY && t * CB + cb + PF < CB * TPW) issue_w(t * CB + cb + PF);
         const u32x4 wv = w[cb][t];
         const i32x4 b0 = {(int)((wv.x << 4) & 0xf0f0f0f0u), (int)(wv.x & 0xf0f0f0f0u),
                           (int)((wv.y << 4) & 0xf0f0f0f0u), (int)(wv.y & 0xf0f0f0f0u)};
@@ -372,7 +386,7 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_tile_kernel(
       }
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) {
-        if (t * CB + cb + PF < CB * TPW) issue_w(t * CB + cb + PF);
+        if (!WOQ_REST_EARLY && t * CB + cb + PF < CB * TPW) issue_w(t * CB + cb + PF);
         const u32x4 wv = w[cb][t];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
