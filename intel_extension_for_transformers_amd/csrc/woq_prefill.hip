@@ -18,7 +18,8 @@
 //    B = the packed fp16 probabilities; the output again has query i16 in lane i16, so the running rescale is a
 //    plain per-lane multiply.
 // Tiles entirely above a wave's causal diagonal are skipped by that wave; the workgroups with the most tiles are
-// scheduled first. fp32 accumulation throughout; Q, K, V, P enter the MFMAs as fp16.
+// scheduled first. One LDS buffer, two barriers per tile (a two-buffer, one-barrier variant measured 28 % slower:
+// 450 vs 353 us per layer at 4 x 2048 tokens — two workgroups per CU already overlap each other's staging). fp32 accumulation throughout; Q, K, V, P enter the MFMAs as fp16.
 #include "woq_device.h"
 #include "woq_launch.h"
 
@@ -266,20 +267,25 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const _Float16* __
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[rt], mx * sc);
       const float m_use = m_new == -INFINITY ? 0.f : m_new;  // a row with nothing visible yet: keep exp2 finite
-      const float alpha = exp2f(m_run[rt] - m_use);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[rt] - m_use);  // raw v_exp_f32: arguments are <= 0
+      const bool moved = m_new != m_run[rt];
       m_run[rt] = m_new;
       float ps = 0.f;
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float p = exp2f(fmaf(s[a][rt][j], sc, -m_use));
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[a][rt][j], sc, -m_use));
           ps += p;
           pb[a >> 1][rt][(a & 1) * 4 + j] = (_Float16)p;
         }
       l_part[rt] = fmaf(l_part[rt], alpha, ps);
+      // once the running maxima have settled (most tiles after the first few) alpha is exactly 1 for every query of
+      // the wave: skip the rescale of the output accumulators then (wave-uniform branch)
+      if (__builtin_amdgcn_ballot_w64(moved) != 0) {
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) o[dt][rt] *= alpha;
+        for (int dt = 0; dt < DT; ++dt) o[dt][rt] *= alpha;
+      }
     }
     // ---- O^T += V^T P^T ----
 #pragma unroll
