@@ -135,7 +135,9 @@ __device__ __forceinline__ float limb_combine(const i32x4& d) {
 
 // flags: bit 0 scales are bf16 (else fp16; ignored for fp32 scales), bit 1 SiLU(gate)*up epilogue (CB == 2)
 template <int TPW, int CB, int SMODE, bool ASYM, bool S32, bool M1>
-__global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_tile_kernel(
+// register budget by workgroup size: 1024 threads -> 128 VGPRs (group-128 paths), 768 -> 168 (per-32 scales keep
+// 3 more registers per tile and twice the A fragments), 512 -> 256
+__global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) void gemv_tile_kernel(
     const u32x4* __restrict__ q, const void* __restrict__ scales, const float* __restrict__ x,
     const float* __restrict__ norm_w, int tiles_k, int K, int base_tiles, int rem_tiles, int n_groups, int tpg_shift,
     const uint8_t* __restrict__ zp, void* __restrict__ out, const float* __restrict__ bias, const float* residual,
@@ -316,7 +318,15 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_tile_kernel(
   const unsigned char* a_hi = kq < 2 ? zero_blk : a_base;
   const int st_lo_t = kq < 2 ? a_step_t : 0, st_lo_h = kq < 2 ? a_step_h : 0;
   const int st_hi_t = kq < 2 ? 0 : a_step_t, st_hi_h = kq < 2 ? 0 : a_step_h;
-  const float unsc = __shfl(my_unsc, kq, 64);
+  // group-32, batch 1: MFMA rows 4..7 are free, so they carry the SAME activation row restricted to the second 32-k
+  // group of the 64-k block (lanes kq >= 2) while rows 0..3 keep the first group (lanes kq < 2): ONE MFMA per 64-k
+  // half leaves group 2h in output rows 0..3 (lane quarter 0) and group 2h+1 in rows 4..7 (lane quarter 1)
+  const int g_sel = i16 >> 2;
+  const bool g_mine = (g_sel == 0 && kq < 2) || (g_sel == 1 && kq >= 2);
+  const unsigned char* a_g32 = !g_mine ? zero_blk + kq * 16
+                                       : (a_part == 3 ? ones_blk + kq * 16 : strip + (size_t)a_part * RB + kq * 16);
+  const int g32_step_t = (g_mine && a_part != 3) ? 128 : 0, g32_step_h = (g_mine && a_part != 3) ? 64 : 0;
+  const float unsc = __shfl(my_unsc, M1 && SMODE == 1 ? 0 : kq, 64);
   const i32x4 izero = {0, 0, 0, 0};
   const i32x4 b_ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
   float tot[CB];
@@ -369,6 +379,37 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_tile_kernel(
         else
           prev_sc = tscale16(rsc[cb][t], bf);
       }
+    } else if constexpr (M1) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const i32x4 av = *(const i32x4*)(a_g32 + t * g32_step_t + h * g32_step_h);
+        float sx = 0.f;
+        if constexpr (ASYM) sx = limb_combine(__builtin_amdgcn_mfma_i32_16x16x64_i8(av, b_ones, izero, 0, 0, 0));
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+          if (h == 0 && !WOQ_REST_EARLY && t * CB + cb + PF < CB * TPW) issue_w(t * CB + cb + PF);
+          const u32x4 wv = w[cb][t];
+          const uint32_t w0 = h == 0 ? wv.x : wv.z, w1 = h == 0 ? wv.y : wv.w;
+          const i32x4 b = {(int)((w0 << 4) & 0xf0f0f0f0u), (int)(w0 & 0xf0f0f0f0u), (int)((w1 << 4) & 0xf0f0f0f0u),
+                           (int)(w1 & 0xf0f0f0f0u)};
+          float f = limb_combine(__builtin_amdgcn_mfma_i32_16x16x64_i8(av, b, izero, 0, 0, 0));
+          // this lane quarter's group: s = 2h + (kq & 1) (quarters 2, 3 hold zeros: their A rows are dead)
+          if constexpr (ASYM) {
+            const uint32_t zb = (rzp[cb][t] >> (16 * h)) & 0xffffu;
+            const int uz = (int)((kq & 1) ? (zb >> 8) : (zb & 0xffu));
+            f = fmaf(-16.f * (float)(uz - 8), sx, f);
+          }
+          float scv;
+          if constexpr (S32) {
+            const float s_lo = h == 0 ? rsc[cb][t].x : rsc[cb][t].z, s_hi = h == 0 ? rsc[cb][t].y : rsc[cb][t].w;
+            scv = (kq & 1) ? s_hi : s_lo;
+          } else {
+            const uint32_t r = h == 0 ? rsc[cb][t].x : rsc[cb][t].y;
+            scv = tscale16((kq & 1) ? (r >> 16) : (r & 0xffffu), bf);
+          }
+          tot[cb] = fmaf(scv, f, tot[cb]);
+        }
+      }
     } else {
       i32x4 al[2], ah[2];
 #pragma unroll
@@ -413,6 +454,10 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_tile_kernel(
     if (t == 0) WOQ_STAMP(5);
   }
   if (have_prev) tot[prev_cb] = fmaf(prev_sc, limb_combine(prev_d) + prev_zc, tot[prev_cb]);
+  if constexpr (M1 && SMODE == 1) {  // lane quarter 1 holds the odd 32-k groups' sums: fold them into quarter 0
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) tot[cb] += __shfl_xor(tot[cb], 16, 64);
+  }
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
     // slab layout [wave][cb][activation row = lane >> 4][16 columns]
@@ -524,7 +569,7 @@ static bool tile_geometry(int tiles_k, int cb, int smode, int& nw, int& tpw) {
   }();
   tpw = (tiles_k > 16 && !(cb == 2 && smode == 1) && tiles_k > force4) ? 8 : 4;  // per-32 scales x 2 column tiles: register budget
   nw = (tiles_k + tpw - 1) / tpw;
-  return nw <= (cb * tpw > 8 ? 8 : 16);  // the kernel's __launch_bounds__
+  return nw <= (cb * tpw > 8 ? 8 : (smode == 1 ? 12 : 16));  // the kernel's __launch_bounds__
 }
 
 // largest M the tile kernel takes for this call (LDS budget), 0 if it is not covered: the kernel wants fp32,

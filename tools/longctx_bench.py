@@ -1,6 +1,8 @@
 """BASELINE configs[4] shape: Mistral-7B (hidden 4096, inter 14336, 32 q / 8 kv heads, 32 layers) int4 sym g128 with
 an fp8 (e4m3) KV cache: chunked prefill of an 8k-token prompt, then batch-1 decode at that context.
-args: [ctx=8192] [chunk=2048] [kv=fp8|fp16] [splits=0]. Development / profile tool (bench.py is the headline)."""
+args: [ctx=8192] [chunk=2048] [kv=fp8|fp16] [splits=0] [group=128] [asym=0] [inter=14336] [kv_heads=8] — the last four turn
+it into any Llama-class shape (e.g. configs[2]: `160 160 fp16 0 32 1 11008 32`). Development / profile tool (bench.py
+is the headline)."""
 import json
 import sys
 import time
@@ -16,10 +18,14 @@ def main():
     chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
     kv = sys.argv[3] if len(sys.argv) > 3 else "fp8"
     splits = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-    hidden, inter, heads, kvh, hd, layers, vocab = 4096, 14336, 32, 8, 128, 32, 32000
+    group = int(sys.argv[5]) if len(sys.argv) > 5 else 128
+    asym = bool(int(sys.argv[6])) if len(sys.argv) > 6 else False
+    inter = int(sys.argv[7]) if len(sys.argv) > 7 else 14336
+    kvh = int(sys.argv[8]) if len(sys.argv) > 8 else 8
+    hidden, heads, hd, layers, vocab = 4096, 32, 128, 32, 32000
     eng = WoqDecoderEngine(hidden, inter, heads, kvh, hd, layers, vocab, max_ctx=ctx + 256,
                            kv_dtype=torch.float8_e4m3fn if kv == "fp8" else torch.float16, attn_splits=max(splits, 0) or 1)
-    synth_llama_weights(eng, hidden, inter, heads, kvh, hd, layers, vocab, group=128, sym=True, scale_dtype="fp16")
+    synth_llama_weights(eng, hidden, inter, heads, kvh, hd, layers, vocab, group=group, sym=not asym, scale_dtype="fp16")
     g = torch.Generator().manual_seed(1)
     toks = torch.randint(0, vocab, (ctx,), generator=g).cuda()
 
@@ -44,9 +50,9 @@ def main():
     torch.cuda.synchronize()
     t_dec = (time.perf_counter() - t0) / n
     params = layers * (hidden * (heads + 2 * kvh) * hd + heads * hd * hidden + 3 * hidden * inter)
-    wbytes = params // 2 + params // 128 * 2
+    wbytes = params // 2 + params // group * 2 + (params // group // 2 if asym else 0)
     kv_bytes = 2 * layers * kvh * hd * ctx * (1 if kv == "fp8" else 2)
-    print(json.dumps(dict(ctx=ctx, chunk=chunk, kv=kv, splits=splits, prefill_s=t_pf, prefill_tok_s=ctx / t_pf,
+    print(json.dumps(dict(ctx=ctx, chunk=chunk, kv=kv, splits=splits, group=group, asym=asym, inter=inter, kv_heads=kvh, prefill_s=t_pf, prefill_tok_s=ctx / t_pf,
                           decode_ms=t_dec * 1e3, decode_tok_s=1 / t_dec,
                           decode_gbps_weights=wbytes / t_dec / 1e9, decode_gbps_weights_plus_kv=(wbytes + kv_bytes) / t_dec / 1e9,
                           kv_mb_per_token=kv_bytes / 1e6)))
