@@ -373,7 +373,13 @@ ORC_API int orc_woq_linear(const float* x, int lda, const uint8_t* blob, const f
  * (bestla_weightonly_dispatcher.cpp:150-178: unpack int4 -> fp32, x scale, FMA, fp32 accumulate).
  * This is the function bench.py times as cpu_baseline (kind "port"): it streams the int4 blob
  * like the reference's CPU kernel does, instead of materialising W. M == 1 rows at a time. */
-ORC_API int orc_woq_gemv_stream(const float* x, const uint8_t* blob, const float* bias, float* out) {
+/* Loop order chosen for the host's vector units (AVX2 + FMA; the GPU boxes' EPYC hosts and the build container both
+ * have them): for one 16-column tile, one 32-row scale block at a time, the 16 columns are the vector lanes — a blob
+ * word holds 8 consecutive-k nibbles of ONE column, so word w of lanes (kq, i = 0..15) is a stride-4 gather, the
+ * nibbles are sign-extended with (u ^ 8) - 8 and multiplied by the broadcast activation. Zero points enter as
+ * -zp * sum(x) per block, like BesTLA's asym cores (bestla_weightonly_dispatcher.cpp:154-160,205-207). */
+__attribute__((target("avx2,fma"))) ORC_API int orc_woq_gemv_stream(const float* x, const uint8_t* blob,
+                                                                   const float* bias, float* out) {
   woq_blob_header h;
   memcpy(&h, blob, sizeof(h));
   if (h.magic != WOQ_BLOB_MAGIC) return -1;
@@ -381,6 +387,13 @@ ORC_API int orc_woq_gemv_stream(const float* x, const uint8_t* blob, const float
   const int32_t* shuf = h.off_shuffle ? (const int32_t*)(blob + h.off_shuffle) : NULL;
   float* xs = (float*)calloc((size_t)h.Kpad, sizeof(float));
   for (int k = 0; k < h.K; ++k) xs[k] = x[shuf ? shuf[k] : k];
+  /* sum of the activations of every 32-row block (zero-point term) */
+  float* xsum = (float*)calloc((size_t)tiles_k * 4, sizeof(float));
+  for (int b32 = 0; b32 < tiles_k * 4; ++b32) {
+    float t = 0.f;
+    for (int r = 0; r < 32; ++r) t += xs[b32 * 32 + r];
+    xsum[b32] = t;
+  }
 #pragma omp parallel for schedule(static)
   for (int tn = 0; tn < tiles_n; ++tn) {
     float acc[16];
@@ -388,20 +401,31 @@ ORC_API int orc_woq_gemv_stream(const float* x, const uint8_t* blob, const float
     for (int kt = 0; kt < tiles_k; ++kt) {
       const uint32_t* tile = (const uint32_t*)(blob + h.off_q) + ((size_t)tn * tiles_k + kt) * 256u;
       for (int s = 0; s < 4; ++s) { /* 32-row blocks: the finest scale granularity */
-        int kb = kt * 128 + s * 32;
-        for (int i = 0; i < 16; ++i) {
-          size_t si = woq_scale_index(&h, kb, tn * 16 + i);
-          float sc = orc_load_scalar(blob + h.off_scale, si, (int)h.scale_type);
-          int zpv = h.off_zp ? (int)(blob + h.off_zp)[si] - 8 : 0;
-          float part = 0.f;
-          for (int r = 0; r < 32; ++r) { /* k = kb + r: half hh, sixteenth kq, offset j (woq_blob.h) */
-            int rr = s * 32 + r, hh = rr / 64, kq = (rr % 64) / 16, j = rr % 16;
-            uint32_t w = tile[(size_t)(kq * 16 + i) * 4 + hh * 2 + j / 8];
-            int qv = (int)((w >> woq_nibble_shift(j)) & 0xf);
-            if (qv & 8) qv -= 16;
-            part += (float)(qv - zpv) * xs[kb + r];
+        const int kb = kt * 128 + s * 32, hh = s >> 1;
+        float part[16];
+        for (int i = 0; i < 16; ++i) part[i] = 0.f;
+        for (int kq2 = 0; kq2 < 2; ++kq2) {
+          const int kq = 2 * (s & 1) + kq2;
+          for (int p = 0; p < 2; ++p) { /* word 2 hh + p of lane (kq, i): k = kb + 16 kq2 + 8 p + jj */
+            const float* xk = xs + kb + 16 * kq2 + 8 * p;
+            const uint32_t* wp = tile + (size_t)(kq * 16) * 4 + hh * 2 + p;
+#pragma omp simd
+            for (int i = 0; i < 16; ++i) {
+              const uint32_t w = wp[i * 4];
+              float t = 0.f;
+              for (int jj = 0; jj < 8; ++jj) {
+                const int u = (int)((w >> (8 * (jj & 3) + 4 * (jj >> 2))) & 0xfu);
+                t += (float)((u ^ 8) - 8) * xk[jj];
+              }
+              part[i] += t;
+            }
           }
-          acc[i] += part * sc;
+        }
+        for (int i = 0; i < 16; ++i) {
+          const size_t si = woq_scale_index(&h, kb, tn * 16 + i);
+          const float sc = orc_load_scalar(blob + h.off_scale, si, (int)h.scale_type);
+          const int zpv = h.off_zp ? (int)(blob + h.off_zp)[si] - 8 : 0;
+          acc[i] += (part[i] - (float)zpv * xsum[kt * 4 + s]) * sc;
         }
       }
     }
@@ -411,6 +435,7 @@ ORC_API int orc_woq_gemv_stream(const float* x, const uint8_t* blob, const float
     }
   }
   free(xs);
+  free(xsum);
   return 0;
 }
 
