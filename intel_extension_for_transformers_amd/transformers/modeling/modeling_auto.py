@@ -157,12 +157,84 @@ def _materialise_buffers(model, device):
             (model.get_submodule(parent_name) if parent_name else model)._modules[leaf] = fresh.to(device)
 
 
+def _engine_generate(self, inputs=None, generation_config=None, **kwargs):
+    """`model.generate` with the fused native engine underneath when the request is one it covers — a single
+    sequence, greedy, one beam, no logits processing beyond the default — and HF's own generate (over the
+    QuantizedLinearQBits modules) for everything else. Same return value as HF for the covered case: LongTensor
+    [1, prompt + new]. The reference has no counterpart (its CPU path always runs the module-by-module loop); the
+    precedent for swapping the loop after from_pretrained is ipex.optimize_transformers (docs/weightonlyquant.md:199)."""
+    hf_generate = self._woq_hf_generate
+    ids = inputs if inputs is not None else kwargs.get("input_ids")
+    gc = generation_config if generation_config is not None else self.generation_config
+    opt = lambda k, d=None: kwargs[k] if k in kwargs else getattr(gc, k, d)  # noqa: E731
+    simple = (torch.is_tensor(ids) and ids.dim() == 2 and ids.shape[0] == 1 and ids.shape[1] >= 1
+              and not opt("do_sample", False) and (opt("num_beams", 1) or 1) == 1
+              and (opt("repetition_penalty", 1.0) or 1.0) == 1.0 and (opt("num_return_sequences", 1) or 1) == 1
+              and not opt("no_repeat_ngram_size", 0) and not opt("bad_words_ids") and not opt("force_words_ids")
+              and not opt("min_new_tokens", 0) and not opt("min_length", 0)
+              and not any(kwargs.get(k) is not None for k in ("logits_processor", "stopping_criteria",
+                                                              "prefix_allowed_tokens_fn", "assistant_model",
+                                                              "past_key_values", "inputs_embeds"))
+              and not kwargs.get("return_dict_in_generate", False) and not kwargs.get("output_scores", False))
+    mask = kwargs.get("attention_mask")
+    if simple and mask is not None and not bool(torch.all(mask == 1)):
+        simple = False
+    if not simple or getattr(self, "_woq_engine_off", False):
+        return hf_generate(inputs, generation_config=generation_config, **kwargs) if inputs is not None else \
+            hf_generate(generation_config=generation_config, **kwargs)
+    n_in = int(ids.shape[1])
+    max_new = opt("max_new_tokens")
+    if max_new is None:
+        max_new = max(int(opt("max_length", 20)) - n_in, 0)
+    eng = getattr(self, "woq_engine", None)
+    if eng is None or eng.cfg.max_ctx < n_in + max_new:
+        from ...runtime.engine import optimize_transformers
+
+        want = n_in + max_new
+        ctx = int(min(max(want, 512), getattr(self.config, "max_position_embeddings", want) or want))
+        if ctx < want:
+            return hf_generate(inputs, generation_config=generation_config, **kwargs)
+        try:
+            eng = optimize_transformers(self, max_ctx=1 << (ctx - 1).bit_length())
+        except RuntimeError:  # not a Llama-class int4 model: the module path serves it
+            self._woq_engine_off = True
+            return hf_generate(inputs, generation_config=generation_config, **kwargs)
+    eos = opt("eos_token_id")
+    eos = set() if eos is None else set(eos if isinstance(eos, (list, tuple)) else [eos])
+    streamer = kwargs.get("streamer")
+    prompt = ids[0].tolist()
+    if streamer is not None:
+        streamer.put(ids.cpu())
+    for s0 in range(0, n_in, 2048):
+        eng.prefill(prompt[s0:s0 + 2048], start_pos=s0, greedy=True)
+    eng.tune_attn_for(n_in + max_new)
+    if max_new > 1 and not eng.captured:
+        eng.capture(greedy=True)
+    out = []
+    for i in range(max_new):
+        t = int(eng.token.item())
+        out.append(t)
+        if streamer is not None:
+            streamer.put(torch.tensor([t]))
+        if t in eos:
+            break
+        if i + 1 < max_new:
+            eng.replay(1)
+    if streamer is not None:
+        streamer.end()
+    return torch.cat([ids, torch.tensor([out], dtype=ids.dtype, device=ids.device)], dim=1)
+
+
 def _finish(model, qcfg):
-    """reference modeling_auto.py:896-903."""
+    """reference modeling_auto.py:896-903, plus the engine-backed `generate` for Llama-class int4 models."""
     qcfg.remove_redundant_parameters()
     model.quantization_config = qcfg
     model.config.quantization_config = qcfg.to_dict()
     model.save_pretrained = types.MethodType(save_low_bit, model)
+    if getattr(model.config, "model_type", "") in ("llama", "mistral") and getattr(qcfg, "bits", 4) == 4 \
+            and hasattr(model, "generate") and not hasattr(model, "_woq_hf_generate"):
+        model._woq_hf_generate = model.generate
+        model.generate = types.MethodType(_engine_generate, model)
     return model
 
 

@@ -208,7 +208,7 @@ def test_optimize_transformers_engine_matches_hf_path(tmp_path, kv_heads):
     ids = torch.tensor([prompt], device="cuda")
     with torch.no_grad():
         ref_logits = qmodel(ids).logits[0, -1].float()
-        ref_out = qmodel.generate(ids, max_new_tokens=6, do_sample=False)[0, len(prompt):].tolist()
+        ref_out = qmodel._woq_hf_generate(ids, max_new_tokens=6, do_sample=False)[0, len(prompt):].tolist()
     for i, t in enumerate(prompt):
         eng.token.fill_(t)
         eng.pos.fill_(i)
@@ -256,10 +256,12 @@ def test_neural_chat_build_chatbot_predict_and_stream(tmp_path):
     assert "".join(pieces) == text and len(text.split()) == 8
     # the module path (HF generate over the QuantizedLinearQBits model) gives the same greedy continuation
     bot_engine, bot.engine = bot.engine, None
+    bot.model._woq_engine_off = True  # and keep model.generate itself on the HF loop
     try:
         assert bot.predict(q, config=cfg) == text
     finally:
         bot.engine = bot_engine
+        bot.model._woq_engine_off = False
     # sampling -> HF generate + streamer thread; stats block in the v2 table format
     scfg = GenerationConfig(max_new_tokens=5, do_sample=True, temperature=0.7, return_stats=True)
     out = list(bot.predict_stream(q, config=scfg))
@@ -311,3 +313,44 @@ def _dequantised_twin8(qmodel, fp_model):
             with torch.no_grad():
                 mod.weight.copy_(deq.t())
     return twin
+
+
+def test_model_generate_is_engine_backed_for_greedy(tmp_path):
+    """`model.generate` of a Llama-class int4 model rides the fused engine for the requests it covers (one sequence,
+    greedy) and HF's loop for the rest; both give the same greedy continuation; eos stops the engine path; a
+    streamer receives the prompt and every new token."""
+    from intel_extension_for_transformers_amd.transformers import AutoModelForCausalLM, RtnConfig
+
+    fp = _tiny_llama()
+    fp.generation_config.eos_token_id = None
+    src = tmp_path / "fp"
+    fp.save_pretrained(str(src))
+    qmodel = AutoModelForCausalLM.from_pretrained(str(src), quantization_config=RtnConfig(bits=4, group_size=128,
+                                                                                          scale_dtype="fp16"))
+    ids = torch.tensor([[5, 17, 200, 3, 77, 12, 9]], device="cuda")
+    hf = qmodel._woq_hf_generate(ids, max_new_tokens=8, do_sample=False, pad_token_id=0)
+    assert not hasattr(qmodel, "woq_engine")
+    out = qmodel.generate(ids, max_new_tokens=8, do_sample=False, pad_token_id=0)
+    assert hasattr(qmodel, "woq_engine") and torch.equal(out, hf)
+    # eos: stop right after the first token the model itself would emit
+    first = int(hf[0, ids.shape[1]])
+    short = qmodel.generate(ids, max_new_tokens=8, do_sample=False, eos_token_id=first)
+    assert short.shape[1] == ids.shape[1] + 1 and int(short[0, -1]) == first
+
+    class Collect:
+        def __init__(self):
+            self.items, self.ended = [], False
+
+        def put(self, v):
+            self.items.append(v.reshape(-1).tolist())
+
+        def end(self):
+            self.ended = True
+
+    st = Collect()
+    qmodel.generate(ids, max_new_tokens=4, do_sample=False, streamer=st)
+    assert st.ended and st.items[0] == ids[0].tolist() and sum(st.items[1:], []) == hf[0, 7:11].tolist()
+    # a sampling request is not the engine's: it takes HF's loop and still works
+    torch.manual_seed(0)
+    samp = qmodel.generate(ids, max_new_tokens=4, do_sample=True, top_k=5, pad_token_id=0)
+    assert samp.shape == (1, ids.shape[1] + 4)
