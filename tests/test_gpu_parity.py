@@ -412,3 +412,66 @@ def test_int8_quantize_to_packed_weight_roundtrip(qbits):
         deq = torch.empty(96, 256, dtype=torch.float32, device="cuda")
         qbits.dequantize_packed_weight(blob, deq, True, "fp32", "int8", "fp32")
         assert np.abs(deq.cpu().numpy() - w).max() <= 0.51 * s.max()  # within half a quantisation step
+
+
+# ---- edge cases: empty / boundary batch sizes, dispatch seams, long K ----------------------------------------------
+def test_woq_linear_empty_batch_is_a_noop(qbits):
+    """M = 0 (an empty activation batch) returns without touching the output, like the reference's GEMM with m = 0."""
+    q, s, z, idx = _mk(256, 48, 32, True, False, seed=31)
+    blob = _gpu_blob(qbits, q, s, z, idx, 32)
+    out = torch.empty(0, 48, device="cuda")
+    qbits.woq_linear(torch.empty(0, 256, device="cuda"), blob, torch.empty(0), out, "fp32", "int4_clip", "fp32", True)
+    assert out.shape == (0, 48)
+
+
+@pytest.mark.parametrize("M", [4, 5, 8, 9, 127, 128, 129])
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_woq_linear_dispatch_seams(qbits, M, compute):
+    """Row counts on both sides of every kernel switch: 4 | 5 (rows per decode-GEMV pass), 8 | 9 (GEMV -> MFMA GEMM),
+    127 / 128 / 129 (GEMM row-block edge). Same bound as the route's own test."""
+    K, N, group = 384, 80, 128
+    q, s, z, idx = _mk(K, N, group, True, False, seed=32)
+    blob = qbits.repack_quantized_weight(torch.from_numpy(q).cuda(), torch.from_numpy(s).cuda(),
+                                         torch.from_numpy(z).cuda(), torch.empty(0, dtype=torch.int32), "int4_clip",
+                                         "fp32", compute, True, group)
+    rng = np.random.default_rng(33)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    ref = orc.woq_linear(x, orc.repack(q, s, z, None, group), None)
+    out = torch.zeros(M, N, device="cuda")
+    qbits.woq_linear(torch.from_numpy(x).cuda(), blob, torch.empty(0), out, compute, "int4_clip", "fp32", True)
+    rel = 1e-4 if (compute == "fp32" or M <= 8) else 2e-3
+    assert (np.abs(out.cpu().numpy() - ref) <= rel * np.abs(ref).max(axis=1, keepdims=True) + 1e-5).all()
+
+
+@pytest.mark.parametrize("K", [16384, 16512])
+def test_decode_gemv_longest_k(qbits, K):
+    """K = 16384 is the longest contraction the tile kernel takes (16 waves x 8 tiles); one tile more goes to the
+    generic kernel. Both against the oracle."""
+    N, group = 32, 128
+    q, s, z, idx = _mk(K, N, group, False, False, seed=34)
+    blob = _gpu_blob(qbits, q, s, None, None, group)
+    x = np.random.default_rng(35).standard_normal((1, K)).astype(np.float32)
+    ref = orc.woq_linear(x, orc.repack(q, s, None, None, group), None)
+    out = torch.zeros(1, N, device="cuda")
+    qbits.woq_linear(torch.from_numpy(x).cuda(), blob, torch.empty(0), out, "fp32", "int4_clip", "fp32", False)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-5
+
+
+def test_shape_and_type_errors_keep_the_reference_prefix(qbits):
+    """Every rejection surfaces as RuntimeError with the reference's 'QBits:' / 'Qbits:' prefix
+    (bestla_weightonly_dispatcher.cpp:289,368; qbits.cpp:35,150)."""
+    q, s, z, idx = _mk(256, 48, 32, False, False, seed=36)
+    blob = _gpu_blob(qbits, q, s, None, None, 32)
+    with pytest.raises(RuntimeError, match="QBits: woq_linear shape mismatch"):
+        qbits.woq_linear(torch.zeros(2, 255, device="cuda"), blob, torch.empty(0), torch.zeros(2, 48, device="cuda"),
+                         "fp32", "int4_clip", "fp32", False)
+    with pytest.raises(RuntimeError, match="unsupported qbits data type"):
+        qbits.woq_linear(torch.zeros(2, 256, device="cuda", dtype=torch.float64), blob, torch.empty(0),
+                         torch.zeros(2, 48, device="cuda"), "fp32", "int4_clip", "fp32", False)
+    with pytest.raises(RuntimeError, match="[Qq]bits: unsupported bestla packq config"):
+        qbits.get_packed_weight_size(256, 48, "int3_clip", "fp32", "fp32", False, 32, False)
+    with pytest.raises(RuntimeError, match="QBits: unsupported blocksize"):
+        qbits.get_packed_weight_size(256, 48, "int4_clip", "fp32", "fp32", False, 48, False)
+    with pytest.raises(RuntimeError, match="QBits: not a WQH1 packed weight"):
+        qbits.woq_linear(torch.zeros(2, 256, device="cuda"), torch.zeros(4096, dtype=torch.int8, device="cuda"),
+                         torch.empty(0), torch.zeros(2, 48, device="cuda"), "fp32", "int4_clip", "fp32", False)
