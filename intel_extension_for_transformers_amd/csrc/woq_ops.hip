@@ -291,24 +291,45 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
   }
 }
 
-// merge the slices of attn_decode_kernel<SPLIT>: out[h][d] = sum_s o_s[d] e^(m_s - m) / sum_s l_s e^(m_s - m)
+// merge the slices of attn_decode_kernel<SPLIT>: out[h][d] = sum_s o_s[d] e^(m_s - m) / sum_s l_s e^(m_s - m).
+// 256 threads per head: the slice maxima / sums go through LDS once, then two thread groups of HD walk alternate
+// slices with their loads unrolled (independent addresses) — a serial per-thread walk over 32 slices of freshly
+// written partials cost 14 us of pure load latency.
 template <int HD>
-__global__ __launch_bounds__(HD) void attn_combine_kernel(const float* __restrict__ part, int ns,
-                                                         float* __restrict__ out) {
-  const int h = blockIdx.x, d = threadIdx.x;
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part, int ns,
+                                                          float* __restrict__ out) {
+  __shared__ float ms[64], wl[64], wsc[64], red[256];
+  const int h = blockIdx.x, tid = threadIdx.x;
   const float* p = part + (size_t)h * ns * (HD + 2);
-  float m = -INFINITY;
-  for (int s = 0; s < ns; ++s) m = fmaxf(m, p[(size_t)s * (HD + 2) + HD]);
-  float l = 0.f, o = 0.f;
-  for (int s = 0; s < ns; ++s) {
-    const float ms = p[(size_t)s * (HD + 2) + HD];
-    const float w = ms == -INFINITY ? 0.f : __expf(ms - m);
-    l = fmaf(p[(size_t)s * (HD + 2) + HD + 1], w, l);
-    o = fmaf(p[(size_t)s * (HD + 2) + d], w, o);
+  if (tid < ns) {
+    ms[tid] = p[(size_t)tid * (HD + 2) + HD];
+    wl[tid] = p[(size_t)tid * (HD + 2) + HD + 1];
   }
-  out[(size_t)h * HD + d] = o / l;
+  __syncthreads();
+  float m = -INFINITY;
+  for (int s = 0; s < ns; ++s) m = fmaxf(m, ms[s]);
+  if (tid < ns) {
+    const float w = ms[tid] == -INFINITY ? 0.f : __expf(ms[tid] - m);
+    wsc[tid] = w;
+    wl[tid] *= w;
+  }
+  __syncthreads();
+  float l = 0.f;
+  for (int s = 0; s < ns; ++s) l += wl[s];
+  constexpr int GROUPS = 256 / HD;  // 2 for head_dim 128, 4 for 64
+  const int d = tid % HD, grp = tid / HD;
+  float o = 0.f;
+#pragma unroll 8
+  for (int s = grp; s < ns; s += GROUPS) o = fmaf(p[(size_t)s * (HD + 2) + d], wsc[s], o);
+  red[tid] = o;
+  __syncthreads();
+  if (grp == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < GROUPS; ++g2) t += red[g2 * HD + d];
+    out[(size_t)h * HD + d] = t / l;
+  }
 }
-
 
 // logits[v] = sum_h xn[h] * W[v][h], W dense fp16/bf16 [vocab, hidden] (lm_head is NOT quantised:
 // utils/config.py:836-837). Final RMSNorm fused in the prologue. One wave per vocab row, 4 rows per WG.
@@ -423,7 +444,7 @@ static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int
     }
     hipLaunchKernelGGL(k, dim3(heads, splits), dim3(256), lds, st, qkv, (KV*)kcache, (KV*)vcache, pos, cs, sn, heads,
                        kv_heads, part);
-    hipLaunchKernelGGL(attn_combine_kernel<HD>, dim3(heads), dim3(HD), 0, st, part, splits, out);
+    hipLaunchKernelGGL(attn_combine_kernel<HD>, dim3(heads), dim3(256), 0, st, part, splits, out);
     return 0;
   }
   auto k = attn_decode_kernel<KV, HD, false>;
