@@ -161,7 +161,7 @@ class WoqDecoderEngine:
         return _device_view(ptr, (n_seq, self.cfg.vocab), self.device)
 
     # ---- decode attention regime -----------------------------------------------------------------------------
-    LONG_CTX = 512  # cached positions beyond which the sliced decode attention wins over one workgroup per head
+    LONG_CTX = 256  # cached positions beyond which the sliced decode attention wins (measured: 160 -> one workgroup per head 1.43 vs 1.48 ms/token sliced; 400 -> 1.59 vs 1.50)
 
     def set_attn_splits(self, n):
         """1 = one workgroup per head, n > 1 = n context slices per head + combine. Invalidates a captured graph."""
