@@ -3,8 +3,8 @@
 // woq_linear replaces qbits.woq_linear (qbits/qbits.cpp:113-140) and the string-driven template
 // selection under it (bestla_weightonly_dispatcher.cpp:230-382: parse_launcher / parse_store /
 // parse_activation / parse_weight / parse_gemm_core). Here the "dispatcher" is a few integer
-// compares on the cached header: M <= 8 -> decode GEMV, else an MFMA GEMM (exact two-plane kernel for compute_dtype
-// fp32, fp16-operand kernel for the reduced-precision compute modes).
+// compares on the cached header: M <= 8 -> decode GEMV, else the MFMA GEMM (three-product fp32-class form for
+// compute_dtype fp32, single fp16 product for the reduced-precision compute modes).
 #include "woq_device.h"
 #include "woq_launch.h"
 
@@ -18,12 +18,9 @@ struct GemvArgs;
 int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                             const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w,
                             float eps, const float* residual, int ld_res, int epi, int nt, hipStream_t st);
-int launch_gemm_mfma(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
-                     const float* bias, void* out, int out_dtype, int ldo, int M, const float* residual, int ld_res,
-                     hipStream_t st);
 int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                     const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w, float eps,
-                    const float* residual, int ld_res, int epi, void* ws, hipStream_t st);
+                    const float* residual, int ld_res, int epi, void* ws, int fp32_class, hipStream_t st);
 }  // namespace woq
 
 using namespace woq;
@@ -38,18 +35,18 @@ int woq_device_count(void) {
   return n;
 }
 
-// one int4 blob: M <= 8 -> decode GEMV, else an MFMA GEMM by compute type. `residual` (fp32 [M][ld_res]) is added.
+// one int4 blob: M <= 8 -> decode GEMV, else the MFMA GEMM (woq_gemm_f16.hip): one fp16 product per operand pair for
+// the reduced-precision compute modes, the three-product hi + lo form for compute_dtype fp32.
+// `residual` (fp32 [M][ld_res]) is added.
 static int linear_int4(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                        const float* bias, void* out, int out_dtype, int ldo, int M, const float* residual, int ld_res,
                        hipStream_t st) {
   static const bool gemm_as_gemv = getenv("WOQ_GEMM_AS_GEMV") != nullptr;  // A/B switch for tests
-  if (M > 8 && h.compute_type != WOQ_C_FP32 && !gemm_as_gemv)  // reduced-precision compute modes: fp16-operand MFMA GEMM
+  if (M > 8 && !gemm_as_gemv)
     return launch_gemm_f16(act, act_dtype, lda, blob, h, bias, out, out_dtype, ldo, M, nullptr, 0.f, residual, ld_res, 0,
-                           nullptr, st);
-  if (M <= 8 || h.off_shuffle != 0)
-    return launch_gemv_from_header(act, act_dtype, lda, blob, h, bias, out, out_dtype, ldo, M, nullptr, 0.f, residual,
-                                   ld_res, 0, 1, st);
-  return launch_gemm_mfma(act, act_dtype, lda, blob, h, bias, out, out_dtype, ldo, M, residual, ld_res, st);
+                           nullptr, h.compute_type == WOQ_C_FP32 ? 1 : 0, st);
+  return launch_gemv_from_header(act, act_dtype, lda, blob, h, bias, out, out_dtype, ldo, M, nullptr, 0.f, residual,
+                                 ld_res, 0, 1, st);
 }
 
 int woq_linear(const void* act_dev, int act_dtype, int lda, const void* blob_dev, const woq_blob_header* hdr,

@@ -30,10 +30,10 @@ void launch_lm_head(const float* hidden_in, const float* norm_w, float eps, cons
                     int vocab, float* logits, hipStream_t st);
 void launch_argmax(const float* logits, int vocab, int32_t* token, int32_t* pos, hipStream_t st);
 // prompt pass (woq_gemm_f16.hip, woq_prefill.hip)
-size_t gemm_f16_workspace_bytes(int M, int Kpad, int Npad);
+size_t gemm_f16_workspace_bytes(int M, int Kpad, int Npad, int planes);
 int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                     const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w, float eps,
-                    const float* residual, int ld_res, int epi, void* ws, hipStream_t st);
+                    const float* residual, int ld_res, int epi, void* ws, int fp32_class, hipStream_t st);
 void launch_embed_rows(const void* embed, int dtype, const int32_t* tokens, int M, int hidden, float* out,
                        hipStream_t st);
 int launch_rope_append(_Float16* qkv, int n_seq, int T, int start, int heads, int kv_heads, int HD, const float* cs,
@@ -150,7 +150,7 @@ static int engine_prefill_reserve(woq_engine* e, size_t rows) {
     kpad = std::max(kpad, (int)h->Kpad);
     npad = std::max(npad, (int)h->Npad);
   }
-  const size_t ws = gemm_f16_workspace_bytes((int)rows, kpad, npad);
+  const size_t ws = gemm_f16_workspace_bytes((int)rows, kpad, npad, 1);
   if (rows <= e->pf_rows && ws <= e->pf_ws_bytes) return 0;
   WOQ_HIP(hipDeviceSynchronize());
   for (void* p : {(void*)e->pf_h, (void*)e->pf_qkv, (void*)e->pf_attn, (void*)e->pf_act, e->pf_ws})
@@ -183,7 +183,7 @@ static int engine_prefill_impl(woq_engine* e, const int32_t* tokens, int n_seq, 
     uint8_t* kc = e->kcache + (size_t)l * e->kv_layer_bytes;
     uint8_t* vc = e->vcache + (size_t)l * e->kv_layer_bytes;
     if ((rc = launch_gemm_f16(e->pf_h, WOQ_F32, c.hidden, w.qkv_blob, w.qkv_hdr, nullptr, e->pf_qkv, WOQ_F16, qkv_n, M,
-                              w.ln1, c.rms_eps, nullptr, 0, 0, e->pf_ws, st)) != 0)
+                              w.ln1, c.rms_eps, nullptr, 0, 0, e->pf_ws, 0, st)) != 0)
       return rc;
     if ((rc = launch_rope_append(e->pf_qkv, n_seq, T, start, c.heads, c.kv_heads, c.head_dim, e->cs, e->sn, kc, vc,
                                  c.kv_dtype, seq_stride, st)) != 0)
@@ -192,15 +192,15 @@ static int engine_prefill_impl(woq_engine* e, const int32_t* tokens, int n_seq, 
                                   seq_stride, e->pf_attn, st)) != 0)
       return rc;
     if ((rc = launch_gemm_f16(e->pf_attn, WOQ_F16, c.heads * c.head_dim, w.o_blob, w.o_hdr, nullptr, e->pf_h, WOQ_F32,
-                              c.hidden, M, nullptr, 0.f, res, c.hidden, 0, e->pf_ws, st)) != 0)
+                              c.hidden, M, nullptr, 0.f, res, c.hidden, 0, e->pf_ws, 0, st)) != 0)
       return rc;
     if (e->allreduce && e->allreduce(e->allreduce_user, e->pf_h, (size_t)M * c.hidden, st) != 0)
       return woq::fail("QBits: tensor-parallel all-reduce callback failed");
     if ((rc = launch_gemm_f16(e->pf_h, WOQ_F32, c.hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, e->pf_act, WOQ_F16,
-                              c.inter, M, w.ln2, c.rms_eps, nullptr, 0, 1, e->pf_ws, st)) != 0)
+                              c.inter, M, w.ln2, c.rms_eps, nullptr, 0, 1, e->pf_ws, 0, st)) != 0)
       return rc;
     if ((rc = launch_gemm_f16(e->pf_act, WOQ_F16, c.inter, w.down_blob, w.down_hdr, nullptr, e->pf_h, WOQ_F32,
-                              c.hidden, M, nullptr, 0.f, res, c.hidden, 0, e->pf_ws, st)) != 0)
+                              c.hidden, M, nullptr, 0.f, res, c.hidden, 0, e->pf_ws, 0, st)) != 0)
       return rc;
     if (e->allreduce && e->allreduce(e->allreduce_user, e->pf_h, (size_t)M * c.hidden, st) != 0)
       return woq::fail("QBits: tensor-parallel all-reduce callback failed");

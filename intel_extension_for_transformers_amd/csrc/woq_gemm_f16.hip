@@ -1,13 +1,14 @@
-// woq_gemm_f16.hip — prefill-side int4 weight x activation GEMM for the reduced-precision compute modes
-// (compute_dtype bf16 / fp16 / int8 in the blob header), M > 8.
+// woq_gemm_f16.hip — prefill-side int4 weight x activation GEMM on the matrix cores, M > 8: one fp16 product per
+// operand pair for the reduced-precision compute modes (compute_dtype bf16 / fp16 / int8 in the blob header), three
+// (hi + lo operands, fp32-class) for compute_dtype fp32.
 //
 // Replaces the arithmetic behind qbits.woq_linear at large M for those modes: qbits.cpp:113-140 ->
 // bestla_weightonly_dispatcher.cpp:150-178, where the reference's HCoreRowNAmxbf16 core rounds BOTH operands to
 // bf16 (8-bit significand) before the AMX tile product. Parity definition: autograd/functions.py:41-63 at the
 // reference's own tolerance for these modes (qbits_ut/test_weightonly.py:82-88, rtol 0.03).
 //
-// compute_dtype fp32 keeps the exact two-plane kernel of woq_gemm.hip. Here both operands are fp16 (11-bit
-// significand, 8x tighter than the reference's bf16 operands) and every scale that can be is folded into them, so
+// Both operands are fp16 (11-bit significand, 8x tighter than the reference's bf16 operands; for compute_dtype fp32 a
+// hi + lo PAIR of fp16 each, ~22 bits) and every scale that can be is folded into them, so
 // the K loop is nothing but loads, a short dequantisation and MFMAs — v_mfma_f32_16x16x32_f16 accumulating ONE
 // fp32 fragment set over all of K:
 //  * A: a pack pass turns the activations into fp16 with one power-of-two scale PER ROW (exact scaling; elements
@@ -49,7 +50,7 @@ struct GemmF16Args {
   const void* scales;
   const uint8_t* zp;
   int K, N, tiles_k, tiles_n, n_groups, group, scale_type;
-  const _Float16* ap;  // packed activation tiles [mb][kt][128][16 slots][8]
+  const _Float16* ap;  // packed activation tiles [mb][kt][planes][128][16 slots][8] (planes: hi, and lo for NP == 3)
   const float* rs;     // [Mpad] 2^e per row
   const float* cs;     // [Npad] 2^E per column
   int M, nb_m, nb_n, sup_n, n_sup;
@@ -71,6 +72,7 @@ __device__ __forceinline__ int fperm(int e) { return (e < 4) ? 2 * e : 2 * (e - 
 // Blocks [Mpad, ...): one thread per weight column -> 2^E[col] >= max |scale| of the column.
 // ---------------------------------------------------------------------------------------------------------------
 struct PackF16Args {
+  int planes;  // 1: fp16 plane; 2: hi + lo planes (x 2^-e = hi + lo to ~22 bits) for the three-product kernel
   const void* x;
   int x_dtype, lda, M, Mpad, K, Kpad;
   const int32_t* shuffle;  // GPTQ act-order gather (converted g_idx) or null
@@ -118,7 +120,7 @@ __device__ __forceinline__ void pack_row(const PackF16Args& a, int r, float* red
   const int mb = r >> 7, rl = r & 127;
   const int chunks = a.Kpad >> 3;
   const int full = a.K >> 3;  // chunks that lie wholly inside K (modes 0 / 1 load only those)
-  const size_t tile_halves = (size_t)128 * 128;
+  const size_t tile_halves = (size_t)128 * 128 * a.planes;  // one (row block, K step): planes x 32 KiB
   _Float16* dst_row = a.ap + (size_t)mb * (a.Kpad >> 7) * tile_halves + (size_t)rl * 128;
   const size_t base = (size_t)r * a.lda;
   const bool norm = a.norm_w != nullptr;
@@ -189,10 +191,16 @@ __device__ __forceinline__ void pack_row(const PackF16Args& a, int r, float* red
   const float p2 = ldexpf(1.f, -e) * nf;  // |x| nf 2^-e < 2^14
   if (tid == 0) a.rs[r] = ldexpf(1.f, e);
   auto emit = [&](int c, const float (&d)[8]) {
-    h8 hh;
+    h8 hh, ll;
 #pragma unroll
-    for (int e8 = 0; e8 < 8; ++e8) hh[e8] = (_Float16)(d[fperm(e8)] * p2);
-    *(h8*)(dst_row + (size_t)(c >> 4) * tile_halves + (size_t)(((c & 15) ^ (rl & 15)) << 3)) = hh;
+    for (int e8 = 0; e8 < 8; ++e8) {
+      const float xs = d[fperm(e8)] * p2;
+      hh[e8] = (_Float16)xs;
+      ll[e8] = (_Float16)(xs - (float)hh[e8]);
+    }
+    _Float16* dp = dst_row + (size_t)(c >> 4) * tile_halves + (size_t)(((c & 15) ^ (rl & 15)) << 3);
+    *(h8*)dp = hh;
+    if (a.planes == 2) *(h8*)(dp + 128 * 128) = ll;
   };
   if constexpr (CACHED) {
 #pragma unroll
@@ -231,10 +239,13 @@ __global__ __launch_bounds__(256) void pack_f16_kernel(PackF16Args a) {
   const int r = (int)blockIdx.x;
   if (r >= a.M) {  // padding rows of the last row block: zeros
     const int mb = r >> 7, rl = r & 127;
-    const size_t tile_halves = (size_t)128 * 128;
+    const size_t tile_halves = (size_t)128 * 128 * a.planes;
     _Float16* dst_row = a.ap + (size_t)mb * (a.Kpad >> 7) * tile_halves + (size_t)rl * 128;
-    for (int c = tid; c < (a.Kpad >> 3); c += 256)
-      *(u32x4*)(dst_row + (size_t)(c >> 4) * tile_halves + (size_t)(((c & 15) ^ (rl & 15)) << 3)) = (u32x4){0, 0, 0, 0};
+    for (int c = tid; c < (a.Kpad >> 3); c += 256) {
+      _Float16* dp = dst_row + (size_t)(c >> 4) * tile_halves + (size_t)(((c & 15) ^ (rl & 15)) << 3);
+      *(u32x4*)dp = (u32x4){0, 0, 0, 0};
+      if (a.planes == 2) *(u32x4*)(dp + 128 * 128) = (u32x4){0, 0, 0, 0};
+    }
     if (tid == 0) a.rs[r] = 0.f;
     return;
   }
@@ -288,8 +299,37 @@ __device__ __forceinline__ h8 dq8s(uint32_t w, h2 nlo, h2 nhi, h2 r) {
                                         __builtin_bit_cast(uint32_t, f2), __builtin_bit_cast(uint32_t, f3)});
 }
 
-template <int SMODE, bool ASYM, bool S32>
-__global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(GemmF16Args a) {
+// fp32-class operand: (q - zp) * r with r = r_hi + r_lo (two fp16) -> hi = fl(d r_hi), lo = fl(d r_lo + (d r_hi - hi)).
+// d r_hi has at most 16 significant bits, so the residual d r_hi - hi is exact in one v_pk_fma_f16.
+__device__ __forceinline__ void dq8s_hl(uint32_t w, h2 nlo, h2 nhi, h2 rh, h2 rl, h8& hi, h8& lo) {
+  const uint32_t y = w >> 8;
+  h2 d[4];
+  d[0] = __builtin_bit_cast(h2, (w & 0x000f000fu) ^ 0x64086408u) + nlo;
+  d[1] = __builtin_bit_cast(h2, (w & 0x00f000f0u) ^ 0x54805480u) + nhi;
+  d[2] = __builtin_bit_cast(h2, (y & 0x000f000fu) ^ 0x64086408u) + nlo;
+  d[3] = __builtin_bit_cast(h2, (y & 0x00f000f0u) ^ 0x54805480u) + nhi;
+  u32x4 uh, ul;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const h2 ph = d[i] * rh;
+    const h2 res = __builtin_elementwise_fma(d[i], rh, -ph);
+    const h2 pl = __builtin_elementwise_fma(d[i], rl, res);
+    uh[i] = __builtin_bit_cast(uint32_t, ph);
+    ul[i] = __builtin_bit_cast(uint32_t, pl);
+  }
+  hi = __builtin_bit_cast(h8, uh);
+  lo = __builtin_bit_cast(h8, ul);
+}
+
+// NP = 1: one fp16 product per fragment pair (compute_dtype bf16 / fp16 / int8). NP = 3: fp32-class — activations
+// and scaled weights both carried as hi + lo fp16 pairs (~22 bits each), A_hi B_hi + A_hi B_lo + A_lo B_hi
+// accumulated in the same fp32 fragments (the dropped A_lo B_lo term is 2^-22 of the product). Same data flow, same
+// per-group scale folding, so group-32 blobs cost what group-128 blobs cost. One workgroup per CU (the A stage is
+// 64 KiB: two planes).
+template <int SMODE, bool ASYM, bool S32, int NP = 1>
+__global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gemm_f16s_kernel(GemmF16Args a) {
+  constexpr int PLANES = NP == 1 ? 1 : 2;
+  constexpr int STAGE = FTILE_BYTES * PLANES;
   extern __shared__ __attribute__((aligned(1024))) unsigned char fsm[];  // 2 x 32 KiB A tiles
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -312,13 +352,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(GemmF16Args a) {
     for (int c = 0; c < 2; ++c) acc[rt][c] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
   // ---- operand movers ----
-  const _Float16* a_tiles = a.ap + (size_t)mb * a.tiles_k * (FTILE_BYTES / 2);
+  const _Float16* a_tiles = a.ap + (size_t)mb * a.tiles_k * (STAGE / 2);
   auto issue_a = [&](int kt, int buf) {  // 8 LDS-DMA pieces of 1 KiB per wave
-    const _Float16* src = a_tiles + (size_t)kt * (FTILE_BYTES / 2) + (size_t)wid * 4096 + lane * 8;
-    unsigned char* dst = fsm + buf * FTILE_BYTES + wid * 8192;
+    const _Float16* src = a_tiles + (size_t)kt * (STAGE / 2) + (size_t)wid * (4096 * PLANES) + lane * 8;
+    unsigned char* dst = fsm + buf * STAGE + wid * (8192 * PLANES);
     // the instruction offset advances the global AND the LDS address: four 1-KiB pieces per address / M0 setup
 #pragma unroll
-    for (int j = 0; j < 8; j += 4) {
+    for (int j = 0; j < 8 * PLANES; j += 4) {
       const __attribute__((address_space(1))) void* g = (const __attribute__((address_space(1))) void*)(src + j * 512);
       __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(dst + j * 1024);
       __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
@@ -368,9 +408,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(GemmF16Args a) {
   for (int hp = 0; hp < 4; ++hp) a_off[hp] = i16 * 256 + ((((hp >> 1) * 8 + kq * 2 + (hp & 1)) ^ i16) << 4);
 
   auto compute = [&](int buf, const BRegs<SMODE, S32>& b) {
-    const unsigned char* at = fsm + buf * FTILE_BYTES;
+    const unsigned char* at = fsm + buf * STAGE;
     constexpr int NS = SMODE == 0 ? 1 : 2;
-    h2 r2[2][NS], nlo[2][NS], nhi[2][NS];
+    h2 r2[2][NS], r2l[2][NS], nlo[2][NS], nhi[2][NS];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -382,8 +422,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(GemmF16Args a) {
           const float fb = bf16_bits_to_f32((uint16_t)b.sc[c][s]), fh = f16_bits_to_f32((uint16_t)b.sc[c][s]);
           sv = sc_bf ? fb : fh;
         }
-        const _Float16 rr = (_Float16)(sv * icol[c]);
+        const float rf = sv * icol[c];
+        const _Float16 rr = (_Float16)rf;
         r2[c][s] = (h2){rr, rr};
+        if constexpr (NP == 3) {
+          const _Float16 rl_ = (_Float16)(rf - (float)rr);
+          r2l[c][s] = (h2){rl_, rl_};
+        }
         const float uz = ASYM ? (float)(b.zp[c][s] & 0xff) : 8.f;
         const _Float16 l = (_Float16)(-(1024.f + uz)), hgh = (_Float16)(-(64.f + uz));
         nlo[c][s] = (h2){l, l};
@@ -394,14 +439,27 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(GemmF16Args a) {
 #pragma unroll
     for (int hp = 0; hp < 4; ++hp) {
       const int s = SMODE == 0 ? 0 : (hp >> 1);
-      h8 bfr[2];
+      h8 bfr[2], bfl[2];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) bfr[c] = dq8s(b.wv[c][hp], nlo[c][s], nhi[c][s], r2[c][s]);
+      for (int c = 0; c < 2; ++c) {
+        if constexpr (NP == 3)
+          dq8s_hl(b.wv[c][hp], nlo[c][s], nhi[c][s], r2[c][s], r2l[c][s], bfr[c], bfl[c]);
+        else
+          bfr[c] = dq8s(b.wv[c][hp], nlo[c][s], nhi[c][s], r2[c][s]);
+      }
 #pragma unroll
       for (int rt = 0; rt < 8; ++rt) {
         const h8 af = *(const h8*)(at + rt * 4096 + a_off[hp]);
 #pragma unroll
         for (int c = 0; c < 2; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr[c], acc[rt][c], 0, 0, 0);
+        if constexpr (NP == 3) {
+          const h8 al = *(const h8*)(at + FTILE_BYTES + rt * 4096 + a_off[hp]);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfl[c], acc[rt][c], 0, 0, 0);
+            acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bfr[c], acc[rt][c], 0, 0, 0);
+          }
+        }
       }
     }
   };
@@ -503,33 +561,35 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(GemmF16Args a) {
               });
 }
 
-template <int SMODE, bool ASYM, bool S32>
+template <int SMODE, bool ASYM, bool S32, int NP>
 static int launch_f16_t(GemmF16Args& a, hipStream_t st) {
-  auto kern = gemm_f16s_kernel<SMODE, ASYM, S32>;
+  auto kern = gemm_f16s_kernel<SMODE, ASYM, S32, NP>;
+  constexpr int LDS = 2 * FTILE_BYTES * (NP == 1 ? 1 : 2);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FTILE_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return woq::fail(std::string("QBits: hipFuncSetAttribute: ") + hipGetErrorString(e));
     attr_set = true;
   }
   const int n_sup8 = (a.n_sup + 7) / 8;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(n_sup8 * 8 * 64)), dim3(256), 2 * FTILE_BYTES, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(n_sup8 * 8 * 64)), dim3(256), LDS, st, a);
   return 0;
 }
 
 // Workspace bytes for an [M, K] x [K, N] call (activation tiles + row scales + column scales).
-size_t gemm_f16_workspace_bytes(int M, int Kpad, int Npad) {
+size_t gemm_f16_workspace_bytes(int M, int Kpad, int Npad, int planes) {
   const size_t Mpad = ((size_t)M + FBM - 1) / FBM * FBM;
-  return Mpad * Kpad * sizeof(_Float16) + Mpad * sizeof(float) + (size_t)Npad * sizeof(float);
+  return Mpad * Kpad * sizeof(_Float16) * planes + Mpad * sizeof(float) + (size_t)Npad * sizeof(float);
 }
 
 // out[M,N] = act[M,K] . W_deq (+ bias) with fp16 operands. `ws` = caller workspace of gemm_f16_workspace_bytes or
 // null (stream-ordered allocation per call, like the reference's per-call amalloc,
 // bestla_weightonly_dispatcher.cpp:108-118,179). norm_w/eps: RMSNorm fused into the pack pass (null = none);
-// residual / epi: see GemmF16Args.
+// residual / epi: see GemmF16Args; fp32_class: the three-product hi + lo form (compute_dtype fp32).
 int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                     const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w, float eps,
-                    const float* residual, int ld_res, int epi, void* ws, hipStream_t st) {
+                    const float* residual, int ld_res, int epi, void* ws, int fp32_class, hipStream_t st) {
+  const int planes = fp32_class ? 2 : 1;
   if (epi == 1 && (((h.Npad / WOQ_TILE_N) & 1) != 0 || (h.N & 31) != 0))
     return woq::fail("QBits: the SiLU*mul epilogue needs whole gate / up column-tile pairs");
   GemmF16Args a;
@@ -558,7 +618,7 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   a.ld_res = ld_res;
   a.epi = epi;
   const size_t Mpad = (size_t)a.nb_m * FBM;
-  const size_t total = gemm_f16_workspace_bytes(M, h.Kpad, h.Npad);
+  const size_t total = gemm_f16_workspace_bytes(M, h.Kpad, h.Npad, planes);
   unsigned char* w = (unsigned char*)ws;
   const bool own = w == nullptr;
   if (own) {
@@ -566,10 +626,11 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
     if (e != hipSuccess) return woq::fail(std::string("QBits: workspace allocation failed: ") + hipGetErrorString(e));
   }
   a.ap = (const _Float16*)w;
-  a.rs = (const float*)(w + Mpad * h.Kpad * sizeof(_Float16));
+  a.rs = (const float*)(w + Mpad * h.Kpad * sizeof(_Float16) * planes);
   a.cs = a.rs + Mpad;
 
   PackF16Args p;
+  p.planes = planes;
   p.x = act;
   p.x_dtype = act_dtype;
   p.lda = lda;
@@ -597,7 +658,9 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   const bool s32 = h.scale_type == WOQ_F32;
   int rc = 1;
 #define WOQ_F16_CASE(SM, AS)                                                                   \
-  if (sm == SM && asym == AS) rc = s32 ? launch_f16_t<SM, AS, true>(a, st) : launch_f16_t<SM, AS, false>(a, st);
+  if (sm == SM && asym == AS)                                                                   \
+    rc = fp32_class ? (s32 ? launch_f16_t<SM, AS, true, 3>(a, st) : launch_f16_t<SM, AS, false, 3>(a, st))  \
+                    : (s32 ? launch_f16_t<SM, AS, true, 1>(a, st) : launch_f16_t<SM, AS, false, 1>(a, st));
   WOQ_F16_CASE(0, false)
   WOQ_F16_CASE(0, true)
   WOQ_F16_CASE(1, false)

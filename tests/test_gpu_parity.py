@@ -246,9 +246,9 @@ def test_errors_are_runtime_errors(qbits):
 @pytest.mark.parametrize("M", [9, 130, 256])
 @pytest.mark.parametrize("compute", ["fp32", "bf16"])
 def test_woq_linear_prefill_gemm_vs_oracle(qbits, K, N, group, asym, M, compute):
-    """MFMA GEMM path (M > 8, csrc/woq_gemm.hip) vs the parity definition, ragged M / N / K included.
-    compute_dtype fp32: two fp16 planes per activation (hi + lo, block floating point per row and K step) ->
-    fp32-class, stated bound 2e-5 * sum|x||w| expressed as 1e-4 * max|ref| + 1e-5. compute_dtype bf16: one plane,
+    """MFMA GEMM path (M > 8, csrc/woq_gemm_f16.hip) vs the parity definition, ragged M / N / K included.
+    compute_dtype fp32: activations and scaled weights as hi + lo fp16 pairs (~22 bits each), three products per
+    pair -> fp32-class, stated bound 2e-5 * sum|x||w| expressed as 1e-4 * max|ref| + 1e-5. compute_dtype bf16: one plane,
     activation rounded to fp16 (2^-11 relative): stated bound 2e-3 * max|ref| (the reference's own criterion for
     reduced-precision compute is allclose(rtol=0.03), qbits_ut/test_weightonly.py:88)."""
     q, s, z, idx = _mk(K, N, group, asym, False, seed=7)

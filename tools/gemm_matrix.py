@@ -13,6 +13,7 @@ def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     K = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
     N = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+    only = sys.argv[4] if len(sys.argv) > 4 else None  # restrict to one compute type
     g = torch.Generator(device="cuda").manual_seed(0)
     q = torch.randint(-8, 8, (K, N), generator=g, device="cuda", dtype=torch.int8)
     e = torch.empty(0)
@@ -24,15 +25,17 @@ def main():
             z = torch.randint(-8, 8, (G, N), generator=g, device="cuda", dtype=torch.int8) if asym else torch.empty(0, dtype=torch.int8)
             for scale, compute, act in (("fp16", "bf16", "fp32"), ("fp32", "bf16", "bf16"), ("bf16", "fp16", "fp16"),
                                         ("fp16", "fp32", "fp32"), ("fp16", "int8", "fp32")):
+                if only and compute != only:
+                    continue
                 blob = qbits.repack_quantized_weight(q, s, z, torch.empty(0, dtype=torch.int32), "int4_clip", scale,
                                                      compute, asym, group)
                 dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[act]
                 x = torch.randn(M, K, generator=g, device="cuda").to(dt)
                 out = torch.empty(M, N, device="cuda", dtype=dt)
-                for _ in range(2):
+                for _ in range(5):
                     qbits.woq_linear(x, blob, e, out, compute, "int4_clip", scale, asym)
                 torch.cuda.synchronize()
-                n = 5
+                n = 20
                 t0 = time.perf_counter()
                 for _ in range(n):
                     qbits.woq_linear(x, blob, e, out, compute, "int4_clip", scale, asym)
