@@ -120,7 +120,9 @@ typedef struct woq_engine_config {
   int32_t kv_dtype;         /* WOQ_F16 | WOQ_BF16 | WOQ_FP8_E4M3 (unscaled e4m3fn, saturating at +-448) */
   int32_t reserved[3];      /* [0] = max_batch: sequences the KV cache holds for woq_engine_prefill (0 / 1 = one);
                              * [1] = attn_splits: context slices per head in the decode attention (0 = automatic:
-                             *       1 up to max_ctx 4096, else 1024 / heads clamped to [2, 32]) */
+                             *       1 up to max_ctx 4096, else 1024 / heads clamped to [2, 32]);
+                             * [2] = sliding window (HF Mistral `sliding_window`): a query sees the last `window`
+                             *       positions, itself included; 0 = full causal attention */
 } woq_engine_config;
 
 typedef struct woq_layer_weights {

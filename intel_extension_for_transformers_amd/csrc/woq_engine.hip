@@ -24,8 +24,8 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
                             float eps, const float* residual, int ld_res, int epi, int nt, hipStream_t st);
 void launch_embed(const void* embed, int dtype, const int32_t* token, int hidden, float* out, hipStream_t st);
 int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
-                       const float* cs, const float* sn, int heads, int kv_heads, int D, int max_ctx, float* out,
-                       int splits, float* part, hipStream_t st);
+                       const float* cs, const float* sn, int heads, int kv_heads, int D, int max_ctx, int window,
+                       float* out, int splits, float* part, hipStream_t st);
 void launch_lm_head(const float* hidden_in, const float* norm_w, float eps, const void* W, int w_dtype, int hidden,
                     int vocab, float* logits, hipStream_t st);
 void launch_argmax(const float* logits, int vocab, int32_t* token, int32_t* pos, hipStream_t st);
@@ -41,7 +41,7 @@ int launch_rope_append(_Float16* qkv, int n_seq, int T, int start, int heads, in
                        hipStream_t st);
 int launch_attn_prefill(const _Float16* qkv, int n_seq, int T, int start, int heads, int kv_heads, int HD,
                         const void* kcache, const void* vcache, int kv_dtype, size_t seq_stride_elems, _Float16* out,
-                        hipStream_t st);
+                        int window, hipStream_t st);
 void launch_gather_last(const float* h, int n_seq, int T, int hidden, float* dst, hipStream_t st);
 }  // namespace woq
 
@@ -72,6 +72,7 @@ struct woq_engine {
   int nt = 1;
   std::vector<void*> owned;  // everything hipMalloc'ed by create()
   // prompt pass: [n_seq * T] rows at a time; buffers grow on demand (never inside a captured graph)
+  int window = 0;               // sliding-window attention (HF Mistral sliding_window), 0 = full causal
   int attn_splits = 1;          // decode attention: context slices per head (long contexts)
   float* attn_part = nullptr;   // fp32 [heads][attn_splits][head_dim + 2] partials
   int max_batch = 1;
@@ -94,8 +95,8 @@ static int engine_attn_block(woq_engine* e, int l, hipStream_t st) {
                                    w.qkv_hdr.N, 1, w.ln1, c.rms_eps, nullptr, 0, 0, e->nt, st);
   if (rc) return rc;
   rc = launch_attn_decode(e->qkv, e->kcache + (size_t)l * e->kv_layer_bytes, e->vcache + (size_t)l * e->kv_layer_bytes,
-                          c.kv_dtype, e->pos, e->cs, e->sn, c.heads, c.kv_heads, c.head_dim, c.max_ctx, e->attn,
-                          e->attn_splits, e->attn_part, st);
+                          c.kv_dtype, e->pos, e->cs, e->sn, c.heads, c.kv_heads, c.head_dim, c.max_ctx, e->window,
+                          e->attn, e->attn_splits, e->attn_part, st);
   if (rc) return rc;
   // row-parallel o_proj: rank 0 carries the residual so that the sum over ranks adds it exactly once
   const float* res = (c.tp_size <= 1 || c.tp_rank == 0) ? e->hidden : nullptr;
@@ -189,7 +190,7 @@ static int engine_prefill_impl(woq_engine* e, const int32_t* tokens, int n_seq, 
                                  c.kv_dtype, seq_stride, st)) != 0)
       return rc;
     if ((rc = launch_attn_prefill(e->pf_qkv, n_seq, T, start, c.heads, c.kv_heads, c.head_dim, kc, vc, c.kv_dtype,
-                                  seq_stride, e->pf_attn, st)) != 0)
+                                  seq_stride, e->pf_attn, e->window, st)) != 0)
       return rc;
     if ((rc = launch_gemm_f16(e->pf_attn, WOQ_F16, c.heads * c.head_dim, w.o_blob, w.o_hdr, nullptr, e->pf_h, WOQ_F32,
                               c.hidden, M, nullptr, 0.f, res, c.hidden, 0, e->pf_ws, 0, st)) != 0)
@@ -274,6 +275,7 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
   e->attn_splits = cfg->reserved[1] > 0 ? cfg->reserved[1]
                    : (cfg->max_ctx > 4096 ? std::max(2, std::min(32, 1024 / std::max(1, (int)cfg->heads))) : 1);
   WOQ_CHECK(e->attn_splits <= 64, "QBits: attn_splits must be <= 64");
+  e->window = cfg->reserved[2] > 0 ? cfg->reserved[2] : 0;
   WOQ_HIP(hipMalloc((void**)&e->attn_part, (size_t)cfg->heads * 64 * (cfg->head_dim + 2) * 4));  // room for 64 slices
   WOQ_HIP(hipMalloc((void**)&e->pf_last, (size_t)e->max_batch * cfg->hidden * 4));
   WOQ_HIP(hipMalloc((void**)&e->pf_logits, (size_t)e->max_batch * cfg->vocab * 4));

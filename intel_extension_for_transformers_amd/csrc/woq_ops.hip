@@ -101,7 +101,8 @@ template <typename KV, int HD, bool SPLIT>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv, KV* __restrict__ kcache,
                                                           KV* __restrict__ vcache, const int32_t* __restrict__ pos_p,
                                                           const float* __restrict__ cs, const float* __restrict__ sn,
-                                                          int heads, int kv_heads, float* __restrict__ out) {
+                                                          int heads, int kv_heads, int window,
+                                                          float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   typedef typename KvVec8<KV>::type kv8;
   constexpr int half = HD / 2;
@@ -115,17 +116,20 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int rep = heads / kv_heads, kh = h / rep;
   const int apos = pos_p[0];  // absolute position of the new token = number of cached positions
-  int t_lo = 0, pos = apos;   // this workgroup's cached slice is [t_lo, t_lo + pos)
+  // sliding window (HF Mistral `sliding_window`, 0 = none): the query sees positions [apos + 1 - window, apos]
+  const int w_lo = window > 0 ? max(0, apos + 1 - window) : 0;
+  int t_lo = w_lo, pos = apos - w_lo;  // this workgroup's cached slice is [t_lo, t_lo + pos)
   bool incl_new = true;
   if constexpr (SPLIT) {
     const int ns = (int)gridDim.y, sp = (int)blockIdx.y;
-    const int chunk = (((apos + ns - 1) / ns) + 63) & ~63;
-    t_lo = min(sp * chunk, apos);
+    const int span = apos - w_lo;
+    const int chunk = (((span + ns - 1) / ns) + 63) & ~63;
+    t_lo = w_lo + min(sp * chunk, span);
     pos = min(apos - t_lo, chunk);
     incl_new = sp == ns - 1;
-    kcache += (size_t)t_lo * kv_heads * HD;
-    vcache += (size_t)t_lo * kv_heads * HD;
   }
+  kcache += (size_t)t_lo * kv_heads * HD;
+  vcache += (size_t)t_lo * kv_heads * HD;
   const int npos_abs = apos - t_lo;  // row of the new position relative to the re-based cache pointers
   float* qs = sm;                 // [HD] rotated q (pre-scaled by 1/sqrt(HD))
   float* kn = qs + HD;            // [HD] rotated new k, rounded to the cache dtype
@@ -429,10 +433,11 @@ void launch_embed(const void* embed, int dtype, const int32_t* token, int hidden
 
 template <typename KV, int HD>
 static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int32_t* pos, const float* cs,
-                         const float* sn, int heads, int kv_heads, int max_ctx, float* out, int splits, float* part,
-                         hipStream_t st) {
+                         const float* sn, int heads, int kv_heads, int max_ctx, int window, float* out, int splits,
+                         float* part, hipStream_t st) {
   constexpr int GP = 64 / (HD / 8);
-  const int span = splits > 1 ? ((((max_ctx + splits - 1) / splits) + 63) & ~63) + 64 : max_ctx;
+  const int reach = window > 0 ? min(window, max_ctx) : max_ctx;  // positions a query can see
+  const int span = splits > 1 ? ((((reach + splits - 1) / splits) + 63) & ~63) + 64 : reach;
   const size_t lds = (size_t)(3 * HD + 8 + 4 * GP * HD + ((span + 4) & ~3)) * 4;
   if (lds > 160 * 1024) return woq::fail("QBits: max_ctx too large for the decode attention (raise attn_splits)");
   if (splits > 1) {
@@ -443,7 +448,7 @@ static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int
       once = true;
     }
     hipLaunchKernelGGL(k, dim3(heads, splits), dim3(256), lds, st, qkv, (KV*)kcache, (KV*)vcache, pos, cs, sn, heads,
-                       kv_heads, part);
+                       kv_heads, window, part);
     hipLaunchKernelGGL(attn_combine_kernel<HD>, dim3(heads), dim3(256), 0, st, part, splits, out);
     return 0;
   }
@@ -454,21 +459,21 @@ static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int
     once = true;
   }
   hipLaunchKernelGGL(k, dim3(heads), dim3(256), lds, st, qkv, (KV*)kcache, (KV*)vcache, pos, cs, sn, heads, kv_heads,
-                     out);
+                     window, out);
   return 0;
 }
 
 // splits <= 1: one workgroup per head (short contexts); else `splits` slices per head + a combine launch, partials in
 // `part` (fp32 [heads][splits][D + 2]).
 int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
-                       const float* cs, const float* sn, int heads, int kv_heads, int D, int max_ctx, float* out,
-                       int splits, float* part, hipStream_t st) {
+                       const float* cs, const float* sn, int heads, int kv_heads, int D, int max_ctx, int window,
+                       float* out, int splits, float* part, hipStream_t st) {
   if (D != 64 && D != 128) return woq::fail("QBits: attention head_dim must be 64 or 128");
 #define WOQ_ATTN_DEC(T)                                                                                              \
-  return D == 128 ? launch_attn_t<T, 128>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, splits,   \
-                                          part, st)                                                                 \
-                  : launch_attn_t<T, 64>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, out, splits,    \
-                                         part, st);
+  return D == 128 ? launch_attn_t<T, 128>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, window, out,   \
+                                          splits, part, st)                                                         \
+                  : launch_attn_t<T, 64>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, window, out,    \
+                                         splits, part, st);
   if (kv_dtype == WOQ_F16) { WOQ_ATTN_DEC(_Float16) }
   if (kv_dtype == WOQ_FP8_E4M3) { WOQ_ATTN_DEC(Fp8) }
   WOQ_ATTN_DEC(__bf16)

@@ -150,7 +150,7 @@ template <int KVD, int HD>
 __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const _Float16* __restrict__ qkv, int T, int start,
                                                               int heads, int kv_heads, const void* __restrict__ kcache,
                                                               const void* __restrict__ vcache, size_t seq_stride_elems,
-                                                              _Float16* __restrict__ out, int n_qblocks) {
+                                                              _Float16* __restrict__ out, int n_qblocks, int window) {
   constexpr int CPR = HD / 8;   // 16-B chunks per K row
   constexpr int DC = HD / 32;   // 32-wide d chunks of the QK^T contraction
   constexpr int DT = HD / 16;   // 16-wide d tiles of the output
@@ -171,6 +171,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const _Float16* __
   const size_t cache_row = (size_t)kv_heads * HD;
   const int kv_len = start + min(qb * AQB + AQB, T);  // positions this workgroup may look at
   const int n_tiles = (kv_len + AKT - 1) / AKT;
+  // sliding window (0 = none): query position p sees [p + 1 - window, p]; tiles wholly below the workgroup's first
+  // query's window are never loaded
+  const int tile0 = window > 0 ? max(0, start + qb * AQB + 1 - window) / AKT : 0;
   const float sc = 1.44269504088896f / sqrtf((float)HD);  // softmax scale in the exp2 domain
 
   // Q^T fragments: lane (query i16 of row tile rt, quarter kq) holds d = 32c + 8kq .. +8
@@ -225,14 +228,15 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const _Float16* __
     }
   };
 
-  fetch(0);
-  for (int tile = 0; tile < n_tiles; ++tile) {
+  fetch(tile0);
+  for (int tile = tile0; tile < n_tiles; ++tile) {
     __syncthreads();  // everyone is done with the previous tile
     stage();
     __syncthreads();
     if (tile + 1 < n_tiles) fetch(tile + 1);  // flies under this tile's MFMAs
     const int t0 = tile * AKT;
     if (t0 > start + q0 + 31) continue;  // wholly above this wave's diagonal (wave-uniform)
+    if (window > 0 && t0 + AKT - 1 < start + q0 + 1 - window) continue;  // wholly below this wave's windows
 
     // ---- S^T = K Q^T ----
     float4_t s[4][2];
@@ -250,7 +254,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const _Float16* __
       }
     }
     // ---- causal mask + online softmax (query = lane column i16, positions 16a + 4kq + j) ----
-    const bool diag = t0 + AKT - 1 > start + q0;  // some position of the tile may exceed some query of the wave
+    // some position of the tile may exceed some query of the wave, or fall below some query's window
+    const bool diag = t0 + AKT - 1 > start + q0 || (window > 0 && t0 < start + q0 + 32 - window);
     h8 pb[2][2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -260,7 +265,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const _Float16* __
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (diag && t0 + a * 16 + kq * 4 + j > qpos) s[a][rt][j] = -INFINITY;
+          const int tp = t0 + a * 16 + kq * 4 + j;
+          if (diag && (tp > qpos || (window > 0 && tp < qpos + 1 - window))) s[a][rt][j] = -INFINITY;
           mx = fmaxf(mx, s[a][rt][j]);
         }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -359,24 +365,24 @@ int launch_rope_append(_Float16* qkv, int n_seq, int T, int start, int heads, in
 template <int KVD, int HD>
 static int launch_attn_prefill_t(const _Float16* qkv, int n_seq, int T, int start, int heads, int kv_heads,
                                  const void* kcache, const void* vcache, size_t seq_stride_elems, _Float16* out,
-                                 hipStream_t st) {
+                                 int window, hipStream_t st) {
   auto k = attn_prefill_kernel<KVD, HD>;
   const int nqb = (T + AQB - 1) / AQB;
   hipLaunchKernelGGL(k, dim3((unsigned)nqb, (unsigned)heads, (unsigned)n_seq), dim3(256), attn_lds_bytes<HD>(), st, qkv,
-                     T, start, heads, kv_heads, kcache, vcache, seq_stride_elems, out, nqb);
+                     T, start, heads, kv_heads, kcache, vcache, seq_stride_elems, out, nqb, window);
   return 0;
 }
 
 int launch_attn_prefill(const _Float16* qkv, int n_seq, int T, int start, int heads, int kv_heads, int HD,
                         const void* kcache, const void* vcache, int kv_dtype, size_t seq_stride_elems, _Float16* out,
-                        hipStream_t st) {
+                        int window, hipStream_t st) {
   if (HD != 64 && HD != 128) return woq::fail("QBits: attention head_dim must be 64 or 128");
 #define WOQ_ATTN_CASE(KVD)                                                                                          \
   if (kv_dtype == KVD)                                                                                              \
     return HD == 128 ? launch_attn_prefill_t<KVD, 128>(qkv, n_seq, T, start, heads, kv_heads, kcache, vcache,       \
-                                                       seq_stride_elems, out, st)                                  \
+                                                       seq_stride_elems, out, window, st)                          \
                      : launch_attn_prefill_t<KVD, 64>(qkv, n_seq, T, start, heads, kv_heads, kcache, vcache,        \
-                                                      seq_stride_elems, out, st);
+                                                      seq_stride_elems, out, window, st);
   WOQ_ATTN_CASE(WOQ_F16)
   WOQ_ATTN_CASE(WOQ_BF16)
   WOQ_ATTN_CASE(WOQ_FP8_E4M3)

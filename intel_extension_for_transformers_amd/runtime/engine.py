@@ -44,7 +44,7 @@ class WoqDecoderEngine:
 
     def __init__(self, hidden, inter, heads, kv_heads, head_dim, layers, vocab, max_ctx=2048, rms_eps=1e-5,
                  rope_theta=10000.0, kv_dtype=torch.float16, tp_rank=0, tp_size=1, device=None, max_batch=1,
-                 attn_splits=0):
+                 attn_splits=0, sliding_window=0):
         L.require_gpu()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.cfg = L.EngineConfig(hidden=hidden, inter=inter, heads=heads, kv_heads=kv_heads, head_dim=head_dim,
@@ -53,6 +53,7 @@ class WoqDecoderEngine:
         self.kv_dtype = kv_dtype
         self.cfg.reserved[0] = int(max_batch)
         self.cfg.reserved[1] = int(attn_splits)
+        self.cfg.reserved[2] = int(sliding_window or 0)
         self.max_batch = int(max_batch)
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
@@ -313,8 +314,10 @@ def optimize_transformers(model, max_ctx=2048, kv_dtype=torch.float16):
     if theta is None:
         theta = (getattr(cfg, "rope_parameters", None) or {}).get("rope_theta", 10000.0)
     dev = first.weight.device
+    window = getattr(cfg, "sliding_window", None) or 0  # Mistral v0.1: 4096; null / absent = full causal attention
     eng = WoqDecoderEngine(hidden, inter, heads, kv_heads, head_dim, len(layers), cfg.vocab_size, max_ctx=max_ctx,
-                           rms_eps=cfg.rms_norm_eps, rope_theta=float(theta), kv_dtype=kv_dtype, device=dev)
+                           rms_eps=cfg.rms_norm_eps, rope_theta=float(theta), kv_dtype=kv_dtype, device=dev,
+                           sliding_window=int(window))
     asym = first.scheme == "asym"
     group, sdt = first.blocksize, first.scale_dtype
 

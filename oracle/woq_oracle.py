@@ -359,7 +359,9 @@ class LlamaOracle:
             k = rope(k, [pos], c["theta"])
             self.k[li] = np.concatenate([self.k[li], k], 0)
             self.v[li] = np.concatenate([self.v[li], v], 0)
-            a = attn_decode(q[0], self.k[li], self.v[li]).reshape(1, H * D)
+            w = c.get("window", 0)  # HF Mistral sliding_window: a query sees the last `window` positions (itself included)
+            kk, vv = (self.k[li][-w:], self.v[li][-w:]) if w else (self.k[li], self.v[li])
+            a = attn_decode(q[0], kk, vv).reshape(1, H * D)
             h = h + woq_linear(a, ly["o"])
             x = rmsnorm(h, ly["ln2"], c["eps"])
             g = woq_linear(x, ly["gate"])

@@ -14,16 +14,16 @@ pytestmark = pytest.mark.gpu
 
 
 def _tiny(group, asym, scale_dtype, seed=0, max_ctx=64, max_batch=1, head_dim=64, kv_dtype=torch.float16,
-          attn_splits=0):
+          attn_splits=0, window=0):
     from intel_extension_for_transformers_amd import qbits
     from intel_extension_for_transformers_amd.runtime import WoqDecoderEngine, fuse_gate_up
 
     cfg = dict(hidden=256, inter=512, heads=256 // head_dim, kv_heads=128 // head_dim, head_dim=head_dim, layers=2,
-               vocab=384, eps=1e-5, theta=10000.0)
+               vocab=384, eps=1e-5, theta=10000.0, window=window)
     rng = np.random.default_rng(seed)
     eng = WoqDecoderEngine(cfg["hidden"], cfg["inter"], cfg["heads"], cfg["kv_heads"], cfg["head_dim"], cfg["layers"],
                            cfg["vocab"], max_ctx=max_ctx, rms_eps=cfg["eps"], rope_theta=cfg["theta"],
-                           max_batch=max_batch, kv_dtype=kv_dtype, attn_splits=attn_splits)
+                           max_batch=max_batch, kv_dtype=kv_dtype, attn_splits=attn_splits, sliding_window=window)
     st = {"fp32": orc.F32, "fp16": orc.F16, "bf16": orc.BF16}[scale_dtype]
     e8, e32 = torch.empty(0, dtype=torch.int8), torch.empty(0, dtype=torch.int32)
 
@@ -294,3 +294,32 @@ def test_tp_seam_world_size_one_rccl():
             assert int(eng.token.item()) == int(ref_eng.token.item())
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("head_dim,splits", [(64, 0), (128, 3)])
+def test_sliding_window_attention_vs_oracle(head_dim, splits):
+    """HF Mistral `sliding_window` (a query sees the last W positions, itself included): prompt pass over 150 tokens
+    (window 40: whole tiles below the window are skipped, both tile edges masked), then decode steps — one workgroup
+    per head and the sliced form — and token-by-token decode from an empty cache, against the fp32 oracle with the
+    same window."""
+    W = 40
+    eng, oracle, cfg = _tiny(128, False, "fp16", seed=8, max_ctx=256, head_dim=head_dim, attn_splits=splits, window=W)
+    rng = np.random.default_rng(4)
+    prompt = rng.integers(0, cfg["vocab"], 150).tolist()
+    got = eng.prefill(prompt, greedy=True)[0].cpu().numpy()
+    ref = _oracle_prompt(oracle, prompt)
+    assert np.abs(got - ref).max() <= PF_TOL * np.abs(ref).max() + 1e-3
+    nxt = int(ref.argmax())
+    for j in range(4):
+        eng.step(greedy=True)
+        ref = oracle.forward_token(nxt, 150 + j)
+        assert np.abs(eng.logits.cpu().numpy() - ref).max() <= PF_TOL * np.abs(ref).max() + 1e-3
+        nxt = int(ref.argmax())
+    eng2, oracle2, _ = _tiny(128, False, "fp16", seed=8, max_ctx=256, head_dim=head_dim, attn_splits=splits, window=W)
+    for i, t in enumerate(prompt[:90]):
+        eng2.token.fill_(t)
+        eng2.pos.fill_(i)
+        eng2.step(greedy=False)
+        r = oracle2.forward_token(t, i)
+        if i in (0, 38, 39, 40, 41, 64, 89):
+            assert np.abs(eng2.logits.cpu().numpy() - r).max() <= 2e-3 * np.abs(r).max() + 1e-4, i
