@@ -99,22 +99,29 @@ class _ShellLinear(torch.nn.Module):
         self.bias = tensors.get("bias")
 
 
-def load_low_bit(pretrained_model_name_or_path, device="cuda", **kwargs):
-    """reference modeling_auto.py:1311-1990: config -> empty model -> packed-linear shells -> repack on the device."""
+def _read_safetensors(paths):
     from safetensors import safe_open
 
-    d = str(pretrained_model_name_or_path)
-    with open(os.path.join(d, QUANT_CONFIG)) as f:
-        qcfg = _config_from_dict(json.load(f))
-    qcfg.post_init_hip()
+    tensors, meta = {}, {}
+    for path in paths:
+        with safe_open(path, framework="pt", device="cpu") as f:
+            meta.update(f.metadata() or {})
+            for k in f.keys():
+                tensors[k] = f.get_tensor(k)
+    return tensors, meta
+
+
+def _load_packed(d, qcfg, tensors, quantized, aliases, device):
+    """config -> empty model -> packed-linear shells -> repack on the device (the tail of reference
+    modeling_auto.py:1311-1990, shared by our own saved format and by HF-hub GPTQ checkpoints)."""
     config = transformers.AutoConfig.from_pretrained(d)
+    if hasattr(config, "quantization_config"):  # keep HF from looking for its own quantizer back end
+        try:
+            delattr(config, "quantization_config")
+        except AttributeError:
+            config.quantization_config = None
     with torch.device("meta"):
         model = transformers.AutoModelForCausalLM.from_config(config)
-    with safe_open(os.path.join(d, WEIGHTS_NAME), framework="pt", device="cpu") as f:
-        meta = f.metadata() or {}
-        tensors = {k: f.get_tensor(k) for k in f.keys()}
-    aliases = json.loads(meta.get("aliases", "{}"))
-    quantized = json.loads(meta.get("quantized", "[]"))
     for name in quantized:
         parent_name, _, leaf = name.rpartition(".")
         parent = model.get_submodule(parent_name) if parent_name else model
@@ -136,12 +143,57 @@ def load_low_bit(pretrained_model_name_or_path, device="cuda", **kwargs):
     missing, unexpected = model.load_state_dict(state, strict=False, assign=True)
     missing = [m for m in missing if not any(m.startswith(q + ".") for q in quantized)]
     if missing:
-        logger.warning("load_low_bit: tensors not found in the checkpoint: %s", missing[:8])
+        logger.warning("packed checkpoint: tensors not found: %s", missing[:8])
     model.tie_weights()
     _materialise_buffers(model, device)
     model.to(device)
     model.eval()
     return _finish(model, qcfg)
+
+
+def load_low_bit(pretrained_model_name_or_path, device="cuda", **kwargs):
+    """reference modeling_auto.py:1311-1990: a directory written by `save_low_bit`."""
+    d = str(pretrained_model_name_or_path)
+    with open(os.path.join(d, QUANT_CONFIG)) as f:
+        qcfg = _config_from_dict(json.load(f))
+    qcfg.post_init_hip()
+    tensors, meta = _read_safetensors([os.path.join(d, WEIGHTS_NAME)])
+    aliases = json.loads(meta.get("aliases", "{}"))
+    quantized = json.loads(meta.get("quantized", "[]"))
+    return _load_packed(d, qcfg, tensors, quantized, aliases, device)
+
+
+def _hf_gptq_dir(path):
+    """A Hugging Face GPTQ checkpoint directory (AutoGPTQ / optimum writer): config.json carries
+    quantization_config.quant_method == "gptq"; tensors `<linear>.qweight / .qzeros / .scales / .g_idx` in the same
+    packing `unpack_weight` reads (int32 words of 8 nibbles along K, zeros stored as zp - 1, utils.py:82-125)."""
+    cfg_file = os.path.join(str(path), "config.json")
+    if not os.path.isfile(cfg_file) or os.path.isfile(os.path.join(str(path), QUANT_CONFIG)):
+        return None
+    with open(cfg_file) as f:
+        q = (json.load(f).get("quantization_config") or {})
+    return q if str(q.get("quant_method", "")).lower() == "gptq" else None
+
+
+def load_hf_gptq(path, q, device="cuda"):
+    """a pre-quantised GPTQ checkpoint straight to the GPU layout, act-order (desc_act)
+    included — the rows are regrouped at load and the activation shuffle is applied by the kernels."""
+    d = str(path)
+    qcfg = GPTQConfig(bits=int(q.get("bits", 4)), group_size=int(q.get("group_size", 128)), sym=bool(q.get("sym", True)),
+                      desc_act=bool(q.get("desc_act", False)), static_groups=bool(q.get("static_groups", False)),
+                      scale_dtype="fp16")
+    qcfg.post_init_hip()
+    index = os.path.join(d, "model.safetensors.index.json")
+    if os.path.isfile(index):
+        with open(index) as f:
+            files = sorted(set(json.load(f)["weight_map"].values()))
+    else:
+        files = ["model.safetensors"]
+    tensors, _ = _read_safetensors([os.path.join(d, f) for f in files])
+    quantized = sorted(k[:-len(".qweight")] for k in tensors if k.endswith(".qweight"))
+    if not quantized:
+        raise RuntimeError("QBits: no packed linears (*.qweight) found in %s" % d)
+    return _load_packed(d, qcfg, tensors, quantized, {}, device)
 
 
 def _materialise_buffers(model, device):
@@ -259,6 +311,11 @@ class _BaseAutoModelClass:
         if isinstance(pretrained_model_name_or_path, (str, os.PathLike)) and os.path.isfile(
                 os.path.join(str(pretrained_model_name_or_path), QUANT_CONFIG)):
             return load_low_bit(pretrained_model_name_or_path, device=device)  # :598-657
+        if isinstance(pretrained_model_name_or_path, (str, os.PathLike)) and os.path.isdir(
+                str(pretrained_model_name_or_path)):
+            gq = _hf_gptq_dir(pretrained_model_name_or_path)
+            if gq is not None:
+                return load_hf_gptq(pretrained_model_name_or_path, gq, device=device)
         if qcfg is None and (load_in_4bit or load_in_8bit):  # :717-741: load_in_{4,8}bit -> RtnConfig(bits=4 | 8)
             qcfg = RtnConfig(bits=4 if load_in_4bit else 8, compute_dtype=kwargs.pop("compute_dtype", None),
                              weight_dtype=kwargs.pop("weight_dtype", None), scale_dtype=kwargs.pop("scale_dtype", None))

@@ -354,3 +354,85 @@ def test_model_generate_is_engine_backed_for_greedy(tmp_path):
     torch.manual_seed(0)
     samp = qmodel.generate(ids, max_new_tokens=4, do_sample=True, top_k=5, pad_token_id=0)
     assert samp.shape == (1, ids.shape[1] + 4)
+
+
+def _write_hf_gptq_checkpoint(fp, d, group, sym, desc_act, shards=2, seed=0):
+    """A Hugging Face GPTQ checkpoint directory (AutoGPTQ tensor names / packing) synthesised from a tiny fp model with
+    the oracle's RTN per (act-ordered) group: qweight int32 [K/8, N] in ORIGINAL row order, g_idx [K], qzeros storing
+    zp - 1, fp16 scales. Returns {linear name: dequantised weight [N, K]} for the fp32 twin."""
+    import json
+    import os
+
+    from safetensors.torch import save_file
+
+    from intel_extension_for_transformers_amd.transformers.llm.quantization.utils import pack_weight
+
+    rng = np.random.default_rng(seed)
+    tensors, deq = {}, {}
+    for name, mod in fp.named_modules():
+        if not isinstance(mod, torch.nn.Linear) or name == "lm_head":
+            continue
+        w = mod.weight.detach().float().numpy().T.copy()  # [K, N]
+        K, N = w.shape
+        perm = rng.permutation(K) if desc_act else np.arange(K)
+        q_p, s, z = orc.rtn_quantize(w[perm], False, group, not sym)  # groups are contiguous in the permuted order
+        s = s.astype(np.float16).astype(np.float32)
+        q = np.empty_like(q_p)
+        q[perm] = q_p
+        g_idx = np.empty(K, np.int32)
+        g_idx[perm] = np.arange(K, dtype=np.int32) // group
+        zz = np.zeros_like(s) if z is None else z.astype(np.float32)
+        deq[name] = ((q.astype(np.float32) - zz[g_idx]) * s[g_idx]).T.copy()
+        uz = torch.from_numpy((z.astype(np.int16) + 8) if z is not None else np.full(s.shape, 8, np.int16))
+        qweight, sc16, qzeros = pack_weight(torch.from_numpy(q.astype(np.int16) + 8), torch.from_numpy(s), uz, bits=4)
+        tensors[name + ".qweight"], tensors[name + ".scales"] = qweight.contiguous(), sc16.contiguous()
+        tensors[name + ".qzeros"], tensors[name + ".g_idx"] = qzeros.contiguous(), torch.from_numpy(g_idx)
+    for k, v in fp.state_dict().items():
+        owner = k.rsplit(".", 1)[0]
+        if owner + ".qweight" not in tensors:
+            tensors[k] = v.detach().clone().contiguous()
+    os.makedirs(d, exist_ok=True)
+    keys = sorted(tensors)
+    weight_map = {}
+    for i in range(shards):
+        part = {k: tensors[k] for k in keys[i::shards]}
+        fname = "model-%05d-of-%05d.safetensors" % (i + 1, shards)
+        save_file(part, os.path.join(d, fname), metadata={"format": "pt"})
+        weight_map.update({k: fname for k in part})
+    with open(os.path.join(d, "model.safetensors.index.json"), "w") as f:
+        json.dump({"metadata": {}, "weight_map": weight_map}, f)
+    cfg = fp.config.to_dict()
+    cfg["quantization_config"] = {"quant_method": "gptq", "bits": 4, "group_size": group, "sym": sym,
+                                  "desc_act": desc_act, "static_groups": False, "damp_percent": 0.1}
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    return deq
+
+
+@pytest.mark.parametrize("sym,desc_act", [(True, False), (False, True)])
+def test_from_pretrained_hf_gptq_checkpoint(tmp_path, sym, desc_act):
+    """a Hugging Face GPTQ checkpoint directory (sharded safetensors, AutoGPTQ names,
+    zp - 1 zeros, act-order g_idx) loads straight to the GPU layout; logits match the fp32 twin carrying the
+    checkpoint's own dequantised weights; the engine-backed generate works on it when there is no act-order."""
+    from intel_extension_for_transformers_amd.transformers import AutoModelForCausalLM
+
+    fp = _tiny_llama()
+    fp.generation_config.eos_token_id = None
+    d = tmp_path / "tiny-llama-gptq"
+    deq = _write_hf_gptq_checkpoint(fp, str(d), 128, sym, desc_act)
+    model = AutoModelForCausalLM.from_pretrained(str(d))
+    assert model.quantization_config.quant_method in ("gptq", getattr(model.quantization_config.quant_method, "value", None))
+    twin = copy.deepcopy(fp).cuda()
+    with torch.no_grad():
+        for name, mod in twin.named_modules():
+            if name in deq:
+                mod.weight.copy_(torch.from_numpy(deq[name]))
+    ids = torch.tensor([[5, 17, 200, 3, 77, 140, 9, 31]], device="cuda")
+    with torch.no_grad():
+        a = model(ids).logits.float()
+        b = twin(ids).logits.float()
+    assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-5
+    out = model.generate(ids, max_new_tokens=6, do_sample=False, pad_token_id=0)
+    ref = twin.generate(ids, max_new_tokens=6, do_sample=False, pad_token_id=0)
+    assert torch.equal(out, ref)
+    assert hasattr(model, "woq_engine") == (not desc_act)  # act-order layers stay on the module path
