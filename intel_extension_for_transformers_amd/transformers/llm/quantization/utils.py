@@ -77,6 +77,41 @@ def unpack_weight(qweight, scales, qzeros, q_config):
     return w.contiguous(), scales.contiguous(), zeros
 
 
+_AWQ_ORDER = (0, 2, 4, 6, 1, 3, 5, 7)  # nibble i of an AutoAWQ word holds column 8 * word + _AWQ_ORDER[i]
+
+
+def unpack_awq_gemm(qweight, scales, qzeros):
+    """AutoAWQ "GEMM" checkpoint tensors -> (unsigned int8 [K, N], scales, unsigned zeros [G, N]). Packing of that
+    writer (4-bit): `qweight` int32 [K, N/8] and `qzeros` int32 [G, N/8], both packed ALONG N, nibble i of word c =
+    column 8c + (0,2,4,6,1,3,5,7)[i]; zero points stored as they are (no -1, unlike the GPTQ / INC format that
+    `unpack_weight` reads). w = (q - z) * s."""
+    shifts = torch.arange(0, 32, 4, dtype=torch.int32, device=qweight.device)
+    order = torch.tensor(_AWQ_ORDER, device=qweight.device)
+
+    def along_n(t):
+        v = ((t.to(torch.int32).unsqueeze(-1) >> shifts.view(1, 1, 8)) & 15).to(torch.int8)  # [R, N/8, 8]: nibble order
+        out = torch.empty_like(v)
+        out[:, :, order] = v  # column 8c + order[i] <- nibble i
+        return out.reshape(t.shape[0], -1)
+
+    w = along_n(qweight)[:, :scales.shape[1]].contiguous()
+    z = along_n(qzeros)[:, :scales.shape[1]].contiguous() if qzeros is not None else None
+    return w, scales.contiguous(), z
+
+
+def pack_awq_gemm(int_weight, zeros):
+    """Inverse of unpack_awq_gemm (test / export helper): unsigned [K, N] and [G, N] -> int32 words along N."""
+    order = torch.tensor(_AWQ_ORDER, device=int_weight.device)
+    shifts = torch.arange(0, 32, 4, dtype=torch.int64, device=int_weight.device)
+
+    def along_n(t):
+        r, n = t.shape
+        v = t.to(torch.int64).reshape(r, n // 8, 8)[:, :, order]  # nibble i <- column 8c + order[i]
+        return _to_i32((v << shifts.view(1, 1, 8)).sum(-1))
+
+    return along_n(int_weight), along_n(zeros)
+
+
 def pack_weight(int_weight, scales, zeros, bits=4):
     """Inverse of unpack_weight for the save path (what INC's WeightOnlyLinear.pack writes, reference
     modeling_auto.py:128-149): unsigned int8 [K, N] -> qweight int32 [ceil(K/n_pack), N]; unsigned zeros [G, N] ->
@@ -158,8 +193,12 @@ def _replace_linear(model, modules_to_not_convert, current_key_name, quantizatio
                 bias = module.bias.data if has_bias else None
                 if _packed_checkpoint_linear(module):
                     g_idx = getattr(module, "g_idx", None)
-                    int_w, scales, zeros = unpack_weight(module.qweight, module.scales,
-                                                         getattr(module, "qzeros", None), cfg)
+                    if getattr(module, "awq_gemm", False):
+                        int_w, scales, zeros = unpack_awq_gemm(module.qweight, module.scales,
+                                                               getattr(module, "qzeros", None))
+                    else:
+                        int_w, scales, zeros = unpack_weight(module.qweight, module.scales,
+                                                             getattr(module, "qzeros", None), cfg)
                     int_w = int_w[:in_features]
                     new.set_weights_bias(int_w, scales, zeros,
                                          g_idx if g_idx is not None else torch.empty(0, dtype=torch.int32), cfg, bias)

@@ -89,9 +89,10 @@ class _ShellLinear(torch.nn.Module):
     """Holder of optimum-format tensors between file and repack (the role INC's WeightOnlyLinear shells play in
     `build_woq_model`, reference modeling_auto.py:160-187)."""
 
-    def __init__(self, in_features, out_features, tensors):
+    def __init__(self, in_features, out_features, tensors, awq_gemm=False):
         super().__init__()
         self.in_features, self.out_features = in_features, out_features
+        self.awq_gemm = awq_gemm  # AutoAWQ "GEMM" packing (along N, interleaved nibble order) instead of optimum's
         self.qweight = tensors["qweight"]
         self.scales = tensors["scales"]
         self.qzeros = tensors.get("qzeros")
@@ -111,7 +112,7 @@ def _read_safetensors(paths):
     return tensors, meta
 
 
-def _load_packed(d, qcfg, tensors, quantized, aliases, device):
+def _load_packed(d, qcfg, tensors, quantized, aliases, device, awq_gemm=False):
     """config -> empty model -> packed-linear shells -> repack on the device (the tail of reference
     modeling_auto.py:1311-1990, shared by our own saved format and by HF-hub GPTQ checkpoints)."""
     config = transformers.AutoConfig.from_pretrained(d)
@@ -132,7 +133,7 @@ def _load_packed(d, qcfg, tensors, quantized, aliases, device):
             k, n = old.in_features, old.out_features
         parts = {s: tensors[name + "." + s].to(device) for s in ("qweight", "scales", "qzeros", "g_idx", "bias")
                  if name + "." + s in tensors}
-        parent._modules[leaf] = _ShellLinear(k, n, parts)
+        parent._modules[leaf] = _ShellLinear(k, n, parts, awq_gemm=awq_gemm)
     skip = [n for n, m in model.named_modules()
             if isinstance(m, torch.nn.Linear) or type(m).__name__ == "Conv1D"]  # whatever was left unquantised
     replace_linear(model, skip, None, qcfg, device=device)
@@ -164,24 +165,32 @@ def load_low_bit(pretrained_model_name_or_path, device="cuda", **kwargs):
 
 
 def _hf_gptq_dir(path):
-    """A Hugging Face GPTQ checkpoint directory (AutoGPTQ / optimum writer): config.json carries
-    quantization_config.quant_method == "gptq"; tensors `<linear>.qweight / .qzeros / .scales / .g_idx` in the same
-    packing `unpack_weight` reads (int32 words of 8 nibbles along K, zeros stored as zp - 1, utils.py:82-125)."""
+    """A Hugging Face GPTQ or AWQ checkpoint directory: config.json carries quantization_config.quant_method ==
+    "gptq" (AutoGPTQ / optimum writer: `<linear>.qweight / .qzeros / .scales / .g_idx` in the packing `unpack_weight`
+    reads — int32 words of 8 nibbles along K, zeros stored as zp - 1, utils.py:82-125) or "awq" (AutoAWQ "GEMM"
+    writer: packed along N, see utils.unpack_awq_gemm)."""
     cfg_file = os.path.join(str(path), "config.json")
     if not os.path.isfile(cfg_file) or os.path.isfile(os.path.join(str(path), QUANT_CONFIG)):
         return None
     with open(cfg_file) as f:
         q = (json.load(f).get("quantization_config") or {})
-    return q if str(q.get("quant_method", "")).lower() == "gptq" else None
+    return q if str(q.get("quant_method", "")).lower() in ("gptq", "awq") else None
 
 
 def load_hf_gptq(path, q, device="cuda"):
-    """a pre-quantised GPTQ checkpoint straight to the GPU layout, act-order (desc_act)
-    included — the rows are regrouped at load and the activation shuffle is applied by the kernels."""
+    """a pre-quantised GPTQ / AWQ checkpoint straight to the GPU layout, act-order
+    (desc_act) included — the rows are regrouped at load and the activation shuffle is applied by the kernels."""
     d = str(path)
-    qcfg = GPTQConfig(bits=int(q.get("bits", 4)), group_size=int(q.get("group_size", 128)), sym=bool(q.get("sym", True)),
-                      desc_act=bool(q.get("desc_act", False)), static_groups=bool(q.get("static_groups", False)),
-                      scale_dtype="fp16")
+    awq = str(q.get("quant_method", "")).lower() == "awq"
+    if awq:
+        if str(q.get("version", "gemm")).lower() != "gemm" or int(q.get("bits", q.get("w_bit", 4))) != 4:
+            raise RuntimeError("QBits: only 4-bit AutoAWQ 'GEMM' checkpoints are read")
+        qcfg = AwqConfig(bits=4, group_size=int(q.get("group_size", q.get("q_group_size", 128))),
+                         zero_point=bool(q.get("zero_point", True)), scale_dtype="fp16")
+    else:
+        qcfg = GPTQConfig(bits=int(q.get("bits", 4)), group_size=int(q.get("group_size", 128)),
+                          sym=bool(q.get("sym", True)), desc_act=bool(q.get("desc_act", False)),
+                          static_groups=bool(q.get("static_groups", False)), scale_dtype="fp16")
     qcfg.post_init_hip()
     index = os.path.join(d, "model.safetensors.index.json")
     if os.path.isfile(index):
@@ -193,7 +202,7 @@ def load_hf_gptq(path, q, device="cuda"):
     quantized = sorted(k[:-len(".qweight")] for k in tensors if k.endswith(".qweight"))
     if not quantized:
         raise RuntimeError("QBits: no packed linears (*.qweight) found in %s" % d)
-    return _load_packed(d, qcfg, tensors, quantized, {}, device)
+    return _load_packed(d, qcfg, tensors, quantized, {}, device, awq_gemm=awq)
 
 
 def _materialise_buffers(model, device):

@@ -213,3 +213,27 @@ def test_pack_unpack_weight_8bit_roundtrip(sym):
     assert w.dtype == torch.int8 and torch.equal(w.to(torch.int16), q)
     if not sym:
         assert torch.equal(zeros.to(torch.int16), z)
+
+
+def test_awq_gemm_pack_unpack_matches_writer_definition():
+    """AutoAWQ "GEMM" packing: nibble i of word c (along N) = column 8c + (0,2,4,6,1,3,5,7)[i], zeros stored as they
+    are. unpack_awq_gemm inverts it; checked against the writer's loop form on random tensors."""
+    import torch
+
+    from intel_extension_for_transformers_amd.transformers.llm.quantization.utils import pack_awq_gemm, unpack_awq_gemm
+
+    g = torch.Generator().manual_seed(1)
+    K, N, G = 32, 40, 2
+    q = torch.randint(0, 16, (K, N), generator=g, dtype=torch.int8)
+    z = torch.randint(0, 16, (G, N), generator=g, dtype=torch.int8)
+    s = torch.rand(G, N, generator=g)
+    order = [0, 2, 4, 6, 1, 3, 5, 7]
+    want = torch.zeros(K, N // 8, dtype=torch.int64)
+    for col in range(N // 8):          # the writer's definition, verbatim in loop form
+        for i in range(8):
+            want[:, col] |= q[:, col * 8 + order[i]].to(torch.int64) << (i * 4)
+    want = torch.where(want >= 2 ** 31, want - 2 ** 32, want).to(torch.int32)
+    qw, qz = pack_awq_gemm(q, z)
+    assert torch.equal(qw, want)
+    w, _, zz = unpack_awq_gemm(qw, s, qz)
+    assert torch.equal(w, q) and torch.equal(zz, z)

@@ -436,3 +436,56 @@ def test_from_pretrained_hf_gptq_checkpoint(tmp_path, sym, desc_act):
     ref = twin.generate(ids, max_new_tokens=6, do_sample=False, pad_token_id=0)
     assert torch.equal(out, ref)
     assert hasattr(model, "woq_engine") == (not desc_act)  # act-order layers stay on the module path
+
+
+def test_from_pretrained_hf_awq_checkpoint(tmp_path):
+    """BASELINE configs[2] is "AWQ-style" (asym, small groups): a Hugging Face AWQ checkpoint directory (AutoAWQ "GEMM"
+    tensors packed along N, zero points as they are) loads straight to the GPU layout and reproduces its own
+    dequantised fp32 twin; the fused engine serves its greedy generate."""
+    import json
+    import os
+
+    from safetensors.torch import save_file
+
+    from intel_extension_for_transformers_amd.transformers import AutoModelForCausalLM
+    from intel_extension_for_transformers_amd.transformers.llm.quantization.utils import pack_awq_gemm
+
+    fp = _tiny_llama()
+    fp.generation_config.eos_token_id = None
+    d = str(tmp_path / "tiny-llama-awq")
+    os.makedirs(d)
+    group, tensors, deq = 32, {}, {}
+    for name, mod in fp.named_modules():
+        if not isinstance(mod, torch.nn.Linear) or name == "lm_head":
+            continue
+        w = mod.weight.detach().float().numpy().T.copy()  # [K, N]
+        q, s, z = orc.rtn_quantize(w, False, group, True)
+        s = s.astype(np.float16).astype(np.float32)
+        K = w.shape[0]
+        rows = np.arange(K) // group
+        deq[name] = ((q.astype(np.float32) - z.astype(np.float32)[rows]) * s[rows]).T.copy()
+        qw, qz = pack_awq_gemm(torch.from_numpy(q.astype(np.int16) + 8), torch.from_numpy(z.astype(np.int16) + 8))
+        tensors[name + ".qweight"], tensors[name + ".qzeros"] = qw.contiguous(), qz.contiguous()
+        tensors[name + ".scales"] = torch.from_numpy(s).half().contiguous()
+    for k, v in fp.state_dict().items():
+        if k.rsplit(".", 1)[0] + ".qweight" not in tensors:
+            tensors[k] = v.detach().clone().contiguous()
+    save_file(tensors, os.path.join(d, "model.safetensors"), metadata={"format": "pt"})
+    cfg = fp.config.to_dict()
+    cfg["quantization_config"] = {"quant_method": "awq", "bits": 4, "group_size": group, "zero_point": True,
+                                  "version": "gemm"}
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    model = AutoModelForCausalLM.from_pretrained(d)
+    twin = copy.deepcopy(fp).cuda()
+    with torch.no_grad():
+        for name, mod in twin.named_modules():
+            if name in deq:
+                mod.weight.copy_(torch.from_numpy(deq[name]))
+    ids = torch.tensor([[5, 17, 200, 3, 77, 140, 9, 31]], device="cuda")
+    with torch.no_grad():
+        a, b = model(ids).logits.float(), twin(ids).logits.float()
+    assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-5
+    out = model.generate(ids, max_new_tokens=6, do_sample=False, pad_token_id=0)
+    assert torch.equal(out, twin.generate(ids, max_new_tokens=6, do_sample=False, pad_token_id=0))
+    assert hasattr(model, "woq_engine")
