@@ -27,8 +27,9 @@ int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtyp
                        const float* cs, const float* sn, int heads, int kv_heads, int D, int max_ctx, int window,
                        float* out, int splits, float* part, hipStream_t st);
 void launch_lm_head(const float* hidden_in, const float* norm_w, float eps, const void* W, int w_dtype, int hidden,
-                    int vocab, float* logits, hipStream_t st);
+                    int vocab, float* logits, float* pmax, int32_t* pidx, hipStream_t st);
 void launch_argmax(const float* logits, int vocab, int32_t* token, int32_t* pos, hipStream_t st);
+void launch_argmax_pairs(const float* pmax, const int32_t* pidx, int n, int32_t* token, int32_t* pos, hipStream_t st);
 // prompt pass (woq_gemm_f16.hip, woq_prefill.hip)
 size_t gemm_f16_workspace_bytes(int M, int Kpad, int Npad, int planes);
 int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
@@ -72,6 +73,8 @@ struct woq_engine {
   int nt = 1;
   std::vector<void*> owned;  // everything hipMalloc'ed by create()
   // prompt pass: [n_seq * T] rows at a time; buffers grow on demand (never inside a captured graph)
+  float* am_val = nullptr;      // per-workgroup (max logit, index) pairs of the lm_head launch, for the greedy argmax
+  int32_t* am_idx = nullptr;
   int window = 0;               // sliding-window attention (HF Mistral sliding_window), 0 = full causal
   int attn_splits = 1;          // decode attention: context slices per head (long contexts)
   float* attn_part = nullptr;   // fp32 [heads][attn_splits][head_dim + 2] partials
@@ -117,8 +120,9 @@ static int engine_mlp_block(woq_engine* e, int l, hipStream_t st) {
 
 static int engine_head(woq_engine* e, int greedy, hipStream_t st) {
   const woq_engine_config& c = e->cfg;
-  launch_lm_head(e->hidden, e->final_norm, c.rms_eps, e->lm_head, e->lm_dtype, c.hidden, c.vocab, e->logits, st);
-  if (greedy) launch_argmax(e->logits, c.vocab, e->token, e->pos, st);
+  launch_lm_head(e->hidden, e->final_norm, c.rms_eps, e->lm_head, e->lm_dtype, c.hidden, c.vocab, e->logits,
+                 greedy ? e->am_val : nullptr, greedy ? e->am_idx : nullptr, st);
+  if (greedy) launch_argmax_pairs(e->am_val, e->am_idx, (c.vocab + 15) / 16, e->token, e->pos, st);
   return 0;
 }
 
@@ -210,7 +214,7 @@ static int engine_prefill_impl(woq_engine* e, const int32_t* tokens, int n_seq, 
   launch_gather_last(e->pf_h, n_seq, T, c.hidden, e->pf_last, st);
   for (int s = 0; s < n_seq; ++s)
     launch_lm_head(e->pf_last + (size_t)s * c.hidden, e->final_norm, c.rms_eps, e->lm_head, e->lm_dtype, c.hidden,
-                   c.vocab, e->pf_logits + (size_t)s * c.vocab, st);
+                   c.vocab, e->pf_logits + (size_t)s * c.vocab, nullptr, nullptr, st);
   WOQ_HIP(hipMemcpyAsync(e->hidden, e->pf_last, (size_t)c.hidden * 4, hipMemcpyDeviceToDevice, st));
   WOQ_HIP(hipMemcpyAsync(e->logits, e->pf_logits, (size_t)c.vocab * 4, hipMemcpyDeviceToDevice, st));
   WOQ_HIP(hipMemsetD32Async((hipDeviceptr_t)e->pos, start + T - 1, 1, st));
@@ -277,10 +281,12 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
   WOQ_CHECK(e->attn_splits <= 64, "QBits: attn_splits must be <= 64");
   e->window = cfg->reserved[2] > 0 ? cfg->reserved[2] : 0;
   WOQ_HIP(hipMalloc((void**)&e->attn_part, (size_t)cfg->heads * 64 * (cfg->head_dim + 2) * 4));  // room for 64 slices
+  WOQ_HIP(hipMalloc((void**)&e->am_val, (size_t)((cfg->vocab + 15) / 16) * 4));
+  WOQ_HIP(hipMalloc((void**)&e->am_idx, (size_t)((cfg->vocab + 15) / 16) * 4));
   WOQ_HIP(hipMalloc((void**)&e->pf_last, (size_t)e->max_batch * cfg->hidden * 4));
   WOQ_HIP(hipMalloc((void**)&e->pf_logits, (size_t)e->max_batch * cfg->vocab * 4));
   e->owned = {e->hidden, e->qkv, e->attn, e->act, e->logits, e->token, e->pos, e->kcache, e->vcache, e->pf_last,
-              e->pf_logits, e->attn_part};
+              e->pf_logits, e->attn_part, e->am_val, e->am_idx};
   *out = e;
   WOQ_END
 }

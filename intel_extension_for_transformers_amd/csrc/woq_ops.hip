@@ -340,11 +340,16 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
 __global__ __launch_bounds__(256) void lm_head_kernel(const float* __restrict__ hidden_in,
                                                       const float* __restrict__ norm_w, float eps,
                                                       const void* __restrict__ W, int w_dtype, int hidden, int vocab,
-                                                      float* __restrict__ logits) {
+                                                      float* __restrict__ logits, float* __restrict__ pmax,
+                                                      int32_t* __restrict__ pidx) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* xs = sm;  // [hidden]
   __shared__ float part[4];
+  __shared__ float bestv[4];
+  __shared__ int besti[4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float wbest = -INFINITY;  // this wave's best (logit, row) — rows ascend, so '>' keeps the lowest index on ties
+  int wbi = 0x7fffffff;
   float ss = 0.f;
   for (int i = tid; i < hidden; i += 256) {
     const float v = hidden_in[i];
@@ -383,12 +388,37 @@ __global__ __launch_bounds__(256) void lm_head_kernel(const float* __restrict__ 
     }
     acc = wave_sum(acc);
     if (lane == 0) logits[v] = acc;
+    if (acc > wbest) {
+      wbest = acc;
+      wbi = v;
+    }
+  }
+  // per-workgroup (max, index) for the greedy argmax: it then reduces vocab / 16 pairs instead of vocab logits
+  if (pmax) {
+    if (lane == 0) {
+      bestv[wid] = wbest;
+      besti[wid] = wbi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float b = bestv[0];
+      int bi = besti[0];
+      for (int w = 1; w < 4; ++w)
+        if (bestv[w] > b || (bestv[w] == b && besti[w] < bi)) {
+          b = bestv[w];
+          bi = besti[w];
+        }
+      pmax[blockIdx.x] = b;
+      pidx[blockIdx.x] = bi;
+    }
   }
 }
 
 // greedy: token = argmax(logits) (lowest index on ties, like torch.argmax), pos += 1. One workgroup.
-__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int vocab,
-                                                      int32_t* __restrict__ token, int32_t* __restrict__ pos) {
+// `cand` null: candidate i is logit i; else (logits[i], cand[i]) are the per-workgroup pairs lm_head_kernel left.
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, const int32_t* __restrict__ cand,
+                                                      int vocab, int32_t* __restrict__ token,
+                                                      int32_t* __restrict__ pos) {
   __shared__ float bv[16];
   __shared__ int bi[16];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -396,9 +426,10 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
   int idx = 0x7fffffff;
   for (int i = tid; i < vocab; i += 1024) {
     const float v = logits[i];
-    if (v > best || (v == best && i < idx)) {
+    const int ci = cand ? cand[i] : i;
+    if (v > best || (v == best && ci < idx)) {
       best = v;
-      idx = i;
+      idx = ci;
     }
   }
 #pragma unroll
@@ -480,14 +511,20 @@ int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtyp
 #undef WOQ_ATTN_DEC
 }
 
+// pmax / pidx (nullable): per-workgroup (max logit, its index), (vocab + 15) / 16 entries each
 void launch_lm_head(const float* hidden_in, const float* norm_w, float eps, const void* W, int w_dtype, int hidden,
-                    int vocab, float* logits, hipStream_t st) {
+                    int vocab, float* logits, float* pmax, int32_t* pidx, hipStream_t st) {
   hipLaunchKernelGGL(lm_head_kernel, dim3((vocab + 15) / 16), dim3(256), (size_t)hidden * 4, st, hidden_in, norm_w,
-                     eps, W, w_dtype, hidden, vocab, logits);
+                     eps, W, w_dtype, hidden, vocab, logits, pmax, pidx);
 }
 
 void launch_argmax(const float* logits, int vocab, int32_t* token, int32_t* pos, hipStream_t st) {
-  hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, logits, vocab, token, pos);
+  hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, logits, (const int32_t*)nullptr, vocab, token, pos);
+}
+
+// greedy token from the (max, index) pairs of launch_lm_head
+void launch_argmax_pairs(const float* pmax, const int32_t* pidx, int n, int32_t* token, int32_t* pos, hipStream_t st) {
+  hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, pmax, pidx, n, token, pos);
 }
 
 }  // namespace woq
