@@ -67,7 +67,29 @@ enum woq_dtype { WOQ_F32 = 0, WOQ_BF16 = 1, WOQ_F16 = 2,
                  WOQ_FP8_E4M3 = 3 /* OCP e4m3fn; KV-cache storage only (woq_engine_config.kv_dtype) */ };
 
 /* weight types (reference strings: bestla_weightonly_dispatcher.hpp:62-70) */
-enum woq_weight_type { WOQ_W_INT4_CLIP = 0, WOQ_W_INT8 = 1 };
+enum woq_weight_type {
+  WOQ_W_INT4_CLIP = 0,
+  WOQ_W_INT8 = 1,         /* composite of two int4 blobs, see woq_int8_headers */
+  WOQ_W_NF4 = 2,          /* 4-bit table types: the nibble is an INDEX into a 16-entry table, w = table[code] * scale, */
+  WOQ_W_FP4_E2M1 = 3,     /* symmetric only (no zero points), same qdata layout as int4                              */
+  WOQ_W_FP4_E2M1_BNB = 4
+};
+static inline int woq_weight_is_table(uint32_t t) { return t >= 2u && t <= 4u; }
+
+/* The tables (reference strings "nf4", "fp4_e2m1", "fp4_e2m1_bnb", bestla_weightonly_dispatcher.hpp:62-70; BesTLA's
+ * own constants are not in the reference tree, so these are the published definitions: NF4 = the 16 normal-float
+ * quantiles of bitsandbytes; e2m1 = sign | 2-bit exponent | 1-bit mantissa, values 0, .5, 1, 1.5, 2, 3, 4, 6;
+ * the bitsandbytes fp4 variant = its sign-magnitude table over 12). `max` = the largest magnitude: scale = absmax / max. */
+#define WOQ_LUT_NF4                                                                                                   \
+  {-1.0f, -0.6961928009986877f, -0.5250730514526367f, -0.39491748809814453f, -0.28444138169288635f,                   \
+   -0.18477343022823334f, -0.09105003625154495f, 0.0f, 0.07958029955625534f, 0.16093020141124725f,                    \
+   0.24611230194568634f, 0.33791524171829224f, 0.44070982933044434f, 0.5626170039176941f, 0.7229568362236023f, 1.0f}
+#define WOQ_LUT_FP4_E2M1 \
+  {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f, -0.f, -0.5f, -1.f, -1.5f, -2.f, -3.f, -4.f, -6.f}
+#define WOQ_LUT_FP4_BNB                                                                                               \
+  {0.f, 0.0625f / 12.f, 8.f / 12.f, 1.f, 4.f / 12.f, 0.5f, 2.f / 12.f, 0.25f, -0.f,                      \
+   -0.0625f / 12.f, -8.f / 12.f, -1.f, -4.f / 12.f, -0.5f, -2.f / 12.f, -0.25f}
+static inline float woq_lut_max(uint32_t t) { return t == 3u ? 6.0f : 1.0f; }
 
 /* compute types (reference strings "fp32" | "bf16" | "int8"; recorded) */
 enum woq_compute_type { WOQ_C_FP32 = 0, WOQ_C_BF16 = 1, WOQ_C_INT8 = 2, WOQ_C_FP16 = 3 };

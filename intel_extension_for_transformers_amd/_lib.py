@@ -11,16 +11,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WOQ_HIP_LIB") or os.path.join(_HERE, "libwoq_hip.so")  # env: A/B builds in development
 
 F32, BF16, F16, FP8_E4M3 = 0, 1, 2, 3
-W_INT4_CLIP, W_INT8 = 0, 1
+W_INT4_CLIP, W_INT8, W_NF4, W_FP4_E2M1, W_FP4_E2M1_BNB = 0, 1, 2, 3, 4
 C_FP32, C_BF16, C_INT8, C_FP16 = 0, 1, 2, 3
 HEADER_BYTES = 256
 
-WEIGHT_TYPES = {"int4_clip": W_INT4_CLIP, "int4": W_INT4_CLIP, "int8": W_INT8}
+WEIGHT_TYPES = {"int4_clip": W_INT4_CLIP, "int4": W_INT4_CLIP, "int8": W_INT8, "nf4": W_NF4, "fp4_e2m1": W_FP4_E2M1,
+                "fp4": W_FP4_E2M1, "fp4_e2m1_bnb": W_FP4_E2M1_BNB}
 SCALE_TYPES = {"fp32": F32, "bf16": BF16, "fp16": F16}
 COMPUTE_TYPES = {"fp32": C_FP32, "bf16": C_BF16, "int8": C_INT8, "fp16": C_FP16}
 SCALE_NAMES = {v: k for k, v in SCALE_TYPES.items()}
 COMPUTE_NAMES = {v: k for k, v in COMPUTE_TYPES.items()}
-WEIGHT_NAMES = {W_INT4_CLIP: "int4_clip", W_INT8: "int8"}
+WEIGHT_NAMES = {W_INT4_CLIP: "int4_clip", W_INT8: "int8", W_NF4: "nf4", W_FP4_E2M1: "fp4_e2m1",
+                W_FP4_E2M1_BNB: "fp4_e2m1_bnb"}
 
 
 class BlobHeader(ctypes.Structure):

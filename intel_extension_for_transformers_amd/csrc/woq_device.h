@@ -115,4 +115,15 @@ struct KvVec8<Fp8> {
   typedef Fp8x8 type;
 };
 
+
+// ---- 4-bit table weight types (woq_blob.h): w = table[code] * scale ----
+__host__ __device__ __forceinline__ bool is_table_type(uint32_t t) { return t >= 2u && t <= 4u; }
+__host__ __device__ __forceinline__ float lut_max(uint32_t t) { return t == 3u ? 6.0f : 1.0f; }
+__device__ __forceinline__ float lut_value(uint32_t weight_type, int code) {
+  constexpr float nf4[16] = WOQ_LUT_NF4;
+  constexpr float e2m1[16] = WOQ_LUT_FP4_E2M1;
+  constexpr float bnb[16] = WOQ_LUT_FP4_BNB;
+  return weight_type == WOQ_W_NF4 ? nf4[code] : (weight_type == WOQ_W_FP4_E2M1 ? e2m1[code] : bnb[code]);
+}
+
 }  // namespace woq

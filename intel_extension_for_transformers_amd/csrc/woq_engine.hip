@@ -305,6 +305,9 @@ int woq_engine_set_layer(woq_engine* e, int layer, const woq_layer_weights* w) {
   WOQ_TRY
   WOQ_CHECK(e && w && layer >= 0 && layer < e->cfg.layers, "QBits: bad layer index");
   const woq_engine_config& c = e->cfg;
+  WOQ_CHECK(w->qkv_hdr.weight_type == WOQ_W_INT4_CLIP && w->o_hdr.weight_type == WOQ_W_INT4_CLIP &&
+                w->gate_up_hdr.weight_type == WOQ_W_INT4_CLIP && w->down_hdr.weight_type == WOQ_W_INT4_CLIP,
+            "QBits: the fused engine takes int4_clip layers");
   WOQ_CHECK(w->qkv_hdr.magic == WOQ_BLOB_MAGIC && w->o_hdr.magic == WOQ_BLOB_MAGIC &&
                 w->gate_up_hdr.magic == WOQ_BLOB_MAGIC && w->down_hdr.magic == WOQ_BLOB_MAGIC,
             "QBits: layer weights must be WQH1 blobs");

@@ -41,6 +41,7 @@ struct GenArgs {
   float eps;
   const float* residual;
   int epi;
+  uint32_t weight_type;  // WOQ_W_INT4_CLIP, or a 4-bit table type (w = table[code] * scale)
 };
 
 constexpr int GEN_NW = 4;    // waves per workgroup
@@ -59,6 +60,9 @@ __global__ __launch_bounds__(GEN_NW * 64) void gemv_generic_kernel(GenArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int M = a.M, ncb = a.epi == 1 ? 2 : 1;
+  __shared__ float lut_s[16];  // table weight types: the 16 values, read back by code
+  const bool table = is_table_type(a.weight_type);
+  if (table && tid < 16) lut_s[tid] = lut_value(a.weight_type, tid);
 
   // ---- stage the activation rows: gather (dtype, shuffle), optional RMSNorm, fp32 in LDS, zero K padding ----
   for (int m = 0; m < M; ++m) {
@@ -111,8 +115,13 @@ __global__ __launch_bounds__(GEN_NW * 64) void gemv_generic_kernel(GenArgs a) {
         for (int j = 0; j < 16; ++j) {
           const uint32_t word = (j < 8) ? (h == 0 ? wv.x : wv.z) : (h == 0 ? wv.y : wv.w);
           int qv = (int)((word >> nibble_shift(j)) & 0xfu);
-          qv = (qv & 8) ? qv - 16 : qv;
-          const float wq = (float)(qv - zpv);
+          float wq;
+          if (table) {
+            wq = lut_s[qv];
+          } else {
+            qv = (qv & 8) ? qv - 16 : qv;
+            wq = (float)(qv - zpv);
+          }
 #pragma unroll
           for (int m = 0; m < GEN_MAXM; ++m)
             if (m < M) p[m] = fmaf(wq, xs[(size_t)m * a.Kpad + kb + j], p[m]);
@@ -188,14 +197,15 @@ static int launch_gemv_generic(const void* act, int act_dtype, int lda, int M, c
   a.eps = eps;
   a.residual = residual;
   a.epi = epi;
+  a.weight_type = h.weight_type;
   const int tiles_n = h.Npad / WOQ_TILE_N;
   if (epi == 1 && (tiles_n & 1)) return woq::fail("QBits: fused gate/up weight needs an even number of column tiles");
   const size_t lds = gen_lds_bytes(M, h.Kpad);
-  if (lds > 160 * 1024) return woq::fail("QBits: K too large for the small-M GEMV (activation row does not fit LDS)");
+  if (lds > 159 * 1024) return woq::fail("QBits: K too large for the small-M GEMV (activation row does not fit LDS)");
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gemv_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
+                                       159 * 1024);  // the kernel also holds 64 B of static LDS (the value table)
     if (e != hipSuccess) return woq::fail(std::string("QBits: hipFuncSetAttribute: ") + hipGetErrorString(e));
     attr_set = true;
   }

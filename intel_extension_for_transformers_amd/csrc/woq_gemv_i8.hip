@@ -577,7 +577,8 @@ static bool tile_geometry(int tiles_k, int cb, int smode, int& nw, int& tpw) {
 // boundary always holds, modules.py:152-154); anything else goes to the generic kernel in woq_gemv.hip.
 int gemv_tile_max_rows(const void* act, int act_dtype, int lda, const woq_blob_header& h, const float* norm_w,
                        int epi) {
-  if (act_dtype != WOQ_F32 || h.off_shuffle != 0 || (h.K & 3) != 0 || (lda & 3) != 0 ||
+  if (h.weight_type != WOQ_W_INT4_CLIP || act_dtype != WOQ_F32 || h.off_shuffle != 0 || (h.K & 3) != 0 ||
+      (lda & 3) != 0 ||
       (((uintptr_t)act) & 15) != 0 || (((uintptr_t)norm_w) & 15) != 0)
     return 0;
   const int tiles_k = h.Kpad / WOQ_TILE_K;

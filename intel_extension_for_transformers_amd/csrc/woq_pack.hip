@@ -99,7 +99,12 @@ __device__ __forceinline__ void blob_elem(const uint8_t* blob, const woq_blob_he
   size_t word = (((size_t)tn * tiles_k + kt) * 64 + (size_t)(kq * 16 + i)) * 4 + hh * 2 + (j >> 3);
   uint32_t w = ((const uint32_t*)(blob + h.off_q))[word];
   int qv = (int)((w >> nibble_shift(j)) & 0xfu);
-  u = (qv & 8) ? qv + 8 - 16 : qv + 8;  // unsigned-domain value u = q + 8
+  if (is_table_type(h.weight_type)) {  // table types: hand the raw code back, no zero point
+    u = qv;
+    uz = 0;
+    sc = 0.f;
+  } else
+    u = (qv & 8) ? qv + 8 - 16 : qv + 8;  // unsigned-domain value u = q + 8
   size_t si;
   if (h.scale_mode == 0) {
     int g = k / h.group;
@@ -109,7 +114,7 @@ __device__ __forceinline__ void blob_elem(const uint8_t* blob, const woq_blob_he
     si = ((((size_t)tn * tiles_k + kt) * 16 + i) << 2) + s;
   }
   sc = load_f32(blob + h.off_scale, si, (int)h.scale_type);
-  uz = h.off_zp ? (int)(blob + h.off_zp)[si] : 8;
+  if (!is_table_type(h.weight_type)) uz = h.off_zp ? (int)(blob + h.off_zp)[si] : 8;
 }
 
 // w[k][n] = (u - uz) * scale  == (q - zp) * scale, modules.py:264-295
@@ -129,7 +134,7 @@ __global__ void dequant_kernel(const uint8_t* __restrict__ blob, woq_blob_header
   int u, uz;
   float sc;
   blob_elem(blob, h, k, n, u, uz, sc);
-  const float v = (float)(u - uz) * sc;
+  const float v = is_table_type(h.weight_type) ? lut_value(h.weight_type, u) * sc : (float)(u - uz) * sc;
   out[idx] = accumulate ? out[idx] + v : v;
 }
 
@@ -225,6 +230,34 @@ __global__ void rtn_kernel(const float* __restrict__ w, int transpose, int K, in
   }
 }
 
+// RTN onto a 16-entry table: scale = max|w| / table_max per group, code = nearest table entry of w / scale (lowest
+// code on ties). Parity unpinned like the integer rule (BesTLA's quantiser is not in the reference tree).
+__global__ void rtn_lut_kernel(const float* __restrict__ w, int transpose, int K, int N, int group, int n_groups,
+                               uint32_t weight_type, int8_t* __restrict__ q, float* __restrict__ scales) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)n_groups * N) return;
+  int g = (int)(idx / (size_t)N), n = (int)(idx % (size_t)N);
+  int k0 = g * group, k1 = min(k0 + group, K);
+  float amax = 0.f;
+  for (int k = k0; k < k1; ++k) amax = fmaxf(amax, fabsf(transpose ? w[(size_t)n * K + k] : w[(size_t)k * N + n]));
+  float s = amax / lut_max(weight_type);
+  if (s == 0.f) s = 1.f;
+  scales[idx] = s;
+  for (int k = k0; k < k1; ++k) {
+    const float v = (transpose ? w[(size_t)n * K + k] : w[(size_t)k * N + n]) / s;
+    int best = 0;
+    float bd = INFINITY;
+    for (int c = 0; c < 16; ++c) {
+      const float d = fabsf(v - lut_value(weight_type, c));
+      if (d < bd) {
+        bd = d;
+        best = c;
+      }
+    }
+    q[(size_t)k * N + n] = (int8_t)best;
+  }
+}
+
 }  // namespace woq
 
 using namespace woq;
@@ -243,7 +276,8 @@ size_t woq_packed_weight_size(int K, int N, int blocksize, int weight_type, int 
     return woq_int8_headers(&h, &hi, &lo, K, N, blocksize, (uint32_t)scale_type, WOQ_C_FP32, asym, act_shuffle) == 0
                ? h.total_bytes
                : 0;
-  if (weight_type != WOQ_W_INT4_CLIP) return 0;
+  if (weight_type != WOQ_W_INT4_CLIP && !is_table_type((uint32_t)weight_type)) return 0;
+  if (is_table_type((uint32_t)weight_type) && asym) return 0;  // table types are symmetric (no zero points)
   if (woq_header_init(&h, K, N, blocksize, (uint32_t)weight_type, (uint32_t)scale_type, WOQ_C_FP32, asym,
                       act_shuffle) != 0)
     return 0;
@@ -276,8 +310,10 @@ int woq_repack_quantized_weight(const int8_t* qweight_dev, const float* scale_de
                                 int scale_type, int compute_type, void* blob_dev, size_t blob_bytes,
                                 void* stream) {
   WOQ_TRY
-  WOQ_CHECK(weight_type == WOQ_W_INT4_CLIP || weight_type == WOQ_W_INT8,
-            "QBits: unsupported weight_type in repack (int4_clip | int8)");
+  WOQ_CHECK(weight_type == WOQ_W_INT4_CLIP || weight_type == WOQ_W_INT8 || is_table_type((uint32_t)weight_type),
+            "QBits: unsupported weight_type in repack (int4_clip | int8 | nf4 | fp4_e2m1 | fp4_e2m1_bnb)");
+  WOQ_CHECK(!(is_table_type((uint32_t)weight_type) && zp_dev != nullptr),
+            "QBits: table weight types (nf4 / fp4) are symmetric: no zero points");
   WOQ_CHECK(scale_type >= WOQ_F32 && scale_type <= WOQ_F16, "QBits: unsupported scale_type");
   WOQ_CHECK(((uintptr_t)blob_dev & 255u) == 0, "QBits: packed-weight buffer must be 256-byte aligned");
   hipStream_t st = (hipStream_t)stream;
@@ -320,8 +356,10 @@ int woq_quantize_to_packed_weight(const float* weight_dev, int transpose, int K,
                                   int weight_type, int scale_type, int compute_type, int asym, void* blob_dev,
                                   size_t blob_bytes, void* stream) {
   WOQ_TRY
-  WOQ_CHECK(weight_type == WOQ_W_INT4_CLIP || weight_type == WOQ_W_INT8,
-            "QBits: unsupported weight_type in quantize (int4_clip | int8)");
+  WOQ_CHECK(weight_type == WOQ_W_INT4_CLIP || weight_type == WOQ_W_INT8 || is_table_type((uint32_t)weight_type),
+            "QBits: unsupported weight_type in quantize (int4_clip | int8 | nf4 | fp4_e2m1 | fp4_e2m1_bnb)");
+  WOQ_CHECK(!(is_table_type((uint32_t)weight_type) && asym),
+            "QBits: table weight types (nf4 / fp4) are symmetric: asym is not supported");
   int group = (blocksize <= 0 || blocksize > K) ? K : blocksize;  // blocksize -1 -> K (dispatcher.cpp:296)
   int n_groups = (K + group - 1) / group;
   hipStream_t st = (hipStream_t)stream;
@@ -332,8 +370,12 @@ int woq_quantize_to_packed_weight(const float* weight_dev, int transpose, int K,
   WOQ_HIP(hipMalloc((void**)&sc, (size_t)n_groups * N * sizeof(float)));
   if (asym) WOQ_HIP(hipMalloc((void**)&zp, (size_t)n_groups * N));
   size_t nt = (size_t)n_groups * N;
-  hipLaunchKernelGGL(rtn_kernel, dim3((unsigned)((nt + 127) / 128)), dim3(128), 0, st, weight_dev, transpose, K, N,
-                     group, n_groups, asym, weight_type == WOQ_W_INT8 ? 8 : 4, q, sc, zp);
+  if (is_table_type((uint32_t)weight_type))
+    hipLaunchKernelGGL(rtn_lut_kernel, dim3((unsigned)((nt + 127) / 128)), dim3(128), 0, st, weight_dev, transpose, K,
+                       N, group, n_groups, (uint32_t)weight_type, q, sc);
+  else
+    hipLaunchKernelGGL(rtn_kernel, dim3((unsigned)((nt + 127) / 128)), dim3(128), 0, st, weight_dev, transpose, K, N,
+                       group, n_groups, asym, weight_type == WOQ_W_INT8 ? 8 : 4, q, sc, zp);
   int rc = woq_repack_quantized_weight(q, sc, zp, nullptr, K, N, blocksize, weight_type, scale_type, compute_type,
                                        blob_dev, blob_bytes, stream);
   hipError_t e = hipStreamSynchronize(st);

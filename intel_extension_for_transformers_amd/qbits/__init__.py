@@ -30,7 +30,7 @@ def _blocksize_ok(k, blocksize):
 def _wtype(weight_type):
     if weight_type not in L.WEIGHT_TYPES:
         # reference text: bestla_packq_impl.cpp "unsupported bestla packq config"
-        raise RuntimeError("Qbits: unsupported bestla packq config, weight_type: %s (MI355X path: int4_clip, int8)"
+        raise RuntimeError("Qbits: unsupported bestla packq config, weight_type: %s (MI355X path: int4_clip, int8, nf4, fp4_e2m1, fp4_e2m1_bnb)"
                            % weight_type)
     return L.WEIGHT_TYPES[weight_type]
 
@@ -67,6 +67,8 @@ def header_of(packed):
 
 def get_packed_weight_size(k, n, weight_type, scale_type, compute_type, asym, blocksize, act_shuf):
     """qbits.cpp:79-88."""
+    if asym and _wtype(weight_type) in (L.W_NF4, L.W_FP4_E2M1, L.W_FP4_E2M1_BNB):
+        raise RuntimeError("QBits: table weight types (nf4 / fp4) are symmetric: asym is not supported")
     size = L.lib().woq_packed_weight_size(k, n, blocksize, _wtype(weight_type), _stype(scale_type), int(asym),
                                           int(act_shuf))
     if size == 0:

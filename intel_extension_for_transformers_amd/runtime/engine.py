@@ -304,8 +304,9 @@ def optimize_transformers(model, max_ctx=2048, kv_dtype=torch.float16):
         raise RuntimeError("QBits: the fused decode engine covers Llama-class decoders, got %r" % cfg.model_type)
     layers = model.model.layers
     first = layers[0].self_attn.q_proj
-    if getattr(first, "bits", 4) != 4:
-        raise RuntimeError("QBits: the fused decode engine takes int4 layers (int8 models run on the module path)")
+    if getattr(first, "bits", 4) != 4 or getattr(first, "weight_dtype", "int4_clip") != "int4_clip":
+        raise RuntimeError("QBits: the fused decode engine takes int4_clip layers (int8 / nf4 / fp4 models run on the "
+                           "module path)")
     hidden, inter = cfg.hidden_size, cfg.intermediate_size
     heads = cfg.num_attention_heads
     kv_heads = getattr(cfg, "num_key_value_heads", heads) or heads

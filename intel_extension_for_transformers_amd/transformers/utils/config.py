@@ -188,9 +188,16 @@ class ITREXQuantizationConfigMixin(_HFBase):
                                  % self.weight_dtype)
         elif self.weight_dtype in (None, "int4", "int4_fullrange"):
             self.weight_dtype = "int4_clip"
+        elif self.weight_dtype in ("nf4", "fp4", "fp4_e2m1", "fp4_e2m1_bnb"):
+            # 4-bit table types: symmetric only, like the reference (config.py:360-370: asym is illegal with float
+            # weights); they run on the generic kernel (functional, untuned) and stay off the fused engine
+            if self.weight_dtype == "fp4":
+                self.weight_dtype = "fp4_e2m1"
+            if not self.sym:
+                raise ValueError("asym quantization is not supported with %s weights" % self.weight_dtype)
         elif self.weight_dtype != "int4_clip":
-            raise ValueError("weight_dtype must be 'int4' / 'int4_clip' (bits=4) or 'int8' (bits=8) on the MI355X "
-                             "path, got %s" % self.weight_dtype)
+            raise ValueError("weight_dtype must be 'int4' / 'int4_clip' / 'nf4' / 'fp4_e2m1' / 'fp4_e2m1_bnb' (bits=4) "
+                             "or 'int8' (bits=8) on the MI355X path, got %s" % self.weight_dtype)
         if self.scale_dtype is None:
             self.scale_dtype = "fp32"
         elif self.scale_dtype not in ("fp32", "bf16", "fp16"):

@@ -123,6 +123,77 @@ def repack(q, scales, zp=None, shuffle=None, group=-1, scale_type=F32, compute_t
     return blob
 
 
+# ---- 4-bit table weight types (nf4 / fp4_e2m1 / fp4_e2m1_bnb): w = table[code] * scale (include/woq_blob.h) -------------
+W_NF4, W_FP4_E2M1, W_FP4_E2M1_BNB = 2, 3, 4
+LUTS = {
+    W_NF4: np.array([-1.0, -0.6961928009986877, -0.5250730514526367, -0.39491748809814453, -0.28444138169288635,
+                     -0.18477343022823334, -0.09105003625154495, 0.0, 0.07958029955625534, 0.16093020141124725,
+                     0.24611230194568634, 0.33791524171829224, 0.44070982933044434, 0.5626170039176941,
+                     0.7229568362236023, 1.0], np.float32),
+    W_FP4_E2M1: np.array([0, .5, 1, 1.5, 2, 3, 4, 6, -0.0, -.5, -1, -1.5, -2, -3, -4, -6], np.float32),
+    W_FP4_E2M1_BNB: np.array([0, 0.0625 / 12, 8 / 12, 1, 4 / 12, .5, 2 / 12, .25,
+                              -0.0, -0.0625 / 12, -8 / 12, -1, -4 / 12, -.5, -2 / 12, -.25], np.float32),
+}
+LUT_MAX = {W_NF4: 1.0, W_FP4_E2M1: 6.0, W_FP4_E2M1_BNB: 1.0}
+
+
+def rtn_quantize_table(w, transpose, group, wtype):
+    """scale = max|w| / table_max per group, code = nearest table entry of w / scale, lowest code on ties — fp32
+    arithmetic like the device kernel (rounding rule parity-unpinned: BesTLA's quantiser is not in the reference tree)."""
+    w = np.asarray(w, np.float32)
+    w = w.T if transpose else w
+    K, N = w.shape
+    g = K if group in (-1, 0) or group > K else group
+    G = (K + g - 1) // g
+    lut = LUTS[wtype]
+    q = np.empty((K, N), np.int8)
+    s = np.empty((G, N), np.float32)
+    for gi in range(G):
+        blk = w[gi * g:min(K, (gi + 1) * g)]
+        sc = (np.abs(blk).max(0) / np.float32(LUT_MAX[wtype])).astype(np.float32)
+        sc[sc == 0] = 1
+        d = np.abs((blk / sc)[..., None].astype(np.float32) - lut[None, None, :])
+        q[gi * g:gi * g + blk.shape[0]] = d.argmin(-1).astype(np.int8)  # argmin returns the first (lowest) on ties
+        s[gi] = sc
+    return q, s
+
+
+def repack_table(codes, scales, wtype, group=-1, scale_type=F32, compute_type=0):
+    """codes int8 [K, N] in 0..15 -> blob: the int4 layout with the nibble holding the code, header weight_type set."""
+    blob = repack(np.asarray(codes, np.int8), scales, None, None, group, scale_type, compute_type)
+    blob[:HEADER_BYTES].view(np.uint32)[10] = wtype
+    return blob
+
+
+def _codes_of(blob):
+    """raw 4-bit codes [K, N] of a blob (nibble (k, n) per include/woq_blob.h woq_q_byte)."""
+    h = header(blob)
+    K, N, tiles_k = h["K"], h["N"], h["Kpad"] // 128
+    k = np.arange(K)[:, None]
+    n = np.arange(N)[None, :]
+    tn, i, kt, r = n // 16, n % 16, k // 128, k % 128
+    hh, kq, j = r // 64, (r % 64) // 16, r % 16
+    lane = kq * 16 + i
+    word = ((tn * tiles_k + kt) * 64 + lane) * 4 + hh * 2 + j // 8
+    jj = j % 8
+    sh = 8 * (jj & 3) + 4 * (jj >> 2)
+    words = blob[h["off_q"]:h["off_q"] + (h["Npad"] // 16) * tiles_k * 1024].view(np.uint32)
+    return ((words[word] >> sh.astype(np.uint32)) & 15).astype(np.int64)
+
+
+def dequantize_table(blob, transpose=False):
+    h = header(blob)
+    lut = LUTS[h["weight_type"]]
+    codes = _codes_of(blob)
+    # the scales live where an int4 blob keeps them: read them back by dequantising an all-ones int4 view
+    probe = blob.copy()
+    probe[:HEADER_BYTES].view(np.uint32)[10] = W_INT4
+    probe[h["off_q"]:h["off_scale"]].view(np.uint32)[:] = 0x11111111  # every nibble = +1 -> dequant = 1 * scale
+    sc = dequantize_blob(probe)
+    w = (lut[codes] * sc).astype(np.float32)
+    return w.T.copy() if transpose else w
+
+
 # ---- int8 weights: composite of two int4 blobs (include/woq_blob.h woq_int8_headers) -------------------------------
 W_INT4, W_INT8 = 0, 1
 
@@ -209,6 +280,8 @@ def dequantize_blob(blob, transpose=False):
     if h["weight_type"] == W_INT8:  # (hi - zhi) * 16s + (lo - zlo) * s, the two fp32 terms added in this order
         bhi, blo = _int8_parts(blob)
         return dequantize_blob(bhi, transpose) + dequantize_blob(blo, transpose)
+    if h["weight_type"] in LUTS:
+        return dequantize_table(blob, transpose)
     out = np.empty((h["N"], h["K"]) if transpose else (h["K"], h["N"]), np.float32)
     rc = lib().orc_dequantize_blob(_p(blob), _p(out), int(transpose))
     if rc != 0:
@@ -240,7 +313,7 @@ def woq_linear(x, blob, bias=None, out_dtype=F32):
     blob = _c(blob, np.uint8)
     bias = _c(bias, np.float32)
     h = header(blob)
-    if h["weight_type"] == W_INT8:  # dequantise -> fp32 matmul -> + bias on the composite's dequantised weight
+    if h["weight_type"] == W_INT8 or h["weight_type"] in LUTS:  # dequantise -> fp32 matmul -> + bias
         w = dequantize_blob(blob).astype(np.float64)
         xs = x if not h["off_shuffle"] else x[:, np.frombuffer(
             blob[h["off_shuffle"]:h["off_shuffle"] + 4 * h["K"]].tobytes(), np.int32)]

@@ -489,3 +489,38 @@ def test_from_pretrained_hf_awq_checkpoint(tmp_path):
     out = model.generate(ids, max_new_tokens=6, do_sample=False, pad_token_id=0)
     assert torch.equal(out, twin.generate(ids, max_new_tokens=6, do_sample=False, pad_token_id=0))
     assert hasattr(model, "woq_engine")
+
+
+@pytest.mark.parametrize("wname", ["nf4", "fp4_e2m1"])
+def test_from_pretrained_table_weight_dtype(tmp_path, wname):
+    """RtnConfig(weight_dtype="nf4" | "fp4_e2m1") (reference docs/weightonlyquant.md dtype table): quantised on the
+    device, module path (no fused engine), logits against the fp32 twin carrying the dequantised weights."""
+    from intel_extension_for_transformers_amd import qbits
+    from intel_extension_for_transformers_amd.transformers import AutoModelForCausalLM, RtnConfig
+    from intel_extension_for_transformers_amd.transformers.llm.quantization.nn.modules import QuantizedLinearQBits
+
+    fp = _tiny_llama()
+    fp.generation_config.eos_token_id = None
+    src = tmp_path / "fp"
+    fp.save_pretrained(str(src))
+    qmodel = AutoModelForCausalLM.from_pretrained(str(src), quantization_config=RtnConfig(bits=4, group_size=64,
+                                                                                          weight_dtype=wname))
+    assert qmodel.quantization_config.weight_dtype == wname
+    twin = copy.deepcopy(fp).cuda()
+    qmods = dict(qmodel.named_modules())
+    with torch.no_grad():
+        for name, mod in twin.named_modules():
+            qm = qmods.get(name)
+            if isinstance(qm, QuantizedLinearQBits):
+                deq = torch.empty(qm.in_features, qm.out_features, dtype=torch.float32, device="cuda")
+                qbits.dequantize_packed_weight(qm.weight.data, deq, False, "fp32", wname, qm.scale_dtype)
+                mod.weight.copy_(deq.t())
+    ids = torch.tensor([[5, 17, 200, 3, 77, 140, 9, 31]], device="cuda")
+    with torch.no_grad():
+        a, b = qmodel(ids).logits.float(), twin(ids).logits.float()
+    assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-5
+    out = qmodel.generate(ids, max_new_tokens=4, do_sample=False, pad_token_id=0)
+    assert torch.equal(out, twin.generate(ids, max_new_tokens=4, do_sample=False, pad_token_id=0))
+    assert not hasattr(qmodel, "woq_engine")
+    with pytest.raises(ValueError, match="asym"):
+        RtnConfig(bits=4, weight_dtype=wname, sym=False).post_init_hip()

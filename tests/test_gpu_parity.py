@@ -475,3 +475,39 @@ def test_shape_and_type_errors_keep_the_reference_prefix(qbits):
     with pytest.raises(RuntimeError, match="QBits: not a WQH1 packed weight"):
         qbits.woq_linear(torch.zeros(2, 256, device="cuda"), torch.zeros(4096, dtype=torch.int8, device="cuda"),
                          torch.empty(0), torch.zeros(2, 48, device="cuda"), "fp32", "int4_clip", "fp32", False)
+
+
+# ---- 4-bit table weight types: nf4, fp4_e2m1, fp4_e2m1_bnb (reference strings, bestla_weightonly_dispatcher.hpp:62-70) --
+TABLE_TYPES = {"nf4": orc.W_NF4, "fp4_e2m1": orc.W_FP4_E2M1, "fp4_e2m1_bnb": orc.W_FP4_E2M1_BNB}
+
+
+@pytest.mark.parametrize("wname", sorted(TABLE_TYPES))
+@pytest.mark.parametrize("K,N,group", [(512, 1024, 128), (256, 48, 32), (160, 24, 64), (512, 64, -1)])
+def test_table_weight_types_quantize_dequant_linear(qbits, wname, K, N, group):
+    """w = table[code] * scale. quantize_to_packed_weight == the oracle's nearest-entry RTN + repack byte for byte
+    (rounding rule parity-unpinned); dequantisation bit-exact; woq_linear at decode and at prefill row
+    counts (the generic fp32 kernel serves every M for these types) within fp32 summation error of
+    dequantise -> matmul -> + bias; asym is rejected like the reference does for float weight types."""
+    wt = TABLE_TYPES[wname]
+    rng = np.random.default_rng(41)
+    w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)  # nn.Linear layout
+    blob = qbits.quantize_to_packed_weight(torch.from_numpy(w).cuda(), True, group, "fp32", wname, "fp32", False)
+    q, s = orc.rtn_quantize_table(w, True, group, wt)
+    ref_blob = orc.repack_table(q, s, wt, group)
+    assert np.array_equal(blob.cpu().numpy().view(np.uint8), ref_blob)
+    deq = torch.empty(K, N, dtype=torch.float32, device="cuda")
+    qbits.dequantize_packed_weight(blob, deq, False, "fp32", wname, "fp32")
+    want = orc.dequantize_blob(ref_blob)
+    assert np.array_equal(deq.cpu().numpy(), want)
+    assert "".join(chr(c) for c in qbits.acquire_packed_weight_info(blob, 6).tolist()) == wname
+    bias = rng.random(N, dtype=np.float32)
+    for M in (1, 3, 37):
+        x = rng.standard_normal((M, K)).astype(np.float32)
+        ref = orc.woq_linear(x, ref_blob, bias)
+        out = torch.zeros(M, N, device="cuda")
+        qbits.woq_linear(torch.from_numpy(x).cuda(), blob, torch.from_numpy(bias).cuda(), out, "fp32", wname, "fp32",
+                         False)
+        mag = np.abs(x) @ np.abs(want)
+        assert (np.abs(out.cpu().numpy() - ref) <= 2e-6 * mag + 1e-5).all()
+    with pytest.raises(RuntimeError, match="symmetric"):
+        qbits.quantize_to_packed_weight(torch.from_numpy(w).cuda(), True, group, "fp32", wname, "fp32", True)
