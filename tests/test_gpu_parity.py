@@ -238,7 +238,7 @@ def test_errors_are_runtime_errors(qbits):
         qbits.woq_linear(torch.rand(1, 64).double().cuda(), blob, torch.empty(0), torch.zeros(1, 32).cuda(), "fp32",
                          "int4_clip", "fp32", False)
     with pytest.raises(RuntimeError, match="[Qq]bits"):
-        qbits.quantize_to_packed_weight(torch.rand(64, 32).cuda(), False, 32, "fp32", "nf4", "fp32", False)
+        qbits.quantize_to_packed_weight(torch.rand(64, 32).cuda(), False, 32, "fp32", "int3_clip", "fp32", False)
 
 
 @pytest.mark.parametrize("K,N,group,asym", [(512, 1024, 128, False), (512, 1024, 128, True), (256, 48, 32, True),
