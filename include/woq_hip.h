@@ -14,8 +14,11 @@
  *    pointers stored in a woq_engine, which must outlive it (same rule as the reference's
  *    set_woq_workspace, bestla_weightonly_dispatcher.cpp:394-397).
  *  - `stream` is a hipStream_t passed as void* (0 = default stream). All work is asynchronous on
- *    that stream; nothing here synchronises or allocates on the hot calls, so every hot call can
- *    be captured into a hipGraph.
+ *    that stream. The per-token calls (woq_linear with int4 blobs, fp32 activations and M <= 8, the
+ *    woq_engine step) neither synchronise nor allocate and can be captured into a hipGraph; the
+ *    prefill GEMM (M > 8), int8 blobs and 16-bit activations at M <= 8 take stream-ordered scratch
+ *    (hipMallocAsync / hipFreeAsync on `stream`) per call, like the reference's per-call amalloc
+ *    (bestla_weightonly_dispatcher.cpp:108-118,179); the engine's prompt pass owns its scratch.
  *  - return value: 0 on success, non-zero on error; woq_last_error() returns a thread-local
  *    message that starts with "QBits:" like the reference's TORCH_CHECK strings
  *    (bestla_weightonly_dispatcher.cpp:289,368; qbits.cpp:35,150). The Python shim raises
@@ -48,7 +51,9 @@ WOQ_API size_t woq_packed_weight_size(int K, int N, int blocksize, int weight_ty
                                       int act_shuffle);
 
 /* replaces qbits.repack_quantized_weight (qbits.cpp:61-77 -> bestla_packq_impl.cpp:20-41).
- * qweight int8 [K,N] (int4 values, signed domain, modules.py:225-227), scale fp32 [G,N],
+ * weight_type (enum woq_weight_type): int4_clip — qweight int8 [K,N] holds int4 values in the signed domain
+ * (modules.py:225-227); int8 — full int8 values (stored as a composite of two int4 blobs, woq_blob.h); nf4 /
+ * fp4_e2m1 / fp4_e2m1_bnb — table codes 0..15, no zero points. scale fp32 [G,N],
  * zp int8 [G,N] or NULL (sym), g_idx int32 [K] = GPTQ act-order group id of every K row (each group exactly
  * `blocksize` rows) or NULL; like BesTLA, repack converts it to activation shuffle indices
  * (qbits_ut/test_packq.py:22-28,59-64) and the blob keeps those. blob_dev: caller-allocated,
