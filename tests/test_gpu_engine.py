@@ -274,8 +274,13 @@ def test_tp_seam_world_size_one_rccl():
 
     from intel_extension_for_transformers_amd.runtime.tp import TPDecoder
 
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    import socket
+
+    with socket.socket() as sock:  # a free port: the fixed default may be taken on a shared box
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         eng, oracle, cfg = _tiny(128, False, "fp16", seed=5, max_ctx=256)
