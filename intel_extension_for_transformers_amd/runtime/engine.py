@@ -302,6 +302,13 @@ def optimize_transformers(model, max_ctx=2048, kv_dtype=torch.float16):
     cfg = model.config
     if getattr(cfg, "model_type", "") not in ("llama", "mistral"):
         raise RuntimeError("QBits: the fused decode engine covers Llama-class decoders, got %r" % cfg.model_type)
+    # anything the engine's kernels do not implement keeps the model on the module path instead of changing its maths
+    rs = getattr(cfg, "rope_scaling", None) or (getattr(cfg, "rope_parameters", None) or {})
+    rtype = (rs.get("rope_type") or rs.get("type") or "default") if isinstance(rs, dict) else "default"
+    if rtype not in ("default", None):
+        raise RuntimeError("QBits: the fused decode engine implements plain RoPE only (rope scaling %r)" % rtype)
+    if getattr(cfg, "hidden_act", "silu") not in ("silu", "swish"):
+        raise RuntimeError("QBits: the fused decode engine implements the SiLU-gated MLP only (%r)" % cfg.hidden_act)
     layers = model.model.layers
     first = layers[0].self_attn.q_proj
     if getattr(first, "bits", 4) != 4 or getattr(first, "weight_dtype", "int4_clip") != "int4_clip":
