@@ -247,7 +247,6 @@ def synth_llama_weights(engine, hidden, inter, heads, kv_heads, head_dim, layers
     dev = engine.device
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
-    gs = hidden if group == -1 else group
 
     def rand_q(k, n):
         q = torch.randint(-8, 8, (k, n), generator=g, device=dev, dtype=torch.int8)
@@ -280,7 +279,6 @@ def synth_llama_weights(engine, hidden, inter, heads, kv_heads, head_dim, layers
     lm_head = (0.02 * torch.randn(vocab, hidden, generator=g, device=dev)).to(model_dtype)
     norm = 1 + 0.02 * torch.randn(hidden, generator=g, device=dev)
     engine.set_head(embed, norm, lm_head)
-    _ = gs
     return engine
 
 
