@@ -14,11 +14,11 @@ pytestmark = pytest.mark.gpu
 
 
 def _tiny(group, asym, scale_dtype, seed=0, max_ctx=64, max_batch=1, head_dim=64, kv_dtype=torch.float16,
-          attn_splits=0, window=0):
+          attn_splits=0, window=0, hidden=256):
     from intel_extension_for_transformers_amd import qbits
     from intel_extension_for_transformers_amd.runtime import WoqDecoderEngine, fuse_gate_up
 
-    cfg = dict(hidden=256, inter=512, heads=256 // head_dim, kv_heads=128 // head_dim, head_dim=head_dim, layers=2,
+    cfg = dict(hidden=hidden, inter=512, heads=hidden // head_dim, kv_heads=128 // head_dim, head_dim=head_dim, layers=2,
                vocab=384, eps=1e-5, theta=10000.0, window=window)
     rng = np.random.default_rng(seed)
     eng = WoqDecoderEngine(cfg["hidden"], cfg["inter"], cfg["heads"], cfg["kv_heads"], cfg["head_dim"], cfg["layers"],
@@ -328,3 +328,22 @@ def test_sliding_window_attention_vs_oracle(head_dim, splits):
         r = oracle2.forward_token(t, i)
         if i in (0, 38, 39, 40, 41, 64, 89):
             assert np.abs(eng2.logits.cpu().numpy() - r).max() <= 2e-3 * np.abs(r).max() + 1e-4, i
+
+
+def test_sliced_attention_grouped_queries_rep4_fp8():
+    """Sliced decode attention under grouped queries (4 q heads / 1 kv head) with an fp8 KV cache: 5 slices,
+    token-by-token over 150 positions against the engine's own one-workgroup-per-head form (same fp8 cache contents
+    -> same softmax inputs up to summation order)."""
+    kw = dict(seed=9, max_ctx=256, head_dim=128, hidden=512, kv_dtype=torch.float8_e4m3fn)
+    a, _, cfg = _tiny(128, False, "fp16", attn_splits=5, **kw)
+    b, _, _ = _tiny(128, False, "fp16", attn_splits=1, **kw)
+    assert cfg["heads"] == 4 and cfg["kv_heads"] == 1
+    rng = np.random.default_rng(2)
+    for i, t in enumerate(rng.integers(0, cfg["vocab"], 150).tolist()):
+        for e in (a, b):
+            e.token.fill_(t)
+            e.pos.fill_(i)
+            e.step(greedy=False)
+        if i in (0, 1, 15, 16, 63, 64, 65, 127, 128, 149):
+            la, lb = a.logits.cpu().numpy(), b.logits.cpu().numpy()
+            assert np.abs(la - lb).max() <= 1e-4 * np.abs(lb).max() + 1e-5, i
