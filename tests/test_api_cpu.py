@@ -237,3 +237,30 @@ def test_awq_gemm_pack_unpack_matches_writer_definition():
     assert torch.equal(qw, want)
     w, _, zz = unpack_awq_gemm(qw, s, qz)
     assert torch.equal(w, q) and torch.equal(zz, z)
+
+
+def test_library_exports_every_symbol_the_headers_declare():
+    """The C-ABI library loads without a GPU and exports every `WOQ_API` function of include/woq_hip.h (no compute
+    call is made); the ctypes binding's EXPORTS list is exactly that set, and the header structs have the sizes
+    the binding assumes."""
+    import ctypes
+    import os
+    import re
+
+    from intel_extension_for_transformers_amd import _lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "woq_hip.h")).read()
+    declared = set(re.findall(r"WOQ_API[^;(]*?\\b(woq_\\w+)\\s*\\(", header))
+    assert len(declared) >= 30
+    assert declared == set(_lib.EXPORTS)
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libwoq_hip.so not built (python __graft_entry__.py)")
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    lib.woq_abi_version.restype = ctypes.c_int
+    assert lib.woq_abi_version() == 1
+    lib.woq_last_error.restype = ctypes.c_char_p
+    assert isinstance(lib.woq_last_error(), bytes)
+    assert ctypes.sizeof(_lib.BlobHeader) == 256 and ctypes.sizeof(_lib.EngineConfig) == 4 * 16
