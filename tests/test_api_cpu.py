@@ -251,7 +251,7 @@ def test_library_exports_every_symbol_the_headers_declare():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     header = open(os.path.join(root, "include", "woq_hip.h")).read()
-    declared = set(re.findall(r"WOQ_API[^;(]*?\\b(woq_\\w+)\\s*\\(", header))
+    declared = set(re.findall(r"WOQ_API[^;(]*?\b(woq_\w+)\s*\(", header))
     assert len(declared) >= 30
     assert declared == set(_lib.EXPORTS)
     if not os.path.exists(_lib.LIB_PATH):
