@@ -22,15 +22,17 @@
 //    accuracy of an fp32 product — and results do not depend on summation order inside a tile;
 //  * zero points (asym): sum_k (q_k - zp) x_k = sum_k q_k x_k - zp * sum_k x_k, with sum_k x~_k per tile from
 //    one extra MFMA pair against an all-ones B (the same identity BesTLA uses, dispatcher.cpp:154-160);
-//  * per-32 scales (group 32): the 64-k MFMA is issued twice with the A operand of the other 32-k half read
-//    from a zero block, so each result is one group's sum.
+//  * per-32 scales (group 32 / 64): at batch 1 the MFMA's output rows 4..7 are free, so they carry the same
+//    activation row restricted to the second 32-k group of each 64-k block (rows 0..3: the first group) — ONE MFMA
+//    per 64-k half returns both groups' sums, each lane quarter applies its own group's scale and zero point;
+//    for 2..4 rows the 64-k MFMA is issued twice with the A operand of the other 32-k half read from a zero block.
 // Schedule:
 //  * one workgroup = CB adjacent 16-column tiles (CB = 2 for the fused gate/up SiLU*mul pairs) x all of K;
 //    its waves own contiguous balanced K slices of up to TPW = 8 tiles (8 KiB per column tile) each;
 //  * a wave issues its activation-row loads first (they come back from L2 first: loads return in order), then
-//    all scale / zero-point loads and PF weight tiles (buffer_load_dwordx4 nt, straight to VGPRs); the CU's
-//    miss queue holds ~16 KiB, so the remaining tiles are issued one per consumed tile instead of stalling
-//    the wave in front of its own staging; every wait is a counted vmcnt;
+//    all scale / zero-point loads and ALL of its weight tiles (buffer_load_dwordx4 nt, straight to VGPRs): the
+//    CU's miss queue holds ~16 KiB, so the wave may wait at issue, but queueing everything before the staging
+//    measured +2.3 % tokens/s over keeping only four tiles in flight (WOQ_PF below); every wait is a counted vmcnt;
 //  * while the weights fly, the wave stages ONLY ITS OWN K slice of the activation rows into a wave-private
 //    LDS strip — no workgroup barrier, no full-vector dependency: RMSNorm is separable
 //    (out = rsqrt(mean(x^2)+eps) * (W . (x*g)): every wave adds its slice's sum of squares to the reduction
