@@ -156,10 +156,11 @@ def main():
 
     cfg = dict(LLAMA2_7B, layers=args.layers)
     max_ctx = 1 << max(9, (args.prompt + args.warmup + args.steps + 8).bit_length())
-    if args.prefill_seqs > 0:
+    want_prefill = args.prefill_seqs > 0 and world == 1
+    if want_prefill:
         max_ctx = max(max_ctx, args.prefill_len)
     eng = WoqDecoderEngine(cfg["hidden"], cfg["inter"], cfg["heads"], cfg["kv_heads"], cfg["head_dim"], cfg["layers"],
-                           cfg["vocab"], max_ctx=max_ctx, max_batch=max(1, args.prefill_seqs))
+                           cfg["vocab"], max_ctx=max_ctx, max_batch=max(1, args.prefill_seqs) if want_prefill else 1)
     synth_llama_weights(eng, cfg["hidden"], cfg["inter"], cfg["heads"], cfg["kv_heads"], cfg["head_dim"],
                         cfg["layers"], cfg["vocab"], group=128, sym=True, scale_dtype="fp16", seed=1234 + rank)
 
@@ -241,9 +242,9 @@ def main():
                 "launches_per_token": n_launch,
             },
         }
-        if args.prefill_seqs > 0:
+        if args.prefill_seqs > 0 and world == 1:
             out["prefill"] = prefill_measure(eng, cfg, args.prefill_seqs, args.prefill_len)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only (torchrun also pins OMP_NUM_THREADS=1)
             out["cpu_baseline"] = cpu_baseline(eng, cfg)
         print(json.dumps(out), flush=True)
     if dist is not None:
