@@ -175,6 +175,12 @@ WOQ_API void* woq_engine_prefill_logits_ptr(woq_engine* e);
  * captured earlier keeps the regime it was captured with. */
 WOQ_API int woq_engine_set_attn_splits(woq_engine* e, int splits);
 WOQ_API int woq_engine_attn_splits(woq_engine* e);
+/* sliced regime only: on = one workgroup per (kv head, slice) computing all the query heads of the group on the
+ * matrix cores, so each K / V row is fetched once per group instead of once per query head (measured faster at
+ * 8k cached positions, Mistral-7B shape; applies to head_dim 128 with 2 / 4 / 8 query heads per kv head and an fp16 or
+ * fp8 cache — silently the per-query-head slices otherwise). Default off. Same capture rule as attn_splits. */
+WOQ_API int woq_engine_set_attn_grouped(woq_engine* e, int on);
+WOQ_API int woq_engine_attn_grouped(woq_engine* e);
 /* KV cache base pointers (which: 0 = K, 1 = V), layout [sequence][layer][position][kv_head][head_dim] in kv_dtype:
  * inspection / tests, and the seam for an external cache manager. */
 WOQ_API void* woq_engine_kv_cache_ptr(woq_engine* e, int which);

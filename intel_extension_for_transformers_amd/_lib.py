@@ -67,6 +67,7 @@ EXPORTS = [
     "woq_engine_bind_io", "woq_engine_token_ptr", "woq_engine_pos_ptr", "woq_engine_logits_ptr", "woq_engine_hidden_ptr",
     "woq_engine_step", "woq_engine_capture", "woq_engine_replay", "woq_engine_set_allreduce", "woq_engine_phase",
     "woq_engine_time_gemv", "woq_engine_prefill", "woq_engine_prefill_logits_ptr", "woq_engine_kv_cache_ptr", "woq_engine_set_attn_splits", "woq_engine_attn_splits",
+    "woq_engine_set_attn_grouped", "woq_engine_attn_grouped",
 ]
 
 _lib = None
@@ -115,6 +116,8 @@ def lib():
     L.woq_engine_prefill_logits_ptr.argtypes = [vp]
     L.woq_engine_set_attn_splits.argtypes = [vp, ci]
     L.woq_engine_attn_splits.argtypes = [vp]
+    L.woq_engine_set_attn_grouped.argtypes = [vp, ci]
+    L.woq_engine_attn_grouped.argtypes = [vp]
     L.woq_engine_kv_cache_ptr.restype = vp
     L.woq_engine_kv_cache_ptr.argtypes = [vp, ci]
     L.woq_engine_time_gemv.argtypes = [vp, ci, vp, ctypes.POINTER(cf), ctypes.POINTER(ctypes.c_double),

@@ -25,7 +25,7 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
 void launch_embed(const void* embed, int dtype, const int32_t* token, int hidden, float* out, hipStream_t st);
 int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
                        const float* cs, const float* sn, int heads, int kv_heads, int D, int max_ctx, int window,
-                       float* out, int splits, float* part, hipStream_t st);
+                       float* out, int splits, int grouped, float* part, hipStream_t st);
 void launch_lm_head(const float* hidden_in, const float* norm_w, float eps, const void* W, int w_dtype, int hidden,
                     int vocab, float* logits, float* pmax, int32_t* pidx, hipStream_t st);
 void launch_argmax(const float* logits, int vocab, int32_t* token, int32_t* pos, hipStream_t st);
@@ -77,6 +77,7 @@ struct woq_engine {
   int32_t* am_idx = nullptr;
   int window = 0;               // sliding-window attention (HF Mistral sliding_window), 0 = full causal
   int attn_splits = 1;          // decode attention: context slices per head (long contexts)
+  int attn_grouped = 0;         // sliced regime: one workgroup per kv head x slice on the matrix cores (GQA shapes)
   float* attn_part = nullptr;   // fp32 [heads][attn_splits][head_dim + 2] partials
   int max_batch = 1;
   size_t pf_rows = 0, pf_ws_bytes = 0;
@@ -99,7 +100,7 @@ static int engine_attn_block(woq_engine* e, int l, hipStream_t st) {
   if (rc) return rc;
   rc = launch_attn_decode(e->qkv, e->kcache + (size_t)l * e->kv_layer_bytes, e->vcache + (size_t)l * e->kv_layer_bytes,
                           c.kv_dtype, e->pos, e->cs, e->sn, c.heads, c.kv_heads, c.head_dim, c.max_ctx, e->window,
-                          e->attn, e->attn_splits, e->attn_part, st);
+                          e->attn, e->attn_splits, e->attn_grouped, e->attn_part, st);
   if (rc) return rc;
   // row-parallel o_proj: rank 0 carries the residual so that the sum over ranks adds it exactly once
   const float* res = (c.tp_size <= 1 || c.tp_rank == 0) ? e->hidden : nullptr;
@@ -246,6 +247,13 @@ int woq_engine_set_attn_splits(woq_engine* e, int splits) {
   WOQ_END
 }
 int woq_engine_attn_splits(woq_engine* e) { return e ? e->attn_splits : 0; }
+int woq_engine_set_attn_grouped(woq_engine* e, int on) {
+  WOQ_TRY
+  WOQ_CHECK(e != nullptr, "QBits: null engine");
+  e->attn_grouped = on != 0;
+  WOQ_END
+}
+int woq_engine_attn_grouped(woq_engine* e) { return e ? e->attn_grouped : 0; }
 void* woq_engine_kv_cache_ptr(woq_engine* e, int which) { return e ? (which ? e->vcache : e->kcache) : nullptr; }
 
 int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {

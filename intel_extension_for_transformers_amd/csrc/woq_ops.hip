@@ -462,6 +462,11 @@ void launch_embed(const void* embed, int dtype, const int32_t* token, int hidden
   hipLaunchKernelGGL(embed_kernel, dim3((hidden + 255) / 256), dim3(256), 0, st, embed, dtype, token, hidden, out);
 }
 
+bool launch_attn_decode_mfma(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
+                             const float* cs, const float* sn, int heads, int kv_heads, int D, int window, int splits,
+                             float* part, hipStream_t st);
+void launch_attn_combine(const float* part, int heads, int D, int splits, float* out, hipStream_t st);
+
 template <typename KV, int HD>
 static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int32_t* pos, const float* cs,
                          const float* sn, int heads, int kv_heads, int max_ctx, int window, float* out, int splits,
@@ -498,8 +503,15 @@ static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int
 // `part` (fp32 [heads][splits][D + 2]).
 int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
                        const float* cs, const float* sn, int heads, int kv_heads, int D, int max_ctx, int window,
-                       float* out, int splits, float* part, hipStream_t st) {
+                       float* out, int splits, int grouped, float* part, hipStream_t st) {
   if (D != 64 && D != 128) return woq::fail("QBits: attention head_dim must be 64 or 128");
+  // grouped-query form (woq_prefill.hip): only where it applies — head_dim 128, 2 / 4 / 8 query heads per kv head,
+  // an fp16 or fp8 cache — anything else keeps the per-query-head slices
+  if (grouped && launch_attn_decode_mfma(qkv, kcache, vcache, kv_dtype, pos, cs, sn, heads, kv_heads, D, window, splits,
+                                          part, st)) {
+    launch_attn_combine(part, heads, D, splits, out, st);
+    return 0;
+  }
 #define WOQ_ATTN_DEC(T)                                                                                              \
   return D == 128 ? launch_attn_t<T, 128>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, window, out,   \
                                           splits, part, st)                                                         \
@@ -509,6 +521,13 @@ int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtyp
   if (kv_dtype == WOQ_FP8_E4M3) { WOQ_ATTN_DEC(Fp8) }
   WOQ_ATTN_DEC(__bf16)
 #undef WOQ_ATTN_DEC
+}
+
+void launch_attn_combine(const float* part, int heads, int D, int splits, float* out, hipStream_t st) {
+  if (D == 128)
+    hipLaunchKernelGGL(attn_combine_kernel<128>, dim3(heads), dim3(256), 0, st, part, splits, out);
+  else
+    hipLaunchKernelGGL(attn_combine_kernel<64>, dim3(heads), dim3(256), 0, st, part, splits, out);
 }
 
 // pmax / pidx (nullable): per-workgroup (max logit, its index), (vocab + 15) / 16 entries each

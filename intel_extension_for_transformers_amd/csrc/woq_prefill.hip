@@ -327,6 +327,263 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const _Float16* __
   }
 }
 
+// ---- long-context decode attention for grouped-query models, on the matrix cores -----------------------------------
+// One workgroup per (kv head, context slice): the REP query heads that share the kv head are the 16 columns of
+// S^T = K Q^T (REP <= 16 live), so every K / V row of the slice leaves HBM / L2 ONCE for all of them — the
+// per-query-head sliced kernel of woq_ops.hip pulls the same rows through the CUs' load paths REP times.
+// The four waves are independent streams: wave w owns the 32-position sub-tiles w, w + 4, ... of the slice with its
+// own online-softmax state, no workgroup barrier inside the loop, one merge through LDS at the end:
+//  * K fragments come STRAIGHT from the cache into MFMA operand registers: the contraction runs over d, and any
+//    assignment of d to (MFMA, lane quarter, element) is legal as long as Q uses the same one — lane quarter kq takes
+//    d = 32 kq + 8 c + e for MFMA c, i.e. 32 contiguous elements of its row;
+//  * q is split into fp16 hi + lo (two MFMAs per fragment): the scores carry fp32-class accuracy, the bar the
+//    decode parity tests hold (K / V of an fp8 or fp16 cache are exact in fp16);
+//  * V goes through a wave-private transposed LDS tile ([d][32 positions], the 4 x 8 register transpose of
+//    attn_prefill_kernel) because positions are the contraction index of O^T = V^T P^T; the probabilities are the
+//    S^T accumulators repacked in place (positions {4 kq + j, 16 + 4 kq + j} per lane on both operands);
+//  * the next sub-tile's loads are in flight while the current one is in the MFMAs.
+// The new token's k / v are applied from LDS by wave 0 of the last slice (rounded to the cache dtype like the rows a
+// later step reads back) and appended there. Output: un-normalised partials (o[HD], max, sum) per (head, slice) in the
+// natural-exp convention attn_combine_kernel merges.
+constexpr int DST = 32;   // positions per sub-tile
+constexpr int DVRB = 80;  // bytes per V^T row: 32 positions x 2 B + 16 pad
+template <int HD, int REP>
+__host__ __device__ constexpr int attn_dec_lds_bytes() { return 4 * HD * DVRB + 2 * HD * 4 + REP * HD * 4; }
+
+template <int KVD, int HD, int REP>
+__global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const float* __restrict__ qkv, void* __restrict__ kcache,
+                                                               void* __restrict__ vcache,
+                                                               const int32_t* __restrict__ pos_p,
+                                                               const float* __restrict__ cs,
+                                                               const float* __restrict__ sn, int heads, int kv_heads,
+                                                               int window, float* __restrict__ part) {
+  static_assert(HD == 128 && REP <= 16, "one 16-column MFMA tile of query heads, head_dim 128");
+  static_assert(16 * (HD + 2) * 4 <= HD * DVRB, "the merge record of a wave reuses its V^T tile");
+  constexpr int DC = HD / 32, DT = HD / 16, half = HD / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm_raw[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* vw = dsm_raw + wid * (HD * DVRB);    // this wave's V^T tile, later its merge record
+  float* kn = (float*)(dsm_raw + 4 * HD * DVRB);      // [HD] new k (rotated, as the cache holds it), [HD] new v
+  float* vn = kn + HD;
+  float* qs = vn + HD;                                // [REP][HD] rotated query heads
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int kh = blockIdx.x, ns = (int)gridDim.y, sp = (int)blockIdx.y;
+  const int apos = pos_p[0];
+  const int w_lo = window > 0 ? max(0, apos + 1 - window) : 0;
+  const int span = apos - w_lo;
+  const int chunk = (((span + ns - 1) / ns) + 4 * DST - 1) & ~(4 * DST - 1);
+  const int t_lo = w_lo + min(sp * chunk, span);
+  const int npos = min(apos - t_lo, chunk);  // cached positions of this slice
+  const bool incl_new = sp == ns - 1;
+  const size_t cache_row = (size_t)kv_heads * HD;
+  const size_t cache0 = (size_t)t_lo * cache_row + (size_t)kh * HD;
+  const int n_sub = (npos + DST - 1) / DST;
+  const int last = max(npos - 1, 0);
+  const float sc = 1.44269504088896f / sqrtf((float)HD);
+
+  const int v_g = lane >> 3, v_c = lane & 7;  // V staging: positions 4 v_g .. + 4, d = 16 v_c .. + 16
+  // two register sets: a wave's first two sub-tiles are requested back to back, then set X is refilled for
+  // sub-tile n + 8 as soon as sub-tile n has left it (one exposed load latency per wave, not one per sub-tile)
+  h8 kfA[2][DC], vrA[4][2], kfB[2][DC], vrB[4][2];
+  auto fetch = [&](h8 (&kf)[2][DC], h8 (&vr)[4][2], int sub) {
+    const int t0 = sub * DST;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const size_t row = cache0 + (size_t)min(t0 + a * 16 + i16, last) * cache_row + kq * 32;
+#pragma unroll
+      for (int c = 0; c < DC; ++c) kf[a][c] = kv_load8<KVD>(kcache, row + c * 8);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t row = cache0 + (size_t)min(t0 + v_g * 4 + r, last) * cache_row + v_c * 16;
+      vr[r][0] = kv_load8<KVD>(vcache, row);
+      vr[r][1] = kv_load8<KVD>(vcache, row + 8);
+    }
+  };
+  if (wid < n_sub) fetch(kfA, vrA, wid);
+  if (wid + 4 < n_sub) fetch(kfB, vrB, wid + 4);
+
+  // prologue through LDS: threads 0..15 build the new k / v of this kv head (rotated, rounded through the cache dtype
+  // like the rows a later step reads back; the last slice appends them), everyone rotates the REP query heads
+  if (tid < HD / 8) {
+    const float* k = qkv + (size_t)(heads + kh) * HD;
+    const float* v = qkv + (size_t)(heads + kv_heads + kh) * HD;
+    float kk[8], vv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int d = tid * 8 + j, i = d & (half - 1);
+      const float co = cs[(size_t)apos * half + i], si = sn[(size_t)apos * half + i];
+      const float ka = k[d], kb = k[d ^ half];
+      kk[j] = d < half ? ka * co - kb * si : ka * co + kb * si;
+      vv[j] = v[d];
+    }
+    alignas(16) unsigned char tmp[32];
+    kv_store8<KVD>(tmp, 0, kk);
+    const h8 kr = kv_load8<KVD>(tmp, 0);
+    kv_store8<KVD>(tmp, 0, vv);
+    const h8 vr8 = kv_load8<KVD>(tmp, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kn[tid * 8 + j] = (float)kr[j], vn[tid * 8 + j] = (float)vr8[j];
+    if (incl_new) {
+      const size_t e = (size_t)apos * cache_row + (size_t)kh * HD + tid * 8;
+      kv_store8<KVD>(kcache, e, kk);
+      kv_store8<KVD>(vcache, e, vv);
+    }
+  }
+  for (int idx = tid; idx < REP * HD; idx += 256) {
+    const int d = idx & (HD - 1), i = d & (half - 1);
+    const float* q = qkv + (size_t)kh * REP * HD + (idx - d);
+    const float co = cs[(size_t)apos * half + i], si = sn[(size_t)apos * half + i];
+    const float qa = q[d], qb = q[d ^ half];
+    qs[idx] = d < half ? qa * co - qb * si : qa * co + qb * si;
+  }
+  __syncthreads();
+  // Q^T fragments, fp16 hi + lo: lane (head i16, quarter kq) holds d = 32 kq + 8 c + e
+  h8 qh[DC], ql[DC];
+#pragma unroll
+  for (int c = 0; c < DC; ++c) {
+    float qv[8];
+    if (i16 < REP) {
+      const float* src = qs + i16 * HD + kq * 32 + c * 8;
+      *(float4_t*)&qv[0] = *(const float4_t*)src;
+      *(float4_t*)&qv[4] = *(const float4_t*)(src + 4);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qv[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const _Float16 hi = (_Float16)qv[e];
+      qh[c][e] = hi;
+      ql[c][e] = (_Float16)(qv[e] - (float)hi);
+    }
+  }
+  float4_t o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) o[dt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_part = 0.f;
+
+  auto process = [&](h8 (&kf)[2][DC], h8 (&vr)[4][2], int sub) {
+    // this sub-tile: V^T into LDS, K fragments into the score MFMAs; then the refill of the register set
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int d = v_c * 16 + hh * 8 + i;
+        const h4 col = {vr[0][hh][i], vr[1][hh][i], vr[2][hh][i], vr[3][hh][i]};
+        *(h4*)(vw + d * DVRB + ((v_g ^ v_c) << 3)) = col;
+      }
+    float4_t s[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      s[a] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < DC; ++c) {
+        s[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[a][c], ql[c], s[a], 0, 0, 0);
+        s[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[a][c], qh[c], s[a], 0, 0, 0);
+      }
+    }
+    const int t0 = sub * DST;
+    __builtin_amdgcn_sched_barrier(0);  // the loads below reuse the registers the stores / MFMAs above just released
+    if (sub + 8 < n_sub) fetch(kf, vr, sub + 8);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (t0 + a * 16 + kq * 4 + j >= npos) s[a][j] = -INFINITY;
+        mx = fmaxf(mx, s[a][j]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * sc);  // finite: position t0 of a processed sub-tile is always live
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float ps = 0.f;
+    h8 pb;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[a][j], sc, -m_new));
+        ps += p;
+        pb[a * 4 + j] = (_Float16)p;
+      }
+    l_part = fmaf(l_part, alpha, ps);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const unsigned char* vrow = vw + (dt * 16 + i16) * DVRB;
+      const u32x2 lo = *(const u32x2*)(vrow + ((kq ^ dt) << 3));
+      const u32x2 hi = *(const u32x2*)(vrow + (((4 + kq) ^ dt) << 3));
+      const h8 vf = __builtin_bit_cast(h8, (u32x4){lo.x, lo.y, hi.x, hi.y});
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb, o[dt] * alpha, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  for (int sub = wid; sub < n_sub; sub += 8) {
+    process(kfA, vrA, sub);
+    if (sub + 4 < n_sub) process(kfB, vrB, sub + 4);
+  }
+  if (wid == 0 && incl_new) {  // the new position: score from the fragments, value row from LDS
+    float d = 0.f;
+    const float* qrow = qs + min(i16, REP - 1) * HD + kq * 32;
+#pragma unroll 8
+    for (int e = 0; e < 32; ++e) d = fmaf(qrow[e], kn[kq * 32 + e], d);
+    d += __shfl_xor(d, 16, 64);
+    d += __shfl_xor(d, 32, 64);
+    const float m_new = fmaxf(m_run, d * sc);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    const float p = __builtin_amdgcn_exp2f(fmaf(d, sc, -m_new));
+    m_run = m_new;
+    l_part = fmaf(l_part, alpha, kq == 0 ? p : 0.f);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[dt][j] = fmaf(o[dt][j], alpha, p * vn[dt * 16 + kq * 4 + j]);
+  }
+  // merge the four waves: record = o[16 heads][HD], max[16], sum[16] (fp32) in the wave's own V^T tile
+  float l = l_part;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  {
+    float* rec = (float*)vw;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) *(float4_t*)(rec + i16 * HD + dt * 16 + kq * 4) = o[dt];
+    if (kq == 0) {
+      rec[16 * HD + i16] = m_run;
+      rec[16 * HD + 16 + i16] = l;
+    }
+  }
+  __syncthreads();
+  {
+    const int d = tid & (HD - 1);
+    for (int h = tid / HD; h < REP; h += 256 / HD) {
+      float mw[4], m = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        mw[w] = ((const float*)(dsm_raw + w * (HD * DVRB)))[16 * HD + h];
+        m = fmaxf(m, mw[w]);
+      }
+      float acc = 0.f, den = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float* rec = (const float*)(dsm_raw + w * (HD * DVRB));
+        const float wt = mw[w] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mw[w] - m);
+        acc = fmaf(rec[h * HD + d], wt, acc);
+        den = fmaf(rec[16 * HD + 16 + h], wt, den);
+      }
+      float* pp = part + ((size_t)(kh * REP + h) * ns + sp) * (HD + 2);
+      pp[d] = acc;
+      if (d == 0) {
+        pp[HD] = m == -INFINITY ? -INFINITY : m * 0.6931471805599453f;  // exp2 domain -> natural
+        pp[HD + 1] = den;
+      }
+    }
+  }
+}
+
 // last row of every sequence -> dst fp32 [n_seq][hidden]
 __global__ __launch_bounds__(256) void gather_last_kernel(const float* __restrict__ h, int T, int hidden,
                                                           float* __restrict__ dst) {
@@ -388,6 +645,26 @@ int launch_attn_prefill(const _Float16* qkv, int n_seq, int T, int start, int he
   WOQ_ATTN_CASE(WOQ_FP8_E4M3)
 #undef WOQ_ATTN_CASE
   return woq::fail("QBits: unsupported KV cache dtype");
+}
+
+// long-context decode attention of grouped-query models: true when this kernel took the call (head_dim 128, 2 / 4 / 8
+// query heads per kv head), false -> the caller uses the per-query-head sliced kernel
+bool launch_attn_decode_mfma(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
+                             const float* cs, const float* sn, int heads, int kv_heads, int D, int window, int splits,
+                             float* part, hipStream_t st) {
+  const int rep = kv_heads > 0 ? heads / kv_heads : 0;
+  if (D != 128 || splits <= 1 || !(rep == 2 || rep == 4 || rep == 8)) return false;
+  const dim3 grid((unsigned)kv_heads, (unsigned)splits);
+#define WOQ_DEC_CASE(KVD, R)                                                                                       \
+  if (kv_dtype == KVD && rep == R) {                                                                               \
+    hipLaunchKernelGGL((attn_decode_mfma_kernel<KVD, 128, R>), grid, dim3(256), (attn_dec_lds_bytes<128, R>()), st, \
+                       qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, window, part);                           \
+    return true;                                                                                                   \
+  }
+  WOQ_DEC_CASE(WOQ_F16, 2) WOQ_DEC_CASE(WOQ_F16, 4) WOQ_DEC_CASE(WOQ_F16, 8)
+  WOQ_DEC_CASE(WOQ_FP8_E4M3, 2) WOQ_DEC_CASE(WOQ_FP8_E4M3, 4) WOQ_DEC_CASE(WOQ_FP8_E4M3, 8)
+#undef WOQ_DEC_CASE
+  return false;
 }
 
 void launch_gather_last(const float* h, int n_seq, int T, int hidden, float* dst, hipStream_t st) {

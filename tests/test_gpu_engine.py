@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _tiny(group, asym, scale_dtype, seed=0, max_ctx=64, max_batch=1, head_dim=64, kv_dtype=torch.float16,
-          attn_splits=0, window=0, hidden=256):
+          attn_splits=0, window=0, hidden=256, attn_grouped=False):
     from intel_extension_for_transformers_amd import qbits
     from intel_extension_for_transformers_amd.runtime import WoqDecoderEngine, fuse_gate_up
 
@@ -23,7 +23,8 @@ def _tiny(group, asym, scale_dtype, seed=0, max_ctx=64, max_batch=1, head_dim=64
     rng = np.random.default_rng(seed)
     eng = WoqDecoderEngine(cfg["hidden"], cfg["inter"], cfg["heads"], cfg["kv_heads"], cfg["head_dim"], cfg["layers"],
                            cfg["vocab"], max_ctx=max_ctx, rms_eps=cfg["eps"], rope_theta=cfg["theta"],
-                           max_batch=max_batch, kv_dtype=kv_dtype, attn_splits=attn_splits, sliding_window=window)
+                           max_batch=max_batch, kv_dtype=kv_dtype, attn_splits=attn_splits, sliding_window=window,
+                           attn_grouped=attn_grouped)
     st = {"fp32": orc.F32, "fp16": orc.F16, "bf16": orc.BF16}[scale_dtype]
     e8, e32 = torch.empty(0, dtype=torch.int8), torch.empty(0, dtype=torch.int32)
 
@@ -236,12 +237,18 @@ def test_fp8_kv_cache_prefill_and_decode():
     assert (np.abs(k8 - k16) <= 2.0 ** -4 * np.abs(k16) + 2.0 ** -9).all()
 
 
-@pytest.mark.parametrize("head_dim,splits", [(64, 3), (128, 5)])
-def test_decode_attention_context_slices_vs_oracle(head_dim, splits):
-    """Long-context decode attention (context slices per head + combine launch), forced on at a small context:
-    token-by-token decode over 200 positions — empty slices, slice boundaries at multiples of 64, the new position in
-    the last slice — against the fp32 oracle at the decode tolerance, and identical greedy tokens under graph replay."""
-    eng, oracle, cfg = _tiny(128, False, "fp16", seed=2, max_ctx=256, head_dim=head_dim, attn_splits=splits)
+@pytest.mark.parametrize("head_dim,splits,grouped,hidden", [(64, 3, False, 256), (128, 5, False, 256),
+                                                            (128, 5, True, 256), (128, 3, True, 512),
+                                                            (128, 5, True, 1024)])
+def test_decode_attention_context_slices_vs_oracle(head_dim, splits, grouped, hidden):
+    """Long-context decode attention (context slices + combine launch), forced on at a small context: token-by-token
+    decode over 200 positions — empty slices, slice boundaries, ragged last sub-tiles, the new position in the last
+    slice — against the fp32 oracle at the decode tolerance, and identical greedy tokens under graph replay. Both
+    sliced forms: one workgroup per (query head, slice), and the grouped-query matrix-core form (one kv head with
+    2 / 4 / 8 query heads: hidden 256 / 512 / 1024 at head_dim 128)."""
+    eng, oracle, cfg = _tiny(128, False, "fp16", seed=2, max_ctx=256, head_dim=head_dim, attn_splits=splits,
+                             hidden=hidden, attn_grouped=grouped)
+    assert cfg["kv_heads"] == 128 // head_dim and cfg["heads"] == hidden // head_dim
     rng = np.random.default_rng(3)
     toks = rng.integers(0, cfg["vocab"], 200).tolist()
     for i, t in enumerate(toks):
@@ -301,14 +308,15 @@ def test_tp_seam_world_size_one_rccl():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("head_dim,splits", [(64, 0), (128, 3)])
-def test_sliding_window_attention_vs_oracle(head_dim, splits):
+@pytest.mark.parametrize("head_dim,splits,grouped", [(64, 0, False), (128, 3, False), (128, 3, True)])
+def test_sliding_window_attention_vs_oracle(head_dim, splits, grouped):
     """HF Mistral `sliding_window` (a query sees the last W positions, itself included): prompt pass over 150 tokens
     (window 40: whole tiles below the window are skipped, both tile edges masked), then decode steps — one workgroup
     per head and the sliced form — and token-by-token decode from an empty cache, against the fp32 oracle with the
     same window."""
     W = 40
-    eng, oracle, cfg = _tiny(128, False, "fp16", seed=8, max_ctx=256, head_dim=head_dim, attn_splits=splits, window=W)
+    eng, oracle, cfg = _tiny(128, False, "fp16", seed=8, max_ctx=256, head_dim=head_dim, attn_splits=splits, window=W,
+                             attn_grouped=grouped)
     rng = np.random.default_rng(4)
     prompt = rng.integers(0, cfg["vocab"], 150).tolist()
     got = eng.prefill(prompt, greedy=True)[0].cpu().numpy()
@@ -320,7 +328,8 @@ def test_sliding_window_attention_vs_oracle(head_dim, splits):
         ref = oracle.forward_token(nxt, 150 + j)
         assert np.abs(eng.logits.cpu().numpy() - ref).max() <= PF_TOL * np.abs(ref).max() + 1e-3
         nxt = int(ref.argmax())
-    eng2, oracle2, _ = _tiny(128, False, "fp16", seed=8, max_ctx=256, head_dim=head_dim, attn_splits=splits, window=W)
+    eng2, oracle2, _ = _tiny(128, False, "fp16", seed=8, max_ctx=256, head_dim=head_dim, attn_splits=splits, window=W,
+                             attn_grouped=grouped)
     for i, t in enumerate(prompt[:90]):
         eng2.token.fill_(t)
         eng2.pos.fill_(i)
@@ -330,14 +339,18 @@ def test_sliding_window_attention_vs_oracle(head_dim, splits):
             assert np.abs(eng2.logits.cpu().numpy() - r).max() <= 2e-3 * np.abs(r).max() + 1e-4, i
 
 
-def test_sliced_attention_grouped_queries_rep4_fp8():
+@pytest.mark.parametrize("grouped", [False, True])
+def test_sliced_attention_grouped_queries_rep4_fp8(grouped):
     """Sliced decode attention under grouped queries (4 q heads / 1 kv head) with an fp8 KV cache: 5 slices,
-    token-by-token over 150 positions against the engine's own one-workgroup-per-head form (same fp8 cache contents
-    -> same softmax inputs up to summation order)."""
+    token-by-token over 150 positions against the engine's own one-workgroup-per-head form. Per-query-head slices see
+    the same fp8 cache contents and differ by summation order only; the grouped matrix-core form also rounds the
+    probabilities to fp16 for the P V product (and its layer-0 output differences can flip fp8 roundings of layer 1's
+    cache), hence the decode tolerance there."""
     kw = dict(seed=9, max_ctx=256, head_dim=128, hidden=512, kv_dtype=torch.float8_e4m3fn)
-    a, _, cfg = _tiny(128, False, "fp16", attn_splits=5, **kw)
+    a, _, cfg = _tiny(128, False, "fp16", attn_splits=5, attn_grouped=grouped, **kw)
     b, _, _ = _tiny(128, False, "fp16", attn_splits=1, **kw)
     assert cfg["heads"] == 4 and cfg["kv_heads"] == 1
+    rtol, atol = (2e-3, 1e-4) if grouped else (1e-4, 1e-5)
     rng = np.random.default_rng(2)
     for i, t in enumerate(rng.integers(0, cfg["vocab"], 150).tolist()):
         for e in (a, b):
@@ -346,4 +359,4 @@ def test_sliced_attention_grouped_queries_rep4_fp8():
             e.step(greedy=False)
         if i in (0, 1, 15, 16, 63, 64, 65, 127, 128, 149):
             la, lb = a.logits.cpu().numpy(), b.logits.cpu().numpy()
-            assert np.abs(la - lb).max() <= 1e-4 * np.abs(lb).max() + 1e-5, i
+            assert np.abs(la - lb).max() <= rtol * np.abs(lb).max() + atol, i
