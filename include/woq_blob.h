@@ -72,9 +72,13 @@ enum woq_weight_type {
   WOQ_W_INT8 = 1,         /* composite of two int4 blobs, see woq_int8_headers */
   WOQ_W_NF4 = 2,          /* 4-bit table types: the nibble is an INDEX into a 16-entry table, w = table[code] * scale, */
   WOQ_W_FP4_E2M1 = 3,     /* symmetric only (no zero points), same qdata layout as int4                              */
-  WOQ_W_FP4_E2M1_BNB = 4
+  WOQ_W_FP4_E2M1_BNB = 4,
+  WOQ_W_INT3_CLIP = 5,    /* narrow integers (reference strings "int3_clip" / "int2_clip"): values in [-4, 3] / [-2, 1]  */
+  WOQ_W_INT2_CLIP = 6     /* held in int4 storage — names at the ABI only: the blob header says INT4_CLIP plus          */
+                          /* narrow_bits = 3 / 2, and every kernel runs its int4 path on it unchanged                    */
 };
 static inline int woq_weight_is_table(uint32_t t) { return t >= 2u && t <= 4u; }
+static inline int woq_weight_narrow_bits(uint32_t t) { return t == 5u ? 3 : (t == 6u ? 2 : 0); }
 
 /* The tables (reference strings "nf4", "fp4_e2m1", "fp4_e2m1_bnb", bestla_weightonly_dispatcher.hpp:62-70; BesTLA's
  * own constants are not in the reference tree, so these are the published definitions: NF4 = the 16 normal-float
@@ -111,7 +115,7 @@ typedef struct woq_blob_header {
   uint32_t compute_type; /* enum woq_compute_type */
   uint32_t flags;
   uint32_t scale_mode; /* 0 | 1, see above */
-  uint32_t reserved0;
+  uint32_t narrow_bits; /* 0, or 3 / 2: the blob was packed as int3_clip / int2_clip (weight_type is INT4_CLIP) */
   uint64_t off_q, off_scale, off_zp, off_shuffle; /* byte offsets from blob start; 0 = absent */
   uint8_t pad[WOQ_HEADER_BYTES - 96];
 } woq_blob_header;

@@ -52,7 +52,9 @@ WOQ_API size_t woq_packed_weight_size(int K, int N, int blocksize, int weight_ty
 
 /* replaces qbits.repack_quantized_weight (qbits.cpp:61-77 -> bestla_packq_impl.cpp:20-41).
  * weight_type (enum woq_weight_type): int4_clip — qweight int8 [K,N] holds int4 values in the signed domain
- * (modules.py:225-227); int8 — full int8 values (stored as a composite of two int4 blobs, woq_blob.h); nf4 /
+ * (modules.py:225-227); int3_clip / int2_clip — values in [-4, 3] / [-2, 1], kept in int4 storage with a header tag
+ * (woq_blob.h narrow_bits: same bytes and kernels as int4; the name survives acquire_packed_weight_info);
+ * int8 — full int8 values (stored as a composite of two int4 blobs, woq_blob.h); nf4 /
  * fp4_e2m1 / fp4_e2m1_bnb — table codes 0..15, no zero points. scale fp32 [G,N],
  * zp int8 [G,N] or NULL (sym), g_idx int32 [K] = GPTQ act-order group id of every K row (each group exactly
  * `blocksize` rows) or NULL; like BesTLA, repack converts it to activation shuffle indices

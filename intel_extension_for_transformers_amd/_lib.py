@@ -11,12 +11,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WOQ_HIP_LIB") or os.path.join(_HERE, "libwoq_hip.so")  # env: A/B builds in development
 
 F32, BF16, F16, FP8_E4M3 = 0, 1, 2, 3
-W_INT4_CLIP, W_INT8, W_NF4, W_FP4_E2M1, W_FP4_E2M1_BNB = 0, 1, 2, 3, 4
+W_INT4_CLIP, W_INT8, W_NF4, W_FP4_E2M1, W_FP4_E2M1_BNB, W_INT3_CLIP, W_INT2_CLIP = 0, 1, 2, 3, 4, 5, 6
 C_FP32, C_BF16, C_INT8, C_FP16 = 0, 1, 2, 3
 HEADER_BYTES = 256
 
 WEIGHT_TYPES = {"int4_clip": W_INT4_CLIP, "int4": W_INT4_CLIP, "int8": W_INT8, "nf4": W_NF4, "fp4_e2m1": W_FP4_E2M1,
-                "fp4": W_FP4_E2M1, "fp4_e2m1_bnb": W_FP4_E2M1_BNB}
+                "fp4": W_FP4_E2M1, "fp4_e2m1_bnb": W_FP4_E2M1_BNB, "int3_clip": W_INT3_CLIP, "int2_clip": W_INT2_CLIP}
 SCALE_TYPES = {"fp32": F32, "bf16": BF16, "fp16": F16}
 COMPUTE_TYPES = {"fp32": C_FP32, "bf16": C_BF16, "int8": C_INT8, "fp16": C_FP16}
 SCALE_NAMES = {v: k for k, v in SCALE_TYPES.items()}
@@ -33,7 +33,7 @@ class BlobHeader(ctypes.Structure):
         ("K", ctypes.c_int32), ("N", ctypes.c_int32), ("group", ctypes.c_int32), ("Kpad", ctypes.c_int32),
         ("Npad", ctypes.c_int32), ("n_groups", ctypes.c_int32),
         ("weight_type", ctypes.c_uint32), ("scale_type", ctypes.c_uint32), ("compute_type", ctypes.c_uint32),
-        ("flags", ctypes.c_uint32), ("scale_mode", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
+        ("flags", ctypes.c_uint32), ("scale_mode", ctypes.c_uint32), ("narrow_bits", ctypes.c_uint32),
         ("off_q", ctypes.c_uint64), ("off_scale", ctypes.c_uint64), ("off_zp", ctypes.c_uint64),
         ("off_shuffle", ctypes.c_uint64), ("pad", ctypes.c_uint8 * (HEADER_BYTES - 96)),
     ]

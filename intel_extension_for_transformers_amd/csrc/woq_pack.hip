@@ -191,7 +191,8 @@ __global__ void extract_kernel(const uint8_t* __restrict__ blob, woq_blob_header
 __global__ void rtn_kernel(const float* __restrict__ w, int transpose, int K, int N, int group, int n_groups,
                            int asym, int bits, int8_t* __restrict__ q, float* __restrict__ scales,
                            int8_t* __restrict__ zp) {
-  const int qmax = (1 << (bits - 1)) - 1, levels = (1 << bits) - 1, off = 1 << (bits - 1);  // 7 / 15 / 8 or 127 / 255 / 128
+  // bits = 4: 7 / 15 / 8; 8: 127 / 255 / 128; 3: 3 / 7 / 4; 2: 1 / 3 / 2
+  const int qmax = (1 << (bits - 1)) - 1, levels = (1 << bits) - 1, off = 1 << (bits - 1);
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)n_groups * N) return;
   int g = (int)(idx / (size_t)N), n = (int)(idx % (size_t)N);
@@ -272,6 +273,7 @@ extern "C" {
 size_t woq_packed_weight_size(int K, int N, int blocksize, int weight_type, int scale_type, int asym,
                               int act_shuffle) {
   woq_blob_header h, hi, lo;
+  if (woq_weight_narrow_bits((uint32_t)weight_type)) weight_type = WOQ_W_INT4_CLIP;  // int3 / int2 in int4 storage
   if (weight_type == WOQ_W_INT8)
     return woq_int8_headers(&h, &hi, &lo, K, N, blocksize, (uint32_t)scale_type, WOQ_C_FP32, asym, act_shuffle) == 0
                ? h.total_bytes
@@ -310,8 +312,11 @@ int woq_repack_quantized_weight(const int8_t* qweight_dev, const float* scale_de
                                 int scale_type, int compute_type, void* blob_dev, size_t blob_bytes,
                                 void* stream) {
   WOQ_TRY
+  const int narrow = woq_weight_narrow_bits((uint32_t)weight_type);  // int3_clip / int2_clip: int4 storage + a tag
+  if (narrow) weight_type = WOQ_W_INT4_CLIP;
   WOQ_CHECK(weight_type == WOQ_W_INT4_CLIP || weight_type == WOQ_W_INT8 || is_table_type((uint32_t)weight_type),
-            "QBits: unsupported weight_type in repack (int4_clip | int8 | nf4 | fp4_e2m1 | fp4_e2m1_bnb)");
+            "QBits: unsupported weight_type in repack (int4_clip | int3_clip | int2_clip | int8 | nf4 | fp4_e2m1 | "
+            "fp4_e2m1_bnb)");
   WOQ_CHECK(!(is_table_type((uint32_t)weight_type) && zp_dev != nullptr),
             "QBits: table weight types (nf4 / fp4) are symmetric: no zero points");
   WOQ_CHECK(scale_type >= WOQ_F32 && scale_type <= WOQ_F16, "QBits: unsupported scale_type");
@@ -346,6 +351,7 @@ int woq_repack_quantized_weight(const int8_t* qweight_dev, const float* scale_de
                             (uint32_t)compute_type, zp_dev != nullptr, g_idx_dev != nullptr) == 0,
             "QBits: unsupported blocksize (must be -1 or a multiple of 32)");
   WOQ_CHECK(blob_bytes >= h.total_bytes, "QBits: packed-weight buffer too small");
+  h.narrow_bits = (uint32_t)narrow;
   int rc = repack_int4(qweight_dev, scale_dev, zp_dev, g_idx_dev, h, blob, st);
   if (rc) return rc;
   WOQ_HIP(hipGetLastError());
@@ -356,8 +362,11 @@ int woq_quantize_to_packed_weight(const float* weight_dev, int transpose, int K,
                                   int weight_type, int scale_type, int compute_type, int asym, void* blob_dev,
                                   size_t blob_bytes, void* stream) {
   WOQ_TRY
-  WOQ_CHECK(weight_type == WOQ_W_INT4_CLIP || weight_type == WOQ_W_INT8 || is_table_type((uint32_t)weight_type),
-            "QBits: unsupported weight_type in quantize (int4_clip | int8 | nf4 | fp4_e2m1 | fp4_e2m1_bnb)");
+  const int narrow = woq_weight_narrow_bits((uint32_t)weight_type);
+  WOQ_CHECK(narrow || weight_type == WOQ_W_INT4_CLIP || weight_type == WOQ_W_INT8 ||
+                is_table_type((uint32_t)weight_type),
+            "QBits: unsupported weight_type in quantize (int4_clip | int3_clip | int2_clip | int8 | nf4 | fp4_e2m1 | "
+            "fp4_e2m1_bnb)");
   WOQ_CHECK(!(is_table_type((uint32_t)weight_type) && asym),
             "QBits: table weight types (nf4 / fp4) are symmetric: asym is not supported");
   int group = (blocksize <= 0 || blocksize > K) ? K : blocksize;  // blocksize -1 -> K (dispatcher.cpp:296)
@@ -375,7 +384,7 @@ int woq_quantize_to_packed_weight(const float* weight_dev, int transpose, int K,
                        N, group, n_groups, (uint32_t)weight_type, q, sc);
   else
     hipLaunchKernelGGL(rtn_kernel, dim3((unsigned)((nt + 127) / 128)), dim3(128), 0, st, weight_dev, transpose, K, N,
-                       group, n_groups, asym, weight_type == WOQ_W_INT8 ? 8 : 4, q, sc, zp);
+                       group, n_groups, asym, narrow ? narrow : (weight_type == WOQ_W_INT8 ? 8 : 4), q, sc, zp);
   int rc = woq_repack_quantized_weight(q, sc, zp, nullptr, K, N, blocksize, weight_type, scale_type, compute_type,
                                        blob_dev, blob_bytes, stream);
   hipError_t e = hipStreamSynchronize(st);

@@ -30,7 +30,7 @@ def _blocksize_ok(k, blocksize):
 def _wtype(weight_type):
     if weight_type not in L.WEIGHT_TYPES:
         # reference text: bestla_packq_impl.cpp "unsupported bestla packq config"
-        raise RuntimeError("Qbits: unsupported bestla packq config, weight_type: %s (MI355X path: int4_clip, int8, nf4, fp4_e2m1, fp4_e2m1_bnb)"
+        raise RuntimeError("Qbits: unsupported bestla packq config, weight_type: %s (MI355X path: int4_clip, int3_clip, int2_clip, int8, nf4, fp4_e2m1, fp4_e2m1_bnb)"
                            % weight_type)
     return L.WEIGHT_TYPES[weight_type]
 
@@ -168,7 +168,8 @@ def acquire_packed_weight_info(packw, acquire_type):
     if t == 11:
         return one(1 if hdr.off_zp else 0)
     if t == 6:
-        return _ascii(L.WEIGHT_NAMES[hdr.weight_type])
+        # int3_clip / int2_clip blobs are int4 storage with a tag (include/woq_blob.h narrow_bits)
+        return _ascii({3: "int3_clip", 2: "int2_clip"}.get(hdr.narrow_bits) or L.WEIGHT_NAMES[hdr.weight_type])
     if t == 7:
         return _ascii(L.COMPUTE_NAMES[hdr.compute_type])
     if t == 8:

@@ -235,6 +235,29 @@ def rtn_quantize_int8(w, transpose, group, asym):
     """8-bit form of the (parity-unpinned) RTN rule of woq_oracle.c, in fp32 arithmetic like the device kernel:
     sym s = max|w| / 127, q = clip(rne(w / s), -128, 127); asym s = (max - min) / 255, z = clip(rne(-min / s), 0, 255),
     q = clip(rne(w / s) + z, 0, 255) - 128, zp = z - 128."""
+    return rtn_quantize_bits(w, transpose, group, asym, 8)
+
+
+NARROW_BITS = {"int3_clip": 3, "int2_clip": 2}
+
+
+def repack_narrow(q, scales, zp=None, shuffle=None, group=-1, scale_type=F32, compute_type=0, bits=3):
+    """int3_clip / int2_clip (reference weight-type strings, bestla_weightonly_dispatcher.hpp:62-70): values in
+    [-4, 3] / [-2, 1] in int4 storage — the int4 blob with header word 15 (narrow_bits) = bits."""
+    q = np.asarray(q, np.int8)
+    lim = 1 << (bits - 1)
+    assert q.min() >= -lim and q.max() < lim, "values outside the %d-bit signed range" % bits
+    blob = repack(q, scales, zp, shuffle, group, scale_type, compute_type)
+    blob.view(np.uint32)[15] = bits
+    return blob
+
+
+def rtn_quantize_bits(w, transpose, group, asym, bits):
+    """The (parity-unpinned) RTN rule of woq_oracle.c for any width, in fp32 arithmetic like the device kernel:
+    qmax = 2^(bits-1) - 1, levels = 2^bits - 1, off = 2^(bits-1);
+    sym s = max|w| / qmax, q = clip(rne(w / s), -off, qmax); asym s = (max - min) / levels,
+    z = clip(rne(-min / s), 0, levels), q = clip(rne(w / s) + z, 0, levels) - off, zp = z - off."""
+    qmax, levels, off = (1 << (bits - 1)) - 1, (1 << bits) - 1, 1 << (bits - 1)
     w = np.asarray(w, np.float32)
     w = w.T if transpose else w
     K, N = w.shape
@@ -246,16 +269,16 @@ def rtn_quantize_int8(w, transpose, group, asym):
     for gi in range(G):
         blk = w[gi * g:min(K, (gi + 1) * g)]
         if not asym:
-            sc = (np.abs(blk).max(0) / np.float32(127)).astype(np.float32)
+            sc = (np.abs(blk).max(0) / np.float32(qmax)).astype(np.float32)
             sc[sc == 0] = 1
-            q[gi * g:gi * g + blk.shape[0]] = np.clip(np.rint(blk / sc), -128, 127).astype(np.int8)
+            q[gi * g:gi * g + blk.shape[0]] = np.clip(np.rint(blk / sc), -off, qmax).astype(np.int8)
         else:
             mx, mn = blk.max(0), blk.min(0)
-            sc = ((mx - mn) / np.float32(255)).astype(np.float32)
+            sc = ((mx - mn) / np.float32(levels)).astype(np.float32)
             sc[sc == 0] = 1
-            zz = np.clip(np.rint(-mn / sc), 0, 255).astype(np.int32)
-            q[gi * g:gi * g + blk.shape[0]] = (np.clip(np.rint(blk / sc).astype(np.int32) + zz, 0, 255) - 128).astype(np.int8)
-            z[gi] = (zz - 128).astype(np.int8)
+            zz = np.clip(np.rint(-mn / sc), 0, levels).astype(np.int32)
+            q[gi * g:gi * g + blk.shape[0]] = (np.clip(np.rint(blk / sc).astype(np.int32) + zz, 0, levels) - off).astype(np.int8)
+            z[gi] = (zz - off).astype(np.int8)
         s[gi] = sc
     return q, s, z
 
@@ -269,7 +292,7 @@ def header(blob):
     return dict(magic=int(u32[0]), version=int(u32[1]), total_bytes=int(u64[1]), K=int(i32[4]), N=int(i32[5]),
                 group=int(i32[6]), Kpad=int(i32[7]), Npad=int(i32[8]), n_groups=int(i32[9]),
                 weight_type=int(u32[10]), scale_type=int(u32[11]), compute_type=int(u32[12]), flags=int(u32[13]),
-                scale_mode=int(u32[14]), off_q=int(u64[8]), off_scale=int(u64[9]), off_zp=int(u64[10]),
+                scale_mode=int(u32[14]), narrow_bits=int(u32[15]), off_q=int(u64[8]), off_scale=int(u64[9]), off_zp=int(u64[10]),
                 off_shuffle=int(u64[11]))
 
 

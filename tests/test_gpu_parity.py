@@ -238,7 +238,7 @@ def test_errors_are_runtime_errors(qbits):
         qbits.woq_linear(torch.rand(1, 64).double().cuda(), blob, torch.empty(0), torch.zeros(1, 32).cuda(), "fp32",
                          "int4_clip", "fp32", False)
     with pytest.raises(RuntimeError, match="[Qq]bits"):
-        qbits.quantize_to_packed_weight(torch.rand(64, 32).cuda(), False, 32, "fp32", "int3_clip", "fp32", False)
+        qbits.quantize_to_packed_weight(torch.rand(64, 32).cuda(), False, 32, "fp32", "fp8_e4m3", "fp32", False)
 
 
 @pytest.mark.parametrize("K,N,group,asym", [(512, 1024, 128, False), (512, 1024, 128, True), (256, 48, 32, True),
@@ -414,6 +414,71 @@ def test_int8_quantize_to_packed_weight_roundtrip(qbits):
         assert np.abs(deq.cpu().numpy() - w).max() <= 0.51 * s.max()  # within half a quantisation step
 
 
+# ---- int3_clip / int2_clip (reference weight-type strings): narrow integers in int4 storage ------------------------
+@pytest.mark.parametrize("wname,group,asym,shuf", [("int3_clip", 128, False, False), ("int3_clip", 32, True, True),
+                                                   ("int2_clip", 64, True, False), ("int2_clip", -1, False, False)])
+def test_narrow_int_blob_dequant_info_and_linear(qbits, wname, group, asym, shuf):
+    """User-supplied int3 / int2 values pass through the blob exactly (the reference's packq contract,
+    qbits_ut/test_packq.py:100-109): blob bytes = the oracle's int4 blob + the narrow_bits tag, same size as int4,
+    dequantize = (q - zp) * scale, acquire_packed_weight_info keeps the name; woq_linear (decode GEMV, small batch,
+    MFMA GEMM) against the oracle at the int4 bounds."""
+    bits = orc.NARROW_BITS[wname]
+    K, N, lim = 384, 80, 1 << (bits - 1)
+    rng = np.random.default_rng(40 + bits)
+    g = K if group == -1 else group
+    G = K // g
+    q = rng.integers(-lim, lim, (K, N), dtype=np.int8)
+    s = (rng.random((G, N), dtype=np.float32) * 0.02 + 0.005).astype(np.float32)
+    z = rng.integers(-lim, lim, (G, N), dtype=np.int8) if asym else None
+    idx = rng.permutation(np.repeat(np.arange(G), g)).astype(np.int32) if shuf else None
+    e8, e32 = torch.empty(0, dtype=torch.int8), torch.empty(0, dtype=torch.int32)
+    blob = qbits.repack_quantized_weight(torch.from_numpy(q).cuda(), torch.from_numpy(s).cuda(),
+                                         e8 if z is None else torch.from_numpy(z).cuda(),
+                                         e32 if idx is None else torch.from_numpy(idx).cuda(), wname, "fp32", "fp32",
+                                         asym, group)
+    ref_blob = orc.repack_narrow(q, s, z, _cvt(idx, K, group), group, bits=bits)
+    got = blob.cpu().numpy().view(np.uint8)
+    assert got.size == qbits.get_packed_weight_size(K, N, wname, "fp32", "fp32", asym, group, shuf) \
+        == qbits.get_packed_weight_size(K, N, "int4_clip", "fp32", "fp32", asym, group, shuf)
+    assert np.array_equal(got, ref_blob)
+    deq = torch.empty(K, N, dtype=torch.float32, device="cuda")
+    qbits.dequantize_packed_weight(blob, deq, False, "fp32", wname, "fp32")
+    assert np.array_equal(deq.cpu().numpy(), orc.dequant_raw(q, s, z, g))
+    assert "".join(chr(c) for c in qbits.acquire_packed_weight_info(blob, 6).tolist()) == wname
+    w = np.abs(orc.dequant_raw(q, s, z, g))
+    for M, compute in ((1, "fp32"), (5, "fp32"), (64, "fp32"), (64, "bf16")):
+        x = rng.standard_normal((M, K)).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        ref = orc.woq_linear(x, ref_blob, bias)
+        out = torch.zeros(M, N, device="cuda")
+        blob_c = blob if compute == "fp32" else qbits.repack_quantized_weight(
+            torch.from_numpy(q).cuda(), torch.from_numpy(s).cuda(), e8 if z is None else torch.from_numpy(z).cuda(),
+            e32 if idx is None else torch.from_numpy(idx).cuda(), wname, "fp32", compute, asym, group)
+        qbits.woq_linear(torch.from_numpy(x).cuda(), blob_c, torch.from_numpy(bias).cuda(), out, compute, wname, "fp32",
+                         asym)
+        xs = np.abs(x if idx is None else x[:, _cvt(idx, K, group)])
+        mag = xs @ w + np.abs(bias)
+        rel = 2e-5 if (M <= 8 or compute == "fp32") else 2e-3
+        assert (np.abs(out.cpu().numpy() - ref) <= rel * mag + 1e-5).all(), (M, compute)
+
+
+@pytest.mark.parametrize("wname", ["int3_clip", "int2_clip"])
+def test_narrow_int_quantize_to_packed_weight_roundtrip(qbits, wname):
+    """qbits.quantize_to_packed_weight on the narrow widths == the oracle's RTN rule at that width + repack (rounding
+    rule parity-unpinned), sym and asym, nn.Linear layout; dequantised within half a step (one step at
+    the clipped top code of the symmetric range)."""
+    bits = orc.NARROW_BITS[wname]
+    rng = np.random.default_rng(50 + bits)
+    w = (rng.standard_normal((96, 256)) * 0.05).astype(np.float32)  # [N, K]
+    for asym in (False, True):
+        blob = qbits.quantize_to_packed_weight(torch.from_numpy(w).cuda(), True, 64, "fp32", wname, "fp32", asym)
+        q, s, z = orc.rtn_quantize_bits(w, True, 64, asym, bits)
+        assert np.array_equal(blob.cpu().numpy().view(np.uint8), orc.repack_narrow(q, s, z, None, 64, bits=bits))
+        deq = torch.empty(96, 256, dtype=torch.float32, device="cuda")
+        qbits.dequantize_packed_weight(blob, deq, True, "fp32", wname, "fp32")
+        assert np.abs(deq.cpu().numpy() - w).max() <= 0.51 * s.max()
+
+
 # ---- edge cases: empty / boundary batch sizes, dispatch seams, long K ----------------------------------------------
 def test_woq_linear_empty_batch_is_a_noop(qbits):
     """M = 0 (an empty activation batch) returns without touching the output, like the reference's GEMM with m = 0."""
@@ -469,7 +534,7 @@ def test_shape_and_type_errors_keep_the_reference_prefix(qbits):
         qbits.woq_linear(torch.zeros(2, 256, device="cuda", dtype=torch.float64), blob, torch.empty(0),
                          torch.zeros(2, 48, device="cuda"), "fp32", "int4_clip", "fp32", False)
     with pytest.raises(RuntimeError, match="[Qq]bits: unsupported bestla packq config"):
-        qbits.get_packed_weight_size(256, 48, "int3_clip", "fp32", "fp32", False, 32, False)
+        qbits.get_packed_weight_size(256, 48, "fp8_e5m2", "fp32", "fp32", False, 32, False)
     with pytest.raises(RuntimeError, match="QBits: unsupported blocksize"):
         qbits.get_packed_weight_size(256, 48, "int4_clip", "fp32", "fp32", False, 48, False)
     with pytest.raises(RuntimeError, match="QBits: not a WQH1 packed weight"):

@@ -172,3 +172,38 @@ def test_unsupported_blocksize():
     q = np.zeros((96, 16), np.int8)
     with pytest.raises(RuntimeError):
         orc.repack(q, np.ones((6, 16), np.float32), None, None, 16)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4, 8])
+@pytest.mark.parametrize("asym", [False, True])
+def test_rtn_rule_any_width(bits, asym):
+    """The RTN restatement at every integer width the boundary names (int2_clip / int3_clip / int4_clip / int8): codes
+    stay in the signed `bits` range, zero points too, dequantisation lands within half a step (one step where the
+    symmetric range clips its top code), and the 4-bit case equals the C oracle's rule bit for bit."""
+    rng = np.random.default_rng(7 + bits)
+    w = (rng.standard_normal((96, 64)) * 0.05).astype(np.float32)
+    q, s, z = orc.rtn_quantize_bits(w, False, 32, asym, bits)
+    lim = 1 << (bits - 1)
+    assert q.min() >= -lim and q.max() < lim and s.shape == (3, 64)
+    assert (z is None) == (not asym) and (z is None or (z.min() >= -lim and z.max() < lim))
+    deq = orc.dequant_raw(q, s, z, 32)
+    step = np.repeat(s, 32, axis=0)
+    assert (np.abs(deq - w) <= 0.5001 * step + 1e-7).all()
+    if bits == 4:
+        q4, s4, z4 = orc.rtn_quantize(w, False, 32, asym)
+        assert np.array_equal(q, q4) and np.array_equal(s, s4) and (z is None or np.array_equal(z, z4))
+
+
+def test_narrow_int_blob_is_the_int4_blob_plus_a_tag():
+    rng = np.random.default_rng(3)
+    q = rng.integers(-4, 4, (256, 48), dtype=np.int8)
+    s = (rng.random((2, 48), dtype=np.float32) + 0.5).astype(np.float32)
+    z = rng.integers(-4, 4, (2, 48), dtype=np.int8)
+    b4, b3 = orc.repack(q, s, z, None, 128), orc.repack_narrow(q, s, z, None, 128, bits=3)
+    assert orc.header(b3)["narrow_bits"] == 3 and orc.header(b4)["narrow_bits"] == 0
+    assert orc.header(b3)["weight_type"] == orc.W_INT4
+    b3.view(np.uint32)[15] = 0
+    assert np.array_equal(b3, b4)
+    assert np.array_equal(orc.dequantize_blob(b4), orc.dequant_raw(q, s, z, 128))
+    with pytest.raises(AssertionError):
+        orc.repack_narrow(q, s, z, None, 128, bits=2)
