@@ -74,9 +74,18 @@ enum woq_weight_type {
   WOQ_W_FP4_E2M1 = 3,     /* symmetric only (no zero points), same qdata layout as int4                              */
   WOQ_W_FP4_E2M1_BNB = 4,
   WOQ_W_INT3_CLIP = 5,    /* narrow integers (reference strings "int3_clip" / "int2_clip"): values in [-4, 3] / [-2, 1]  */
-  WOQ_W_INT2_CLIP = 6     /* held in int4 storage — names at the ABI only: the blob header says INT4_CLIP plus          */
+  WOQ_W_INT2_CLIP = 6,    /* held in int4 storage — names at the ABI only: the blob header says INT4_CLIP plus          */
                           /* narrow_bits = 3 / 2, and every kernel runs its int4 path on it unchanged                    */
+  WOQ_W_FP8_E4M3 = 7,     /* 8-bit float codes (OCP e4m3fn / e5m2), w = value(code) * scale, symmetric only: the code  */
+  WOQ_W_FP8_E5M2 = 8      /* byte is stored as two nibble planes in the int8 composite layout, see woq_fp8_headers     */
 };
+static inline int woq_weight_is_fp8(uint32_t t) { return t == 7u || t == 8u; }
+/* largest finite magnitude: RTN scale = absmax / max */
+static inline float woq_fp8_max(uint32_t t) { return t == 7u ? 448.0f : 57344.0f; }
+/* scale_type value accepted by the pack entry points for fp8 weights only (reference string "fp8_e8m0",
+ * qbits_ut/test_weightonly.py:24-25): power-of-two scales. Stored as bf16 (exact for every power of two in range);
+ * the header says scale_type = WOQ_BF16 and sets WOQ_FLAG_SCALE_E8M0 so the name survives. */
+#define WOQ_SCALE_FP8_E8M0 4
 static inline int woq_weight_is_table(uint32_t t) { return t >= 2u && t <= 4u; }
 static inline int woq_weight_narrow_bits(uint32_t t) { return t == 5u ? 3 : (t == 6u ? 2 : 0); }
 
@@ -100,6 +109,7 @@ enum woq_compute_type { WOQ_C_FP32 = 0, WOQ_C_BF16 = 1, WOQ_C_INT8 = 2, WOQ_C_FP
 
 #define WOQ_FLAG_ASYM 1u
 #define WOQ_FLAG_ACT_SHUFFLE 2u
+#define WOQ_FLAG_SCALE_E8M0 4u
 
 typedef struct woq_blob_header {
   uint32_t magic;
@@ -216,6 +226,20 @@ static inline int woq_int8_headers(woq_blob_header* outer, woq_blob_header* hi, 
   outer->off_zp = asym ? outer->off_scale + lo->off_zp : 0;
   outer->off_shuffle = act_shuffle ? outer->off_scale + lo->off_shuffle : 0;
   outer->total_bytes = WOQ_HEADER_BYTES + hi->total_bytes + lo->total_bytes;
+  return 0;
+}
+
+/* fp8 weights (WOQ_W_FP8_E4M3 / WOQ_W_FP8_E5M2): the same composite container as int8 — [outer header][HI blob][LO
+ * blob], both in the int4 tile layout — holding the two nibbles of every code byte c: the HI plane stores c >> 4, the
+ * LO plane (c & 15) ^ 8 (what the int8 splitter produces for the byte read as a signed value), so
+ *     c = (hi_nibble << 4) | (lo_nibble ^ 8).
+ * Both planes carry the scales s (the LO plane's zero-point section exists and is unused); symmetric only. A table
+ * lookup is not linear in the nibbles, so unlike int8 the two planes are read TOGETHER by one kernel. */
+static inline int woq_fp8_headers(woq_blob_header* outer, woq_blob_header* hi, woq_blob_header* lo, int K, int N,
+                                  int group, uint32_t weight_type, uint32_t scale_type, uint32_t compute_type,
+                                  int act_shuffle) {
+  if (woq_int8_headers(outer, hi, lo, K, N, group, scale_type, compute_type, 0, act_shuffle) != 0) return -1;
+  outer->weight_type = weight_type;
   return 0;
 }
 

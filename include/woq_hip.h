@@ -55,7 +55,8 @@ WOQ_API size_t woq_packed_weight_size(int K, int N, int blocksize, int weight_ty
  * (modules.py:225-227); int3_clip / int2_clip — values in [-4, 3] / [-2, 1], kept in int4 storage with a header tag
  * (woq_blob.h narrow_bits: same bytes and kernels as int4; the name survives acquire_packed_weight_info);
  * int8 — full int8 values (stored as a composite of two int4 blobs, woq_blob.h); nf4 /
- * fp4_e2m1 / fp4_e2m1_bnb — table codes 0..15, no zero points. scale fp32 [G,N],
+ * fp4_e2m1 / fp4_e2m1_bnb — table codes 0..15, no zero points; fp8_e4m3 / fp8_e5m2 — code bytes (as int8), no zero
+ * points, scale_type may be WOQ_SCALE_FP8_E8M0 (power-of-two scales, stored as bf16). scale fp32 [G,N],
  * zp int8 [G,N] or NULL (sym), g_idx int32 [K] = GPTQ act-order group id of every K row (each group exactly
  * `blocksize` rows) or NULL; like BesTLA, repack converts it to activation shuffle indices
  * (qbits_ut/test_packq.py:22-28,59-64) and the blob keeps those. blob_dev: caller-allocated,

@@ -12,17 +12,21 @@ LIB_PATH = os.environ.get("WOQ_HIP_LIB") or os.path.join(_HERE, "libwoq_hip.so")
 
 F32, BF16, F16, FP8_E4M3 = 0, 1, 2, 3
 W_INT4_CLIP, W_INT8, W_NF4, W_FP4_E2M1, W_FP4_E2M1_BNB, W_INT3_CLIP, W_INT2_CLIP = 0, 1, 2, 3, 4, 5, 6
+W_FP8_E4M3, W_FP8_E5M2 = 7, 8
+S_FP8_E8M0 = 4       # pack-time scale type for fp8 weights: stored as bf16, header flag FLAG_SCALE_E8M0
+FLAG_SCALE_E8M0 = 4
 C_FP32, C_BF16, C_INT8, C_FP16 = 0, 1, 2, 3
 HEADER_BYTES = 256
 
 WEIGHT_TYPES = {"int4_clip": W_INT4_CLIP, "int4": W_INT4_CLIP, "int8": W_INT8, "nf4": W_NF4, "fp4_e2m1": W_FP4_E2M1,
-                "fp4": W_FP4_E2M1, "fp4_e2m1_bnb": W_FP4_E2M1_BNB, "int3_clip": W_INT3_CLIP, "int2_clip": W_INT2_CLIP}
-SCALE_TYPES = {"fp32": F32, "bf16": BF16, "fp16": F16}
+                "fp4": W_FP4_E2M1, "fp4_e2m1_bnb": W_FP4_E2M1_BNB, "int3_clip": W_INT3_CLIP, "int2_clip": W_INT2_CLIP,
+                "fp8_e4m3": W_FP8_E4M3, "fp8": W_FP8_E4M3, "fp8_e5m2": W_FP8_E5M2}
+SCALE_TYPES = {"fp32": F32, "bf16": BF16, "fp16": F16, "fp8_e8m0": S_FP8_E8M0}
 COMPUTE_TYPES = {"fp32": C_FP32, "bf16": C_BF16, "int8": C_INT8, "fp16": C_FP16}
-SCALE_NAMES = {v: k for k, v in SCALE_TYPES.items()}
+SCALE_NAMES = {F32: "fp32", BF16: "bf16", F16: "fp16"}
 COMPUTE_NAMES = {v: k for k, v in COMPUTE_TYPES.items()}
 WEIGHT_NAMES = {W_INT4_CLIP: "int4_clip", W_INT8: "int8", W_NF4: "nf4", W_FP4_E2M1: "fp4_e2m1",
-                W_FP4_E2M1_BNB: "fp4_e2m1_bnb"}
+                W_FP4_E2M1_BNB: "fp4_e2m1_bnb", W_FP8_E4M3: "fp8_e4m3", W_FP8_E5M2: "fp8_e5m2"}
 
 
 class BlobHeader(ctypes.Structure):

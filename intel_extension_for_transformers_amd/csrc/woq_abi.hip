@@ -21,6 +21,9 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
 int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                     const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w, float eps,
                     const float* residual, int ld_res, int epi, void* ws, int fp32_class, hipStream_t st);
+int launch_gemv_fp8(const void* act, int act_dtype, int lda, const void* hi_blob, const woq_blob_header& hi,
+                    const void* lo_q, uint32_t fp8_type, const float* bias, void* out, int out_dtype, int ldo, int M,
+                    hipStream_t st);
 }  // namespace woq
 
 using namespace woq;
@@ -60,7 +63,16 @@ int woq_linear(const void* act_dev, int act_dtype, int lda, const void* blob_dev
   if (M <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (hdr->weight_type == WOQ_W_INT8) {
+  if (woq_weight_is_fp8(hdr->weight_type)) {
+    // two nibble planes read together by the generic kernel (woq_blob.h woq_fp8_headers); every M, rows in chunks
+    woq_blob_header o, hi, lo;
+    WOQ_CHECK(woq_fp8_headers(&o, &hi, &lo, hdr->K, hdr->N, hdr->group, hdr->weight_type, hdr->scale_type,
+                              hdr->compute_type, hdr->off_shuffle != 0) == 0, "QBits: corrupt fp8 header");
+    const uint8_t* bhi = (const uint8_t*)blob_dev + hdr->off_q;
+    const uint8_t* blo = (const uint8_t*)blob_dev + hdr->off_scale;
+    rc = launch_gemv_fp8(act_dev, act_dtype, lda, bhi, hi, blo + lo.off_q, hdr->weight_type, bias_dev, out_dev,
+                         out_dtype, ldo, M, st);
+  } else if (hdr->weight_type == WOQ_W_INT8) {
     // (q8 - zp8) s = (hi - zhi) 16s + (lo - zlo) s: two int4 linears on the same activations (woq_blob.h); the
     // first goes to an fp32 scratch, the second adds it (and the bias) and stores the caller's dtype
     woq_blob_header o, hi, lo;

@@ -126,4 +126,26 @@ __device__ __forceinline__ float lut_value(uint32_t weight_type, int code) {
   return weight_type == WOQ_W_NF4 ? nf4[code] : (weight_type == WOQ_W_FP4_E2M1 ? e2m1[code] : bnb[code]);
 }
 
+// ---- fp8 weight types (woq_blob.h): w = value(code) * scale ----
+__host__ __device__ __forceinline__ bool is_fp8_type(uint32_t t) { return t == 7u || t == 8u; }
+// OCP e4m3fn (no infinities, S.1111.111 = NaN) / e5m2 (IEEE-like: exponent 31 = inf / NaN), by the definition
+__host__ __device__ __forceinline__ float fp8_code_value(uint32_t weight_type, int code) {
+  const int s = (code >> 7) & 1;
+  float v;
+  if (weight_type == WOQ_W_FP8_E4M3) {
+    const int e = (code >> 3) & 15, m = code & 7;
+    if (e == 15 && m == 7)
+      v = NAN;
+    else
+      v = e == 0 ? ldexpf((float)m, -9) : ldexpf((float)(8 + m), e - 10);
+  } else {
+    const int e = (code >> 2) & 31, m = code & 3;
+    if (e == 31)
+      v = m == 0 ? INFINITY : NAN;
+    else
+      v = e == 0 ? ldexpf((float)m, -16) : ldexpf((float)(4 + m), e - 17);
+  }
+  return s ? -v : v;
+}
+
 }  // namespace woq

@@ -28,6 +28,7 @@ int launch_gemv_tile(const void* act, int act_dtype, int lda, int M, const void*
 
 struct GenArgs {
   const u32x4* q;
+  const u32x4* q_lo;  // fp8 weight types: the LO nibble plane (same tile layout as q = the HI plane), else null
   const void* scales;
   const uint8_t* zp;
   const int32_t* shuffle;
@@ -41,7 +42,7 @@ struct GenArgs {
   float eps;
   const float* residual;
   int epi;
-  uint32_t weight_type;  // WOQ_W_INT4_CLIP, or a 4-bit table type (w = table[code] * scale)
+  uint32_t weight_type;  // WOQ_W_INT4_CLIP, a 4-bit table type (w = table[code] * scale), or an fp8 type (two planes)
 };
 
 constexpr int GEN_NW = 4;    // waves per workgroup
@@ -60,9 +61,13 @@ __global__ __launch_bounds__(GEN_NW * 64) void gemv_generic_kernel(GenArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int M = a.M, ncb = a.epi == 1 ? 2 : 1;
-  __shared__ float lut_s[16];  // table weight types: the 16 values, read back by code
+  __shared__ float lut_s[256];  // table weight types: the 16 values (fp8: all 256), read back by code
   const bool table = is_table_type(a.weight_type);
-  if (table && tid < 16) lut_s[tid] = lut_value(a.weight_type, tid);
+  const bool fp8 = a.q_lo != nullptr;
+  if (fp8)
+    lut_s[tid] = fp8_code_value(a.weight_type, tid);  // GEN_NW * 64 = 256 threads
+  else if (table && tid < 16)
+    lut_s[tid] = lut_value(a.weight_type, tid);
 
   // ---- stage the activation rows: gather (dtype, shuffle), optional RMSNorm, fp32 in LDS, zero K padding ----
   for (int m = 0; m < M; ++m) {
@@ -95,6 +100,8 @@ __global__ __launch_bounds__(GEN_NW * 64) void gemv_generic_kernel(GenArgs a) {
     for (int m = 0; m < GEN_MAXM; ++m) acc[m] = 0.f;
     for (int kt = wid; kt < a.tiles_k; kt += GEN_NW) {
       const u32x4 wv = a.q[((size_t)tn * a.tiles_k + kt) * 64 + lane];
+      u32x4 wl = {0u, 0u, 0u, 0u};
+      if (fp8) wl = a.q_lo[((size_t)tn * a.tiles_k + kt) * 64 + lane];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int kb = kt * 128 + h * 64 + kq * 16;
@@ -116,7 +123,10 @@ __global__ __launch_bounds__(GEN_NW * 64) void gemv_generic_kernel(GenArgs a) {
           const uint32_t word = (j < 8) ? (h == 0 ? wv.x : wv.z) : (h == 0 ? wv.y : wv.w);
           int qv = (int)((word >> nibble_shift(j)) & 0xfu);
           float wq;
-          if (table) {
+          if (fp8) {  // code = (hi nibble << 4) | (lo nibble ^ 8), include/woq_blob.h woq_fp8_headers
+            const uint32_t wordl = (j < 8) ? (h == 0 ? wl.x : wl.z) : (h == 0 ? wl.y : wl.w);
+            wq = lut_s[(qv << 4) | (int)(((wordl >> nibble_shift(j)) & 0xfu) ^ 8u)];
+          } else if (table) {
             wq = lut_s[qv];
           } else {
             qv = (qv & 8) ? qv - 16 : qv;
@@ -169,10 +179,11 @@ __global__ __launch_bounds__(GEN_NW * 64) void gemv_generic_kernel(GenArgs a) {
 static int launch_gemv_generic(const void* act, int act_dtype, int lda, int M, const void* blob,
                                const woq_blob_header& h, const float* bias, void* out, int out_dtype, int ldo,
                                const float* norm_w, float eps, const float* residual, int ld_res, int epi,
-                               hipStream_t st) {
+                               hipStream_t st, const void* lo_plane = nullptr, uint32_t fp8_type = 0) {
   GenArgs a;
   const uint8_t* b = (const uint8_t*)blob;
   a.q = (const u32x4*)(b + h.off_q);
+  a.q_lo = (const u32x4*)lo_plane;
   a.scales = b + h.off_scale;
   a.zp = h.off_zp ? b + h.off_zp : nullptr;
   a.shuffle = h.off_shuffle ? (const int32_t*)(b + h.off_shuffle) : nullptr;
@@ -197,15 +208,15 @@ static int launch_gemv_generic(const void* act, int act_dtype, int lda, int M, c
   a.eps = eps;
   a.residual = residual;
   a.epi = epi;
-  a.weight_type = h.weight_type;
+  a.weight_type = lo_plane ? fp8_type : h.weight_type;
   const int tiles_n = h.Npad / WOQ_TILE_N;
   if (epi == 1 && (tiles_n & 1)) return woq::fail("QBits: fused gate/up weight needs an even number of column tiles");
   const size_t lds = gen_lds_bytes(M, h.Kpad);
-  if (lds > 159 * 1024) return woq::fail("QBits: K too large for the small-M GEMV (activation row does not fit LDS)");
+  if (lds > 158 * 1024) return woq::fail("QBits: K too large for the small-M GEMV (activation row does not fit LDS)");
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gemv_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       159 * 1024);  // the kernel also holds 64 B of static LDS (the value table)
+                                       158 * 1024);  // the kernel also holds 1 KiB of static LDS (the value table)
     if (e != hipSuccess) return woq::fail(std::string("QBits: hipFuncSetAttribute: ") + hipGetErrorString(e));
     attr_set = true;
   }
@@ -275,6 +286,24 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
     }
   }
   if (widened) hipFreeAsync(widened, st);
+  return 0;
+}
+
+// fp8 weights: rows in chunks of GEN_MAXM through the generic kernel reading both nibble planes (functional, untuned).
+// `hi` = the HI plane's header (scales, shuffle), `lo_q` = the LO plane's qdata.
+int launch_gemv_fp8(const void* act, int act_dtype, int lda, const void* hi_blob, const woq_blob_header& hi,
+                    const void* lo_q, uint32_t fp8_type, const float* bias, void* out, int out_dtype, int ldo, int M,
+                    hipStream_t st) {
+  const size_t esz_a = act_dtype == WOQ_F32 ? 4 : 2, esz_o = out_dtype == WOQ_F32 ? 4 : 2;
+  int rows = GEN_MAXM;
+  while (rows > 1 && gen_lds_bytes(rows, hi.Kpad) > 150 * 1024) --rows;
+  for (int m0 = 0; m0 < M; m0 += rows) {
+    const int mc = M - m0 < rows ? M - m0 : rows;
+    const int rc = launch_gemv_generic((const char*)act + (size_t)m0 * lda * esz_a, act_dtype, lda, mc, hi_blob, hi,
+                                       bias, (char*)out + (size_t)m0 * ldo * esz_o, out_dtype, ldo, nullptr, 0.f,
+                                       nullptr, 0, 0, st, lo_q, fp8_type);
+    if (rc) return rc;
+  }
   return 0;
 }
 

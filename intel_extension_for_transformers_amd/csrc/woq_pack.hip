@@ -259,6 +259,68 @@ __global__ void rtn_lut_kernel(const float* __restrict__ w, int transpose, int K
   }
 }
 
+// ---- fp8 weights (include/woq_blob.h woq_fp8_headers) ------------------------------------------------------------
+// RTN onto the fp8 grid: scale = max|w| / fp8_max per group (e8m0: the next power of two at or above it, so nothing
+// leaves the range), code = the finite code whose value is nearest to w / scale in fp32, lowest code on ties (so +0
+// beats -0 and a midpoint takes the smaller code). Parity unpinned like the other rules (BesTLA's quantiser is not
+// in the reference tree). Load-time kernel: a plain search over the 256 codes.
+__global__ void rtn_fp8_kernel(const float* __restrict__ w, int transpose, int K, int N, int group, int n_groups,
+                               uint32_t weight_type, int e8m0, int8_t* __restrict__ q, float* __restrict__ scales) {
+  __shared__ float val[256];
+  val[threadIdx.x & 255] = fp8_code_value(weight_type, threadIdx.x & 255);
+  __syncthreads();
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)n_groups * N) return;
+  int g = (int)(idx / (size_t)N), n = (int)(idx % (size_t)N);
+  int k0 = g * group, k1 = min(k0 + group, K);
+  float amax = 0.f;
+  for (int k = k0; k < k1; ++k) amax = fmaxf(amax, fabsf(transpose ? w[(size_t)n * K + k] : w[(size_t)k * N + n]));
+  float s = amax / (weight_type == WOQ_W_FP8_E4M3 ? 448.0f : 57344.0f);
+  if (s == 0.f) s = 1.f;
+  if (e8m0) {
+    int e;
+    const float f = frexpf(s, &e);  // s = f * 2^e, f in [0.5, 1)
+    s = ldexpf(1.0f, f == 0.5f ? e - 1 : e);
+  }
+  scales[idx] = s;
+  for (int k = k0; k < k1; ++k) {
+    const float v = (transpose ? w[(size_t)n * K + k] : w[(size_t)k * N + n]) / s;
+    int best = 0;
+    float bd = INFINITY;
+    for (int c = 0; c < 256; ++c) {
+      const float t = val[c];
+      if (!(fabsf(t) <= 3.0e38f)) continue;  // NaN / inf codes are never produced
+      const float d = fabsf(v - t);
+      if (d < bd) {
+        bd = d;
+        best = c;
+      }
+    }
+    q[(size_t)k * N + n] = (int8_t)best;
+  }
+}
+
+// w[k][n] = value((hi_nibble << 4) | (lo_nibble ^ 8)) * scale, both planes read together
+__global__ void dequant_fp8_kernel(const uint8_t* __restrict__ bhi, woq_blob_header hh, const uint8_t* __restrict__ blo,
+                                   woq_blob_header hl, uint32_t weight_type, float* __restrict__ out, int transpose) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)hh.K * hh.N;
+  if (idx >= total) return;
+  int k, n;
+  if (transpose) {
+    n = (int)(idx / (size_t)hh.K);
+    k = (int)(idx % (size_t)hh.K);
+  } else {
+    k = (int)(idx / (size_t)hh.N);
+    n = (int)(idx % (size_t)hh.N);
+  }
+  int uh, ul, uz;
+  float sc, sc2;
+  blob_elem(bhi, hh, k, n, uh, uz, sc);   // u = stored signed nibble + 8
+  blob_elem(blo, hl, k, n, ul, uz, sc2);
+  out[idx] = fp8_code_value(weight_type, ((uh ^ 8) << 4) | ul) * sc;
+}
+
 }  // namespace woq
 
 using namespace woq;
@@ -274,6 +336,14 @@ size_t woq_packed_weight_size(int K, int N, int blocksize, int weight_type, int 
                               int act_shuffle) {
   woq_blob_header h, hi, lo;
   if (woq_weight_narrow_bits((uint32_t)weight_type)) weight_type = WOQ_W_INT4_CLIP;  // int3 / int2 in int4 storage
+  if (woq_weight_is_fp8((uint32_t)weight_type)) {  // symmetric only; e8m0 scales are stored as bf16
+    if (asym) return 0;
+    const uint32_t st = scale_type == WOQ_SCALE_FP8_E8M0 ? (uint32_t)WOQ_BF16 : (uint32_t)scale_type;
+    return woq_fp8_headers(&h, &hi, &lo, K, N, blocksize, (uint32_t)weight_type, st, WOQ_C_FP32, act_shuffle) == 0
+               ? h.total_bytes
+               : 0;
+  }
+  if (scale_type == WOQ_SCALE_FP8_E8M0) return 0;  // fp8_e8m0 scales go with fp8 weights only
   if (weight_type == WOQ_W_INT8)
     return woq_int8_headers(&h, &hi, &lo, K, N, blocksize, (uint32_t)scale_type, WOQ_C_FP32, asym, act_shuffle) == 0
                ? h.total_bytes
@@ -314,15 +384,41 @@ int woq_repack_quantized_weight(const int8_t* qweight_dev, const float* scale_de
   WOQ_TRY
   const int narrow = woq_weight_narrow_bits((uint32_t)weight_type);  // int3_clip / int2_clip: int4 storage + a tag
   if (narrow) weight_type = WOQ_W_INT4_CLIP;
-  WOQ_CHECK(weight_type == WOQ_W_INT4_CLIP || weight_type == WOQ_W_INT8 || is_table_type((uint32_t)weight_type),
+  const bool fp8 = woq_weight_is_fp8((uint32_t)weight_type);
+  WOQ_CHECK(weight_type == WOQ_W_INT4_CLIP || weight_type == WOQ_W_INT8 || is_table_type((uint32_t)weight_type) || fp8,
             "QBits: unsupported weight_type in repack (int4_clip | int3_clip | int2_clip | int8 | nf4 | fp4_e2m1 | "
-            "fp4_e2m1_bnb)");
-  WOQ_CHECK(!(is_table_type((uint32_t)weight_type) && zp_dev != nullptr),
-            "QBits: table weight types (nf4 / fp4) are symmetric: no zero points");
+            "fp4_e2m1_bnb | fp8_e4m3 | fp8_e5m2)");
+  WOQ_CHECK(!((is_table_type((uint32_t)weight_type) || fp8) && zp_dev != nullptr),
+            "QBits: float weight types (nf4 / fp4 / fp8) are symmetric: no zero points");
+  const bool e8m0 = scale_type == WOQ_SCALE_FP8_E8M0;
+  WOQ_CHECK(!e8m0 || fp8, "QBits: fp8_e8m0 scales are only used with fp8_e4m3 / fp8_e5m2 weights");
+  if (e8m0) scale_type = WOQ_BF16;  // every power of two in range is an exact bf16
   WOQ_CHECK(scale_type >= WOQ_F32 && scale_type <= WOQ_F16, "QBits: unsupported scale_type");
   WOQ_CHECK(((uintptr_t)blob_dev & 255u) == 0, "QBits: packed-weight buffer must be 256-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   uint8_t* blob = (uint8_t*)blob_dev;
+  if (fp8) {  // code bytes -> two nibble planes in the int8 composite container, scales s on both
+    woq_blob_header h, hi, lo;
+    WOQ_CHECK(woq_fp8_headers(&h, &hi, &lo, K, N, blocksize, (uint32_t)weight_type, (uint32_t)scale_type,
+                              (uint32_t)compute_type, g_idx_dev != nullptr) == 0,
+              "QBits: unsupported blocksize (must be -1 or a multiple of 32)");
+    WOQ_CHECK(blob_bytes >= h.total_bytes, "QBits: packed-weight buffer too small");
+    if (e8m0) h.flags |= WOQ_FLAG_SCALE_E8M0;
+    const size_t kn = (size_t)K * N, gn = (size_t)h.n_groups * N;
+    int8_t* tmp = nullptr;  // q_hi [kn] | q_lo [kn] | zp_lo [gn] (zeros)
+    WOQ_HIP(hipMallocAsync((void**)&tmp, 2 * kn + gn, st));
+    int8_t *q_hi = tmp, *q_lo = tmp + kn, *z_lo = tmp + 2 * kn;
+    hipLaunchKernelGGL(split_int8_kernel, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, st, qweight_dev, kn, q_hi,
+                       q_lo);
+    WOQ_HIP(hipMemsetAsync(z_lo, 0, gn, st));
+    hipLaunchKernelGGL(write_header_kernel, dim3(1), dim3(64), 0, st, h, (woq_blob_header*)blob);
+    int rc = repack_int4(q_hi, scale_dev, nullptr, g_idx_dev, hi, blob + h.off_q, st);
+    if (rc == 0) rc = repack_int4(q_lo, scale_dev, z_lo, g_idx_dev, lo, blob + h.off_scale, st);
+    hipFreeAsync(tmp, st);
+    if (rc) return rc;
+    WOQ_HIP(hipGetLastError());
+    return 0;
+  }
   if (weight_type == WOQ_W_INT8) {
     woq_blob_header h, hi, lo;
     WOQ_CHECK(woq_int8_headers(&h, &hi, &lo, K, N, blocksize, (uint32_t)scale_type, (uint32_t)compute_type,
@@ -363,12 +459,15 @@ int woq_quantize_to_packed_weight(const float* weight_dev, int transpose, int K,
                                   size_t blob_bytes, void* stream) {
   WOQ_TRY
   const int narrow = woq_weight_narrow_bits((uint32_t)weight_type);
+  const bool fp8 = woq_weight_is_fp8((uint32_t)weight_type);
   WOQ_CHECK(narrow || weight_type == WOQ_W_INT4_CLIP || weight_type == WOQ_W_INT8 ||
-                is_table_type((uint32_t)weight_type),
+                is_table_type((uint32_t)weight_type) || fp8,
             "QBits: unsupported weight_type in quantize (int4_clip | int3_clip | int2_clip | int8 | nf4 | fp4_e2m1 | "
-            "fp4_e2m1_bnb)");
-  WOQ_CHECK(!(is_table_type((uint32_t)weight_type) && asym),
-            "QBits: table weight types (nf4 / fp4) are symmetric: asym is not supported");
+            "fp4_e2m1_bnb | fp8_e4m3 | fp8_e5m2)");
+  WOQ_CHECK(!((is_table_type((uint32_t)weight_type) || fp8) && asym),
+            "QBits: float weight types (nf4 / fp4 / fp8) are symmetric: asym is not supported");
+  WOQ_CHECK(scale_type != WOQ_SCALE_FP8_E8M0 || fp8,
+            "QBits: fp8_e8m0 scales are only used with fp8_e4m3 / fp8_e5m2 weights");
   int group = (blocksize <= 0 || blocksize > K) ? K : blocksize;  // blocksize -1 -> K (dispatcher.cpp:296)
   int n_groups = (K + group - 1) / group;
   hipStream_t st = (hipStream_t)stream;
@@ -379,7 +478,10 @@ int woq_quantize_to_packed_weight(const float* weight_dev, int transpose, int K,
   WOQ_HIP(hipMalloc((void**)&sc, (size_t)n_groups * N * sizeof(float)));
   if (asym) WOQ_HIP(hipMalloc((void**)&zp, (size_t)n_groups * N));
   size_t nt = (size_t)n_groups * N;
-  if (is_table_type((uint32_t)weight_type))
+  if (fp8)
+    hipLaunchKernelGGL(rtn_fp8_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, weight_dev, transpose, K,
+                       N, group, n_groups, (uint32_t)weight_type, scale_type == WOQ_SCALE_FP8_E8M0 ? 1 : 0, q, sc);
+  else if (is_table_type((uint32_t)weight_type))
     hipLaunchKernelGGL(rtn_lut_kernel, dim3((unsigned)((nt + 127) / 128)), dim3(128), 0, st, weight_dev, transpose, K,
                        N, group, n_groups, (uint32_t)weight_type, q, sc);
   else
@@ -401,6 +503,16 @@ int woq_dequantize_packed_weight(const void* blob_dev, const woq_blob_header* hd
   WOQ_TRY
   WOQ_CHECK(hdr && hdr->magic == WOQ_BLOB_MAGIC, "QBits: not a WQH1 packed weight");
   size_t total = (size_t)hdr->K * hdr->N;
+  if (woq_weight_is_fp8(hdr->weight_type)) {
+    woq_blob_header o, hi, lo;
+    WOQ_CHECK(woq_fp8_headers(&o, &hi, &lo, hdr->K, hdr->N, hdr->group, hdr->weight_type, hdr->scale_type,
+                              hdr->compute_type, hdr->off_shuffle != 0) == 0, "QBits: corrupt fp8 header");
+    hipLaunchKernelGGL(dequant_fp8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)blob_dev + hdr->off_q, hi, (const uint8_t*)blob_dev + hdr->off_scale, lo,
+                       hdr->weight_type, out_dev, transpose);
+    WOQ_HIP(hipGetLastError());
+    return 0;
+  }
   if (hdr->weight_type == WOQ_W_INT8) {  // (hi - zhi) * 16s + (lo - zlo) * s, two fp32 terms
     woq_blob_header o, hi, lo;
     WOQ_CHECK(woq_int8_headers(&o, &hi, &lo, hdr->K, hdr->N, hdr->group, hdr->scale_type, hdr->compute_type,
@@ -430,7 +542,7 @@ int woq_blob_extract(const void* blob_dev, const woq_blob_header* hdr, int what,
   WOQ_TRY
   WOQ_CHECK(hdr && hdr->magic == WOQ_BLOB_MAGIC, "QBits: not a WQH1 packed weight");
   hipStream_t st = (hipStream_t)stream;
-  if (hdr->weight_type == WOQ_W_INT8) {
+  if (hdr->weight_type == WOQ_W_INT8 || woq_weight_is_fp8(hdr->weight_type)) {  // composite: sections of the LO blob
     woq_blob_header o, hi, lo;
     WOQ_CHECK(woq_int8_headers(&o, &hi, &lo, hdr->K, hdr->N, hdr->group, hdr->scale_type, hdr->compute_type,
                                hdr->off_zp != 0, hdr->off_shuffle != 0) == 0, "QBits: corrupt int8 header");

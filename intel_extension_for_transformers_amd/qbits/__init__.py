@@ -30,14 +30,14 @@ def _blocksize_ok(k, blocksize):
 def _wtype(weight_type):
     if weight_type not in L.WEIGHT_TYPES:
         # reference text: bestla_packq_impl.cpp "unsupported bestla packq config"
-        raise RuntimeError("Qbits: unsupported bestla packq config, weight_type: %s (MI355X path: int4_clip, int3_clip, int2_clip, int8, nf4, fp4_e2m1, fp4_e2m1_bnb)"
+        raise RuntimeError("Qbits: unsupported bestla packq config, weight_type: %s (MI355X path: int4_clip, int3_clip, int2_clip, int8, nf4, fp4_e2m1, fp4_e2m1_bnb, fp8_e4m3, fp8_e5m2)"
                            % weight_type)
     return L.WEIGHT_TYPES[weight_type]
 
 
 def _stype(scale_type):
     if scale_type not in L.SCALE_TYPES:
-        raise RuntimeError("QBits: unsupported scale_type %s (fp32 | bf16 | fp16)" % scale_type)
+        raise RuntimeError("QBits: unsupported scale_type %s (fp32 | bf16 | fp16; fp8_e8m0 with fp8 weights)" % scale_type)
     return L.SCALE_TYPES[scale_type]
 
 
@@ -67,8 +67,12 @@ def header_of(packed):
 
 def get_packed_weight_size(k, n, weight_type, scale_type, compute_type, asym, blocksize, act_shuf):
     """qbits.cpp:79-88."""
-    if asym and _wtype(weight_type) in (L.W_NF4, L.W_FP4_E2M1, L.W_FP4_E2M1_BNB):
-        raise RuntimeError("QBits: table weight types (nf4 / fp4) are symmetric: asym is not supported")
+    wt = _wtype(weight_type)
+    if asym and wt in (L.W_NF4, L.W_FP4_E2M1, L.W_FP4_E2M1_BNB, L.W_FP8_E4M3, L.W_FP8_E5M2):
+        raise RuntimeError("QBits: float weight types (nf4 / fp4 / fp8) are symmetric: asym is not supported")
+    if _stype(scale_type) == L.S_FP8_E8M0 and wt not in (L.W_FP8_E4M3, L.W_FP8_E5M2):
+        # the reference's validity matrix: qbits_ut/test_weightonly.py:24-25
+        raise RuntimeError("QBits: fp8_e8m0 scales are only used with fp8_e4m3 / fp8_e5m2 weights")
     size = L.lib().woq_packed_weight_size(k, n, blocksize, _wtype(weight_type), _stype(scale_type), int(asym),
                                           int(act_shuf))
     if size == 0:
@@ -173,7 +177,7 @@ def acquire_packed_weight_info(packw, acquire_type):
     if t == 7:
         return _ascii(L.COMPUTE_NAMES[hdr.compute_type])
     if t == 8:
-        return _ascii(L.SCALE_NAMES[hdr.scale_type])
+        return _ascii("fp8_e8m0" if hdr.flags & L.FLAG_SCALE_E8M0 else L.SCALE_NAMES[hdr.scale_type])
     if t == 5:
         if not hdr.off_shuffle:
             raise RuntimeError("QBits: not pack g_idx tensor.")

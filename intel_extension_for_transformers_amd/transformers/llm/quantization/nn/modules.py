@@ -142,8 +142,8 @@ class QuantizedLinearQBits(torch.nn.Linear):
         g_idx int32 [K] or None). The reference dequantises and re-quantises with the stored scales
         (modules.py:356-372) because BesTLA cannot hand the integers back; the WQH1 blob can, so the integers are
         recovered exactly: q = dequant / scale + zp computed from the blob's own tensors."""
-        if self.weight_dtype in ("nf4", "fp4_e2m1", "fp4_e2m1_bnb"):
-            raise NotImplementedError("QBits: table weight types (%s) have no integer export format" % self.weight_dtype)
+        if self.weight_dtype in ("nf4", "fp4_e2m1", "fp4_e2m1_bnb", "fp8_e4m3", "fp8_e5m2"):
+            raise NotImplementedError("QBits: float weight types (%s) have no integer export format" % self.weight_dtype)
         w = self.weight.data
         info = lambda t: qbits.acquire_packed_weight_info(w, t)  # noqa: E731
         k, n = int(info(2)[0]), int(info(3)[0])

@@ -180,12 +180,25 @@ class ITREXQuantizationConfigMixin(_HFBase):
             self.bits = 4
         elif self.bits not in (4, 8):
             raise ValueError("Only support quantization to [4, 8] bits but found %s" % self.bits)
-        if self.bits == 8:
+        fp8 = self.weight_dtype in ("fp8", "fp8_e4m3", "fp8_e5m2")
+        if fp8:
+            # 8-bit float weights (reference config.py:298-299,313: "fp8" -> "fp8_e4m3", bits = 8): symmetric only,
+            # fp32 or power-of-two (fp8_e8m0) scales; generic kernel, off the fused engine
+            self.bits = 8
+            if self.weight_dtype == "fp8":
+                self.weight_dtype = "fp8_e4m3"
+            if not self.sym:
+                raise ValueError("asym quantization is not supported with %s weights" % self.weight_dtype)
+            if self.scale_dtype == "fp8":
+                self.scale_dtype = "fp8_e8m0"
+            if self.scale_dtype not in (None, "fp32", "fp8_e8m0"):
+                raise ValueError("scale_dtype must be 'fp32' or 'fp8_e8m0' with fp8 weights")
+        elif self.bits == 8:
             if self.weight_dtype in (None, "int8"):
                 self.weight_dtype = "int8"
             else:
-                raise ValueError("weight_dtype must be 'int8' for bits=8 on the MI355X path, got %s"
-                                 % self.weight_dtype)
+                raise ValueError("weight_dtype must be 'int8', 'fp8_e4m3' or 'fp8_e5m2' for bits=8 on the MI355X path, "
+                                 "got %s" % self.weight_dtype)
         elif self.weight_dtype in (None, "int4", "int4_fullrange"):
             self.weight_dtype = "int4_clip"
         elif self.weight_dtype in ("nf4", "fp4", "fp4_e2m1", "fp4_e2m1_bnb"):
@@ -200,8 +213,8 @@ class ITREXQuantizationConfigMixin(_HFBase):
                              "or 'int8' (bits=8) on the MI355X path, got %s" % self.weight_dtype)
         if self.scale_dtype is None:
             self.scale_dtype = "fp32"
-        elif self.scale_dtype not in ("fp32", "bf16", "fp16"):
-            raise ValueError("scale_dtype must be a string in 'fp32', 'bf16', 'fp16'")
+        elif self.scale_dtype not in ("fp32", "bf16", "fp16") and not (fp8 and self.scale_dtype == "fp8_e8m0"):
+            raise ValueError("scale_dtype must be a string in 'fp32', 'bf16', 'fp16' ('fp8_e8m0' with fp8 weights)")
         self._common_checks()
         if self.group_size != -1 and (self.group_size <= 0 or self.group_size % 32 != 0):
             raise ValueError("group_size must be -1 or a positive multiple of 32")

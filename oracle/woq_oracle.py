@@ -283,6 +283,99 @@ def rtn_quantize_bits(w, transpose, group, asym, bits):
     return q, s, z
 
 
+# ---- fp8 weights (fp8_e4m3 / fp8_e5m2, reference strings bestla_weightonly_dispatcher.hpp:62-70): two nibble planes in
+# the int8 composite container, w = value(code) * scale, symmetric only (include/woq_blob.h woq_fp8_headers) -----------
+W_FP8_E4M3, W_FP8_E5M2 = 7, 8
+FLAG_SCALE_E8M0 = 4
+
+
+def _fp8_table(wtype):
+    """OCP e4m3fn (no infinities, S.1111.111 = NaN) / e5m2 (exponent 31 = inf / NaN), by the definition."""
+    t = np.empty(256, np.float32)
+    for c in range(256):
+        s = -1.0 if c & 0x80 else 1.0
+        if wtype == W_FP8_E4M3:
+            e, m = (c >> 3) & 15, c & 7
+            v = np.nan if (e == 15 and m == 7) else (m * 2.0 ** -9 if e == 0 else (8 + m) * 2.0 ** (e - 10))
+        else:
+            e, m = (c >> 2) & 31, c & 3
+            v = (np.inf if m == 0 else np.nan) if e == 31 else (m * 2.0 ** -16 if e == 0 else (4 + m) * 2.0 ** (e - 17))
+        t[c] = s * v
+    return t
+
+
+FP8_TABLES = {W_FP8_E4M3: _fp8_table(W_FP8_E4M3), W_FP8_E5M2: _fp8_table(W_FP8_E5M2)}
+FP8_MAX = {W_FP8_E4M3: 448.0, W_FP8_E5M2: 57344.0}
+
+
+def rtn_quantize_fp8(w, transpose, group, wtype, e8m0=False):
+    """scale = max|w| / fp8_max per group (e8m0: the next power of two at or above it), code = the finite code whose
+    value is nearest to w / scale in fp32, lowest code on ties — the device kernel's rule (parity unpinned: BesTLA's
+    quantiser is not in the reference tree). Returns codes uint8 [K, N], scales fp32 [G, N]."""
+    w = np.asarray(w, np.float32)
+    w = w.T if transpose else w
+    K, N = w.shape
+    g = K if group in (-1, 0) or group > K else group
+    G = (K + g - 1) // g
+    tab = FP8_TABLES[wtype]
+    finite = np.isfinite(tab)
+    q = np.empty((K, N), np.uint8)
+    s = np.empty((G, N), np.float32)
+    for gi in range(G):
+        blk = w[gi * g:min(K, (gi + 1) * g)]
+        sc = (np.abs(blk).max(0) / np.float32(FP8_MAX[wtype])).astype(np.float32)
+        sc[sc == 0] = 1
+        if e8m0:
+            f, e = np.frexp(sc)
+            sc = np.ldexp(np.float32(1), np.where(f == 0.5, e - 1, e)).astype(np.float32)
+        d = np.abs((blk / sc)[..., None].astype(np.float32) - tab[None, None, :])
+        d[..., ~finite] = np.inf
+        q[gi * g:gi * g + blk.shape[0]] = d.argmin(-1).astype(np.uint8)  # first (lowest) code on ties
+        s[gi] = sc
+    return q, s
+
+
+def repack_fp8(codes, scales, wtype, shuffle=None, group=-1, scale_type=F32, compute_type=0, e8m0=False):
+    """code bytes [K, N] + fp32 scales [G, N] -> composite blob: HI plane = code >> 4, LO plane = (code & 15) ^ 8 as
+    stored nibbles (what the int8 splitter makes of the byte read as a signed value), scales on both planes; e8m0
+    scales are stored as bf16 with the header flag set."""
+    c = np.asarray(codes).astype(np.uint8).view(np.int8).astype(np.int32)
+    hi, lo = (c >> 4).astype(np.int8), ((c & 15) - 8).astype(np.int8)
+    st = BF16 if e8m0 else scale_type
+    scales = np.asarray(scales, np.float32)
+    bhi = repack(hi, scales, None, shuffle, group, st, compute_type)
+    blo = repack(lo, scales, np.zeros(scales.shape, np.int8), shuffle, group, st, compute_type)
+    outer = bhi[:HEADER_BYTES].copy()
+    lo_h = header(blo)
+    u32 = outer.view(np.uint32)
+    u32[10] = wtype
+    if e8m0:
+        u32[13] |= FLAG_SCALE_E8M0
+    u64 = outer.view(np.uint64)
+    u64[8] = HEADER_BYTES
+    u64[9] = HEADER_BYTES + bhi.size
+    u64[10] = 0
+    u64[11] = HEADER_BYTES + bhi.size + lo_h["off_shuffle"] if shuffle is not None else 0
+    u64[1] = HEADER_BYTES + bhi.size + blo.size
+    return np.concatenate([outer, bhi, blo])
+
+
+def fp8_codes_of(blob):
+    bhi, blo = _int8_parts(blob)
+    return ((_codes_of(bhi) << 4) | (_codes_of(blo) ^ 8)).astype(np.uint8)
+
+
+def dequantize_fp8(blob, transpose=False):
+    h = header(blob)
+    bhi, _ = _int8_parts(blob)
+    probe = bhi.copy()  # scales: dequantise an all-ones int4 view of the HI plane
+    hh = header(probe)
+    probe[hh["off_q"]:hh["off_scale"]].view(np.uint32)[:] = 0x11111111
+    sc = dequantize_blob(probe)
+    w = (FP8_TABLES[h["weight_type"]][fp8_codes_of(blob)] * sc).astype(np.float32)
+    return w.T.copy() if transpose else w
+
+
 def header(blob):
     """Parse the WQH1 header (include/woq_blob.h) into a dict."""
     h = np.frombuffer(np.ascontiguousarray(blob[:HEADER_BYTES]).tobytes(), dtype=np.uint8)
@@ -305,6 +398,8 @@ def dequantize_blob(blob, transpose=False):
         return dequantize_blob(bhi, transpose) + dequantize_blob(blo, transpose)
     if h["weight_type"] in LUTS:
         return dequantize_table(blob, transpose)
+    if h["weight_type"] in FP8_TABLES:
+        return dequantize_fp8(blob, transpose)
     out = np.empty((h["N"], h["K"]) if transpose else (h["K"], h["N"]), np.float32)
     rc = lib().orc_dequantize_blob(_p(blob), _p(out), int(transpose))
     if rc != 0:
@@ -336,7 +431,8 @@ def woq_linear(x, blob, bias=None, out_dtype=F32):
     blob = _c(blob, np.uint8)
     bias = _c(bias, np.float32)
     h = header(blob)
-    if h["weight_type"] == W_INT8 or h["weight_type"] in LUTS:  # dequantise -> fp32 matmul -> + bias
+    if h["weight_type"] == W_INT8 or h["weight_type"] in LUTS or h["weight_type"] in FP8_TABLES:
+        # dequantise -> fp32 matmul -> + bias
         w = dequantize_blob(blob).astype(np.float64)
         xs = x if not h["off_shuffle"] else x[:, np.frombuffer(
             blob[h["off_shuffle"]:h["off_shuffle"] + 4 * h["K"]].tobytes(), np.int32)]

@@ -264,3 +264,20 @@ def test_library_exports_every_symbol_the_headers_declare():
     lib.woq_last_error.restype = ctypes.c_char_p
     assert isinstance(lib.woq_last_error(), bytes)
     assert ctypes.sizeof(_lib.BlobHeader) == 256 and ctypes.sizeof(_lib.EngineConfig) == 4 * 16
+
+
+def test_fp8_weight_dtype_config_on_the_hip_path():
+    """fp8 weights at the config level (reference config.py:298-299,313,335-340): "fp8" means fp8_e4m3, bits = 8,
+    symmetric only, fp32 or fp8_e8m0 ("fp8") scales; fp8_e8m0 scales are refused for integer weights."""
+    from intel_extension_for_transformers_amd.transformers import RtnConfig
+
+    c = RtnConfig(weight_dtype="fp8", scale_dtype="fp8", group_size=64)
+    c.post_init_hip()
+    assert (c.bits, c.weight_dtype, c.scale_dtype, c.scheme) == (8, "fp8_e4m3", "fp8_e8m0", "sym")
+    c = RtnConfig(bits=8, weight_dtype="fp8_e5m2", group_size=32)
+    c.post_init_hip()
+    assert (c.weight_dtype, c.scale_dtype) == ("fp8_e5m2", "fp32")
+    for kw in (dict(bits=8, weight_dtype="fp8_e4m3", sym=False), dict(bits=8, weight_dtype="fp8_e4m3", scale_dtype="bf16"),
+               dict(bits=4, scale_dtype="fp8_e8m0")):
+        with pytest.raises(ValueError):
+            RtnConfig(group_size=64, **kw).post_init_hip()

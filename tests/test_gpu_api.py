@@ -491,10 +491,12 @@ def test_from_pretrained_hf_awq_checkpoint(tmp_path):
     assert hasattr(model, "woq_engine")
 
 
-@pytest.mark.parametrize("wname", ["nf4", "fp4_e2m1"])
-def test_from_pretrained_table_weight_dtype(tmp_path, wname):
-    """RtnConfig(weight_dtype="nf4" | "fp4_e2m1") (reference docs/weightonlyquant.md dtype table): quantised on the
-    device, module path (no fused engine), logits against the fp32 twin carrying the dequantised weights."""
+@pytest.mark.parametrize("wname,bits,sname", [("nf4", 4, "fp32"), ("fp4_e2m1", 4, "fp32"), ("fp8_e4m3", 8, "fp32"),
+                                              ("fp8_e5m2", 8, "fp8_e8m0")])
+def test_from_pretrained_table_weight_dtype(tmp_path, wname, bits, sname):
+    """RtnConfig(weight_dtype="nf4" | "fp4_e2m1" | "fp8_e4m3" | "fp8_e5m2") (reference docs/weightonlyquant.md dtype
+    table; fp8 weights take fp32 or power-of-two fp8_e8m0 scales): quantised on the device, module path (no fused
+    engine), logits against the fp32 twin carrying the dequantised weights."""
     from intel_extension_for_transformers_amd import qbits
     from intel_extension_for_transformers_amd.transformers import AutoModelForCausalLM, RtnConfig
     from intel_extension_for_transformers_amd.transformers.llm.quantization.nn.modules import QuantizedLinearQBits
@@ -503,9 +505,10 @@ def test_from_pretrained_table_weight_dtype(tmp_path, wname):
     fp.generation_config.eos_token_id = None
     src = tmp_path / "fp"
     fp.save_pretrained(str(src))
-    qmodel = AutoModelForCausalLM.from_pretrained(str(src), quantization_config=RtnConfig(bits=4, group_size=64,
-                                                                                          weight_dtype=wname))
-    assert qmodel.quantization_config.weight_dtype == wname
+    qmodel = AutoModelForCausalLM.from_pretrained(str(src), quantization_config=RtnConfig(bits=bits, group_size=64,
+                                                                                          weight_dtype=wname,
+                                                                                          scale_dtype=sname))
+    assert qmodel.quantization_config.weight_dtype == wname and qmodel.quantization_config.scale_dtype == sname
     twin = copy.deepcopy(fp).cuda()
     qmods = dict(qmodel.named_modules())
     with torch.no_grad():
@@ -523,4 +526,4 @@ def test_from_pretrained_table_weight_dtype(tmp_path, wname):
     assert torch.equal(out, twin.generate(ids, max_new_tokens=4, do_sample=False, pad_token_id=0))
     assert not hasattr(qmodel, "woq_engine")
     with pytest.raises(ValueError, match="asym"):
-        RtnConfig(bits=4, weight_dtype=wname, sym=False).post_init_hip()
+        RtnConfig(bits=bits, weight_dtype=wname, sym=False).post_init_hip()

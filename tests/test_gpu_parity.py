@@ -576,3 +576,85 @@ def test_table_weight_types_quantize_dequant_linear(qbits, wname, K, N, group):
         assert (np.abs(out.cpu().numpy() - ref) <= 2e-6 * mag + 1e-5).all()
     with pytest.raises(RuntimeError, match="symmetric"):
         qbits.quantize_to_packed_weight(torch.from_numpy(w).cuda(), True, group, "fp32", wname, "fp32", True)
+
+
+# ---- fp8 weight types: fp8_e4m3, fp8_e5m2 (+ fp8_e8m0 scales) — reference strings, qbits_ut/test_weightonly.py:20-27 -----
+FP8_TYPES = {"fp8_e4m3": orc.W_FP8_E4M3, "fp8_e5m2": orc.W_FP8_E5M2}
+
+
+@pytest.mark.parametrize("wname,sname", [("fp8_e4m3", "fp32"), ("fp8_e4m3", "fp8_e8m0"), ("fp8_e5m2", "fp32"),
+                                         ("fp8_e5m2", "fp8_e8m0")])
+@pytest.mark.parametrize("K,N,group", [(512, 256, 128), (256, 48, 32), (160, 24, 64), (384, 64, -1)])
+def test_fp8_weight_types_quantize_dequant_linear(qbits, wname, sname, K, N, group):
+    """w = value(code) * scale on the OCP fp8 grids. quantize_to_packed_weight == the oracle's nearest-finite-code RTN
+    (power-of-two scales for fp8_e8m0) + the two-plane composite blob, byte for byte (rounding rule parity-unpinned,
+    DESIGN.md §4); dequantisation bit-exact; both names survive acquire_packed_weight_info; woq_linear at decode and
+    at prefill row counts, fp32 and bf16 activations, within fp32 summation error of dequantise -> matmul -> + bias;
+    asym and an fp8_e8m0 scale on a non-fp8 weight are rejected (the reference's validity matrix)."""
+    wt, e8 = FP8_TYPES[wname], sname == "fp8_e8m0"
+    rng = np.random.default_rng(61)
+    w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)  # nn.Linear layout
+    blob = qbits.quantize_to_packed_weight(torch.from_numpy(w).cuda(), True, group, "fp32", wname, sname, False)
+    q, s = orc.rtn_quantize_fp8(w, True, group, wt, e8)
+    ref_blob = orc.repack_fp8(q, s, wt, None, group, e8m0=e8)
+    got = blob.cpu().numpy().view(np.uint8)
+    assert got.size == ref_blob.size == qbits.get_packed_weight_size(K, N, wname, sname, "fp32", False, group, False)
+    assert np.array_equal(got, ref_blob)
+    deq = torch.empty(K, N, dtype=torch.float32, device="cuda")
+    qbits.dequantize_packed_weight(blob, deq, False, "fp32", wname, sname)
+    want = orc.dequantize_blob(ref_blob)
+    assert np.array_equal(deq.cpu().numpy(), want)
+    deq_t = torch.empty(N, K, dtype=torch.float32, device="cuda")
+    qbits.dequantize_packed_weight(blob, deq_t, True, "fp32", wname, sname)
+    assert np.array_equal(deq_t.cpu().numpy(), want.T)
+    name = lambda t: "".join(chr(c) for c in qbits.acquire_packed_weight_info(blob, t).tolist())  # noqa: E731
+    assert name(6) == wname and name(8) == sname
+    g = K if group == -1 else group
+    assert np.array_equal(qbits.acquire_packed_weight_info(blob, 9).cpu().numpy(), s)
+    # relative error of the grid: half a ulp of a 3- / 2-bit mantissa on the group's scale (twice that with e8m0)
+    assert np.abs(want - w.T).max() <= (2.0 ** -4 if wt == orc.W_FP8_E4M3 else 2.0 ** -3) * np.abs(w).max() * (2 if e8 else 1)
+    bias = rng.random(N, dtype=np.float32)
+    for M, adt in ((1, torch.float32), (3, torch.float32), (37, torch.float32), (5, torch.bfloat16)):
+        x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(adt)
+        xf = x.float().numpy()
+        ref = orc.woq_linear(xf, ref_blob, bias)
+        out = torch.zeros(M, N, device="cuda")
+        qbits.woq_linear(x.cuda(), blob, torch.from_numpy(bias).cuda(), out, "fp32", wname, sname, False)
+        mag = np.abs(xf) @ np.abs(want)
+        assert (np.abs(out.cpu().numpy() - ref) <= 2e-6 * mag + 1e-5).all(), M
+    with pytest.raises(RuntimeError, match="symmetric"):
+        qbits.quantize_to_packed_weight(torch.from_numpy(w).cuda(), True, group, "fp32", wname, sname, True)
+    with pytest.raises(RuntimeError, match="fp8_e8m0"):
+        qbits.quantize_to_packed_weight(torch.from_numpy(w).cuda(), True, group, "fp32", "int4_clip", "fp8_e8m0", False)
+
+
+@pytest.mark.parametrize("wname", sorted(FP8_TYPES))
+def test_fp8_repack_passes_codes_through_with_act_shuffle(qbits, wname):
+    """User-supplied code bytes (every finite code), scales and a GPTQ g_idx pass through the composite blob exactly
+    (the packq contract, qbits_ut/test_packq.py:100-109): blob bytes = oracle, g_idx comes back as the shuffle
+    indices, woq_linear applies the activation shuffle."""
+    wt = FP8_TYPES[wname]
+    K, N, group = 256, 80, 64
+    rng = np.random.default_rng(62)
+    finite = np.flatnonzero(np.isfinite(orc.FP8_TABLES[wt])).astype(np.uint8)
+    codes = finite[rng.integers(0, finite.size, (K, N))]
+    codes[:finite.size // N * N].flat[:finite.size] = finite  # every finite code at least once
+    s = (rng.random((K // group, N), dtype=np.float32) * 1e-3 + 1e-4).astype(np.float32)
+    idx = rng.permutation(np.arange(K, dtype=np.int32) // group).astype(np.int32)
+    blob = qbits.repack_quantized_weight(torch.from_numpy(codes.view(np.int8)).cuda(), torch.from_numpy(s).cuda(),
+                                         torch.empty(0, dtype=torch.int8), torch.from_numpy(idx).cuda(), wname, "fp32",
+                                         "fp32", False, group)
+    ref_blob = orc.repack_fp8(codes, s, wt, _cvt(idx, K, group), group)
+    assert np.array_equal(blob.cpu().numpy().view(np.uint8), ref_blob)
+    assert np.array_equal(orc.fp8_codes_of(ref_blob), codes)
+    assert np.array_equal(qbits.acquire_packed_weight_info(blob, 5).cpu().numpy(), _cvt(idx, K, group))
+    deq = torch.empty(K, N, dtype=torch.float32, device="cuda")
+    qbits.dequantize_packed_weight(blob, deq, False, "fp32", wname, "fp32")
+    want = orc.FP8_TABLES[wt][codes] * np.repeat(s, group, axis=0)
+    assert np.array_equal(deq.cpu().numpy(), want)
+    x = rng.standard_normal((6, K)).astype(np.float32)
+    ref = orc.woq_linear(x, ref_blob, None)
+    out = torch.zeros(6, N, device="cuda")
+    qbits.woq_linear(torch.from_numpy(x).cuda(), blob, torch.empty(0), out, "fp32", wname, "fp32", False)
+    mag = np.abs(x)[:, _cvt(idx, K, group)] @ np.abs(want)
+    assert (np.abs(out.cpu().numpy() - ref) <= 2e-6 * mag + 1e-5).all()

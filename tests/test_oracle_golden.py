@@ -207,3 +207,34 @@ def test_narrow_int_blob_is_the_int4_blob_plus_a_tag():
     assert np.array_equal(orc.dequantize_blob(b4), orc.dequant_raw(q, s, z, 128))
     with pytest.raises(AssertionError):
         orc.repack_narrow(q, s, z, None, 128, bits=2)
+
+
+@pytest.mark.parametrize("wt,tname", [(orc.W_FP8_E4M3, "float8_e4m3fn"), (orc.W_FP8_E5M2, "float8_e5m2")])
+def test_fp8_tables_and_rtn_against_torch_float8(wt, tname):
+    """Pins the fp8 restatement on an independent implementation: the 256-entry value tables equal torch's float8
+    dtypes code for code (NaN / inf codes included), and the nearest-finite-code rule reproduces torch's
+    round-to-nearest-even conversion of w / scale wherever no exact tie occurs (ties: lowest code here)."""
+    import torch
+
+    dt = getattr(torch, tname)
+    ref = torch.arange(256, dtype=torch.uint8).view(dt).float().numpy()
+    tab = orc.FP8_TABLES[wt]
+    assert np.array_equal(np.isnan(ref), np.isnan(tab)) and np.array_equal(ref[~np.isnan(ref)], tab[~np.isnan(tab)])
+    assert np.nanmax(np.where(np.isfinite(tab), tab, np.nan)) == orc.FP8_MAX[wt]
+    rng = np.random.default_rng(5)
+    w = (rng.standard_normal((48, 192)) * 0.05).astype(np.float32)
+    for e8 in (False, True):
+        q, s = orc.rtn_quantize_fp8(w, True, 64, wt, e8)
+        v = (w.T / np.repeat(s, 64, axis=0)).astype(np.float32)
+        tq = torch.from_numpy(v).to(dt).view(torch.uint8).numpy()
+        assert (tq != q).mean() <= 1e-3  # exact ties only
+        assert np.abs(v).max() <= orc.FP8_MAX[wt] * (1 + 2.0 ** -22)  # amax / (amax / max), two fp32 roundings
+        if e8:
+            assert np.all(np.frexp(s)[0] == 0.5)  # powers of two
+            assert np.all(s >= np.abs(w.T).reshape(3, 64, 48).max(1) / np.float32(orc.FP8_MAX[wt]))
+        blob = orc.repack_fp8(q, s, wt, None, 64, e8m0=e8)
+        h = orc.header(blob)
+        assert h["weight_type"] == wt and bool(h["flags"] & orc.FLAG_SCALE_E8M0) == e8
+        assert h["scale_type"] == (orc.BF16 if e8 else orc.F32)
+        assert np.array_equal(orc.fp8_codes_of(blob), q)
+        assert np.array_equal(orc.dequantize_blob(blob), tab[q] * np.repeat(s, 64, axis=0))
