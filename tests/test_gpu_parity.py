@@ -238,7 +238,7 @@ def test_errors_are_runtime_errors(qbits):
         qbits.woq_linear(torch.rand(1, 64).double().cuda(), blob, torch.empty(0), torch.zeros(1, 32).cuda(), "fp32",
                          "int4_clip", "fp32", False)
     with pytest.raises(RuntimeError, match="[Qq]bits"):
-        qbits.quantize_to_packed_weight(torch.rand(64, 32).cuda(), False, 32, "fp32", "fp8_e4m3", "fp32", False)
+        qbits.quantize_to_packed_weight(torch.rand(64, 32).cuda(), False, 32, "fp32", "int5_clip", "fp32", False)
 
 
 @pytest.mark.parametrize("K,N,group,asym", [(512, 1024, 128, False), (512, 1024, 128, True), (256, 48, 32, True),
@@ -534,7 +534,7 @@ def test_shape_and_type_errors_keep_the_reference_prefix(qbits):
         qbits.woq_linear(torch.zeros(2, 256, device="cuda", dtype=torch.float64), blob, torch.empty(0),
                          torch.zeros(2, 48, device="cuda"), "fp32", "int4_clip", "fp32", False)
     with pytest.raises(RuntimeError, match="[Qq]bits: unsupported bestla packq config"):
-        qbits.get_packed_weight_size(256, 48, "fp8_e5m2", "fp32", "fp32", False, 32, False)
+        qbits.get_packed_weight_size(256, 48, "int5_clip", "fp32", "fp32", False, 32, False)
     with pytest.raises(RuntimeError, match="QBits: unsupported blocksize"):
         qbits.get_packed_weight_size(256, 48, "int4_clip", "fp32", "fp32", False, 48, False)
     with pytest.raises(RuntimeError, match="QBits: not a WQH1 packed weight"):
