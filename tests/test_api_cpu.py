@@ -281,3 +281,30 @@ def test_fp8_weight_dtype_config_on_the_hip_path():
                dict(bits=4, scale_dtype="fp8_e8m0")):
         with pytest.raises(ValueError):
             RtnConfig(group_size=64, **kw).post_init_hip()
+
+
+def test_plain_c_client_of_the_abi(tmp_path):
+    """include/woq_blob.h + include/woq_hip.h are valid C99 (what a cgo / JNI / FFI binding would include), and a
+    plain-C program links against libwoq_hip.so and agrees with the library on the blob geometry of every weight
+    type (examples/c_client.c: host arithmetic only, no GPU call)."""
+    import os
+    import shutil
+    import subprocess
+
+    from intel_extension_for_transformers_amd import _lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("needs gcc and a built libwoq_hip.so")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "c_client")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "c_client.c"), "-L" + libdir, "-lwoq_hip",
+                    "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "host checks ok" in out
+    first = out.splitlines()[0].split()
+    assert first[0] == "int4" and first[1] == first[2]
+    from oracle import woq_oracle as orc
+
+    assert int(first[1]) == orc.packed_size(4096, 11008, 128, orc.F16, False, False)
