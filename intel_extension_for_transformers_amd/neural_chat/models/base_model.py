@@ -83,11 +83,13 @@ class BaseModel:
         return conv.get_prompt()
 
     def predict_stream(self, query, origin_query="", config=None):
-        """Generator of text pieces; with config.return_stats the reference's trailing stats block follows
-        (model_utils.py:1340-1380, format v1 / v2)."""
+        """-> (generator of text pieces, link) like the reference (base_model.py:150-273: `return response, link`;
+        `link` is the retrieval plugin's source list, always empty here — plugins are out of scope). With
+        config.return_stats the reference's trailing stats block follows the text (model_utils.py:1340-1380,
+        format v1 / v2)."""
         config = config or GenerationConfig()
         prompt = self.prepare_prompt(query, config)
-        return self._stream(prompt, config)
+        return self._stream(prompt, config), []
 
     def predict(self, query, origin_query="", config=None):
         config = config or GenerationConfig()

@@ -252,7 +252,9 @@ def test_neural_chat_build_chatbot_predict_and_stream(tmp_path):
     q = "w5 w17 w200 w3 w77"
     cfg = GenerationConfig(max_new_tokens=8, do_sample=False, repetition_penalty=1.0)
     text = bot.predict(q, config=cfg)
-    pieces = list(bot.predict_stream(q, config=cfg))
+    stream, link = bot.predict_stream(q, config=cfg)  # (generator, link) like the reference
+    assert link == []
+    pieces = list(stream)
     assert "".join(pieces) == text and len(text.split()) == 8
     # the module path (HF generate over the QuantizedLinearQBits model) gives the same greedy continuation
     bot_engine, bot.engine = bot.engine, None
@@ -264,7 +266,7 @@ def test_neural_chat_build_chatbot_predict_and_stream(tmp_path):
         bot.model._woq_engine_off = False
     # sampling -> HF generate + streamer thread; stats block in the v2 table format
     scfg = GenerationConfig(max_new_tokens=5, do_sample=True, temperature=0.7, return_stats=True)
-    out = list(bot.predict_stream(q, config=scfg))
+    out = list(bot.predict_stream(q, config=scfg)[0])
     joined = "".join(out)
     assert "| Key" in joined and "msecond_per_token" in joined and "input_token_len" in joined
 

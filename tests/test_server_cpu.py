@@ -1,0 +1,173 @@
+"""The OpenAI-compatible text-chat routes (neural_chat/server/restful/textchat_api.py) over a stand-in chatbot: routes,
+request validation, prompt construction through the conversation template, response / SSE objects, stop strings.
+The generation behind `predict` / `predict_stream` is GPU work and is covered by tests/test_gpu_api.py; here the
+chatbot is a stub with the same surface (reference route: neural_chat/server/restful/textchat_api.py:374-713)."""
+import json
+
+import pytest
+
+fastapi = pytest.importorskip("fastapi")
+pytest.importorskip("httpx")
+from fastapi.testclient import TestClient  # noqa: E402
+
+from intel_extension_for_transformers_amd.neural_chat.prompts import get_conv_template  # noqa: E402
+from intel_extension_for_transformers_amd.neural_chat.server import create_app  # noqa: E402
+
+
+class _Tok:
+    def __call__(self, text):
+        class R:
+            input_ids = text.split()
+        return R
+
+
+class _Bot:
+    """Echo model: answers with `reply`, streamed word by word; records what it was asked."""
+
+    def __init__(self, template="llama-2", reply="the quick brown fox STOP jumps"):
+        self.model_name = "/models/tiny-llama-2-7b-chat"
+        self.conv_template = get_conv_template(template)
+        self.tokenizer = _Tok()
+        self.reply = reply
+        self.calls = []
+
+    def predict(self, query, origin_query="", config=None):
+        self.calls.append((query, config))
+        return self.reply
+
+    def predict_stream(self, query, origin_query="", config=None):
+        self.calls.append((query, config))
+
+        def gen():
+            words = self.reply.split(" ")
+            for i, w in enumerate(words):
+                yield w + (" " if i + 1 < len(words) else "")
+        return gen(), []
+
+
+@pytest.fixture()
+def client():
+    bot = _Bot()
+    c = TestClient(create_app(bot))
+    c.bot = bot
+    return c
+
+
+def _events(resp):
+    out = []
+    for line in resp.text.split("\n\n"):
+        if line.startswith("data: "):
+            body = line[len("data: "):]
+            out.append(body if body == "[DONE]" else json.loads(body))
+    return out
+
+
+def test_health_and_models(client):
+    assert client.get("/health").status_code == 200
+    for r in (client.post("/v1/models"), client.get("/v1/models")):
+        body = r.json()
+        assert body["object"] == "list" and body["data"][0]["id"] == client.bot.model_name
+        assert body["data"][0]["owned_by"] == "neuralchat"
+
+
+def test_chat_completion_builds_the_template_prompt_and_answers(client):
+    r = client.post("/v1/chat/completions", json={
+        "model": "llama-2-7b-chat",  # substring of the served model's name, like the reference's check_model
+        "messages": [{"role": "system", "content": "Be brief."}, {"role": "user", "content": "Hi"},
+                     {"role": "assistant", "content": "Hello."}, {"role": "user", "content": "Name a fox."}],
+        "max_tokens": 32})
+    assert r.status_code == 200
+    body = r.json()
+    assert body["object"] == "chat.completion" and body["id"].startswith("chatcmpl-")
+    ch = body["choices"][0]
+    assert ch["message"] == {"role": "assistant", "content": client.bot.reply} and ch["finish_reason"] == "stop"
+    prompt, cfg = client.bot.calls[-1]
+    assert prompt == ("[INST] <<SYS>>\nBe brief.\n<</SYS>>\n\nHi [/INST] Hello. </s><s>[INST] Name a fox. [/INST]")
+    # the route's OpenAI defaults (temperature 0.7, top_k 1) mean greedy: the request rides the fused engine
+    assert cfg.do_sample is False and cfg.max_new_tokens == 32 and cfg.task == "chat"
+    u = body["usage"]
+    assert u["completion_tokens"] == 6 and u["total_tokens"] == u["prompt_tokens"] + 6
+    # a plain string is the prompt as it stands; sampling when asked for
+    client.post("/v1/chat/completions", json={"model": "llama-2", "messages": "raw text", "temperature": 0.9,
+                                              "top_k": 40, "top_p": 0.8})
+    prompt, cfg = client.bot.calls[-1]
+    assert prompt == "raw text" and cfg.do_sample is True and (cfg.top_k, cfg.top_p, cfg.max_new_tokens) == (40, 0.8, 512)
+
+
+def test_chat_completion_stop_strings_and_n(client):
+    r = client.post("/v1/chat/completions", json={"model": "llama-2", "messages": "x", "stop": ["STOP", "zzz"], "n": 2})
+    body = r.json()
+    assert [c["index"] for c in body["choices"]] == [0, 1]
+    assert all(c["message"]["content"] == "the quick brown fox " and c["finish_reason"] == "stop"
+               for c in body["choices"])
+    # finish_reason "length" when the answer fills max_tokens
+    r = client.post("/v1/chat/completions", json={"model": "llama-2", "messages": "x", "max_tokens": 6})
+    assert r.json()["choices"][0]["finish_reason"] == "length"
+
+
+def test_chat_completion_stream_is_an_event_stream_of_deltas(client):
+    with client.stream("POST", "/v1/chat/completions", json={"model": "llama-2", "messages": "x", "stream": True,
+                                                             "stop": "STOP"}) as r:
+        assert r.status_code == 200 and r.headers["content-type"].startswith("text/event-stream")
+        r.read()
+        ev = _events(r)
+    assert ev[-1] == "[DONE]"
+    assert ev[0]["object"] == "chat.completion.chunk" and ev[0]["choices"][0]["delta"] == {"role": "assistant"}
+    text = "".join(e["choices"][0]["delta"].get("content", "") for e in ev[1:-1])
+    assert text == "the quick brown fox "  # spaces survive (the reference's re-split on whitespace drops them)
+    assert ev[-2]["choices"][0]["finish_reason"] == "stop" and ev[-2]["choices"][0]["delta"] == {}
+    assert len({e["id"] for e in ev[:-1]}) == 1
+
+
+def test_completions_route(client):
+    r = client.post("/v1/completions", json={"model": "llama-2", "prompt": ["a b", "c"], "echo": True})
+    body = r.json()
+    assert body["object"] == "text_completion" and len(body["choices"]) == 2
+    assert body["choices"][0]["text"] == "a b" + client.bot.reply and body["choices"][1]["index"] == 1
+    assert client.bot.calls[-1][1].max_new_tokens == 16 and body["usage"]["prompt_tokens"] == 3
+    with client.stream("POST", "/v1/completions", json={"model": "llama-2", "prompt": "p", "stream": True}) as r:
+        r.read()
+        ev = _events(r)
+    assert "".join(e["choices"][0]["text"] for e in ev[:-1]) == client.bot.reply and ev[-1] == "[DONE]"
+
+
+def test_errors_have_the_reference_shape(client):
+    r = client.post("/v1/chat/completions", json={"model": "gpt-4", "messages": "x"})
+    assert r.status_code == 404 and r.json() == {"object": "error", "message": "The model `gpt-4` does not exist.",
+                                                 "code": 404}
+    for bad, frag in (({"max_tokens": 0}, "max_tokens"), ({"n": 0}, "'n'"), ({"temperature": 2.5}, "temperature"),
+                      ({"top_p": 1.5}, "top_p"), ({"top_k": 0}, "top_k")):
+        r = client.post("/v1/chat/completions", json=dict({"model": "llama-2", "messages": "x"}, **bad))
+        assert r.status_code == 400 and r.json()["object"] == "error" and frag in r.json()["message"]
+    r = client.post("/v1/chat/completions", json={"model": "llama-2", "messages": [{"role": "tool", "content": "x"}]})
+    assert r.status_code == 400 and "Unknown role" in r.json()["message"]
+    assert client.post("/v1/chat/completions", json={"messages": "x"}).status_code == 422  # pydantic: model missing
+
+
+def test_generation_errors_surface_as_500_and_in_band_on_streams():
+    class Broken(_Bot):
+        def predict(self, query, origin_query="", config=None):
+            raise RuntimeError("QBits: HIP library missing")
+
+        def predict_stream(self, query, origin_query="", config=None):
+            def gen():
+                yield "a "
+                raise RuntimeError("QBits: device lost")
+            return gen(), []
+
+    c = TestClient(create_app(Broken()))
+    r = c.post("/v1/chat/completions", json={"model": "llama-2", "messages": "x"})
+    assert r.status_code == 500 and "QBits: HIP library missing" in r.json()["message"]
+    with c.stream("POST", "/v1/chat/completions", json={"model": "llama-2", "messages": "x", "stream": True}) as r:
+        r.read()
+        ev = _events(r)
+    assert ev[-1] == "[DONE]" and ev[-2] == {"text": "QBits: device lost", "error_code": 500}
+
+
+def test_deepspeed_fanout_is_refused():
+    from intel_extension_for_transformers_amd.neural_chat.server.restful import TextChatAPIRouter
+
+    with pytest.raises(NotImplementedError):
+        TextChatAPIRouter().set_chatbot(_Bot(), use_deepspeed=True, world_size=8)
+    with pytest.raises(RuntimeError, match="has not been set"):
+        TextChatAPIRouter().get_chatbot()
