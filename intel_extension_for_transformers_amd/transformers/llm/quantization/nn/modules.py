@@ -10,6 +10,8 @@ Differences that are deliberate (SURVEY.md §3.2 "overheads the GPU build should
   * the packed blob's header is parsed once per tensor, not per call (bestla_weightonly_dispatcher.cpp:335);
   * there is no CPU fallback: without the HIP library / a GPU the module raises (parity claims depend on it).
 """
+import os
+
 import torch
 
 from ..... import qbits
@@ -88,7 +90,10 @@ class QuantizedLinearQBits(torch.nn.Linear):
             bias = self._bias32 = self.bias.detach().to(x.device, torch.float32).contiguous()
         qbits.woq_linear(x2, self.weight.data, bias if bias is not None else _EMPTY_F32, out, self.compute_dtype,
                          self.weight_dtype, self.scale_dtype, self.scheme == "asym")
-        return out.view(*shape, self.out_features)
+        out = out.view(*shape, self.out_features)
+        if os.environ.get("backend", None) == "use_vllm":  # vLLM's linear layers return (output, output_bias):
+            return out, None                               # the reference's seam, modules.py:166-167
+        return out
 
     # ---- load-time (reference modules.py:171-262) -----------------------------------------------------------------
     def _adopt(self, packw, bias):

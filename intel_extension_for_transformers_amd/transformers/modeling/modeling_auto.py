@@ -312,6 +312,14 @@ class _BaseAutoModelClass:
             raise RuntimeError("QBits: the MI355X backend has no CPU path; use device_map='cuda'")
         if kwargs.pop("use_neural_speed", False) or kwargs.pop("use_llm_runtime", False):
             logger.warning("use_neural_speed is an x86 runtime switch; ignored on the MI355X backend")
+        if kwargs.pop("use_vllm", None):
+            # reference modeling_auto.py:364-480 builds a vllm.LLM, swaps its parallel linears for torch linears,
+            # reloads the weights and quantises them. vLLM is not part of this image; what this build keeps of that
+            # seam is the module-side contract (QuantizedLinearQBits.forward returns (output, None) under
+            # backend=use_vllm), so the same surgery works where vLLM exists.
+            raise RuntimeError("QBits: use_vllm needs the vllm package, which this build does not ship; the "
+                               "quantised linear honours vLLM's (output, bias) return convention under "
+                               "backend=use_vllm")
         qcfg = kwargs.pop("quantization_config", None)
         load_in_4bit = kwargs.pop("load_in_4bit", False)
         load_in_8bit = kwargs.pop("load_in_8bit", False)

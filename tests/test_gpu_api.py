@@ -529,3 +529,22 @@ def test_from_pretrained_table_weight_dtype(tmp_path, wname, bits, sname):
     assert not hasattr(qmodel, "woq_engine")
     with pytest.raises(ValueError, match="asym"):
         RtnConfig(bits=bits, weight_dtype=wname, sym=False).post_init_hip()
+
+
+def test_quantized_linear_vllm_return_convention(monkeypatch):
+    """backend=use_vllm (set by the reference's from_pretrained(use_vllm=True), modeling_auto.py:364-480): forward
+    returns vLLM's (output, output_bias) pair so the module can stand in for vLLM's parallel linears
+    (reference modules.py:166-167)."""
+    from intel_extension_for_transformers_amd.transformers.llm.quantization.nn.modules import QuantizedLinearQBits
+
+    torch.manual_seed(4)
+    lin = QuantizedLinearQBits(128, 32, True, compute_dtype="fp32", weight_dtype="int4_clip", scale_dtype="fp32",
+                               blocksize=64, scheme="sym")
+    lin.set_fp_weights_bias(torch.randn(32, 128) * 0.05, torch.randn(32))
+    x = torch.randn(3, 128, device="cuda")
+    monkeypatch.delenv("backend", raising=False)
+    plain = lin(x)
+    assert isinstance(plain, torch.Tensor) and plain.shape == (3, 32)
+    monkeypatch.setenv("backend", "use_vllm")
+    out, out_bias = lin(x)
+    assert out_bias is None and torch.equal(out, plain)
