@@ -360,3 +360,28 @@ def test_sliced_attention_grouped_queries_rep4_fp8(grouped):
         if i in (0, 1, 15, 16, 63, 64, 65, 127, 128, 149):
             la, lb = a.logits.cpu().numpy(), b.logits.cpu().numpy()
             assert np.abs(la - lb).max() <= rtol * np.abs(lb).max() + atol, i
+
+
+@pytest.mark.parametrize("rep,kv_dtype", [(4, torch.float16), (8, torch.float8_e4m3fn), (2, torch.float16)])
+def test_grouped_attention_long_slices_match_per_head_slices(rep, kv_dtype):
+    """The grouped-query form at a context where every wave walks several sub-tiles (1000 cached positions in 2
+    slices of 512: 16 sub-tiles per slice, 4 per wave — both register sets, both refills, a ragged last sub-tile),
+    against the per-query-head slices on an identical cache (same chunked prompt pass on both engines). Explicit
+    tokens at explicit positions, so the two engines never branch on a near-tie."""
+    kw = dict(seed=11, max_ctx=1100, head_dim=128, hidden=128 * rep, kv_dtype=kv_dtype, attn_splits=2)
+    a, _, cfg = _tiny(128, False, "fp16", attn_grouped=True, **kw)
+    b, _, _ = _tiny(128, False, "fp16", **kw)
+    assert cfg["heads"] == rep and cfg["kv_heads"] == 1
+    rng = np.random.default_rng(12)
+    prompt = rng.integers(0, cfg["vocab"], 1000)
+    for e in (a, b):
+        for s0 in range(0, 1000, 250):
+            e.prefill(prompt[s0:s0 + 250].tolist(), start_pos=s0)
+    assert torch.equal(a.kv_cache("k")[0, :, :1000].float(), b.kv_cache("k")[0, :, :1000].float())
+    for j, t in enumerate(rng.integers(0, cfg["vocab"], 4).tolist()):
+        for e in (a, b):
+            e.token.fill_(t)
+            e.pos.fill_(1000 + j)
+            e.step(greedy=False)
+        la, lb = a.logits.cpu().numpy(), b.logits.cpu().numpy()
+        assert np.abs(la - lb).max() <= 2e-3 * np.abs(lb).max() + 1e-4, j
