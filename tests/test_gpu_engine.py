@@ -368,7 +368,7 @@ def test_grouped_attention_long_slices_match_per_head_slices(rep, kv_dtype):
     slices of 512: 16 sub-tiles per slice, 4 per wave — both register sets, both refills, a ragged last sub-tile),
     against the per-query-head slices on an identical cache (same chunked prompt pass on both engines). Explicit
     tokens at explicit positions, so the two engines never branch on a near-tie."""
-    kw = dict(seed=11, max_ctx=1100, head_dim=128, hidden=128 * rep, kv_dtype=kv_dtype, attn_splits=2)
+    kw = dict(seed=11, max_ctx=1280, head_dim=128, hidden=128 * rep, kv_dtype=kv_dtype, attn_splits=2)
     a, _, cfg = _tiny(128, False, "fp16", attn_grouped=True, **kw)
     b, _, _ = _tiny(128, False, "fp16", **kw)
     assert cfg["heads"] == rep and cfg["kv_heads"] == 1
