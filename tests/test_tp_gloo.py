@@ -128,3 +128,42 @@ def test_sharding_rules():
     for k in (8192, 28672):
         assert (k // 8) % 128 == 0
     assert tp.shard_vocab(np.zeros((100, 4)), 1, 2).shape == (50, 4)
+
+
+def _greedy_rank(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from intel_extension_for_transformers_amd.runtime import tp
+
+    rng = np.random.default_rng(7)
+    picks = []
+    for vocab in (100, 101, 7, 2, 1):  # even split, ragged last shard, tiny vocabularies (an empty shard on rank 1)
+        for case in range(4):
+            row = rng.standard_normal(vocab).astype(np.float32)
+            if case == 1:  # the maximum twice, once per shard: the lower index wins
+                row[vocab - 1] = row[0] = 9.0
+            if case == 2 and vocab > 3:  # twice inside one shard
+                row[2] = row[1] = 9.0
+            if case == 3:  # all equal
+                row[:] = 0.5
+            local = torch.from_numpy(np.ascontiguousarray(tp.shard_vocab(row[:, None], rank, world)[:, 0]))
+            got = int(tp.greedy_token(local, vocab))
+            gathered = tp.gather_logits(local, vocab).numpy()
+            assert np.array_equal(gathered, row)
+            picks.append((got, int(np.argmax(row))))
+    if rank == 0:
+        np.save(os.path.join(out_dir, "picks.npy"), np.array(picks))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_greedy_token_pair_exchange_matches_argmax_of_gathered_logits(tmp_path):
+    """tp.greedy_token: one (max, global index) pair per rank instead of the logits all-gather; equals numpy's argmax
+    (first maximum) of the full row for even and ragged vocab splits, ties across and inside shards, and a rank whose
+    shard is empty."""
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    mp.spawn(_greedy_rank, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    picks = np.load(tmp_path / "picks.npy")
+    assert len(picks) == 20 and np.array_equal(picks[:, 0], picks[:, 1])
