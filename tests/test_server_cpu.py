@@ -171,3 +171,34 @@ def test_deepspeed_fanout_is_refused():
         TextChatAPIRouter().set_chatbot(_Bot(), use_deepspeed=True, world_size=8)
     with pytest.raises(RuntimeError, match="has not been set"):
         TextChatAPIRouter().get_chatbot()
+
+
+def test_server_yaml_maps_to_pipeline_config(tmp_path):
+    """The reference's server YAML (neuralchat_server.py:250-300) for the keys of this path: weight-only RTN / GPTQ /
+    mixed precision blocks become the same config objects; other back ends' switches and plugins are refused."""
+    from intel_extension_for_transformers_amd.neural_chat.server import pipeline_config_from_yaml
+    from intel_extension_for_transformers_amd.transformers import GPTQConfig, MixedPrecisionConfig, RtnConfig
+
+    y = tmp_path / "neuralchat.yaml"
+    y.write_text("host: 0.0.0.0\nport: 8123\nmodel_name_or_path: /models/llama-2-7b-chat\ndevice: auto\n"
+                 "tasks_list: ['textchat']\n"
+                 "optimization:\n  optimization_type: weight_only\n  compute_dtype: fp32\n  weight_dtype: int4\n"
+                 "  group_size: 128\n  scale_dtype: fp16\n")
+    pc, host, port = pipeline_config_from_yaml(str(y))
+    assert (host, port, pc.device, pc.task) == ("0.0.0.0", 8123, "cuda", "chat")
+    oc = pc.optimization_config
+    assert isinstance(oc, RtnConfig) and (oc.bits, oc.group_size, oc.scale_dtype, oc.compute_dtype) == (4, 128, "fp16",
+                                                                                                      "fp32")
+    pc, _, _ = pipeline_config_from_yaml({"model_name_or_path": "m", "optimization": {
+        "optimization_type": "weight_only", "use_gptq": True}})
+    assert isinstance(pc.optimization_config, GPTQConfig) and pc.optimization_config.bits == 4
+    pc, host, port = pipeline_config_from_yaml({"model_name_or_path": "m", "optimization": {
+        "optimization_type": "mix_precision", "mix_precision_dtype": "bfloat16"}})
+    assert isinstance(pc.optimization_config, MixedPrecisionConfig) and pc.optimization_config.dtype == "bfloat16"
+    assert (host, port) == ("127.0.0.1", 8000)
+    assert isinstance(pipeline_config_from_yaml({"model_name_or_path": "m"})[0].optimization_config,
+                      MixedPrecisionConfig)  # the reference's default on a GPU: fp16
+    for bad in ({"optimization": {"optimization_type": "bits_and_bytes"}}, {"optimization": {"use_neural_speed": True}},
+                {"retrieval": {"enable": True}}, {"use_deepspeed": True}, {"tasks_list": ["textchat", "voicechat"]}):
+        with pytest.raises(ValueError, match="QBits"):
+            pipeline_config_from_yaml(dict({"model_name_or_path": "m"}, **bad))
