@@ -16,6 +16,7 @@ import torch
 
 from ..... import qbits
 from ..... import _lib as L
+from ..autograd import matmul_kbit
 
 
 class ParamsQBits(torch.nn.Parameter):
@@ -88,8 +89,10 @@ class QuantizedLinearQBits(torch.nn.Linear):
         bias = self._bias32
         if bias is None and self.bias is not None:
             bias = self._bias32 = self.bias.detach().to(x.device, torch.float32).contiguous()
-        qbits.woq_linear(x2, self.weight.data, bias if bias is not None else _EMPTY_F32, out, self.compute_dtype,
-                         self.weight_dtype, self.scale_dtype, self.scheme == "asym")
+        # reference modules.py:155-164: matmul_kbit -> qbits.woq_linear, or the dequantise -> matmul reference arm
+        # under QBITS_DEBUG (autograd/functions.py:184-217)
+        out = matmul_kbit(x2, self.weight, bias, out, self.compute_dtype, self.weight_dtype, self.scale_dtype,
+                          self.scheme, do_dequant=False)
         out = out.view(*shape, self.out_features)
         if os.environ.get("backend", None) == "use_vllm":  # vLLM's linear layers return (output, output_bias):
             return out, None                               # the reference's seam, modules.py:166-167

@@ -265,9 +265,11 @@ ORC_API int orc_repack(const int8_t* q, const float* scales, const int8_t* zp, c
   memset(blob, 0, h.total_bytes);
   memcpy(blob, &h, sizeof(h));
   uint8_t* qd = blob + h.off_q;
-  /* padding nibble = 0 (q = 0, signed two's-complement nibbles): the memset above did it */
-  for (int k = 0; k < K; ++k)
-    for (int n = 0; n < N; ++n) {
+  /* padding nibble = 0 (q = 0, signed two's-complement nibbles): the memset above did it.
+   * A qdata byte holds two nibbles of ONE column (woq_blob.h: a lane owns a column), so columns are independent. */
+#pragma omp parallel for schedule(static)
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k) {
       int shift;
       size_t b = woq_q_byte(&h, k, n, &shift);
       uint8_t u = (uint8_t)(q[(size_t)k * N + n] & 0xf); /* two's-complement nibble of q in [-8,7] */
@@ -345,25 +347,27 @@ ORC_API int orc_woq_linear(const float* x, int lda, const uint8_t* blob, const f
   if (!W) return -1;
   orc_dequantize_blob(blob, W, 0);
   const int32_t* shuf = h.off_shuffle ? (const int32_t*)(blob + h.off_shuffle) : NULL;
-#pragma omp parallel
-  {
-    double* acc = (double*)malloc((size_t)h.N * sizeof(double));
-#pragma omp for schedule(static)
-    for (int m = 0; m < M; ++m) {
-      for (int n = 0; n < h.N; ++n) acc[n] = 0.0;
+  /* every output is the same k-sequential double sum whichever loop is parallel: rows for many-row calls, 64-column
+   * blocks for the few-row calls (full-size decode shapes at M = 1 then use every host core) */
+  const int CBLK = 64;
+  const int n_blk = (h.N + CBLK - 1) / CBLK;
+#pragma omp parallel for schedule(static) collapse(2)
+  for (int m = 0; m < M; ++m)
+    for (int nb = 0; nb < n_blk; ++nb) {
+      double acc[64];
+      const int n0 = nb * CBLK, n1 = n0 + CBLK > h.N ? h.N : n0 + CBLK;
+      for (int n = n0; n < n1; ++n) acc[n - n0] = 0.0;
       for (int k = 0; k < h.K; ++k) {
         double xv = (double)x[(size_t)m * lda + (shuf ? shuf[k] : k)];
         const float* wr = W + (size_t)k * h.N;
-        for (int n = 0; n < h.N; ++n) acc[n] += xv * (double)wr[n];
+        for (int n = n0; n < n1; ++n) acc[n - n0] += xv * (double)wr[n];
       }
-      for (int n = 0; n < h.N; ++n) {
-        float r = (float)acc[n];
+      for (int n = n0; n < n1; ++n) {
+        float r = (float)acc[n - n0];
         if (bias) r += bias[n];
         orc_store_scalar(out, (size_t)m * ldo + n, out_dtype, r);
       }
     }
-    free(acc);
-  }
   free(W);
   return 0;
 }

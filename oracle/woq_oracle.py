@@ -520,7 +520,8 @@ class LlamaOracle:
     Composition follows HF LlamaDecoderLayer (RMSNorm -> q/k/v -> RoPE -> attention + KV cache ->
     o ; RMSNorm -> gate/up -> SiLU*mul -> down), which is what the reference executes around its
     QuantizedLinearQBits modules. `layers` is a list of dicts with blobs
-    'q','k','v','o','gate','up','down' (numpy uint8 WQH1 blobs) and 'ln1','ln2' fp32 vectors.
+    'q','k','v','o','gate','up','down' (numpy uint8 WQH1 blobs) and 'ln1','ln2' fp32 vectors; 'qkv' (q | k | v
+    along N) and 'gate_up' (16-column tiles interleaved) may replace the separate projections.
     """
 
     def __init__(self, cfg, embed, layers, norm, lm_head):
@@ -544,9 +545,15 @@ class LlamaOracle:
         h = self.embed[token].reshape(1, -1).copy()
         for li, ly in enumerate(self.layers):
             x = rmsnorm(h, ly["ln1"], c["eps"])
-            q = woq_linear(x, ly["q"]).reshape(1, H, D)
-            k = woq_linear(x, ly["k"]).reshape(1, KV, D)
-            v = woq_linear(x, ly["v"]).reshape(1, KV, D)
+            if "qkv" in ly:  # one blob with q | k | v concatenated along N (the engine's fused layout)
+                qkv = woq_linear(x, ly["qkv"])
+                q = qkv[:, :H * D].reshape(1, H, D)
+                k = qkv[:, H * D:(H + KV) * D].reshape(1, KV, D)
+                v = qkv[:, (H + KV) * D:].reshape(1, KV, D)
+            else:
+                q = woq_linear(x, ly["q"]).reshape(1, H, D)
+                k = woq_linear(x, ly["k"]).reshape(1, KV, D)
+                v = woq_linear(x, ly["v"]).reshape(1, KV, D)
             q = rope(q, [pos], c["theta"])
             k = rope(k, [pos], c["theta"])
             self.k[li] = np.concatenate([self.k[li], k], 0)
@@ -556,8 +563,13 @@ class LlamaOracle:
             a = attn_decode(q[0], kk, vv).reshape(1, H * D)
             h = h + woq_linear(a, ly["o"])
             x = rmsnorm(h, ly["ln2"], c["eps"])
-            g = woq_linear(x, ly["gate"])
-            u = woq_linear(x, ly["up"])
+            if "gate_up" in ly:  # 16-column tiles interleaved gate, up, gate, up, ... (runtime.fuse_gate_up)
+                gu = woq_linear(x, ly["gate_up"]).reshape(1, -1, 2, 16)
+                g = np.ascontiguousarray(gu[:, :, 0, :]).reshape(1, -1)
+                u = np.ascontiguousarray(gu[:, :, 1, :]).reshape(1, -1)
+            else:
+                g = woq_linear(x, ly["gate"])
+                u = woq_linear(x, ly["up"])
             h = h + woq_linear(silu_mul(g, u), ly["down"])
         x = rmsnorm(h, self.norm, c["eps"])
         return (x.astype(np.float64) @ self.lm_head.astype(np.float64).T).astype(np.float32)[0]

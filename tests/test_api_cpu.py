@@ -308,3 +308,24 @@ def test_plain_c_client_of_the_abi(tmp_path):
     from oracle import woq_oracle as orc
 
     assert int(first[1]) == orc.packed_size(4096, 11008, 128, orc.F16, False, False)
+
+
+def test_matmul_kbit_seam_host_logic(monkeypatch):
+    """autograd/functions.py under the reference's names: the acquire-type enum values (functions.py:29-38,
+    bestla_packq_impl.hpp:18-31), the QBITS_DEBUG switch read per call (:108,:203), the training form refused."""
+    from intel_extension_for_transformers_amd.transformers.llm.quantization import autograd
+    from intel_extension_for_transformers_amd.transformers.llm.quantization.autograd import functions as F
+
+    assert callable(autograd.matmul_kbit) and callable(autograd.qbits_woq_linear_ref_impl)
+    T = F.qbits_acquire_type
+    assert [T.SIZE.value, T.BLOCKSIZE.value, T.K.value, T.N.value, T.ACT_SHUFFLE.value, T.G_IDX.value,
+            T.WEI_TYPE.value, T.CMPT_TYPE.value, T.SCALE_TYPE.value] == list(range(9))
+    monkeypatch.delenv("QBITS_DEBUG", raising=False)
+    assert not F.qbits_debug_enabled()
+    monkeypatch.setenv("QBITS_DEBUG", "NULL")
+    assert not F.qbits_debug_enabled()
+    monkeypatch.setenv("QBITS_DEBUG", "1")
+    assert F.qbits_debug_enabled()
+    with pytest.raises(NotImplementedError):
+        F.matmul_kbit(torch.zeros(1, 4), torch.zeros(4, dtype=torch.int8), None, torch.zeros(1, 4), "fp32", "int4_clip",
+                      "fp32", "sym", do_dequant=True)
