@@ -1,28 +1,29 @@
 #!/usr/bin/env python3
 """bench.py — the driver's measurement contract for the int4-WOQ decode hot path.
 
-A "step" is one batch-1 decode token of a Llama-2-7B-shaped decoder (hidden 4096, inter 11008, 32 heads,
-32 layers, vocab 32000) whose 224 linears are int4 sym group-128 WQH1 blobs with fp16 scales (BASELINE.json
-configs[1]); lm_head stays fp16 like the reference (utils/config.py:836-837). Weights are synthetic random-init
-(there are no checkpoints and no network) and already resident in HBM when the timed region starts.
+  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-  python bench.py --gpus N --steps K --warmup W
+A "step" is one batch-1 greedy decode token, weights synthetic (random-init, no checkpoints / network) and resident in
+HBM when the timed region starts; barrier + synchronize on both sides, max over ranks, ONE JSON line from rank 0.
 
-N > 1: the 7B batch-1 decode path does not shard ("replicas only" for configs 1-3,5), so every
-rank runs an independent replica on its own GPU, no data-path collective; value = N*K tokens / max-over-ranks
-time ("weak" scaling). Rank 0 prints ONE JSON line.
+Which workload (`--workload auto`, the default):
+  * N = 1 on a one-GPU box  -> BASELINE.json configs[1]: Llama-2-7B int4 sym g128 (the configuration the metric is
+    quoted on). The same line carries `extra_configs`: configs[2] decode (g32 asym) and its 32 x 2048 prompt pass,
+    configs[4] (Mistral-7B shape, fp8 KV, 8k context, chunked 4 x 2048 prompt pass), and configs[3]'s single-GPU point
+    (Llama-2-70B on one GPU); `parity` (logits of the measured 32-layer model against the CPU oracle on the same
+    (q, scale, zp)), `roofline`, `cpu_baseline`.
+  * N > 1 -> configs[3]: Llama-2-70B int4 sym g128 at tensor-parallel degree N (strong scaling: the SAME model cut N
+    ways; column-parallel q/k/v/gate/up, row-parallel o/down, 2 all-reduces per layer + 1 token exchange per token,
+    SURVEY.md §8(e)). The exchange runs on the device over xGMI inside the captured graph (csrc/woq_comm.hip) after a
+    start-up self-test; if that fails on this node the run falls back to host-issued RCCL all-reduces and says so.
+  * N = 1 on a multi-GPU node (the first point of the driver's 1/2/4/8 sweep) -> the same 70B model on one GPU, so
+    that the sweep's N = 1 value is the strong-scaling base; the 7B number rides along in `extra_configs`.
 
-Extra objects in the line:
-  roofline     : dominant kernel = the int4 decode GEMV (woq::gemv_tile_kernel, csrc/woq_gemv_i8.hip). achieved = algorithmic bytes per
-                 launch (int4 payload + fp16 scales, SURVEY.md §8(d): 3 339 190 272 B / 128 launches per token)
-                 / average launch duration: HIP events on the launch stream around passes of all 128 GEMV launches back to back
-                 (boundaries between launches included, no per-launch event overhead). peak = 8000 GB/s.
-                 traffic = HBM bytes per launch from the rocprofv3 --pmc pass (profiles/*_pmc_traffic.json), or null.
-  cpu_baseline : the oracle's streaming int4 GEMV (oracle/woq_oracle.c orc_woq_gemv_stream, kind "port": the
-                 reference's BesTLA kernels are not buildable here) timed on this host's cores over ONE decoder
-                 layer's four fused linears (same bytes as the GPU's layer 0), extrapolated to 32 layers.
+Objects in the line: see DESIGN.md §6. roofline.achieved = algorithmic bytes per launch of the dominant kernel
+(woq::gemv_tile_kernel) / its average duration from HIP events on the launch stream around back-to-back passes.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -32,15 +33,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-LLAMA2_7B = dict(hidden=4096, inter=11008, heads=32, kv_heads=32, head_dim=128, layers=32, vocab=32000)
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+LLAMA2_7B = dict(name="Llama-2-7B", hidden=4096, inter=11008, heads=32, kv_heads=32, head_dim=128, layers=32, vocab=32000)
+LLAMA2_70B = dict(name="Llama-2-70B", hidden=8192, inter=28672, heads=64, kv_heads=8, head_dim=128, layers=80,
+                  vocab=32000)
+MISTRAL_7B = dict(name="Mistral-7B", hidden=4096, inter=14336, heads=32, kv_heads=8, head_dim=128, layers=32,
+                  vocab=32000)
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_COPY_GBPS = 6290.0   # measured float4-copy ceiling on the same chip (same guide)
+MFMA_PEAK_TFLOPS = 2500.0
+METRIC = "decode tokens/sec + achieved HBM GB/s, Llama-2-7B int4 WOQ, batch=1"
+DTYPE = ("int4 weights x fp32 activations as 3 x int8 fixed-point limbs on i8 MFMA (exact int32 tile sums), fp32 "
+         "across tiles")
 
 
-def algorithmic_bytes_per_token(cfg, group=128, scale_bytes=2, asym=False):
-    """int4 payload + scales (+ 4-bit zero points) of every quantised linear, unpadded."""
-    h, i = cfg["hidden"], cfg["inter"]
-    qkv_n = (cfg["heads"] + 2 * cfg["kv_heads"]) * cfg["head_dim"]
-    shapes = [(h, qkv_n), (cfg["heads"] * cfg["head_dim"], h), (h, 2 * i), (i, h)]
+def algorithmic_bytes_per_token(cfg, group=128, scale_bytes=2, asym=False, tp=1):
+    """int4 payload + scales (+ 4-bit zero points) of every quantised linear, unpadded; per rank."""
+    h, i = cfg["hidden"], cfg["inter"] // tp
+    heads, kv = cfg["heads"] // tp, max(1, cfg["kv_heads"] // tp)
+    shapes = [(h, (heads + 2 * kv) * cfg["head_dim"]), (heads * cfg["head_dim"], h), (h, 2 * i), (i, h)]
     tot = 0
     for k, n in shapes:
         g = (k + group - 1) // group
@@ -48,62 +58,68 @@ def algorithmic_bytes_per_token(cfg, group=128, scale_bytes=2, asym=False):
     return tot * cfg["layers"]
 
 
-def cpu_baseline(eng, cfg, budget_s=12.0):
-    """Time the oracle's streaming int4 GEMV on the host cores over layer 0's four fused linears."""
-    import numpy as np
-
-    from oracle import woq_oracle as orc
-
-    blobs = [b.cpu().numpy().view(np.uint8) for b in eng._keep[:4]]  # qkv, o, gate_up, down of layer 0
-    rng = np.random.default_rng(0)
-    xs = [rng.standard_normal(orc.header(b)["K"]).astype(np.float32) for b in blobs]
-    for b, x in zip(blobs, xs):  # warm (page in, thread pool)
-        orc.woq_gemv_stream(x, b)
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        for b, x in zip(blobs, xs):
-            orc.woq_gemv_stream(x, b)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or reps >= 100000:
-            break
-    t_layer = dt / reps
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return {
-        "value": 1.0 / (t_layer * cfg["layers"]),
-        "unit": "tokens/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": "oracle orc_woq_gemv_stream (fp32-accumulate streaming int4 GEMV, OpenMP) over the 4 fused "
-                  "linears of ONE Llama-2-7B layer x %d reps (%.1f s), extrapolated x32 layers; lm_head/attention "
-                  "excluded" % (reps, dt),
-    }
+def linear_params(cfg):
+    h, i, hd = cfg["hidden"], cfg["inter"], cfg["head_dim"]
+    return cfg["layers"] * (h * (cfg["heads"] + 2 * cfg["kv_heads"]) * hd + cfg["heads"] * hd * h + 3 * h * i)
 
 
-def prefill_measure(eng, cfg, n_seq, T, reps=2):
-    """Prompt pass of the same model (north_star: MFMA utilisation on the prefill side): n_seq x T synthetic tokens
-    through all layers (int4 x fp16-operand MFMA GEMMs + causal attention), after the decode timing. Not `value`."""
+def build_engine(cfg, group=128, sym=True, max_ctx=512, max_batch=1, kv_dtype=None, tp_rank=0, tp=1, seed=1234,
+                 layers=None):
     import torch
 
-    g = torch.Generator().manual_seed(4321)
-    toks = torch.randint(0, cfg["vocab"], (n_seq, T), generator=g).cuda()
-    eng.prefill(toks)
+    from intel_extension_for_transformers_amd.runtime.engine import WoqDecoderEngine, synth_llama_weights
+
+    n_layers = layers or cfg["layers"]
+    heads, kv, inter, vocab = cfg["heads"] // tp, max(1, cfg["kv_heads"] // tp), cfg["inter"] // tp, cfg["vocab"] // tp
+    eng = WoqDecoderEngine(cfg["hidden"], inter, heads, kv, cfg["head_dim"], n_layers, vocab, max_ctx=max_ctx,
+                           max_batch=max_batch, kv_dtype=kv_dtype or torch.float16, tp_rank=tp_rank, tp_size=tp)
+    synth_llama_weights(eng, cfg["hidden"], inter, heads, kv, cfg["head_dim"], n_layers, vocab, group=group, sym=sym,
+                        scale_dtype="fp16", seed=seed + tp_rank, embed_vocab=cfg["vocab"], shared_seed=seed)
+    return eng
+
+
+def free_gpu():
+    """after `del engine`: run the finalisers (woq_engine_destroy frees the engine's own buffers) and hand torch's
+    cached blocks back, so the next configuration starts from an empty device."""
+    import torch
+
+    gc.collect()
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+
+def feed_prompt(eng, vocab, n, step=None):
+    """`n` random tokens through the decode path so that the KV cache holds real entries; the last step is greedy."""
+    import torch
+
+    g = torch.Generator().manual_seed(1234)
+    prompt = torch.randint(0, vocab, (n,), generator=g).tolist()
+    for i, t in enumerate(prompt):
+        eng.token.fill_(int(t))
+        eng.pos.fill_(i)
+        (step or eng.step)(i == len(prompt) - 1)
+
+
+def timed(run, steps, warmup, fence):
+    run(warmup)
+    fence()
     t0 = time.perf_counter()
-    for _ in range(reps):
-        eng.prefill(toks)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    h, i, hd = cfg["hidden"], cfg["inter"], cfg["head_dim"]
-    params = cfg["layers"] * (h * (cfg["heads"] + 2 * cfg["kv_heads"]) * hd + cfg["heads"] * hd * h + 3 * h * i)
-    lin = 2.0 * params * n_seq * T
-    att = cfg["layers"] * n_seq * 4.0 * cfg["heads"] * hd * T * (T + 1) / 2
+    run(steps)
+    fence()
+    return time.perf_counter() - t0
+
+
+def gemv_roofline(eng, traffic=None):
+    ms, by, n_launch = eng.time_gemv(reps=4)
+    us = ms * 1e3 / (4 * n_launch)
+    achieved = (by / n_launch) / (us * 1e-6) / 1e9
     return {
-        "workload": "prompt pass, %d x %d tokens, same int4 g128 weights, fp16-operand MFMA GEMMs + causal attention, "
-                    "lm_head on the last positions" % (n_seq, T),
-        "tokens_per_s": n_seq * T / dt, "ms": dt * 1e3,
-        "achieved_tflops": (lin + att) / dt / 1e12, "linear_tflops": lin / dt / 1e12,
-        "peak_tflops": 2500.0, "mfma_frac": (lin + att) / dt / 1e12 / 2500.0,
+        "bound": "hbm",
+        "kernel": "woq::gemv_tile_kernel (int4 GEMV, M=1, csrc/woq_gemv_i8.hip)",
+        "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+        "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBPS,
+        "traffic": traffic, "us_per_launch": us, "algorithmic_bytes_per_launch": by / n_launch,
+        "launches_per_token": n_launch,
     }
 
 
@@ -124,17 +140,328 @@ def read_traffic():
         return None
 
 
+def prefill_measure(eng, cfg, n_seq, T, chunk=None, reps=2, label=""):
+    """Prompt pass: n_seq x T synthetic tokens through all layers (int4 x fp16-operand MFMA GEMMs + causal attention),
+    in chunks of `chunk` positions when given. tokens/s and achieved TFLOP/s against the dense fp16 MFMA peak."""
+    import torch
+
+    g = torch.Generator().manual_seed(4321)
+    toks = torch.randint(0, cfg["vocab"], (n_seq, T), generator=g).cuda()
+    chunk = chunk or T
+
+    def run():
+        for s0 in range(0, T, chunk):
+            eng.prefill(toks[:, s0:s0 + chunk], start_pos=s0)
+
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    lin = 2.0 * linear_params(cfg) * n_seq * T
+    att = cfg["layers"] * n_seq * 4.0 * cfg["heads"] * cfg["head_dim"] * T * (T + 1) / 2
+    return {
+        "workload": "prompt pass, %d x %d tokens%s%s, fp16-operand MFMA GEMMs + causal attention, lm_head on the last "
+                    "positions" % (n_seq, T, " in chunks of %d" % chunk if chunk != T else "", label),
+        "tokens_per_s": n_seq * T / dt, "ms": dt * 1e3,
+        "achieved_tflops": (lin + att) / dt / 1e12, "linear_tflops": lin / dt / 1e12,
+        "peak_tflops": MFMA_PEAK_TFLOPS, "mfma_frac": (lin + att) / dt / 1e12 / MFMA_PEAK_TFLOPS,
+    }
+
+
+# ---- host-only leg: the CPU baseline ---------------------------------------------------------------------------------
+def cpu_baseline(cfg, budget_s=10.0):
+    """The reference's CPU path restated on this host's cores (oracle/woq_cpu_port.c, kind "port": BesTLA itself is
+    not buildable here): every quantised linear of the FULL model (3.3 GB of int4 + fp32 scales, far beyond the
+    caches), one token = 128 GEMV calls, for ~budget_s seconds. Beside it the torch-CPU restatement SURVEY.md §8(d)
+    asked for — `x.float() @ dequant(W)` with cached fp32 weights and with on-the-fly dequantisation — on a bounded
+    sample, and the reference's only published kernel number."""
+    import numpy as np
+    import torch
+
+    from oracle import woq_oracle as orc
+
+    h, i = cfg["hidden"], cfg["inter"]
+    shapes = [(h, (cfg["heads"] + 2 * cfg["kv_heads"]) * cfg["head_dim"]), (cfg["heads"] * cfg["head_dim"], h),
+              (h, 2 * i), (i, h)]
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    rng = np.random.default_rng(0)
+    t_build = time.perf_counter()
+    lins = [[orc.CpuPortLinear.synthetic(k, n, 128, False, l * 4 + j) for j, (k, n) in enumerate(shapes)]
+            for l in range(cfg["layers"])]
+    xs = [rng.standard_normal(k).astype(np.float32) for k, _ in shapes]
+    outs = [np.empty(n, np.float32) for _, n in shapes]
+    t_build = time.perf_counter() - t_build
+
+    def token():
+        for layer in lins:
+            for lin, x, o in zip(layer, xs, outs):
+                lin(x, out=o)
+
+    token()  # warm: thread pool, page tables
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        token()
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or reps >= 10000:
+            break
+    nbytes = sum(lin.nbytes for layer in lins for lin in layer)
+    out = {
+        "value": reps / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
+        "sample": "oracle/woq_cpu_port.c (%s, OpenMP): all %d layers x 4 fused int4 g128 linears of the %s shape "
+                  "(%.2f GB streamed per token, fp32 scales), %d tokens in %.1f s; lm_head / attention / norms excluded"
+                  % (orc.cpu_port_isa(), cfg["layers"], cfg["name"], nbytes / 1e9, reps, dt),
+        "host_gbps": nbytes * reps / dt / 1e9,
+        "reference_published": "35.84 ms/token = 27.9 tokens/s: MPT-7B int4 g128 next-token latency of the "
+                               "reference's own kernels on a 56-core Xeon Platinum 8480+ (docs/release_data.md:131)",
+    }
+    del lins
+    # torch-CPU restatement (autograd/functions.py:41-63 on torch 2.x CPU ops), bounded sample
+    try:
+        torch.set_num_threads(cores)
+        n_l = 2
+        ws = [[torch.randn(k, n) * 0.02 for k, n in shapes] for _ in range(n_l)]  # cached dequantised fp32 weights
+        xt = [torch.randn(1, k) for k, _ in shapes]
+        for layer in ws:
+            for w, x in zip(layer, xt):
+                torch.matmul(x, w)
+        r, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 3.0:
+            for layer in ws:
+                for w, x in zip(layer, xt):
+                    torch.matmul(x, w)
+            r += 1
+        dt_c = (time.perf_counter() - t0) / r / n_l
+        del ws
+        k, n = shapes[1]  # on-the-fly: unpack nibbles -> (q - zp) * scale -> matmul, one o_proj-sized matrix
+        packed = torch.randint(0, 256, (k // 2, n), dtype=torch.uint8)
+        sc = torch.rand(k // 128, n) * 0.01
+        r, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 2.0:
+            q = torch.stack([packed & 15, packed >> 4], 1).reshape(k, n).to(torch.float32) - 8.0
+            w = (q.reshape(k // 128, 128, n) * sc[:, None, :]).reshape(k, n)
+            torch.matmul(xt[1], w)
+            r += 1
+        dt_f = (time.perf_counter() - t0) / r
+        per_token_f = dt_f * sum(kk * nn for kk, nn in shapes) / (k * n) * cfg["layers"]
+        out["torch_cpu_restatement"] = {
+            "cached_dequant_fp32_tokens_per_s": 1.0 / (dt_c * cfg["layers"]),
+            "on_the_fly_dequant_tokens_per_s": 1.0 / per_token_f,
+            "threads": cores,
+            "sample": "x.float() @ dequant(W) as torch CPU ops: cached fp32 weights over %d layers' linears (timed, "
+                      "x%d), on-the-fly dequantisation of one %d x %d matrix (timed, scaled by parameter count)"
+                      % (n_l, cfg["layers"] // n_l, k, n),
+        }
+    except Exception as ex:  # the restatement is an extra; the port above is the baseline
+        out["torch_cpu_restatement"] = {"error": str(ex)[:200]}
+    return out
+
+
+# ---- parity of the measured model against the oracle ----------------------------------------------------------------
+def parity_check(eng, cfg, tokens=(11, 20000, 317)):
+    """Logits of the measured engine (all layers, its own synthetic weights) against oracle.LlamaOracle on the SAME
+    blobs (fused q|k|v and interleaved gate/up layouts read by the oracle's own dequantiser): north_star's
+    "logits max-abs" at the full BASELINE size. The oracle is the checker only."""
+    import numpy as np
+
+    from oracle import woq_oracle as orc
+
+    t0 = time.perf_counter()
+    host = lambda t: t.detach().cpu().numpy()  # noqa: E731
+    layers = []
+    for l in range(eng.cfg.layers):
+        lt = eng.layer_tensors[l]
+        layers.append(dict(qkv=host(lt["qkv"]).view(np.uint8), o=host(lt["o"]).view(np.uint8),
+                           gate_up=host(lt["gate_up"]).view(np.uint8), down=host(lt["down"]).view(np.uint8),
+                           ln1=host(lt["ln1"]), ln2=host(lt["ln2"])))
+    ht = eng.head_tensors
+    ocfg = dict(heads=cfg["heads"], kv_heads=cfg["kv_heads"], head_dim=cfg["head_dim"], eps=float(eng.cfg.rms_eps),
+                theta=float(eng.cfg.rope_theta))
+    oracle = orc.LlamaOracle(ocfg, host(ht["embed"].float()), layers, host(ht["norm"]), host(ht["lm_head"].float()))
+    worst_abs, worst_rel, same = 0.0, 0.0, True
+    for i, t in enumerate(tokens):
+        eng.token.fill_(int(t))
+        eng.pos.fill_(i)
+        eng.step(greedy=False)
+        got = eng.logits.cpu().numpy()
+        ref = oracle.forward_token(int(t), i)
+        err = float(np.abs(got - ref).max())
+        worst_abs = max(worst_abs, err)
+        worst_rel = max(worst_rel, err / float(np.abs(ref).max()))
+        same = same and int(got.argmax()) == int(ref.argmax())
+        tol = 2e-3 * float(np.abs(ref).max()) + 1e-4
+        if err > tol:
+            raise RuntimeError("parity FAILED: logits max-abs %.3e > tolerance %.3e at token %d" % (err, tol, i))
+    return {
+        "checked": "%s shape, all %d layers, %d decode steps vs oracle.LlamaOracle (fp32 / double accumulate) on the "
+                   "same (q, scale, zp)" % (cfg["name"], eng.cfg.layers, len(tokens)),
+        "logits_max_abs": worst_abs, "logits_max_abs_over_max_logit": worst_rel,
+        "tol": "2e-3 * max|logit| + 1e-4 (fp16 KV cache / embedding / lm_head storage vs fp32 oracle)",
+        "greedy_tokens_equal": same,
+        "unpinned": "RTN rounding rule and BesTLA blob bytes are not on this path (identical (q, scale, zp) on both "
+                    "sides); see DESIGN.md §5",
+        "seconds": time.perf_counter() - t0,
+    }
+
+
+# ---- the other BASELINE configurations (N = 1) ----------------------------------------------------------------------
+def decode_entry(name, cfg, eng, steps, warmup, group, asym, ctx_note, kv_bytes_per_token=0):
+    import torch
+
+    def fence():
+        torch.cuda.synchronize()
+
+    eng.capture(greedy=True)
+    dt = timed(eng.replay, steps, warmup, fence) / steps
+    wbytes = algorithmic_bytes_per_token(cfg, group=group, asym=asym)
+    return {
+        "config": name, "decode_tokens_per_s": 1.0 / dt, "ms_per_token": dt * 1e3,
+        "algorithmic_weight_bytes_per_token": wbytes, "hbm_gbps_weights": wbytes / dt / 1e9,
+        "hbm_frac_weights": wbytes / dt / 1e9 / HBM_PEAK_GBPS,
+        "kv_bytes_per_token": kv_bytes_per_token,
+        "hbm_frac_weights_plus_kv": (wbytes + kv_bytes_per_token) / dt / 1e9 / HBM_PEAK_GBPS, "context": ctx_note,
+    }
+
+
+def extra_configs(args):
+    import torch
+
+    out = []
+    # configs[2]: Llama-2-7B int4 asym group 32 (AWQ-style): batch-1 decode, then the 32 x 2048 prompt pass
+    cfg = LLAMA2_7B
+    eng = build_engine(cfg, group=32, sym=False, max_ctx=2048, max_batch=32)
+    feed_prompt(eng, cfg["vocab"], 32)
+    e = decode_entry("configs[2] Llama-2-7B int4 asym g32 fp16 scales, batch-1 decode", cfg, eng, 64, 8, 32, True,
+                     "prompt 32")
+    e["roofline_gemv"] = gemv_roofline(eng)
+    out.append(e)
+    pf = prefill_measure(eng, cfg, 32, 2048, reps=1, label=", int4 asym g32")
+    pf["config"] = "configs[2] Llama-2-7B int4 asym g32, batch 32 x 2048-token prompt pass (MFMA prefill tile)"
+    out.append(pf)
+    del eng
+    free_gpu()
+    # configs[4]: Mistral-7B shape, int4 sym g128, fp8 (e4m3) KV cache, 8k context: chunked prompt pass then decode
+    cfg, ctx = MISTRAL_7B, 8192
+    eng = build_engine(cfg, group=128, sym=True, max_ctx=ctx + 256, kv_dtype=torch.float8_e4m3fn)
+    pf = prefill_measure(eng, cfg, 1, ctx, chunk=2048, reps=1, label=", int4 sym g128, fp8 KV")
+    pf["config"] = "configs[4] Mistral-7B int4 g128 + fp8 KV-cache, 8k-context chunked prompt pass (4 x 2048)"
+    out.append(pf)
+    g = torch.Generator().manual_seed(1)
+    toks = torch.randint(0, cfg["vocab"], (ctx,), generator=g).cuda()
+    for s0 in range(0, ctx, 2048):
+        eng.prefill(toks[s0:s0 + 2048], start_pos=s0, greedy=True)
+    eng.tune_attn_for(ctx + 128)
+    kvb = 2 * cfg["layers"] * cfg["kv_heads"] * cfg["head_dim"] * ctx
+    out.append(decode_entry("configs[4] Mistral-7B int4 g128 + fp8 KV-cache, batch-1 decode at 8k context", cfg, eng,
+                            64, 8, 128, False, "8192 cached positions, fp8 e4m3 KV", kv_bytes_per_token=kvb))
+    del eng
+    free_gpu()
+    if not args.no_70b:
+        out.append(tp_point(args, LLAMA2_70B, rank=0, world=1, dist=None, steps=32, warmup=4, as_extra=True))
+    return out
+
+
+# ---- configs[3]: Llama-2-70B at tensor-parallel degree = world -------------------------------------------------------
+def tp_point(args, cfg, rank, world, dist, steps, warmup, as_extra=False):
+    import torch
+
+    from intel_extension_for_transformers_amd.runtime.tp import TPDecoder
+
+    n_layers = args.layers if args.layers and not as_extra else cfg["layers"]
+    max_ctx = 1 << max(9, (args.prompt + warmup + steps + 8).bit_length())
+    eng = build_engine(cfg, group=128, sym=True, max_ctx=max_ctx, tp_rank=rank, tp=world, layers=n_layers)
+    transport, comm, dec = "none (one GPU)", None, None
+    if world > 1:
+        from intel_extension_for_transformers_amd.runtime.comm import DeviceComm
+
+        comm = DeviceComm(cfg["hidden"])
+        if not args.host_allreduce and comm.self_test():
+            transport = "device one-shot all-reduce kernels over xGMI (hipIpc inboxes), inside the captured graph"
+            dec = TPDecoder(eng, cfg["vocab"], comm=comm)
+        else:
+            transport = "RCCL all-reduce issued by the host between sub-blocks (device exchange %s)" % (
+                "disabled by flag" if args.host_allreduce else "failed its self-test: %s" % (comm.error or "mismatch"))
+            comm = None
+            dec = TPDecoder(eng, cfg["vocab"])
+
+    def step(greedy):
+        if dec is None:
+            eng.step(greedy=greedy)
+        else:
+            dec.step(greedy=greedy, return_logits=False)
+
+    feed_prompt(eng, cfg["vocab"], args.prompt, step=step)
+    use_graph = not args.no_graph and (world == 1 or comm is not None)
+    if use_graph:
+        eng.capture(greedy=True)
+
+    def run(n):
+        if use_graph:
+            eng.replay(n)
+        else:
+            for _ in range(n):
+                step(True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    elapsed = timed(run, steps, warmup, fence)
+    agree = True
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        toks = [torch.zeros_like(eng.token) for _ in range(world)]
+        dist.all_gather(toks, eng.token)
+        agree = len({int(x.item()) for x in toks}) == 1
+        if comm is not None and comm.status() != 0:
+            raise RuntimeError("tensor-parallel exchange reported a timeout during the timed region")
+        if not agree:
+            raise RuntimeError("tensor-parallel ranks disagree on the greedy token")
+    tok_s = steps / elapsed
+    wbytes = algorithmic_bytes_per_token(cfg, tp=world) * n_layers // cfg["layers"]
+    point = {
+        "workload": "%s int4 sym group_size=128 fp16 scales, batch=1 greedy decode, prompt %d, tensor parallel x%d%s"
+                    % (cfg["name"], args.prompt, world, "" if n_layers == cfg["layers"] else
+                       " [REDUCED to %d layers]" % n_layers),
+        "tokens_per_s": tok_s, "ms_per_token": elapsed * 1e3 / steps, "elapsed_s": elapsed,
+        "algorithmic_weight_bytes_per_token_per_gpu": wbytes,
+        "hbm_gbps_per_gpu": wbytes * tok_s / 1e9, "hbm_frac_per_gpu": wbytes * tok_s / 1e9 / HBM_PEAK_GBPS,
+        "rccl_ranks": world, "allreduces_per_token": 2 * n_layers if world > 1 else 0,
+        "token_exchanges_per_token": 1 if world > 1 else 0, "allreduce_bytes": cfg["hidden"] * 4,
+        "allreduce_transport": transport, "hipgraph": use_graph, "ranks_agree_on_token": agree,
+    }
+    if rank == 0:
+        point["roofline_gemv"] = gemv_roofline(eng)
+    if as_extra:
+        point = dict(config="configs[3] single-GPU point: " + point.pop("workload"), **point)
+    del eng, dec, comm
+    free_gpu()
+    return point
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--prompt", type=int, default=32, help="positions already in the KV cache when timing starts")
-    ap.add_argument("--layers", type=int, default=LLAMA2_7B["layers"])
-    ap.add_argument("--prefill-seqs", type=int, default=4, help="sequences in the prompt-pass measurement (0 = skip)")
-    ap.add_argument("--prefill-len", type=int, default=2048, help="tokens per sequence in the prompt-pass measurement")
+    ap.add_argument("--layers", type=int, default=0, help="override the layer count (marks the line REDUCED)")
+    ap.add_argument("--workload", choices=["auto", "7b", "70b"], default="auto")
+    ap.add_argument("--prefill-seqs", type=int, default=4, help="sequences in the main line's prompt-pass object (0 = skip)")
+    ap.add_argument("--prefill-len", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (configs[2], [3] single GPU, [4])")
+    ap.add_argument("--no-70b", action="store_true", help="skip the 70B single-GPU point of extra_configs")
+    ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--host-allreduce", action="store_true", help="N > 1: force the RCCL host-driven transport")
     args = ap.parse_args()
 
     import torch
@@ -151,26 +478,51 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    workload = args.workload
+    if workload == "auto":
+        workload = "70b" if world > 1 or torch.cuda.device_count() > 1 else "7b"
+    if world > 1 and workload == "7b":
+        raise SystemExit("the 7B batch-1 path does not shard (SURVEY.md §8(e)); N > 1 measures configs[3] (--workload 70b)")
 
-    from intel_extension_for_transformers_amd.runtime.engine import WoqDecoderEngine, synth_llama_weights
+    base = {"metric": METRIC, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": True, "vs_baseline": None, "dtype": DTYPE}
+    if workload == "70b":
+        p = tp_point(args, LLAMA2_70B, rank, world, dist, args.steps, args.warmup)
+        if rank == 0:
+            out = dict(base, value=p["tokens_per_s"], ms_per_step=p["ms_per_token"], scaling="strong",
+                       data="synthetic (random-init int4 weights of the Llama-2-70B shape, random prompt ids)",
+                       config={"workload": p["workload"], "global_batch": 1, "parallelism": "tp%d" % world,
+                               "rccl_ranks": world, "allreduces_per_token": p["allreduces_per_token"],
+                               "token_exchanges_per_token": p["token_exchanges_per_token"],
+                               "allreduce_bytes": p["allreduce_bytes"], "allreduce_transport": p["allreduce_transport"],
+                               "hipgraph": p["hipgraph"], "visible_gpus": torch.cuda.device_count()},
+                       hbm_gbps_per_gpu=p["hbm_gbps_per_gpu"], hbm_frac_of_peak_end_to_end=p["hbm_frac_per_gpu"],
+                       roofline=dict(p["roofline_gemv"], traffic=None))
+            if world == 1 and not args.no_extra:  # first point of a sweep on a multi-GPU node: the 7B number rides along
+                eng = build_engine(LLAMA2_7B, max_ctx=512)
+                feed_prompt(eng, LLAMA2_7B["vocab"], args.prompt)
+                out["extra_configs"] = [decode_entry("configs[1] Llama-2-7B int4 sym g128, batch-1 decode", LLAMA2_7B,
+                                                     eng, 64, 8, 128, False, "prompt %d" % args.prompt)]
+                del eng
+                free_gpu()
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
-    cfg = dict(LLAMA2_7B, layers=args.layers)
+    # ---- configs[1]: Llama-2-7B int4 sym g128, one GPU --------------------------------------------------------------
+    cfg = dict(LLAMA2_7B, layers=args.layers or LLAMA2_7B["layers"])
+    cpu = None
+    if not args.no_cpu_baseline:  # host-only leg first: the rest of the run keeps the GPU busy
+        cpu = cpu_baseline(LLAMA2_7B)
     max_ctx = 1 << max(9, (args.prompt + args.warmup + args.steps + 8).bit_length())
-    want_prefill = args.prefill_seqs > 0 and world == 1
+    want_prefill = args.prefill_seqs > 0
     if want_prefill:
         max_ctx = max(max_ctx, args.prefill_len)
-    eng = WoqDecoderEngine(cfg["hidden"], cfg["inter"], cfg["heads"], cfg["kv_heads"], cfg["head_dim"], cfg["layers"],
-                           cfg["vocab"], max_ctx=max_ctx, max_batch=max(1, args.prefill_seqs) if want_prefill else 1)
-    synth_llama_weights(eng, cfg["hidden"], cfg["inter"], cfg["heads"], cfg["kv_heads"], cfg["head_dim"],
-                        cfg["layers"], cfg["vocab"], group=128, sym=True, scale_dtype="fp16", seed=1234 + rank)
-
-    # synthetic prompt: feed `prompt` random tokens through the decode path so the KV cache holds real entries
-    g = torch.Generator().manual_seed(1234)
-    prompt = torch.randint(0, cfg["vocab"], (args.prompt,), generator=g).tolist()
-    for i, t in enumerate(prompt):
-        eng.token.fill_(int(t))
-        eng.pos.fill_(i)
-        eng.step(greedy=(i == len(prompt) - 1))
+    eng = build_engine(cfg, max_ctx=max_ctx, max_batch=max(1, args.prefill_seqs) if want_prefill else 1,
+                       layers=cfg["layers"])
+    feed_prompt(eng, cfg["vocab"], args.prompt)
     use_graph = not args.no_graph
     if use_graph:
         eng.capture(greedy=True)
@@ -182,74 +534,30 @@ def main():
             for _ in range(n):
                 eng.step(greedy=True)
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    run(args.warmup)
-    fence()
-    t0 = time.perf_counter()
-    run(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    tok_s = world * args.steps / elapsed
-
-    if rank == 0:
-        qbytes = algorithmic_bytes_per_token(cfg)
-        # dominant kernel, timed alone: HIP events on the launch stream around 4 passes of the 128 launches
-        ms, by, n_launch = eng.time_gemv(reps=4)
-        us_per_launch = ms * 1e3 / (4 * n_launch)
-        achieved = (by / n_launch) / (us_per_launch * 1e-6) / 1e9
-        out = {
-            "metric": "decode tokens/sec + achieved HBM GB/s, Llama-2-7B int4 WOQ, batch=1",
-            "value": tok_s,
-            "unit": "tokens/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "int4 weights x fp32 activations as 3 x int8 fixed-point limbs on i8 MFMA (exact int32 tile sums), fp32 across tiles",
-            "data": "synthetic (random-init int4 weights of the Llama-2-7B shape, random prompt ids)",
-            "config": {
-                "workload": "Llama-2-7B int4 sym group_size=128 fp16 scales, batch=1 greedy decode, prompt %d, "
-                            "lm_head fp16 unquantised, KV fp16%s" % (args.prompt, "" if args.layers == 32 else
-                                                                     " [REDUCED to %d layers]" % args.layers),
-                "global_batch": world,
-                "parallelism": "replicas x%d (path does not shard at 7B)" % world if world > 1 else "single GPU",
-                "hipgraph": use_graph,
-            },
-            "hbm_gbps_quantized_weight_stream": qbytes * (tok_s / world) / 1e9,
-            "hbm_frac_of_peak_end_to_end": qbytes * (tok_s / world) / 1e9 / HBM_PEAK_GBPS,
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "woq::gemv_tile_kernel (int4 GEMV, M=1, csrc/woq_gemv_i8.hip)",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": read_traffic(),
-                "us_per_launch": us_per_launch,
-                "algorithmic_bytes_per_launch": by / n_launch,
-                "launches_per_token": n_launch,
-            },
-        }
-        if args.prefill_seqs > 0 and world == 1:
-            out["prefill"] = prefill_measure(eng, cfg, args.prefill_seqs, args.prefill_len)
-        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only (torchrun also pins OMP_NUM_THREADS=1)
-            out["cpu_baseline"] = cpu_baseline(eng, cfg)
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    elapsed = timed(run, args.steps, args.warmup, torch.cuda.synchronize)
+    tok_s = args.steps / elapsed
+    qbytes = algorithmic_bytes_per_token(cfg)
+    out = dict(base, value=tok_s, ms_per_step=elapsed * 1e3 / args.steps, scaling="weak",
+               data="synthetic (random-init int4 weights of the Llama-2-7B shape, random prompt ids)",
+               config={"workload": "Llama-2-7B int4 sym group_size=128 fp16 scales, batch=1 greedy decode, prompt %d, "
+                                   "lm_head fp16 unquantised, KV fp16%s"
+                                   % (args.prompt, "" if cfg["layers"] == 32 else " [REDUCED to %d layers]" % cfg["layers"]),
+                       "global_batch": 1, "parallelism": "single GPU", "hipgraph": use_graph},
+               hbm_gbps_quantized_weight_stream=qbytes * tok_s / 1e9,
+               hbm_frac_of_peak_end_to_end=qbytes * tok_s / 1e9 / HBM_PEAK_GBPS,
+               hbm_frac_of_measured_copy_ceiling_end_to_end=qbytes * tok_s / 1e9 / HBM_COPY_GBPS,
+               roofline=gemv_roofline(eng, read_traffic()))
+    if want_prefill:
+        out["prefill"] = prefill_measure(eng, cfg, args.prefill_seqs, args.prefill_len, label=", same int4 g128 weights")
+    if not args.no_parity:
+        out["parity"] = parity_check(eng, cfg)
+    del eng
+    free_gpu()
+    if not args.no_extra:
+        out["extra_configs"] = extra_configs(args)
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

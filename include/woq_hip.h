@@ -96,7 +96,8 @@ WOQ_API int woq_blob_extract(const void* blob_dev, const woq_blob_header* hdr, i
  *   act: act_dtype [M, lda]; out: out_dtype [M, ldo], written in place; bias fp32 [N] or NULL
  *   (alpha = 1, beta = bias ? 1 : 0, bestla_customop.hpp:22-40). Activation shuffle (g_idx) is
  *   applied when the blob carries indices (autograd/functions.py:52-57).
- * Kernel selection by M: M <= 8 decode GEMV (VALU + wave shuffle reduce), M > 8 MFMA GEMM. */
+ * Kernel selection by M: M <= 8 decode GEMV (int8-MFMA inner product over exact fixed-point activation limbs,
+ * csrc/woq_gemv_i8.hip; the generic fp32-VALU kernel for shuffled / table / fp8 blobs), M > 8 MFMA GEMM. */
 WOQ_API int woq_linear(const void* act_dev, int act_dtype, int lda, const void* blob_dev,
                        const woq_blob_header* hdr, const float* bias_dev, void* out_dev, int out_dtype, int ldo,
                        int M, void* stream);
@@ -195,6 +196,30 @@ WOQ_API int woq_engine_replay(woq_engine* e, int n, void* stream);
  * to RCCL via torch.distributed. NULL = single GPU. */
 typedef int (*woq_allreduce_fn)(void* user, void* buf_dev, size_t count, void* stream);
 WOQ_API int woq_engine_set_allreduce(woq_engine* e, woq_allreduce_fn fn, void* user);
+/* ---- device-side tensor-parallel exchange (one process per GPU) ----------------------------------
+ * The reference has no counterpart (its multi-device inference is DeepSpeed AutoTP on fp models,
+ * neural_chat/models/model_utils.py:238-311); this is the exchange step the sharded int4 path needs: the sum over ranks
+ * of the row-parallel [hidden] partials after o_proj and down_proj, and the greedy-token pick over a vocab-sharded
+ * lm_head. Both are kernels on the caller's stream (capturable): every rank stores 8-byte {fp32, tag} granules straight
+ * into every peer's inbox over xGMI (hipIpc-mapped) and sums what arrives in its own, rank order 0..W-1 (bit-identical
+ * results on all ranks). Set-up, per rank: create -> handle (64 bytes, exchanged by the host, e.g. torch.distributed
+ * all_gather) -> connect(all handles, device ordinal of every rank). All ranks must issue the same sequence of
+ * collectives. A peer that does not show up within the timeout (default 2 s) sets a sticky status instead of hanging. */
+typedef struct woq_comm woq_comm;
+WOQ_API int woq_comm_create(int rank, int world, size_t max_elems, woq_comm** out);
+WOQ_API int woq_comm_handle(woq_comm* c, void* handle_out, size_t bytes);
+WOQ_API int woq_comm_connect(woq_comm* c, const void* handles, const int* peer_devices);
+/* in-place sum over ranks of buf[0..n) fp32, n <= max_elems */
+WOQ_API int woq_comm_allreduce_f32(woq_comm* c, float* buf_dev, size_t n, void* stream);
+/* synchronises `stream`; *status_out: 0 = every collective so far completed, bit 0 / 1 = an all-reduce / a token
+ * exchange timed out (results after that are undefined) */
+WOQ_API int woq_comm_status(woq_comm* c, void* stream, int* status_out);
+WOQ_API int woq_comm_set_timeout_ms(woq_comm* c, int ms);
+WOQ_API void woq_comm_destroy(woq_comm* c);
+/* make the engine's decode step issue the exchange itself (after o_proj and down_proj, and for the greedy token:
+ * token id = vocab_offset + local argmax of this rank's lm_head rows), so woq_engine_capture / replay cover a whole
+ * tensor-parallel token. The comm must outlive the engine's use of it. NULL = back to the callback / single GPU. */
+WOQ_API int woq_engine_set_comm(woq_engine* e, woq_comm* comm, int vocab_offset);
 /* run only the kernels of one sub-block, for TP where the collective is issued by the host
  * between them: phase 0 = embed + attention block up to o_proj partial, 1 = MLP block up to
  * down partial, 2 = head. layer ignored for phase 2. */

@@ -72,6 +72,8 @@ EXPORTS = [
     "woq_engine_step", "woq_engine_capture", "woq_engine_replay", "woq_engine_set_allreduce", "woq_engine_phase",
     "woq_engine_time_gemv", "woq_engine_prefill", "woq_engine_prefill_logits_ptr", "woq_engine_kv_cache_ptr", "woq_engine_set_attn_splits", "woq_engine_attn_splits",
     "woq_engine_set_attn_grouped", "woq_engine_attn_grouped",
+    "woq_comm_create", "woq_comm_handle", "woq_comm_connect", "woq_comm_allreduce_f32", "woq_comm_status",
+    "woq_comm_set_timeout_ms", "woq_comm_destroy", "woq_engine_set_comm",
 ]
 
 _lib = None
@@ -126,6 +128,15 @@ def lib():
     L.woq_engine_kv_cache_ptr.argtypes = [vp, ci]
     L.woq_engine_time_gemv.argtypes = [vp, ci, vp, ctypes.POINTER(cf), ctypes.POINTER(ctypes.c_double),
                                        ctypes.POINTER(ci)]
+    L.woq_comm_create.argtypes = [ci, ci, cs, ctypes.POINTER(vp)]
+    L.woq_comm_handle.argtypes = [vp, vp, cs]
+    L.woq_comm_connect.argtypes = [vp, vp, ctypes.POINTER(ci)]
+    L.woq_comm_allreduce_f32.argtypes = [vp, vp, cs, vp]
+    L.woq_comm_status.argtypes = [vp, vp, ctypes.POINTER(ci)]
+    L.woq_comm_set_timeout_ms.argtypes = [vp, ci]
+    L.woq_comm_destroy.argtypes = [vp]
+    L.woq_comm_destroy.restype = None
+    L.woq_engine_set_comm.argtypes = [vp, vp, ci]
     _lib = L
     return L
 

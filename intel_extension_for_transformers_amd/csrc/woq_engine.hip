@@ -45,6 +45,10 @@ int launch_attn_prefill(const _Float16* qkv, int n_seq, int T, int start, int he
                         int window, hipStream_t st);
 void launch_gather_last(const float* h, int n_seq, int T, int hidden, float* dst, hipStream_t st);
 }  // namespace woq
+// device-side tensor-parallel exchange (woq_comm.hip)
+int woq_comm_launch_allreduce(woq_comm* c, float* buf, size_t n, hipStream_t st);
+int woq_comm_launch_greedy(woq_comm* c, const float* pmax, const int32_t* pidx, int n, int vocab_offset,
+                           int32_t* token, int32_t* pos, hipStream_t st);
 
 struct woq_engine {
   woq_engine_config cfg;
@@ -70,6 +74,8 @@ struct woq_engine {
   hipGraphExec_t exec = nullptr;
   woq_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
+  woq_comm* comm = nullptr;  // device-side exchange: all-reduce kernels inside the (capturable) decode step
+  int vocab_offset = 0;      // first vocabulary row of this rank's lm_head shard
   int nt = 1;
   std::vector<void*> owned;  // everything hipMalloc'ed by create()
   // prompt pass: [n_seq * T] rows at a time; buffers grow on demand (never inside a captured graph)
@@ -123,7 +129,37 @@ static int engine_head(woq_engine* e, int greedy, hipStream_t st) {
   const woq_engine_config& c = e->cfg;
   launch_lm_head(e->hidden, e->final_norm, c.rms_eps, e->lm_head, e->lm_dtype, c.hidden, c.vocab, e->logits,
                  greedy ? e->am_val : nullptr, greedy ? e->am_idx : nullptr, st);
+  if (greedy && e->comm && c.tp_size > 1)  // vocab-sharded head: one (max, global index) pair per rank
+    return woq_comm_launch_greedy(e->comm, e->am_val, e->am_idx, (c.vocab + 15) / 16, e->vocab_offset, e->token,
+                                  e->pos, st);
   if (greedy) launch_argmax_pairs(e->am_val, e->am_idx, (c.vocab + 15) / 16, e->token, e->pos, st);
+  return 0;
+}
+
+// sum of the row-parallel partials over the tensor-parallel ranks, in place on `buf`
+static int engine_allreduce(woq_engine* e, float* buf, size_t count, hipStream_t st) {
+  if (e->comm && e->cfg.tp_size > 1) return woq_comm_launch_allreduce(e->comm, buf, count, st);
+  if (e->allreduce && e->allreduce(e->allreduce_user, buf, count, st) != 0)
+    return woq::fail("QBits: tensor-parallel all-reduce callback failed");
+  return 0;
+}
+
+// prompt pass: [rows, hidden] partials. Bandwidth-bound, so the bound callback (RCCL through torch.distributed) is the
+// transport when there is one; without it the device exchange carries the rows in inbox-sized pieces.
+size_t woq_comm_max_elems(woq_comm* c);
+static int engine_allreduce_rows(woq_engine* e, float* buf, size_t count, hipStream_t st) {
+  if (e->cfg.tp_size <= 1) return 0;
+  if (e->allreduce) {
+    if (e->allreduce(e->allreduce_user, buf, count, st) != 0)
+      return woq::fail("QBits: tensor-parallel all-reduce callback failed");
+    return 0;
+  }
+  if (!e->comm) return woq::fail("QBits: tensor-parallel engine without a communicator");
+  const size_t piece = woq_comm_max_elems(e->comm);
+  for (size_t o = 0; o < count; o += piece) {
+    const int rc = woq_comm_launch_allreduce(e->comm, buf + o, std::min(piece, count - o), st);
+    if (rc) return rc;
+  }
   return 0;
 }
 
@@ -133,12 +169,10 @@ static int engine_step_impl(woq_engine* e, int greedy, hipStream_t st) {
   for (int l = 0; l < c.layers; ++l) {
     int rc = engine_attn_block(e, l, st);
     if (rc) return rc;
-    if (e->allreduce && (rc = e->allreduce(e->allreduce_user, e->hidden, (size_t)c.hidden, st)) != 0)
-      return woq::fail("QBits: tensor-parallel all-reduce callback failed");
+    if ((rc = engine_allreduce(e, e->hidden, (size_t)c.hidden, st)) != 0) return rc;
     rc = engine_mlp_block(e, l, st);
     if (rc) return rc;
-    if (e->allreduce && (rc = e->allreduce(e->allreduce_user, e->hidden, (size_t)c.hidden, st)) != 0)
-      return woq::fail("QBits: tensor-parallel all-reduce callback failed");
+    if ((rc = engine_allreduce(e, e->hidden, (size_t)c.hidden, st)) != 0) return rc;
   }
   return engine_head(e, greedy, st);
 }
@@ -200,16 +234,14 @@ static int engine_prefill_impl(woq_engine* e, const int32_t* tokens, int n_seq, 
     if ((rc = launch_gemm_f16(e->pf_attn, WOQ_F16, c.heads * c.head_dim, w.o_blob, w.o_hdr, nullptr, e->pf_h, WOQ_F32,
                               c.hidden, M, nullptr, 0.f, res, c.hidden, 0, e->pf_ws, 0, st)) != 0)
       return rc;
-    if (e->allreduce && e->allreduce(e->allreduce_user, e->pf_h, (size_t)M * c.hidden, st) != 0)
-      return woq::fail("QBits: tensor-parallel all-reduce callback failed");
+    if ((rc = engine_allreduce_rows(e, e->pf_h, (size_t)M * c.hidden, st)) != 0) return rc;
     if ((rc = launch_gemm_f16(e->pf_h, WOQ_F32, c.hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, e->pf_act, WOQ_F16,
                               c.inter, M, w.ln2, c.rms_eps, nullptr, 0, 1, e->pf_ws, 0, st)) != 0)
       return rc;
     if ((rc = launch_gemm_f16(e->pf_act, WOQ_F16, c.inter, w.down_blob, w.down_hdr, nullptr, e->pf_h, WOQ_F32,
                               c.hidden, M, nullptr, 0.f, res, c.hidden, 0, e->pf_ws, 0, st)) != 0)
       return rc;
-    if (e->allreduce && e->allreduce(e->allreduce_user, e->pf_h, (size_t)M * c.hidden, st) != 0)
-      return woq::fail("QBits: tensor-parallel all-reduce callback failed");
+    if ((rc = engine_allreduce_rows(e, e->pf_h, (size_t)M * c.hidden, st)) != 0) return rc;
   }
   // logits of every sequence's last position; sequence 0 also lands in the decode step's buffers
   launch_gather_last(e->pf_h, n_seq, T, c.hidden, e->pf_last, st);
@@ -369,6 +401,15 @@ int woq_engine_set_allreduce(woq_engine* e, woq_allreduce_fn fn, void* user) {
   WOQ_END
 }
 
+int woq_engine_set_comm(woq_engine* e, woq_comm* comm, int vocab_offset) {
+  WOQ_TRY
+  WOQ_CHECK(e, "QBits: null engine");
+  WOQ_CHECK(vocab_offset >= 0, "QBits: bad vocabulary offset");
+  e->comm = comm;
+  e->vocab_offset = vocab_offset;
+  WOQ_END
+}
+
 int woq_engine_step(woq_engine* e, int greedy, void* stream) {
   WOQ_TRY
   WOQ_CHECK(e && e->embed && e->lm_head, "QBits: engine head not set");
@@ -401,7 +442,8 @@ int woq_engine_phase(woq_engine* e, int layer, int phase, int greedy, void* stre
 int woq_engine_capture(woq_engine* e, int greedy, void* stream) {
   WOQ_TRY
   WOQ_CHECK(e && e->embed && e->lm_head, "QBits: engine head not set");
-  WOQ_CHECK(!e->allreduce, "QBits: graph capture with a host all-reduce callback is not supported");
+  WOQ_CHECK(!e->allreduce || (e->comm && e->cfg.tp_size > 1),
+            "QBits: graph capture with a host all-reduce callback is not supported (bind a device communicator)");
   hipStream_t st = (hipStream_t)stream;
   // one eager, non-advancing step first: sets the lazy kernel attributes outside of capture.
   // (re-writing the KV slot at the current position is idempotent)

@@ -21,7 +21,7 @@ namespace woq {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 int gemv_tile_max_rows(const void* act, int act_dtype, int lda, const woq_blob_header& h, const float* norm_w,
-                       int epi);
+                       int epi, int out_dtype);
 int launch_gemv_tile(const void* act, int act_dtype, int lda, int M, const void* blob, const woq_blob_header& h,
                      const float* bias, void* out, int out_dtype, int ldo, const float* norm_w, float eps,
                      const float* residual, int ld_res, int epi, hipStream_t st);
@@ -252,7 +252,7 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
   float* widened = nullptr;
   if (!force_generic && act_dtype != WOQ_F32 && h.off_shuffle == 0 && (h.K & 3) == 0) {
     const int Kc = (int)h.K;
-    if (gemv_tile_max_rows((const void*)(uintptr_t)16, WOQ_F32, Kc, h, norm_w, epi) > 0) {
+    if (gemv_tile_max_rows((const void*)(uintptr_t)16, WOQ_F32, Kc, h, norm_w, epi, out_dtype) > 0) {
       if (hipMallocAsync((void**)&widened, (size_t)M * Kc * sizeof(float), st) != hipSuccess)
         return woq::fail("QBits: activation staging allocation failed");
       const size_t n = (size_t)M * Kc;
@@ -264,7 +264,7 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
     }
   }
   const size_t esz_a = act_dtype == WOQ_F32 ? 4 : 2, esz_o = out_dtype == WOQ_F32 ? 4 : 2;
-  int rows = force_generic ? 0 : gemv_tile_max_rows(act, act_dtype, lda, h, norm_w, epi);
+  int rows = force_generic ? 0 : gemv_tile_max_rows(act, act_dtype, lda, h, norm_w, epi, out_dtype);
   const bool tile = rows > 0;
   if (!tile) {
     rows = GEN_MAXM;

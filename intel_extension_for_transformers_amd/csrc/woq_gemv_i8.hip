@@ -42,6 +42,8 @@
 //    (RMSNorm factor, bias, residual, SiLU*mul) and store.
 // Kernel arguments are plain scalars (not a struct) so the first 14 dwords are preloaded into SGPRs at dispatch
 // (-mllvm -amdgpu-kernarg-preload-count, see the Makefile): no s_load round trip before the first address.
+#include <algorithm>
+
 #include "woq_device.h"
 #include "woq_launch.h"
 
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
     const u32x4* __restrict__ q, const void* __restrict__ scales, const float* __restrict__ x,
     const float* __restrict__ norm_w, int tiles_k, int K, int base_tiles, int rem_tiles, int n_groups, int tpg_shift,
     const uint8_t* __restrict__ zp, void* __restrict__ out, const float* __restrict__ bias, const float* residual,
-    float eps, int N, int Mrows, int lda, int ldo, int ld_res, int out_dtype, int flags) {
+    float eps, int N, int Mrows, int lda, int ldo, int ld_res, int out_dtype, int flags, int kt_off) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int RB = tile_row_bytes(TPW);
   constexpr int XJ = TPW / 2;  // float4 loads per lane per row covering TPW*128 activations
@@ -162,7 +164,8 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
 
   // this wave's K tiles: balanced contiguous slice [kt0, kt0 + cnt), cnt <= TPW. Everything past the slice end
   // reads as zero through the descriptors' bounds, so tiles t >= cnt contribute exactly 0.
-  const int kt0 = wid * base_tiles + min(wid, rem_tiles);
+  // kt_off: first K tile of this launch (K ranges beyond one launch's reach are covered by chained launches)
+  const int kt0 = kt_off + wid * base_tiles + min(wid, rem_tiles);
   const int cnt = base_tiles + (wid < rem_tiles ? 1 : 0);
   const int i16 = lane & 15, kq = lane >> 4;
   const int kbase = kt0 * 128;
@@ -525,6 +528,7 @@ struct TileLaunch {
   const float* residual;
   float eps;
   int nw, grid;
+  int kt_begin, kt_count;  // K tiles [kt_begin, kt_begin + kt_count) of the blob covered by this launch
 };
 
 template <int TPW, int CB, int SMODE, bool ASYM, bool S32, bool M1>
@@ -538,10 +542,10 @@ static int launch_tile_t(const TileLaunch& a, hipStream_t st) {
     if (e != hipSuccess) return woq::fail(std::string("QBits: hipFuncSetAttribute: ") + hipGetErrorString(e));
     attr_set = true;
   }
-  const int base = a.tiles_k / a.nw, rem = a.tiles_k % a.nw;
+  const int base = a.kt_count / a.nw, rem = a.kt_count % a.nw;
   hipLaunchKernelGGL(kern, dim3(a.grid), dim3(a.nw * 64), lds, st, (const u32x4*)a.q, a.scales, a.x, a.norm_w,
                      a.tiles_k, a.K, base, rem, a.n_groups, a.tpg_shift, (const uint8_t*)a.zp, a.out, a.bias,
-                     a.residual, a.eps, a.N, a.M, a.lda, a.ldo, a.ld_res, a.out_dtype, a.flags);
+                     a.residual, a.eps, a.N, a.M, a.lda, a.ldo, a.ld_res, a.out_dtype, a.flags, a.kt_begin);
   return 0;
 }
 
@@ -562,6 +566,18 @@ static int launch_tile_sm(const TileLaunch& a, int smode, bool asym, bool s32, h
   return woq::fail("QBits: bad tile GEMV configuration");
 }
 
+static bool tile_geometry(int tiles_k, int cb, int smode, int& nw, int& tpw);
+// K ranges one launch cannot hold are split into equal chunks run as chained launches (chunk i + 1 adds onto chunk
+// i's fp32 output through the residual input): linear epilogues only. Returns the number of chunks, 0 = not covered.
+static int tile_k_chunks(int tiles_k, int cb, int smode, bool chainable) {
+  int nw, tpw;
+  if (tile_geometry(tiles_k, cb, smode, nw, tpw)) return 1;
+  if (!chainable) return 0;
+  for (int s = 2; s <= 8; ++s)
+    if (tile_geometry((tiles_k + s - 1) / s, cb, smode, nw, tpw)) return s;
+  return 0;
+}
+
 // geometry pick: nw waves x tpw tiles cover tiles_k (8 tiles = 8 KiB per wave per column tile; 4 for short K so
 // that a workgroup still has a few waves). Returns false when this kernel does not take the shape (K > 16384).
 static bool tile_geometry(int tiles_k, int cb, int smode, int& nw, int& tpw) {
@@ -578,7 +594,7 @@ static bool tile_geometry(int tiles_k, int cb, int smode, int& nw, int& tpw) {
 // 16-B aligned, unshuffled activation rows (what the decode engine feeds it and what the reference's qbits
 // boundary always holds, modules.py:152-154); anything else goes to the generic kernel in woq_gemv.hip.
 int gemv_tile_max_rows(const void* act, int act_dtype, int lda, const woq_blob_header& h, const float* norm_w,
-                       int epi) {
+                       int epi, int out_dtype) {
   if (h.weight_type != WOQ_W_INT4_CLIP || act_dtype != WOQ_F32 || h.off_shuffle != 0 || (h.K & 3) != 0 ||
       (lda & 3) != 0 ||
       (((uintptr_t)act) & 15) != 0 || (((uintptr_t)norm_w) & 15) != 0)
@@ -586,7 +602,8 @@ int gemv_tile_max_rows(const void* act, int act_dtype, int lda, const woq_blob_h
   const int tiles_k = h.Kpad / WOQ_TILE_K;
   const int cb = epi == 1 ? 2 : 1;
   int nw, tpw;
-  if (!tile_geometry(tiles_k, cb, (int)h.scale_mode, nw, tpw)) return 0;
+  const int chunks = tile_k_chunks(tiles_k, cb, (int)h.scale_mode, epi == 0 && !norm_w && out_dtype == WOQ_F32);
+  if (chunks == 0 || !tile_geometry((tiles_k + chunks - 1) / chunks, cb, (int)h.scale_mode, nw, tpw)) return 0;
   if (h.scale_mode == 0 && h.n_groups > 1) {
     const int tpg = h.group / WOQ_TILE_K;
     if (tpg < 1 || (tpg & (tpg - 1)) != 0) return 0;  // tiles per group must be a power of two
@@ -635,15 +652,32 @@ int launch_gemv_tile(const void* act, int act_dtype, int lda, int M, const void*
   const int tiles_n = h.Npad / WOQ_TILE_N;
   const int cb = epi == 1 ? 2 : 1;
   if (epi == 1 && (tiles_n & 1)) return woq::fail("QBits: fused gate/up weight needs an even number of column tiles");
-  int tpw;
-  if (act_dtype != WOQ_F32 || M > TMAXM || !tile_geometry(a.tiles_k, cb, (int)h.scale_mode, a.nw, tpw))
-    return woq::fail("QBits: shape not covered by the tile GEMV");
-  a.grid = tiles_n / cb;
   const int smode = (int)h.scale_mode;
   const bool asym = a.zp != nullptr, s32 = h.scale_type == WOQ_F32;
-  if (cb == 2)
-    return tpw == 4 ? launch_tile_sm<4, 2>(a, smode, asym, s32, st) : launch_tile_sm<8, 2>(a, smode, asym, s32, st);
-  return tpw == 4 ? launch_tile_sm<4, 1>(a, smode, asym, s32, st) : launch_tile_sm<8, 1>(a, smode, asym, s32, st);
+  const int chunks = tile_k_chunks(a.tiles_k, cb, smode, epi == 0 && !norm_w && out_dtype == WOQ_F32);
+  if (act_dtype != WOQ_F32 || M > TMAXM || chunks == 0)
+    return woq::fail("QBits: shape not covered by the tile GEMV");
+  a.grid = tiles_n / cb;
+  const int per = (a.tiles_k + chunks - 1) / chunks;
+  for (int c = 0; c < chunks; ++c) {
+    a.kt_begin = c * per;
+    a.kt_count = std::min(per, a.tiles_k - a.kt_begin);
+    if (a.kt_count <= 0) break;
+    int tpw;
+    if (!tile_geometry(a.kt_count, cb, smode, a.nw, tpw)) return woq::fail("QBits: shape not covered by the tile GEMV");
+    if (c > 0) {  // add onto the previous chunk's output
+      a.bias = nullptr;
+      a.residual = (const float*)out;
+      a.ld_res = ldo;
+    }
+    int rc;
+    if (cb == 2)
+      rc = tpw == 4 ? launch_tile_sm<4, 2>(a, smode, asym, s32, st) : launch_tile_sm<8, 2>(a, smode, asym, s32, st);
+    else
+      rc = tpw == 4 ? launch_tile_sm<4, 1>(a, smode, asym, s32, st) : launch_tile_sm<8, 1>(a, smode, asym, s32, st);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 }  // namespace woq

@@ -67,7 +67,9 @@ class WoqDecoderEngine:
         L.check(L.lib().woq_engine_bind_io(self._h, self.token.data_ptr(), self.pos.data_ptr(),
                                            self.logits.data_ptr(), self.hidden.data_ptr()))
         self._keep = []  # tensors the engine holds raw pointers to
+        self.layer_tensors, self.head_tensors = {}, {}  # the same, by name (inspection / parity checks)
         self._allreduce_cb = None
+        self._comm = None
         self.captured = False
         # hipGraph capture is not allowed on the legacy null stream torch uses by default
         self._stream = torch.cuda.Stream(device=self.device)
@@ -90,6 +92,7 @@ class WoqDecoderEngine:
                            down_hdr=qbits.header_of(down_blob))
         L.check(L.lib().woq_engine_set_layer(self._h, idx, ctypes.byref(w)))
         self._keep += [qkv_blob, o_blob, gate_up_blob, down_blob, ln1, ln2]
+        self.layer_tensors[idx] = dict(qkv=qkv_blob, o=o_blob, gate_up=gate_up_blob, down=down_blob, ln1=ln1, ln2=ln2)
 
     def set_head(self, embed, final_norm, lm_head, cos=None, sin=None):
         embed = embed.to(self.device).contiguous()
@@ -101,6 +104,7 @@ class WoqDecoderEngine:
                                             final_norm.data_ptr(), lm_head.data_ptr(),
                                             L.torch_dtype_code(lm_head.dtype), cos.data_ptr(), sin.data_ptr()))
         self._keep += [embed, lm_head, final_norm, cos, sin]
+        self.head_tensors = dict(embed=embed, norm=final_norm, lm_head=lm_head)
 
     def reset(self, token=0, pos=0):
         self.token.fill_(int(token))
@@ -230,6 +234,16 @@ class WoqDecoderEngine:
         L.check(L.lib().woq_engine_set_allreduce(self._h, self._allreduce_cb, None))
         self.captured = False
 
+    def bind_comm(self, comm, vocab_offset=0):
+        """Tensor parallel with the exchange ON THE DEVICE (runtime/comm.py DeviceComm): the native step then issues
+        the two all-reduce kernels per layer and the greedy-token exchange itself, so `capture()` / `replay()` cover a
+        whole tensor-parallel token. `vocab_offset` = first vocabulary row of this rank's lm_head shard. The prompt
+        pass keeps a bound RCCL callback when there is one (bandwidth-bound rows), else it uses the comm in pieces."""
+        h = comm.handle if comm is not None else None
+        L.check(L.lib().woq_engine_set_comm(self._h, h, int(vocab_offset)))
+        self._comm = comm
+        self.captured = False
+
     def unbind_allreduce(self):
         L.check(L.lib().woq_engine_set_allreduce(self._h, ctypes.cast(None, L.ALLREDUCE_FN), None))
         self._allreduce_cb = None
@@ -239,6 +253,9 @@ class WoqDecoderEngine:
         chained on the device."""
         out = []
         ids = [int(t) for t in prompt_ids]
+        if len(ids) + max_new_tokens > self.cfg.max_ctx:  # the kernels index the KV cache by position, unchecked
+            raise RuntimeError("QBits: prompt (%d) + max_new_tokens (%d) exceeds the engine's max_ctx (%d)"
+                               % (len(ids), max_new_tokens, self.cfg.max_ctx))
         for s0 in range(0, len(ids), chunk):
             self.prefill(ids[s0:s0 + chunk], start_pos=s0, greedy=True)
         self.tune_attn_for(len(ids) + max_new_tokens)
@@ -262,13 +279,22 @@ def _device_view(ptr, shape, device, typestr="<f4"):
 
 
 def synth_llama_weights(engine, hidden, inter, heads, kv_heads, head_dim, layers, vocab, group=128, sym=True,
-                        scale_dtype="fp16", seed=1234, model_dtype=torch.float16):
+                        scale_dtype="fp16", seed=1234, model_dtype=torch.float16, embed_vocab=None,
+                        shared_seed=None):
     """Synthetic random-init quantised Llama-shaped weights built directly on the device (no checkpoint, no
     network): int4 values uniform in [-8,7], scales ~ 0.02-ish/7 so dequantised weights look like N(0, 0.02^2),
-    norms 1 + N(0, 0.02^2), embeddings N(0, 0.02^2). Returns the list of blobs (kept alive by the engine)."""
+    norms 1 + N(0, 0.02^2), embeddings N(0, 0.02^2). Returns the list of blobs (kept alive by the engine).
+    Tensor-parallel shards: pass the PER-RANK heads / kv_heads / inter / vocab (what the engine was built with) and
+    `embed_vocab` = the full vocabulary (the embedding table is replicated, lm_head is the rank's rows), and
+    `shared_seed` = one seed for all ranks: the replicated tensors (norm weights, embedding) are drawn from it so
+    that every rank holds the same copy, while `seed` (per rank) draws the shards."""
     dev = engine.device
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
+    gs = g  # replicated tensors
+    if shared_seed is not None:
+        gs = torch.Generator(device=dev)
+        gs.manual_seed(shared_seed)
 
     def rand_q(k, n):
         q = torch.randint(-8, 8, (k, n), generator=g, device=dev, dtype=torch.int8)
@@ -293,13 +319,13 @@ def synth_llama_weights(engine, hidden, inter, heads, kv_heads, head_dim, layers
         gu_blob = pack(fuse_gate_up(gq, uq), fuse_gate_up(gsc, usc), None if gz is None else fuse_gate_up(gz, uz))
         q, s, z = rand_q(inter, hidden)
         down_blob = pack(q, s, z)
-        ln1 = 1 + 0.02 * torch.randn(hidden, generator=g, device=dev)
-        ln2 = 1 + 0.02 * torch.randn(hidden, generator=g, device=dev)
+        ln1 = 1 + 0.02 * torch.randn(hidden, generator=gs, device=dev)
+        ln2 = 1 + 0.02 * torch.randn(hidden, generator=gs, device=dev)
         engine.set_layer(l, qkv_blob, o_blob, gu_blob, down_blob, ln1, ln2)
         del q, s, z, gq, gsc, gz, uq, usc, uz
-    embed = (0.02 * torch.randn(vocab, hidden, generator=g, device=dev)).to(model_dtype)
+    embed = (0.02 * torch.randn(embed_vocab or vocab, hidden, generator=gs, device=dev)).to(model_dtype)
     lm_head = (0.02 * torch.randn(vocab, hidden, generator=g, device=dev)).to(model_dtype)
-    norm = 1 + 0.02 * torch.randn(hidden, generator=g, device=dev)
+    norm = 1 + 0.02 * torch.randn(hidden, generator=gs, device=dev)
     engine.set_head(embed, norm, lm_head)
     return engine
 

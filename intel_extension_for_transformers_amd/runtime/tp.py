@@ -7,9 +7,10 @@ so this is new, but the plan is the textbook one and the only exchange step is t
   * o_proj and down_proj are ROW-parallel: split K at multiples of the group size, so every rank owns whole groups;
     each rank produces a partial [hidden] sum and ONE all-reduce (sum) follows each of the two — 2 per layer, 16 KB
     at batch 1 for the 70B shape (latency-bound, far below what the 7 x ~153 GB/s xGMI links carry);
-  * lm_head is vocab-sharded; logits are all-gathered (greedy could reduce (max, argmax) pairs instead).
+  * lm_head is vocab-sharded; greedy decoding exchanges one (max, index) pair per rank, sampling gathers the row.
 The host logic here is pure tensor slicing (numpy or torch) and is exercised on CPU with gloo at world size 2
-(tests/test_tp_gloo.py); the device path (`TPDecoder`) feeds the shards to the same WoqDecoderEngine kernels.
+(tests/test_tp_gloo.py); the device path (`TPDecoder`) feeds the shards to the same WoqDecoderEngine kernels and, in
+its production form, leaves the exchange itself to kernels (runtime/comm.py, csrc/woq_comm.hip).
 """
 import numpy as np
 
@@ -76,11 +77,23 @@ def shard_vocab(lm_head, rank, world):
     return lm_head[rank * per:min(v, (rank + 1) * per)]
 
 
+def _host_staged(t, group):
+    """gloo has no device all_gather: device tensors go through the host there (CPU tests, the two-ranks-on-one-GPU
+    test); with RCCL the tensor is used where it is."""
+    import torch.distributed as dist
+
+    return t.cpu() if t.is_cuda and dist.get_backend(group) != "nccl" else t
+
+
 def gather_logits(local_logits, vocab, group=None):
     """All-gather of the vocab-sharded logits (torch.distributed; backend "nccl" = RCCL on the GPUs, gloo on CPU)."""
     import torch
     import torch.distributed as dist
 
+    dev = local_logits.device
+    local_logits = _host_staged(local_logits, group)
+    if local_logits.device != dev:
+        return gather_logits(local_logits, vocab, group).to(dev)
     world = dist.get_world_size(group)
     per = (vocab + world - 1) // world
     buf = torch.zeros(per, dtype=local_logits.dtype, device=local_logits.device)
@@ -98,12 +111,16 @@ def greedy_token(local_logits, vocab, group=None):
     import torch
     import torch.distributed as dist
 
+    dev = local_logits.device
+    local_logits = _host_staged(local_logits, group)
+    if local_logits.device != dev:
+        return greedy_token(local_logits, vocab, group).to(dev)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     per = (vocab + world - 1) // world
     n = max(0, min(per, vocab - rank * per, local_logits.numel()))  # live rows of this rank's (padded) shard
     pair = torch.empty(2, dtype=torch.float64, device=local_logits.device)
     if n > 0:
-        x = local_logits[:n].to(torch.float64)
+        x = torch.nan_to_num(local_logits[:n].to(torch.float64), nan=float("-inf"))  # a NaN never wins (argmax of NaN is not a token)
         val = x.max()
         ar = torch.arange(n, dtype=torch.float64, device=x.device)
         first = torch.where(x == val, ar, torch.full_like(ar, float(n))).min()  # lowest index among equal maxima
@@ -119,33 +136,70 @@ def greedy_token(local_logits, vocab, group=None):
 
 
 class TPDecoder:
-    """One rank of a tensor-parallel decoder: a WoqDecoderEngine over this rank's shards; `step()` issues the
-    engine's sub-blocks and the two RCCL all-reduces per layer between them (engine.step_tp)."""
+    """One rank of a tensor-parallel decoder: a WoqDecoderEngine over this rank's shards.
 
-    def __init__(self, engine, vocab, group=None):
-        self.engine, self.vocab, self.group = engine, vocab, group
+    Two transports for the per-layer exchange:
+      * `comm` (runtime/comm.py DeviceComm) — the production form: the engine issues the all-reduce kernels and the
+        greedy-token exchange itself, `step()` is ONE native call (or one graph replay after `capture()`), nothing
+        crosses the host per collective;
+      * no comm — host-driven: the engine's sub-blocks with one `dist.all_reduce` (RCCL) between them
+        (engine.step_tp), the token from `greedy_token`. Kept as the fallback when the fabric self-test fails and as
+        the cross-check of the device path.
+    `vocab` is the full vocabulary; the engine was built with this rank's lm_head rows (`shard_vocab`)."""
+
+    def __init__(self, engine, vocab, group=None, comm=None):
+        import torch.distributed as dist
+
+        self.engine, self.vocab, self.group, self.comm = engine, vocab, group, comm
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        self.vocab_offset = rank * ((vocab + world - 1) // world)
+        if comm is not None:
+            engine.bind_comm(comm, self.vocab_offset)
 
     def prefill(self, tokens, start_pos=0):
         """Prompt pass over this rank's shards: the engine's native prefill with the all-reduce seam bound to the
-        process group (sum of the row-parallel partials after o_proj / down_proj, [rows, hidden] fp32 each), then
-        the vocab-sharded last-position logits all-gathered. Returns logits [n_seq, vocab]."""
+        process group (sum of the row-parallel partials after o_proj / down_proj, [rows, hidden] fp32 each — RCCL:
+        this one is bandwidth-bound), then the vocab-sharded last-position logits all-gathered. Leaves the engine
+        where single-GPU `prefill(greedy=True)` leaves it: token = argmax of sequence 0's row, pos = start + T, so a
+        following `step()` continues the sequence. Returns logits [n_seq, vocab]."""
         import torch
 
+        import torch.distributed as dist
+
         e = self.engine
-        e.bind_allreduce(self.group)
-        try:
-            local = e.prefill(tokens, start_pos=start_pos, greedy=False)
-        finally:
-            e.unbind_allreduce()
+        if self.comm is not None and dist.get_backend(self.group) != "nccl":
+            local = e.prefill(tokens, start_pos=start_pos, greedy=False)  # no RCCL: rows through the device comm
+        else:
+            e.bind_allreduce(self.group)
+            try:
+                local = e.prefill(tokens, start_pos=start_pos, greedy=False)
+            finally:
+                e.unbind_allreduce()
+        nxt = greedy_token(local[0][:e.cfg.vocab], self.vocab, self.group)
+        e.token.copy_(nxt.to(torch.int32).reshape(e.token.shape))
+        e.pos.add_(1)  # prefill(greedy=False) left start + T - 1
         return torch.stack([gather_logits(row[:e.cfg.vocab], self.vocab, self.group) for row in local])
 
+    def capture(self):
+        """Device transport only: capture the whole tensor-parallel token (5 kernels + 2 all-reduce kernels per layer,
+        head, token exchange) into one hipGraph. Collective on all ranks (the capture runs one eager step first)."""
+        if self.comm is None:
+            raise RuntimeError("QBits: graph capture of a tensor-parallel step needs the device communicator")
+        self.engine.capture(greedy=True)
+
     def step(self, greedy=True, return_logits=True):
-        """One token. greedy + return_logits=False is the production form: the next token comes from a (max, index)
-        pair per rank (`greedy_token`), written to the engine's token slot on the device — no logits gather, no host
-        round trip. With return_logits the full row is all-gathered as well (tests, sampling)."""
+        """One token. greedy + return_logits=False is the production form: the next token is agreed from one
+        (max, global index) pair per rank and written to the engine's token slot on the device — no logits gather, no
+        host round trip. With return_logits the full row is all-gathered as well (tests, sampling)."""
         import torch
 
         e = self.engine
+        if self.comm is not None:
+            if greedy and not return_logits and e.captured:
+                e.replay(1)
+                return None
+            e.step(greedy=greedy)  # all-reduces and, when greedy, the token exchange run inside the native step
+            return gather_logits(e.logits[:e.cfg.vocab], self.vocab, self.group) if return_logits else None
         e.step_tp(self.group, greedy=False)  # logits of this rank's vocab shard
         local = e.logits[:e.cfg.vocab]
         logits = gather_logits(local, self.vocab, self.group) if return_logits else None

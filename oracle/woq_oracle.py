@@ -23,10 +23,10 @@ HEADER_BYTES = 256
 
 def build(force=False):
     """Compile oracle/woq_oracle.c with gcc (idempotent)."""
-    src = os.path.join(_HERE, "woq_oracle.c")
-    hdr = os.path.join(_HERE, "..", "include", "woq_blob.h")
+    srcs = [os.path.join(_HERE, "woq_oracle.c"), os.path.join(_HERE, "woq_cpu_port.c"),
+            os.path.join(_HERE, "..", "include", "woq_blob.h")]
     if (not force and os.path.exists(_LIB_PATH)
-            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(f) for f in srcs)):
         return _LIB_PATH
     subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
     return _LIB_PATH
@@ -44,6 +44,9 @@ def lib():
         L.orc_packed_size.restype = ctypes.c_size_t
         L.orc_packed_size.argtypes = [ctypes.c_int] * 6
         L.orc_load_scalar.restype = ctypes.c_float
+        L.cpk_bytes.restype = ctypes.c_size_t
+        L.cpk_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.cpk_fill_random.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64]
         _lib = L
     return _lib
 
@@ -467,6 +470,50 @@ def woq_gemv_stream(x, blob, bias=None):
     if rc != 0:
         raise RuntimeError("orc_woq_gemv_stream failed")
     return out
+
+
+# ---- the CPU port timed as bench.py's cpu_baseline (oracle/woq_cpu_port.c) ---------------------
+class CpuPortLinear:
+    """One int4 linear on the CPU-friendly "CPK" layout (32-column blocks, K contiguous, nibble pairs): the port of
+    the reference's BesTLA fp32 core that `cpu_baseline` times. From (q, scales, zp) for the parity check, or
+    `synthetic(K, N, group, asym, seed)` for the timing leg (random nibbles filled in place, first-touched by the
+    thread that streams them)."""
+
+    def __init__(self, q, scales, zp, group):
+        q = _c(q, np.int8)
+        self.K, self.N = q.shape
+        self.group = self.K if group in (-1, 0) or group > self.K else group
+        self.scales = _c(scales, np.float32)
+        self.zp = _c(zp, np.int8)
+        self.w = np.empty(lib().cpk_bytes(self.K, self.N), np.uint8)
+        lib().cpk_pack(_p(q), self.K, self.N, _p(self.w))
+
+    @classmethod
+    def synthetic(cls, K, N, group, asym, seed):
+        self = cls.__new__(cls)
+        self.K, self.N, self.group = K, N, group
+        G = (K + group - 1) // group
+        rng = np.random.default_rng(seed)
+        self.scales = ((rng.random((G, N), dtype=np.float32) + 0.5) * 0.005).astype(np.float32)
+        self.zp = rng.integers(-8, 8, (G, N), dtype=np.int8) if asym else None
+        self.w = np.empty(lib().cpk_bytes(K, N), np.uint8)
+        lib().cpk_fill_random(_p(self.w), K, N, seed)
+        return self
+
+    @property
+    def nbytes(self):
+        return self.w.nbytes + self.scales.nbytes + (self.zp.nbytes if self.zp is not None else 0)
+
+    def __call__(self, x, bias=None, out=None):
+        x = _c(x, np.float32).ravel()
+        out = np.empty(self.N, np.float32) if out is None else out
+        lib().cpk_gemv(_p(x), _p(self.w), _p(self.scales), _p(self.zp), _p(_c(bias, np.float32)), self.K, self.N,
+                       self.group, _p(out))
+        return out
+
+
+def cpu_port_isa():
+    return {2: "avx512", 1: "avx2", 0: "scalar"}[lib().cpk_isa()]
 
 
 # ---- ops between the linears (HF semantics, SURVEY.md §8 a17) ---------------------------------

@@ -297,8 +297,9 @@ def test_tp_seam_world_size_one_rccl():
         tp = TPDecoder(eng, cfg["vocab"])
         got = tp.prefill(prompt)[0].cpu().numpy()
         assert np.array_equal(got, want)
-        eng.token.fill_(int(want.argmax()))
-        eng.pos.fill_(len(prompt))
+        # prefill leaves the engine where the single-GPU prefill(greedy=True) does: next token in place, pos = T
+        assert int(eng.token.item()) == int(ref_eng.token.item()) == int(want.argmax())
+        assert int(eng.pos.item()) == int(ref_eng.pos.item()) == len(prompt)
         for _ in range(3):
             lg = tp.step(greedy=True).cpu().numpy()
             ref_eng.step(greedy=True)

@@ -1,0 +1,175 @@
+"""The device-side tensor-parallel exchange (csrc/woq_comm.hip, runtime/comm.py) and TPDecoder on REAL device code at
+world size 2.
+
+The GPU box of the test tier has one GPU and RCCL refuses two ranks on one device, so the two ranks here are two
+processes that both run on cuda:0 (gloo only carries the rendezvous and the test's own gathers): the IPC handle
+exchange, the granule protocol (both inbox buffers, device-side sequence numbers across hipGraph replays), the
+arrival ticket, the token exchange and the engine wiring are exactly the code a multi-GPU node runs — what this
+cannot show is the fabric's memory behaviour (peer writes landing behind the local L2), which is what
+`DeviceComm.self_test()` checks at start-up on a real node. With >= 2 GPUs visible the same test places rank r on GPU r.
+
+Checked against the UNSHARDED oracle decoder (oracle.LlamaOracle on the full (q, scale, zp)): logits within the
+engine tolerance (2e-3 * max|logit| + 1e-4) and identical greedy tokens — eager steps, graph replays, and the prompt
+pass — plus the host-driven transport (TPDecoder without a comm) against the device one, bit for bit.
+"""
+import os
+import socket
+import sys
+import traceback
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+CFG = dict(hidden=256, inter=512, heads=4, kv_heads=2, head_dim=64, layers=2, vocab=384, eps=1e-5, theta=10000.0)
+GROUP = 32
+
+
+def _full_model(seed=3):
+    from oracle import woq_oracle as orc
+
+    rng = np.random.default_rng(seed)
+    c = CFG
+    H, I, NH, KV, D = c["hidden"], c["inter"], c["heads"], c["kv_heads"], c["head_dim"]
+    layers = []
+    for _ in range(c["layers"]):
+        shapes = dict(q=(H, NH * D), k=(H, KV * D), v=(H, KV * D), o=(NH * D, H), gate=(H, I), up=(H, I), down=(I, H))
+        parts = {n: orc.rtn_quantize(rng.standard_normal(s).astype(np.float32) * 0.05, False, GROUP, True)
+                 for n, s in shapes.items()}
+        layers.append(dict(parts=parts, ln1=(1 + 0.1 * rng.standard_normal(H)).astype(np.float32),
+                           ln2=(1 + 0.1 * rng.standard_normal(H)).astype(np.float32)))
+    embed = torch.from_numpy(rng.standard_normal((c["vocab"], H)).astype(np.float32)).half()
+    lm = torch.from_numpy((rng.standard_normal((c["vocab"], H)) * 0.1).astype(np.float32)).half()
+    norm = (1 + 0.1 * rng.standard_normal(H)).astype(np.float32)
+    return layers, embed, lm, norm
+
+
+def _rank_engine(rank, world, layers, embed, lm, norm, max_ctx=128):
+    from intel_extension_for_transformers_amd import qbits
+    from intel_extension_for_transformers_amd.runtime import WoqDecoderEngine, fuse_gate_up, tp
+
+    c = CFG
+    NH, KV, D = c["heads"] // world, c["kv_heads"] // world, c["head_dim"]
+    lm_local = tp.shard_vocab(lm, rank, world)
+    eng = WoqDecoderEngine(c["hidden"], c["inter"] // world, NH, KV, D, c["layers"], lm_local.shape[0], max_ctx=max_ctx,
+                           rms_eps=c["eps"], rope_theta=c["theta"], tp_rank=rank, tp_size=world)
+    e8, e32 = torch.empty(0, dtype=torch.int8), torch.empty(0, dtype=torch.int32)
+    tt = torch.from_numpy
+
+    def pack(q, s, z):
+        return qbits.repack_quantized_weight(tt(np.ascontiguousarray(q)).cuda(), tt(np.ascontiguousarray(s)).cuda(),
+                                             tt(np.ascontiguousarray(z)).cuda() if z is not None else e8, e32,
+                                             "int4_clip", "fp32", "fp32", z is not None, GROUP)
+
+    for l, ly in enumerate(layers):
+        sp = tp.shard_llama_layer(ly["parts"], rank, world, c["heads"], c["kv_heads"], D, GROUP)
+        cat = lambda i: np.concatenate([sp["q"][i], sp["k"][i], sp["v"][i]], 1)  # noqa: E731
+        gu = [fuse_gate_up(tt(np.ascontiguousarray(sp["gate"][i])), tt(np.ascontiguousarray(sp["up"][i]))).numpy()
+              for i in range(3)]
+        eng.set_layer(l, pack(cat(0), cat(1), cat(2)), pack(*sp["o"]), pack(*gu), pack(*sp["down"]), tt(ly["ln1"]),
+                      tt(ly["ln2"]))
+    eng.set_head(embed, tt(norm), lm_local)
+    return eng
+
+
+def _oracle(layers, embed, lm, norm):
+    from oracle import woq_oracle as orc
+
+    ls = [dict({n: orc.repack(q, s, z, None, GROUP) for n, (q, s, z) in ly["parts"].items()}, ln1=ly["ln1"],
+               ln2=ly["ln2"]) for ly in layers]
+    return orc.LlamaOracle(CFG, embed.float().numpy(), ls, norm, lm.float().numpy())
+
+
+def _rank_main(rank, world, port, errfile):
+    try:
+        sys.path.insert(0, ROOT)
+        import torch.distributed as dist
+
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(rank if torch.cuda.device_count() >= world else 0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from intel_extension_for_transformers_amd.runtime.comm import DeviceComm
+        from intel_extension_for_transformers_amd.runtime.tp import TPDecoder
+
+        comm = DeviceComm(CFG["hidden"], timeout_ms=10000)
+        assert comm.error is None, comm.error
+        assert comm.self_test(rounds=6)
+        # uneven arrival: rank 1 shows up late, rank 0 has to wait inside the kernel
+        t = torch.full((CFG["hidden"],), float(rank + 1), device="cuda")
+        if rank == 1:
+            torch.cuda._sleep(200_000_000)
+        comm.all_reduce(t)
+        assert torch.equal(t, torch.full_like(t, 3.0)) and comm.status() == 0
+
+        layers, embed, lm, norm = _full_model()
+        oracle = _oracle(layers, embed, lm, norm)
+        eng = _rank_engine(rank, world, layers, embed, lm, norm)
+        dec = TPDecoder(eng, CFG["vocab"], comm=comm)
+        host_eng = _rank_engine(rank, world, layers, embed, lm, norm)
+        host = TPDecoder(host_eng, CFG["vocab"])  # host-driven transport (gloo all_reduce of the device buffer)
+
+        def close(got, ref):
+            return np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-4 and got.argmax() == ref.argmax()
+
+        prompt = [3, 17, 200, 5]
+        for i, tok in enumerate(prompt):  # eager native steps, logits gathered
+            for e in (eng, host_eng):
+                e.token.fill_(tok)
+                e.pos.fill_(i)
+            got = dec.step(greedy=True).cpu().numpy()
+            got_host = host.step(greedy=True).cpu().numpy()
+            ref = oracle.forward_token(tok, i)
+            assert close(got, ref), (i, np.abs(got - ref).max())
+            assert np.array_equal(got, got_host)  # same kernels, same rank-ordered sum
+            assert int(eng.token.item()) == int(host_eng.token.item()) == int(ref.argmax())
+        # greedy chain: eager, then graph replays (device-side sequence numbers keep advancing), against the oracle
+        nxt, p = int(ref.argmax()), len(prompt)
+        for j in range(3):
+            got = dec.step(greedy=True).cpu().numpy()
+            ref = oracle.forward_token(nxt, p)
+            assert close(got, ref)
+            nxt, p = int(ref.argmax()), p + 1
+            assert int(eng.token.item()) == nxt and int(eng.pos.item()) == p
+        dec.capture()
+        for j in range(6):
+            dec.step(greedy=True, return_logits=False)  # one graph replay
+            ref = oracle.forward_token(nxt, p)
+            nxt, p = int(ref.argmax()), p + 1
+            assert int(eng.token.item()) == nxt and int(eng.pos.item()) == p, (j, int(eng.token.item()), nxt)
+        assert comm.status() == 0
+        # prompt pass under TP (rows through the device comm here; RCCL on a real node), then a step continues it
+        oracle.reset()
+        long_prompt = np.random.default_rng(9).integers(0, CFG["vocab"], 40).tolist()
+        for i, tok in enumerate(long_prompt):
+            ref = oracle.forward_token(tok, i)
+        got = dec.prefill(long_prompt)[0].cpu().numpy()
+        assert np.abs(got - ref).max() <= 1e-2 * np.abs(ref).max() + 1e-3  # fp16-operand GEMMs (test_gpu_engine.py)
+        assert int(eng.token.item()) == int(got.argmax()) and int(eng.pos.item()) == len(long_prompt)
+        step = dec.step(greedy=True).cpu().numpy()
+        ref2 = oracle.forward_token(int(got.argmax()), len(long_prompt))
+        assert np.abs(step - ref2).max() <= 1e-2 * np.abs(ref2).max() + 1e-3
+        assert comm.status() == 0
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException:
+        with open(errfile, "a") as fh:
+            fh.write("rank %d\n%s\n" % (rank, traceback.format_exc()))
+        raise
+
+
+def test_tp_world_size_two_device_exchange(tmp_path):
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    errfile = str(tmp_path / "errors.txt")
+    try:
+        mp.spawn(_rank_main, args=(2, port, errfile), nprocs=2, join=True)
+    except Exception:
+        msg = open(errfile).read() if os.path.exists(errfile) else "(no traceback captured)"
+        pytest.fail("a tensor-parallel rank failed:\n" + msg)

@@ -238,3 +238,22 @@ def test_fp8_tables_and_rtn_against_torch_float8(wt, tname):
         assert h["scale_type"] == (orc.BF16 if e8 else orc.F32)
         assert np.array_equal(orc.fp8_codes_of(blob), q)
         assert np.array_equal(orc.dequantize_blob(blob), tab[q] * np.repeat(s, 64, axis=0))
+
+
+@pytest.mark.parametrize("group,asym", [(128, False), (32, True), (96, True)])
+def test_cpu_port_matches_the_oracle_definition(group, asym):
+    """oracle/woq_cpu_port.c (the port bench.py times as cpu_baseline) against the oracle's definition of the same
+    linear (dequantise -> matmul -> + bias, double accumulate): a port that computes something else would make the
+    reported baseline meaningless. fp32 accumulation in k order per group -> 1e-5 * max|ref| is ample."""
+    rng = np.random.default_rng(group)
+    K, N = 768, 1000  # N not a multiple of the port's 32-column blocks; group 96: 8 whole groups
+    G = (K + group - 1) // group
+    q = rng.integers(-8, 8, (K, N), dtype=np.int8)
+    s = ((rng.random((G, N), dtype=np.float32) + 0.5) * 0.01).astype(np.float32)
+    z = rng.integers(-8, 8, (G, N), dtype=np.int8) if asym else None
+    x = rng.standard_normal(K).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    ref = orc.woq_linear(x[None], orc.repack(q, s, z, None, group), b)[0]
+    got = orc.CpuPortLinear(q, s, z, group)(x, b)
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert orc.cpu_port_isa() in ("avx512", "avx2", "scalar")
