@@ -186,7 +186,7 @@ def cpu_baseline(cfg, budget_s=10.0):
     h, i = cfg["hidden"], cfg["inter"]
     shapes = [(h, (cfg["heads"] + 2 * cfg["kv_heads"]) * cfg["head_dim"]), (cfg["heads"] * cfg["head_dim"], h),
               (h, 2 * i), (i, h)]
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    cores = orc.set_threads(orc.host_threads())  # affinity mask capped by the cgroup quota, not os.cpu_count()
     rng = np.random.default_rng(0)
     t_build = time.perf_counter()
     lins = [[orc.CpuPortLinear.synthetic(k, n, 128, False, l * 4 + j) for j, (k, n) in enumerate(shapes)]
@@ -210,7 +210,7 @@ def cpu_baseline(cfg, budget_s=10.0):
             break
     nbytes = sum(lin.nbytes for layer in lins for lin in layer)
     out = {
-        "value": reps / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
+        "value": reps / dt, "unit": "tokens/s", "cores": cores, "visible_cpus": os.cpu_count(), "kind": "port",
         "sample": "oracle/woq_cpu_port.c (%s, OpenMP): all %d layers x 4 fused int4 g128 linears of the %s shape "
                   "(%.2f GB streamed per token, fp32 scales), %d tokens in %.1f s; lm_head / attention / norms excluded"
                   % (orc.cpu_port_isa(), cfg["layers"], cfg["name"], nbytes / 1e9, reps, dt),
@@ -270,6 +270,7 @@ def parity_check(eng, cfg, tokens=(11, 20000, 317)):
     from oracle import woq_oracle as orc
 
     t0 = time.perf_counter()
+    orc.set_threads(orc.host_threads())
     host = lambda t: t.detach().cpu().numpy()  # noqa: E731
     layers = []
     for l in range(eng.cfg.layers):

@@ -343,12 +343,48 @@ ORC_API int orc_woq_linear(const float* x, int lda, const uint8_t* blob, const f
   woq_blob_header h;
   memcpy(&h, blob, sizeof(h));
   if (h.magic != WOQ_BLOB_MAGIC) return -1;
+  const int32_t* shuf = h.off_shuffle ? (const int32_t*)(blob + h.off_shuffle) : NULL;
+  if (M <= 4) {
+    /* few rows (decode shapes): no [K, N] fp32 copy of W — every thread owns 16-column tiles and dequantises element
+     * by element with the same formula as orc_dequantize_blob ((q - zp) * scale rounded to fp32), the same
+     * k-sequential double sum per output. Full-size matrices then cost milliseconds on a many-core host. */
+    const uint8_t* qd = blob + h.off_q;
+    const int tiles = (h.N + 15) / 16;
+#pragma omp parallel for schedule(static)
+    for (int tn = 0; tn < tiles; ++tn) {
+      double acc[4][16];
+      for (int m = 0; m < M; ++m)
+        for (int i = 0; i < 16; ++i) acc[m][i] = 0.0;
+      const int n1 = tn * 16 + 16 > h.N ? h.N - tn * 16 : 16;
+      for (int k = 0; k < h.K; ++k) {
+        float w[16];
+        for (int i = 0; i < n1; ++i) {
+          int shift;
+          const size_t b = woq_q_byte(&h, k, tn * 16 + i, &shift);
+          int qv = (qd[b] >> shift) & 0xf;
+          if (qv & 8) qv -= 16;
+          const size_t si = woq_scale_index(&h, k, tn * 16 + i);
+          const float sc = orc_load_scalar(blob + h.off_scale, si, (int)h.scale_type);
+          const int zpv = h.off_zp ? (int)(blob + h.off_zp)[si] - 8 : 0;
+          w[i] = (float)(qv - zpv) * sc;
+        }
+        for (int m = 0; m < M; ++m) {
+          const double xv = (double)x[(size_t)m * lda + (shuf ? shuf[k] : k)];
+          for (int i = 0; i < n1; ++i) acc[m][i] += xv * (double)w[i];
+        }
+      }
+      for (int m = 0; m < M; ++m)
+        for (int i = 0; i < n1; ++i) {
+          float r = (float)acc[m][i];
+          if (bias) r += bias[tn * 16 + i];
+          orc_store_scalar(out, (size_t)m * ldo + tn * 16 + i, out_dtype, r);
+        }
+    }
+    return 0;
+  }
   float* W = (float*)malloc((size_t)h.K * h.N * sizeof(float));
   if (!W) return -1;
   orc_dequantize_blob(blob, W, 0);
-  const int32_t* shuf = h.off_shuffle ? (const int32_t*)(blob + h.off_shuffle) : NULL;
-  /* every output is the same k-sequential double sum whichever loop is parallel: rows for many-row calls, 64-column
-   * blocks for the few-row calls (full-size decode shapes at M = 1 then use every host core) */
   const int CBLK = 64;
   const int n_blk = (h.N + CBLK - 1) / CBLK;
 #pragma omp parallel for schedule(static) collapse(2)

@@ -51,6 +51,37 @@ def lib():
     return _lib
 
 
+def host_threads():
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (a container can show
+    256 CPUs and grant 16 of them; an OpenMP team sized by the former then spends its time being descheduled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = int(fq.read()), int(fp.read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    env = os.environ.get("OMP_NUM_THREADS")
+    return min(n, int(env)) if env and env.isdigit() and int(env) > 0 else n
+
+
+def set_threads(n):
+    """Size the oracle's OpenMP team (the shared libgomp runtime of this process)."""
+    lib()
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError:
+        pass
+    return int(n)
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
