@@ -17,15 +17,22 @@
 
 #include "woq_device.h"
 #include "woq_launch.h"
+#include "woq_xq.h"
 
 namespace woq {
 int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                             const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w,
                             float eps, const float* residual, int ld_res, int epi, int nt, hipStream_t st);
-void launch_embed(const void* embed, int dtype, const int32_t* token, int hidden, float* out, hipStream_t st);
+void launch_embed(const void* embed, int dtype, const int32_t* token, int hidden, float* out, const float* norm_w,
+                  const XqPtrs& xo, float* ssq_out, hipStream_t st);
 int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
                        const float* cs, const float* sn, int heads, int kv_heads, int D, int max_ctx, int window,
-                       float* out, int splits, int grouped, float* part, hipStream_t st);
+                       float* out, int splits, int grouped, float* part, const XqPtrs& xo, hipStream_t st);
+// batch-1 GEMV over an XQ activation vector (woq_gemv_xq.hip)
+bool gemv_xq_supported(const woq_blob_header& h, int epi);
+int launch_gemv_xq(const XqPtrs& xin, const void* blob, const woq_blob_header& h, const float* bias, float* out,
+                   const float* ssq_in, float eps, const float* residual, int epi, const XqPtrs& xo,
+                   const float* next_norm_w, float* ssq_out, hipStream_t st);
 void launch_lm_head(const float* hidden_in, const float* norm_w, float eps, const void* W, int w_dtype, int hidden,
                     int vocab, float* logits, float* pmax, int32_t* pidx, hipStream_t st);
 void launch_argmax(const float* logits, int vocab, int32_t* token, int32_t* pos, hipStream_t st);
@@ -49,6 +56,8 @@ void launch_gather_last(const float* h, int n_seq, int T, int hidden, float* dst
 int woq_comm_launch_allreduce(woq_comm* c, float* buf, size_t n, hipStream_t st);
 int woq_comm_launch_greedy(woq_comm* c, const float* pmax, const int32_t* pidx, int n, int vocab_offset,
                            int32_t* token, int32_t* pos, hipStream_t st);
+
+using woq::XqPtrs;
 
 struct woq_engine {
   woq_engine_config cfg;
@@ -74,6 +83,13 @@ struct woq_engine {
   hipGraphExec_t exec = nullptr;
   woq_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
+  // XQ decode path (woq_xq.h): activations travel between the step's kernels as limb blocks written by the
+  // producing epilogue; on when every layer's blobs qualify (woq_engine_set_layer) and WOQ_ENGINE_XQ != 0
+  bool xq_shapes_ok = true, xq_enabled = true;
+  XqPtrs xq_hidden = {nullptr, nullptr, nullptr}, xq_attn = {nullptr, nullptr, nullptr},
+         xq_act = {nullptr, nullptr, nullptr};
+  float* ssq_part = nullptr;  // [hidden / 16] partial sums of squares of the residual stream
+  bool use_xq() const { return xq_enabled && xq_shapes_ok && xq_hidden.limbs != nullptr && cfg.tp_size <= 1; }
   woq_comm* comm = nullptr;  // device-side exchange: all-reduce kernels inside the (capturable) decode step
   int vocab_offset = 0;      // first vocabulary row of this rank's lm_head shard
   int nt = 1;
@@ -98,7 +114,38 @@ struct woq_engine {
 
 using namespace woq;
 
+static const XqPtrs kNoXq = {nullptr, nullptr, nullptr};
+
+// XQ form of the two sub-blocks: the same five launches, activations handed over as limb blocks
+static int engine_attn_block_xq(woq_engine* e, int l, hipStream_t st) {
+  const woq_engine_config& c = e->cfg;
+  const woq_layer_weights& w = e->layers[l];
+  int rc = launch_gemv_xq(e->xq_hidden, w.qkv_blob, w.qkv_hdr, nullptr, e->qkv, e->ssq_part, c.rms_eps, nullptr, 0,
+                          kNoXq, nullptr, nullptr, st);
+  if (rc) return rc;
+  rc = launch_attn_decode(e->qkv, e->kcache + (size_t)l * e->kv_layer_bytes, e->vcache + (size_t)l * e->kv_layer_bytes,
+                          c.kv_dtype, e->pos, e->cs, e->sn, c.heads, c.kv_heads, c.head_dim, c.max_ctx, e->window,
+                          e->attn, e->attn_splits, e->attn_grouped, e->attn_part, e->xq_attn, st);
+  if (rc) return rc;
+  // hidden += attn . W_o ; the new hidden leaves as the MLP's XQ input (times ln2) with its sums of squares
+  return launch_gemv_xq(e->xq_attn, w.o_blob, w.o_hdr, nullptr, e->hidden, nullptr, 0.f, e->hidden, 0, e->xq_hidden,
+                        w.ln2, e->ssq_part, st);
+}
+
+static int engine_mlp_block_xq(woq_engine* e, int l, hipStream_t st) {
+  const woq_engine_config& c = e->cfg;
+  const woq_layer_weights& w = e->layers[l];
+  int rc = launch_gemv_xq(e->xq_hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, nullptr, e->ssq_part, c.rms_eps,
+                          nullptr, 1, e->xq_act, nullptr, nullptr, st);
+  if (rc) return rc;
+  const bool last = l + 1 == c.layers;  // the last layer's output feeds the head, which reads fp32
+  return launch_gemv_xq(e->xq_act, w.down_blob, w.down_hdr, nullptr, e->hidden, nullptr, 0.f, e->hidden, 0,
+                        last ? kNoXq : e->xq_hidden, last ? nullptr : e->layers[l + 1].ln1, last ? nullptr : e->ssq_part,
+                        st);
+}
+
 static int engine_attn_block(woq_engine* e, int l, hipStream_t st) {
+  if (e->use_xq()) return engine_attn_block_xq(e, l, st);
   const woq_engine_config& c = e->cfg;
   const woq_layer_weights& w = e->layers[l];
   int rc = launch_gemv_from_header(e->hidden, WOQ_F32, c.hidden, w.qkv_blob, w.qkv_hdr, nullptr, e->qkv, WOQ_F32,
@@ -106,7 +153,7 @@ static int engine_attn_block(woq_engine* e, int l, hipStream_t st) {
   if (rc) return rc;
   rc = launch_attn_decode(e->qkv, e->kcache + (size_t)l * e->kv_layer_bytes, e->vcache + (size_t)l * e->kv_layer_bytes,
                           c.kv_dtype, e->pos, e->cs, e->sn, c.heads, c.kv_heads, c.head_dim, c.max_ctx, e->window,
-                          e->attn, e->attn_splits, e->attn_grouped, e->attn_part, st);
+                          e->attn, e->attn_splits, e->attn_grouped, e->attn_part, kNoXq, st);
   if (rc) return rc;
   // row-parallel o_proj: rank 0 carries the residual so that the sum over ranks adds it exactly once
   const float* res = (c.tp_size <= 1 || c.tp_rank == 0) ? e->hidden : nullptr;
@@ -115,6 +162,7 @@ static int engine_attn_block(woq_engine* e, int l, hipStream_t st) {
 }
 
 static int engine_mlp_block(woq_engine* e, int l, hipStream_t st) {
+  if (e->use_xq()) return engine_mlp_block_xq(e, l, st);
   const woq_engine_config& c = e->cfg;
   const woq_layer_weights& w = e->layers[l];
   int rc = launch_gemv_from_header(e->hidden, WOQ_F32, c.hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, e->act,
@@ -163,9 +211,15 @@ static int engine_allreduce_rows(woq_engine* e, float* buf, size_t count, hipStr
   return 0;
 }
 
+static void engine_embed(woq_engine* e, hipStream_t st) {
+  const bool xq = e->use_xq();
+  launch_embed(e->embed, e->embed_dtype, e->token, e->cfg.hidden, e->hidden, xq ? e->layers[0].ln1 : nullptr,
+               xq ? e->xq_hidden : kNoXq, xq ? e->ssq_part : nullptr, st);
+}
+
 static int engine_step_impl(woq_engine* e, int greedy, hipStream_t st) {
   const woq_engine_config& c = e->cfg;
-  launch_embed(e->embed, e->embed_dtype, e->token, c.hidden, e->hidden, st);
+  engine_embed(e, st);
   for (int l = 0; l < c.layers; ++l) {
     int rc = engine_attn_block(e, l, st);
     if (rc) return rc;
@@ -327,6 +381,26 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
   WOQ_HIP(hipMalloc((void**)&e->pf_logits, (size_t)e->max_batch * cfg->vocab * 4));
   e->owned = {e->hidden, e->qkv, e->attn, e->act, e->logits, e->token, e->pos, e->kcache, e->vcache, e->pf_last,
               e->pf_logits, e->attn_part, e->am_val, e->am_idx};
+  {  // XQ vectors (woq_xq.h) for the three GEMV inputs of a layer
+    const char* sw = getenv("WOQ_ENGINE_XQ");
+    e->xq_enabled = !(sw && sw[0] == '0');
+    const int attn_k = cfg->heads * cfg->head_dim;
+    if ((cfg->hidden % 16) == 0 && (attn_k % 16) == 0 && (cfg->inter % 16) == 0) {
+      void *bh = nullptr, *ba = nullptr, *bc = nullptr;
+      WOQ_HIP(hipMalloc(&bh, xq_bytes(cfg->hidden)));
+      WOQ_HIP(hipMalloc(&ba, xq_bytes(attn_k)));
+      WOQ_HIP(hipMalloc(&bc, xq_bytes(cfg->inter)));
+      WOQ_HIP(hipMalloc((void**)&e->ssq_part, (size_t)(cfg->hidden / 16) * 4));
+      WOQ_HIP(hipMemset(bh, 0, xq_bytes(cfg->hidden)));
+      WOQ_HIP(hipMemset(ba, 0, xq_bytes(attn_k)));
+      WOQ_HIP(hipMemset(bc, 0, xq_bytes(cfg->inter)));
+      WOQ_HIP(hipMemset(e->ssq_part, 0, (size_t)(cfg->hidden / 16) * 4));
+      e->xq_hidden = xq_carve(bh, cfg->hidden);
+      e->xq_attn = xq_carve(ba, attn_k);
+      e->xq_act = xq_carve(bc, cfg->inter);
+      for (void* p : {bh, ba, bc, (void*)e->ssq_part}) e->owned.push_back(p);
+    }
+  }
   *out = e;
   WOQ_END
 }
@@ -358,6 +432,8 @@ int woq_engine_set_layer(woq_engine* e, int layer, const woq_layer_weights* w) {
             "QBits: gate_up blob shape mismatch (inter must be a multiple of 16)");
   WOQ_CHECK(w->down_hdr.K == c.inter && w->down_hdr.N == c.hidden, "QBits: down_proj blob shape mismatch");
   e->layers[layer] = *w;
+  e->xq_shapes_ok = e->xq_shapes_ok && gemv_xq_supported(w->qkv_hdr, 0) && gemv_xq_supported(w->o_hdr, 0) &&
+                    gemv_xq_supported(w->gate_up_hdr, 1) && gemv_xq_supported(w->down_hdr, 0);
   WOQ_END
 }
 
@@ -426,7 +502,7 @@ int woq_engine_phase(woq_engine* e, int layer, int phase, int greedy, void* stre
   int rc = 0;
   if (phase == 0) {
     WOQ_CHECK(layer >= 0 && layer < e->cfg.layers, "QBits: bad layer index");
-    if (layer == 0) launch_embed(e->embed, e->embed_dtype, e->token, e->cfg.hidden, e->hidden, st);
+    if (layer == 0) engine_embed(e, st);
     rc = engine_attn_block(e, layer, st);
   } else if (phase == 1) {
     WOQ_CHECK(layer >= 0 && layer < e->cfg.layers, "QBits: bad layer index");
@@ -504,6 +580,21 @@ int woq_engine_time_gemv(woq_engine* e, int reps, void* stream, float* total_ms,
     for (int l = 0; l < c.layers; ++l) {
       const woq_layer_weights& w = e->layers[l];
       int rc;
+      if (e->use_xq()) {  // the same four launches in the form the step uses (outputs to scratch, no chaining)
+        if ((rc = launch_gemv_xq(e->xq_hidden, w.qkv_blob, w.qkv_hdr, nullptr, e->qkv, e->ssq_part, c.rms_eps, nullptr,
+                                 0, kNoXq, nullptr, nullptr, st)) != 0)
+          return rc;
+        if ((rc = launch_gemv_xq(e->xq_attn, w.o_blob, w.o_hdr, nullptr, e->act, nullptr, 0.f, nullptr, 0, kNoXq,
+                                 nullptr, nullptr, st)) != 0)
+          return rc;
+        if ((rc = launch_gemv_xq(e->xq_hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, e->act, e->ssq_part, c.rms_eps,
+                                 nullptr, 1, kNoXq, nullptr, nullptr, st)) != 0)
+          return rc;
+        if ((rc = launch_gemv_xq(e->xq_act, w.down_blob, w.down_hdr, nullptr, e->qkv, nullptr, 0.f, nullptr, 0, kNoXq,
+                                 nullptr, nullptr, st)) != 0)
+          return rc;
+        continue;
+      }
       rc = launch_gemv_from_header(e->hidden, WOQ_F32, c.hidden, w.qkv_blob, w.qkv_hdr, nullptr, e->qkv, WOQ_F32,
                                    w.qkv_hdr.N, 1, w.ln1, c.rms_eps, nullptr, 0, 0, e->nt, st);
       if (rc) return rc;

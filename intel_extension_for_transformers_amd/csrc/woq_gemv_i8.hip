@@ -44,8 +44,7 @@
 // (-mllvm -amdgpu-kernarg-preload-count, see the Makefile): no s_load round trip before the first address.
 #include <algorithm>
 
-#include "woq_device.h"
-#include "woq_launch.h"
+#include "woq_gemv_common.h"
 
 // Probe hooks (tools/gemv_probe.hip compiles this file with WOQ_PROBE, plus WOQ_PROBE_STAMPS for the per-stage
 // timeline — the stamps cost ~300 cycles each, so timings are taken without them). Nothing in the product build.
@@ -83,35 +82,9 @@ extern __device__ unsigned long long* g_probe;
 #endif
 namespace woq {
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TMAXM = 4;  // activation rows per launch: 4 MFMA rows (3 limbs + ones) per activation row
 
-// raw (as loaded) scale words of one tile, converted where they are used
-template <int SMODE, bool S32>
-struct RawSc;
-template <>
-struct RawSc<0, false> {
-  typedef uint16_t type;
-};
-template <>
-struct RawSc<0, true> {
-  typedef float type;
-};
-template <>
-struct RawSc<1, false> {
-  typedef uint2 type;
-};
-template <>
-struct RawSc<1, true> {
-  typedef float4_t type;
-};
-
-__device__ __forceinline__ float tscale16(uint32_t bits, bool is_bf16) {
-  const float a = bf16_bits_to_f32((uint16_t)bits), b = f16_bits_to_f32((uint16_t)bits);
-  return is_bf16 ? a : b;
-}
 
 // LDS (dynamic, bytes): [nw zero blocks of 256][nw ones blocks of 256][nw strips: 3*M limb rows x (TPW*128 + 16)]
 //                       [slab nw x CB x 64 f32][sumsq nw x TMAXM f32]
@@ -121,21 +94,7 @@ __host__ __device__ inline size_t tile_lds_bytes(int M, int nw, int TPW, int CB)
          (size_t)nw * TMAXM * 4;
 }
 
-// raw buffer descriptor (gfx950: dword3 = 0x00020000, 32-bit raw data format). Out-of-range reads return 0 and
-// touch no memory, so slice / matrix edges need no clamps or masks anywhere below. `p` must be wave-uniform.
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-__device__ __forceinline__ rsrc_t make_rsrc(const void* p, int bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
-}
-constexpr int AUX_NT = 2;  // non-temporal: streamed-once weights
 
-// three limb sums (D rows 4m..4m+2) + sum of 16*q (row 4m+3) of one lane -> the exact integer
-// sum_k 16 q_k (Q_k - 2^22) rounded once to fp32, Q = 23-bit offset-binary activation:
-//   Q - 2^22 = (b2 - 64) 2^16 + b1 2^8 + b0, rows hold b0 - 128, b1 - 128, b2
-__device__ __forceinline__ float limb_combine(const i32x4& d) {
-  const int i0 = d.x + (d.w << 7), i1 = d.y + (d.w << 7), i2 = d.z - (d.w << 6);
-  return fmaf((float)i2, 65536.f, fmaf((float)i1, 256.f, (float)i0));
-}
 
 // flags: bit 0 scales are bf16 (else fp16; ignored for fp32 scales), bit 1 SiLU(gate)*up epilogue (CB == 2)
 template <int TPW, int CB, int SMODE, bool ASYM, bool S32, bool M1>
@@ -566,21 +525,20 @@ static int launch_tile_sm(const TileLaunch& a, int smode, bool asym, bool s32, h
   return woq::fail("QBits: bad tile GEMV configuration");
 }
 
-static bool tile_geometry(int tiles_k, int cb, int smode, int& nw, int& tpw);
 // K ranges one launch cannot hold are split into equal chunks run as chained launches (chunk i + 1 adds onto chunk
 // i's fp32 output through the residual input): linear epilogues only. Returns the number of chunks, 0 = not covered.
-static int tile_k_chunks(int tiles_k, int cb, int smode, bool chainable) {
+int gemv_tile_k_chunks(int tiles_k, int cb, int smode, bool chainable) {
   int nw, tpw;
-  if (tile_geometry(tiles_k, cb, smode, nw, tpw)) return 1;
+  if (gemv_tile_geometry(tiles_k, cb, smode, nw, tpw)) return 1;
   if (!chainable) return 0;
   for (int s = 2; s <= 8; ++s)
-    if (tile_geometry((tiles_k + s - 1) / s, cb, smode, nw, tpw)) return s;
+    if (gemv_tile_geometry((tiles_k + s - 1) / s, cb, smode, nw, tpw)) return s;
   return 0;
 }
 
 // geometry pick: nw waves x tpw tiles cover tiles_k (8 tiles = 8 KiB per wave per column tile; 4 for short K so
 // that a workgroup still has a few waves). Returns false when this kernel does not take the shape (K > 16384).
-static bool tile_geometry(int tiles_k, int cb, int smode, int& nw, int& tpw) {
+bool gemv_tile_geometry(int tiles_k, int cb, int smode, int& nw, int& tpw) {
   static const int force4 = [] {  // WOQ_TILE_TPW4=<max tiles_k>: 4 tiles per wave up to that K (timing experiments)
     const char* s = getenv("WOQ_TILE_TPW4");
     return s ? atoi(s) : 0;
@@ -602,8 +560,8 @@ int gemv_tile_max_rows(const void* act, int act_dtype, int lda, const woq_blob_h
   const int tiles_k = h.Kpad / WOQ_TILE_K;
   const int cb = epi == 1 ? 2 : 1;
   int nw, tpw;
-  const int chunks = tile_k_chunks(tiles_k, cb, (int)h.scale_mode, epi == 0 && !norm_w && out_dtype == WOQ_F32);
-  if (chunks == 0 || !tile_geometry((tiles_k + chunks - 1) / chunks, cb, (int)h.scale_mode, nw, tpw)) return 0;
+  const int chunks = gemv_tile_k_chunks(tiles_k, cb, (int)h.scale_mode, epi == 0 && !norm_w && out_dtype == WOQ_F32);
+  if (chunks == 0 || !gemv_tile_geometry((tiles_k + chunks - 1) / chunks, cb, (int)h.scale_mode, nw, tpw)) return 0;
   if (h.scale_mode == 0 && h.n_groups > 1) {
     const int tpg = h.group / WOQ_TILE_K;
     if (tpg < 1 || (tpg & (tpg - 1)) != 0) return 0;  // tiles per group must be a power of two
@@ -654,7 +612,7 @@ int launch_gemv_tile(const void* act, int act_dtype, int lda, int M, const void*
   if (epi == 1 && (tiles_n & 1)) return woq::fail("QBits: fused gate/up weight needs an even number of column tiles");
   const int smode = (int)h.scale_mode;
   const bool asym = a.zp != nullptr, s32 = h.scale_type == WOQ_F32;
-  const int chunks = tile_k_chunks(a.tiles_k, cb, smode, epi == 0 && !norm_w && out_dtype == WOQ_F32);
+  const int chunks = gemv_tile_k_chunks(a.tiles_k, cb, smode, epi == 0 && !norm_w && out_dtype == WOQ_F32);
   if (act_dtype != WOQ_F32 || M > TMAXM || chunks == 0)
     return woq::fail("QBits: shape not covered by the tile GEMV");
   a.grid = tiles_n / cb;
@@ -664,7 +622,7 @@ int launch_gemv_tile(const void* act, int act_dtype, int lda, int M, const void*
     a.kt_count = std::min(per, a.tiles_k - a.kt_begin);
     if (a.kt_count <= 0) break;
     int tpw;
-    if (!tile_geometry(a.kt_count, cb, smode, a.nw, tpw)) return woq::fail("QBits: shape not covered by the tile GEMV");
+    if (!gemv_tile_geometry(a.kt_count, cb, smode, a.nw, tpw)) return woq::fail("QBits: shape not covered by the tile GEMV");
     if (c > 0) {  // add onto the previous chunk's output
       a.bias = nullptr;
       a.residual = (const float*)out;

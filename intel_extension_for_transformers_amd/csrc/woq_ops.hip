@@ -6,6 +6,7 @@
 // vector kernels: 16-byte loads, fp32 math, wave64 shuffles; no MFMA.
 #include "woq_device.h"
 #include "woq_launch.h"
+#include "woq_xq.h"
 
 namespace woq {
 
@@ -78,10 +79,21 @@ __global__ void gelu_kernel(const void* __restrict__ x, int dtype, size_t n, int
 // ---- engine kernels (batch-1 decode) --------------------------------------------------------------
 
 // hidden[h] = embed[token][h]  (fp32 residual stream)
+// xo (optional): the row also leaves as the first layer's XQ vector (times its input norm weight) with the per-block
+// sums of squares — hidden % 16 == 0, so every 16-lane row is one whole block
 __global__ void embed_kernel(const void* __restrict__ embed, int dtype, const int32_t* __restrict__ token, int hidden,
-                             float* __restrict__ out) {
+                             float* __restrict__ out, const float* __restrict__ norm_w, XqPtrs xo,
+                             float* __restrict__ ssq_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < hidden) out[i] = load_f32(embed, (size_t)token[0] * hidden + i, dtype);
+  if (i < hidden) {
+    const float v = load_f32(embed, (size_t)token[0] * hidden + i, dtype);
+    out[i] = v;
+    if (xo.limbs != nullptr) {
+      const float ss = row16_sum(v * v);
+      if ((i & 15) == 0) ssq_out[i >> 4] = ss;
+      xq_emit16(v * norm_w[i], xo, i >> 4, i & 15);
+    }
+  }
 }
 
 // Single-query attention for one new token: one workgroup (4 waves) per query head.
@@ -102,7 +114,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
                                                           KV* __restrict__ vcache, const int32_t* __restrict__ pos_p,
                                                           const float* __restrict__ cs, const float* __restrict__ sn,
                                                           int heads, int kv_heads, int window,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, XqPtrs xo) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   typedef typename KvVec8<KV>::type kv8;
   constexpr int half = HD / 2;
@@ -291,6 +303,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
       }
     } else {
       out[(size_t)h * HD + tid] = o / den;
+      // the o_proj GEMV's XQ input: tid < HD is a whole number of 16-lane rows, one block each
+      if (xo.limbs != nullptr) xq_emit16(o / den, xo, (h * HD + tid) >> 4, tid & 15);
     }
   }
 }
@@ -301,7 +315,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
 // written partials cost 14 us of pure load latency.
 template <int HD>
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part, int ns,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, XqPtrs xo) {
   __shared__ float ms[64], wl[64], wsc[64], red[256];
   const int h = blockIdx.x, tid = threadIdx.x;
   const float* p = part + (size_t)h * ns * (HD + 2);
@@ -332,6 +346,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
 #pragma unroll
     for (int g2 = 0; g2 < GROUPS; ++g2) t += red[g2 * HD + d];
     out[(size_t)h * HD + d] = t / l;
+    if (xo.limbs != nullptr) xq_emit16(t / l, xo, (h * HD + d) >> 4, d & 15);
   }
 }
 
@@ -458,19 +473,22 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
 }
 
 // ---- host launchers used by the engine ------------------------------------------------------------
-void launch_embed(const void* embed, int dtype, const int32_t* token, int hidden, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(embed_kernel, dim3((hidden + 255) / 256), dim3(256), 0, st, embed, dtype, token, hidden, out);
+void launch_embed(const void* embed, int dtype, const int32_t* token, int hidden, float* out, const float* norm_w,
+                  const XqPtrs& xo, float* ssq_out, hipStream_t st) {
+  hipLaunchKernelGGL(embed_kernel, dim3((hidden + 255) / 256), dim3(256), 0, st, embed, dtype, token, hidden, out,
+                     norm_w, xo, ssq_out);
 }
 
 bool launch_attn_decode_mfma(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
                              const float* cs, const float* sn, int heads, int kv_heads, int D, int window, int splits,
                              float* part, hipStream_t st);
-void launch_attn_combine(const float* part, int heads, int D, int splits, float* out, hipStream_t st);
+void launch_attn_combine(const float* part, int heads, int D, int splits, float* out, const XqPtrs& xo,
+                         hipStream_t st);
 
 template <typename KV, int HD>
 static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int32_t* pos, const float* cs,
                          const float* sn, int heads, int kv_heads, int max_ctx, int window, float* out, int splits,
-                         float* part, hipStream_t st) {
+                         float* part, const XqPtrs& xo, hipStream_t st) {
   constexpr int GP = 64 / (HD / 8);
   const int reach = window > 0 ? min(window, max_ctx) : max_ctx;  // positions a query can see
   const int span = splits > 1 ? ((((reach + splits - 1) / splits) + 63) & ~63) + 64 : reach;
@@ -484,8 +502,8 @@ static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int
       once = true;
     }
     hipLaunchKernelGGL(k, dim3(heads, splits), dim3(256), lds, st, qkv, (KV*)kcache, (KV*)vcache, pos, cs, sn, heads,
-                       kv_heads, window, part);
-    hipLaunchKernelGGL(attn_combine_kernel<HD>, dim3(heads), dim3(256), 0, st, part, splits, out);
+                       kv_heads, window, part, XqPtrs{nullptr, nullptr, nullptr});
+    hipLaunchKernelGGL(attn_combine_kernel<HD>, dim3(heads), dim3(256), 0, st, part, splits, out, xo);
     return 0;
   }
   auto k = attn_decode_kernel<KV, HD, false>;
@@ -495,7 +513,7 @@ static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int
     once = true;
   }
   hipLaunchKernelGGL(k, dim3(heads), dim3(256), lds, st, qkv, (KV*)kcache, (KV*)vcache, pos, cs, sn, heads, kv_heads,
-                     window, out);
+                     window, out, xo);
   return 0;
 }
 
@@ -503,31 +521,32 @@ static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int
 // `part` (fp32 [heads][splits][D + 2]).
 int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
                        const float* cs, const float* sn, int heads, int kv_heads, int D, int max_ctx, int window,
-                       float* out, int splits, int grouped, float* part, hipStream_t st) {
+                       float* out, int splits, int grouped, float* part, const XqPtrs& xo, hipStream_t st) {
   if (D != 64 && D != 128) return woq::fail("QBits: attention head_dim must be 64 or 128");
   // grouped-query form (woq_prefill.hip): only where it applies — head_dim 128, 2 / 4 / 8 query heads per kv head,
   // an fp16 or fp8 cache — anything else keeps the per-query-head slices
   if (grouped && launch_attn_decode_mfma(qkv, kcache, vcache, kv_dtype, pos, cs, sn, heads, kv_heads, D, window, splits,
                                           part, st)) {
-    launch_attn_combine(part, heads, D, splits, out, st);
+    launch_attn_combine(part, heads, D, splits, out, xo, st);
     return 0;
   }
 #define WOQ_ATTN_DEC(T)                                                                                              \
   return D == 128 ? launch_attn_t<T, 128>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, window, out,   \
-                                          splits, part, st)                                                         \
+                                          splits, part, xo, st)                                                     \
                   : launch_attn_t<T, 64>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, window, out,    \
-                                         splits, part, st);
+                                         splits, part, xo, st);
   if (kv_dtype == WOQ_F16) { WOQ_ATTN_DEC(_Float16) }
   if (kv_dtype == WOQ_FP8_E4M3) { WOQ_ATTN_DEC(Fp8) }
   WOQ_ATTN_DEC(__bf16)
 #undef WOQ_ATTN_DEC
 }
 
-void launch_attn_combine(const float* part, int heads, int D, int splits, float* out, hipStream_t st) {
+void launch_attn_combine(const float* part, int heads, int D, int splits, float* out, const XqPtrs& xo,
+                         hipStream_t st) {
   if (D == 128)
-    hipLaunchKernelGGL(attn_combine_kernel<128>, dim3(heads), dim3(256), 0, st, part, splits, out);
+    hipLaunchKernelGGL(attn_combine_kernel<128>, dim3(heads), dim3(256), 0, st, part, splits, out, xo);
   else
-    hipLaunchKernelGGL(attn_combine_kernel<64>, dim3(heads), dim3(256), 0, st, part, splits, out);
+    hipLaunchKernelGGL(attn_combine_kernel<64>, dim3(heads), dim3(256), 0, st, part, splits, out, xo);
 }
 
 // pmax / pidx (nullable): per-workgroup (max logit, its index), (vocab + 15) / 16 entries each

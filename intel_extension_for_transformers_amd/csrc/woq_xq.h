@@ -1,0 +1,85 @@
+// woq_xq.h — "XQ": an activation vector already in the decode GEMV's A-operand form.
+//
+// Why. gemv_tile_kernel (woq_gemv_i8.hip) converts its fp32 activation row to three int8 limb rows inside EVERY
+// workgroup (768 / 256 / 688 / 256 times per layer for the Llama-2-7B projections) — loads of x and the norm weight,
+// a wave-wide max and sum, ~170 VALU and 12 LDS stores per wave, all on the launch's critical path. Knocking that
+// stage out of the kernel saves 1.8 / 0.9 / 1.6 / 1.5 us of the 8.5 / 5.2 / 12.1 / 8.2 us back-to-back launch times
+// (profiles/r02b_gemv_knockouts.txt): 17 % of the GEMV time is re-deriving the same bytes. XQ moves the conversion to
+// the PRODUCER of the vector — 16 threads of the epilogue that already hold the 16 values — so it happens once.
+//
+// Format, for K = 16 * nb values: block b = values [16 b, 16 b + 16) — exactly what one producer workgroup (one
+// 16-column output tile of the previous GEMV, or 16 lanes of the attention / embedding kernels) owns, so no
+// cross-workgroup reduction is needed:
+//   limbs [nb][3][16] int8 : 22-bit + sign offset-binary fixed point of y * 2^(21 - e_b), e_b = exponent of the
+//                            block's max |y|; rows hold b0 - 128, b1 - 128, b2 (same bytes gemv_tile_kernel stages)
+//   u     [nb] fp32        : 2^(e_b - 25), undoes the block's fixed-point scale and the 16 * q weight bytes
+//   sx    [nb] fp32        : sum over the block of (Q - 2^22), the fixed-point activations' sum (zero-point term)
+// A block is one (64-k half, lane quarter) of the consumer's v_mfma_i32_16x16x64_i8: MFMA rows 4 e .. 4 e + 3 carry
+// quarter e's three limbs and its ones row and zeros elsewhere, so ONE MFMA per half returns the four blocks' sums
+// separately, one per lane quarter, each scaled by its own u (and, for group 32, its own weight scale). The error
+// bound tightens from max|x_slice| * 2^-22 to max|x_block| * 2^-22 per element.
+// RMSNorm stays separable: the producer multiplies by the NEXT norm's weight before converting and leaves one partial
+// sum of squares of the raw values per block; the consumer adds them up in a fixed order.
+#pragma once
+#include "woq_device.h"
+
+namespace woq {
+
+struct XqPtrs {  // device pointers of one XQ vector (all null = absent)
+  uint8_t* limbs;
+  float* u;
+  float* sx;
+};
+
+// bytes of an XQ vector of K values: limbs padded so that 1-KiB LDS-DMA pieces never leave the allocation
+__host__ __device__ inline size_t xq_limb_bytes(int K) { return (((size_t)(K / 16) * 48 + 1023) / 1024) * 1024 + 1024; }
+__host__ __device__ inline size_t xq_bytes(int K) { return xq_limb_bytes(K) + (size_t)(K / 16) * 8; }
+__host__ inline XqPtrs xq_carve(void* base, int K) {
+  XqPtrs p;
+  p.limbs = (uint8_t*)base;
+  p.u = (float*)((uint8_t*)base + xq_limb_bytes(K));
+  p.sx = p.u + K / 16;
+  return p;
+}
+
+// 16-lane (one DPP row) all-reduces: quad_perm xor 1, xor 2, row_half_mirror, row_mirror
+#define WOQ_DPP_I32(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xf, 0xf, false)
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, WOQ_DPP_F32(v, 0xB1));
+  v = fmaxf(v, WOQ_DPP_F32(v, 0x4E));
+  v = fmaxf(v, WOQ_DPP_F32(v, 0x141));
+  return fmaxf(v, WOQ_DPP_F32(v, 0x140));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += WOQ_DPP_F32(v, 0xB1);
+  v += WOQ_DPP_F32(v, 0x4E);
+  v += WOQ_DPP_F32(v, 0x141);
+  return v + WOQ_DPP_F32(v, 0x140);
+}
+__device__ __forceinline__ int row16_sum_i32(int v) {
+  v += WOQ_DPP_I32(v, 0xB1);
+  v += WOQ_DPP_I32(v, 0x4E);
+  v += WOQ_DPP_I32(v, 0x141);
+  return v + WOQ_DPP_I32(v, 0x140);
+}
+
+// Called by the 16 lanes of ONE DPP row (lanes 16 r .. 16 r + 15, all active), lane j = lane & 15 holding value
+// 16 * blk + j of the vector: writes block `blk`. Same conversion as gemv_tile_kernel's stage_row (fp32 sum with
+// 1.5 * 2^23: the mantissa IS round(y * 2^(21 - e)) + 2^22).
+__device__ __forceinline__ void xq_emit16(float y, const XqPtrs& o, int blk, int j) {
+  const float amax = row16_max(fabsf(y));
+  int e = 0;
+  if (amax > 0.f && amax < INFINITY) e = max(-100, min(100, __builtin_amdgcn_frexp_expf(amax)));
+  const uint32_t Q = __float_as_uint(fmaf(y, ldexpf(1.f, 21 - e), 12582912.f));
+  uint8_t* d = o.limbs + (size_t)blk * 48 + j;
+  d[0] = (uint8_t)((Q & 0xffu) ^ 0x80u);          // limb 0: b0 - 128
+  d[16] = (uint8_t)(((Q >> 8) & 0xffu) ^ 0x80u);  // limb 1: b1 - 128
+  d[32] = (uint8_t)((Q >> 16) & 0xffu);           // limb 2: b2 in [0, 127]
+  const int qs = row16_sum_i32((int)(Q & 0x7fffffu) - (1 << 22));
+  if (j == 0) {
+    o.u[blk] = ldexpf(1.f, e - 25);
+    o.sx[blk] = (float)qs;
+  }
+}
+
+}  // namespace woq
