@@ -116,30 +116,37 @@ using namespace woq;
 
 static const XqPtrs kNoXq = {nullptr, nullptr, nullptr};
 
+// one batch-1 projection over an XQ vector
+static int engine_gemv_xq(woq_engine* e, const XqPtrs& xin, const void* blob, const woq_blob_header& h, float* out,
+                          const float* ssq_in, const float* residual, int epi, const XqPtrs& xo,
+                          const float* next_norm_w, float* ssq_out, hipStream_t st) {
+  return launch_gemv_xq(xin, blob, h, nullptr, out, ssq_in, e->cfg.rms_eps, residual, epi, xo, next_norm_w, ssq_out, st);
+}
+
 // XQ form of the two sub-blocks: the same five launches, activations handed over as limb blocks
 static int engine_attn_block_xq(woq_engine* e, int l, hipStream_t st) {
   const woq_engine_config& c = e->cfg;
   const woq_layer_weights& w = e->layers[l];
-  int rc = launch_gemv_xq(e->xq_hidden, w.qkv_blob, w.qkv_hdr, nullptr, e->qkv, e->ssq_part, c.rms_eps, nullptr, 0,
-                          kNoXq, nullptr, nullptr, st);
+  int rc = engine_gemv_xq(e, e->xq_hidden, w.qkv_blob, w.qkv_hdr, e->qkv, e->ssq_part, nullptr, 0, kNoXq, nullptr,
+                          nullptr, st);
   if (rc) return rc;
   rc = launch_attn_decode(e->qkv, e->kcache + (size_t)l * e->kv_layer_bytes, e->vcache + (size_t)l * e->kv_layer_bytes,
                           c.kv_dtype, e->pos, e->cs, e->sn, c.heads, c.kv_heads, c.head_dim, c.max_ctx, e->window,
                           e->attn, e->attn_splits, e->attn_grouped, e->attn_part, e->xq_attn, st);
   if (rc) return rc;
   // hidden += attn . W_o ; the new hidden leaves as the MLP's XQ input (times ln2) with its sums of squares
-  return launch_gemv_xq(e->xq_attn, w.o_blob, w.o_hdr, nullptr, e->hidden, nullptr, 0.f, e->hidden, 0, e->xq_hidden,
-                        w.ln2, e->ssq_part, st);
+  return engine_gemv_xq(e, e->xq_attn, w.o_blob, w.o_hdr, e->hidden, nullptr, e->hidden, 0, e->xq_hidden, w.ln2,
+                        e->ssq_part, st);
 }
 
 static int engine_mlp_block_xq(woq_engine* e, int l, hipStream_t st) {
   const woq_engine_config& c = e->cfg;
   const woq_layer_weights& w = e->layers[l];
-  int rc = launch_gemv_xq(e->xq_hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, nullptr, e->ssq_part, c.rms_eps,
-                          nullptr, 1, e->xq_act, nullptr, nullptr, st);
+  int rc = engine_gemv_xq(e, e->xq_hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, e->ssq_part, nullptr, 1, e->xq_act,
+                          nullptr, nullptr, st);
   if (rc) return rc;
   const bool last = l + 1 == c.layers;  // the last layer's output feeds the head, which reads fp32
-  return launch_gemv_xq(e->xq_act, w.down_blob, w.down_hdr, nullptr, e->hidden, nullptr, 0.f, e->hidden, 0,
+  return engine_gemv_xq(e, e->xq_act, w.down_blob, w.down_hdr, e->hidden, nullptr, e->hidden, 0,
                         last ? kNoXq : e->xq_hidden, last ? nullptr : e->layers[l + 1].ln1, last ? nullptr : e->ssq_part,
                         st);
 }
@@ -581,17 +588,17 @@ int woq_engine_time_gemv(woq_engine* e, int reps, void* stream, float* total_ms,
       const woq_layer_weights& w = e->layers[l];
       int rc;
       if (e->use_xq()) {  // the same four launches in the form the step uses (outputs to scratch, no chaining)
-        if ((rc = launch_gemv_xq(e->xq_hidden, w.qkv_blob, w.qkv_hdr, nullptr, e->qkv, e->ssq_part, c.rms_eps, nullptr,
-                                 0, kNoXq, nullptr, nullptr, st)) != 0)
+        if ((rc = engine_gemv_xq(e, e->xq_hidden, w.qkv_blob, w.qkv_hdr, e->qkv, e->ssq_part, nullptr, 0, kNoXq, nullptr,
+                                 nullptr, st)) != 0)
           return rc;
-        if ((rc = launch_gemv_xq(e->xq_attn, w.o_blob, w.o_hdr, nullptr, e->act, nullptr, 0.f, nullptr, 0, kNoXq,
+        if ((rc = engine_gemv_xq(e, e->xq_attn, w.o_blob, w.o_hdr, e->act, nullptr, nullptr, 0, kNoXq, nullptr, nullptr,
+                                 st)) != 0)
+          return rc;
+        if ((rc = engine_gemv_xq(e, e->xq_hidden, w.gate_up_blob, w.gate_up_hdr, e->act, e->ssq_part, nullptr, 1, kNoXq,
                                  nullptr, nullptr, st)) != 0)
           return rc;
-        if ((rc = launch_gemv_xq(e->xq_hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, e->act, e->ssq_part, c.rms_eps,
-                                 nullptr, 1, kNoXq, nullptr, nullptr, st)) != 0)
-          return rc;
-        if ((rc = launch_gemv_xq(e->xq_act, w.down_blob, w.down_hdr, nullptr, e->qkv, nullptr, 0.f, nullptr, 0, kNoXq,
-                                 nullptr, nullptr, st)) != 0)
+        if ((rc = engine_gemv_xq(e, e->xq_act, w.down_blob, w.down_hdr, e->qkv, nullptr, nullptr, 0, kNoXq, nullptr,
+                                 nullptr, st)) != 0)
           return rc;
         continue;
       }

@@ -30,6 +30,20 @@ __host__ __device__ inline size_t xq_lds_bytes(int nw, int TPW, int CB) {
   return (size_t)nw * 512 + (size_t)nw * TPW * 384 + (size_t)nw * CB * 16 * 4 + 256;
 }
 
+// v of lane ^ 32 (valid in lanes 0..31) and of lane ^ 16 (valid in lanes 0..15), by gfx950's lane-swap VALU ops
+// instead of two ds_bpermute round trips: v_permlane32_swap exchanges the upper half of its first operand with the
+// lower half of the second, v_permlane16_swap the odd 16-lane rows of the first with the even rows of the second
+__device__ __forceinline__ float quarter_swap32(float v) {
+  const uint32_t b = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+  return __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float quarter_swap16(float v) {
+  const uint32_t b = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+  return __uint_as_float(r[1]);
+}
+
 // flags: bit 0 scales are bf16 (else fp16; ignored for fp32 scales), bit 1 SiLU(gate)*up epilogue (CB == 2)
 template <int TPW, int CB, int SMODE, bool ASYM, bool S32>
 __global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_xq_kernel(
@@ -159,17 +173,25 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_xq_kernel(
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) tot[cb] = 0.f;
 
+  // this lane quarter's block factors (and block sums) of every tile, fetched across lanes ONCE: left next to
+  // their uses, each tile would start with two LDS-crossbar round trips on the wave's critical path
+  float ub[TPW][2], sb[TPW][2];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      ub[t][h2] = __shfl(uw, t * 8 + h2 * 4 + kq, 64);
+      sb[t][h2] = ASYM ? __shfl(sxw, t * 8 + h2 * 4 + kq, 64) : 0.f;
+    }
+  __builtin_amdgcn_sched_barrier(0);
+
   // ---- 3. inner products, tiles in arrival order ----
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     const i32x4 a0 = *(const i32x4*)(a_base + t * a_step_t);
     const i32x4 a1 = *(const i32x4*)(a_base + t * a_step_t + a_step_h);
-    const float u0 = __shfl(uw, t * 8 + kq, 64), u1 = __shfl(uw, t * 8 + 4 + kq, 64);
-    float s0 = 0.f, s1 = 0.f;
-    if constexpr (ASYM) {
-      s0 = __shfl(sxw, t * 8 + kq, 64);
-      s1 = __shfl(sxw, t * 8 + 4 + kq, 64);
-    }
+    const float u0 = ub[t][0], u1 = ub[t][1];
+    const float s0 = sb[t][0], s1 = sb[t][1];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
       const u32x4 wv = w[cb][t];
@@ -214,8 +236,8 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_xq_kernel(
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
     float v = tot[cb];
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+    v += quarter_swap32(v);  // lanes 0..31: this lane + lane ^ 32
+    v += quarter_swap16(v);  // lanes 0..15: + lane ^ 16
     if (lane < 16) slab[((size_t)wid * CB + cb) * 16 + lane] = v;
   }
   if (ssq_in != nullptr && wid == 0) {
