@@ -115,7 +115,8 @@ def gemv_roofline(eng, traffic=None):
     achieved = (by / n_launch) / (us * 1e-6) / 1e9
     return {
         "bound": "hbm",
-        "kernel": "woq::gemv_tile_kernel (int4 GEMV, M=1, csrc/woq_gemv_i8.hip)",
+        "kernel": "woq::gemv_xq_kernel (int4 GEMV over XQ limb blocks, M=1, csrc/woq_gemv_xq.hip)" if eng.uses_xq()
+                  else "woq::gemv_tile_kernel (int4 GEMV, M=1, csrc/woq_gemv_i8.hip)",
         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
         "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBPS,
         "traffic": traffic, "us_per_launch": us, "algorithmic_bytes_per_launch": by / n_launch,
@@ -415,11 +416,12 @@ def tp_point(args, cfg, rank, world, dist, steps, warmup, as_extra=False):
     elapsed = timed(run, steps, warmup, fence)
     agree = True
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        on = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=on)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        toks = [torch.zeros_like(eng.token) for _ in range(world)]
-        dist.all_gather(toks, eng.token)
+        toks = [torch.zeros(1, dtype=torch.int32, device=on) for _ in range(world)]
+        dist.all_gather(toks, eng.token.to(on))
         agree = len({int(x.item()) for x in toks}) == 1
         if comm is not None and comm.status() != 0:
             raise RuntimeError("tensor-parallel exchange reported a timeout during the timed region")
@@ -434,7 +436,7 @@ def tp_point(args, cfg, rank, world, dist, steps, warmup, as_extra=False):
         "tokens_per_s": tok_s, "ms_per_token": elapsed * 1e3 / steps, "elapsed_s": elapsed,
         "algorithmic_weight_bytes_per_token_per_gpu": wbytes,
         "hbm_gbps_per_gpu": wbytes * tok_s / 1e9, "hbm_frac_per_gpu": wbytes * tok_s / 1e9 / HBM_PEAK_GBPS,
-        "rccl_ranks": world, "allreduces_per_token": 2 * n_layers if world > 1 else 0,
+        "rccl_ranks": world, "process_group_backend": dist.get_backend() if dist is not None else None, "allreduces_per_token": 2 * n_layers if world > 1 else 0,
         "token_exchanges_per_token": 1 if world > 1 else 0, "allreduce_bytes": cfg["hidden"] * 4,
         "allreduce_transport": transport, "hipgraph": use_graph, "ranks_agree_on_token": agree,
     }
@@ -472,13 +474,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # WOQ_BENCH_BACKEND=gloo (development): the N > 1 code path with several ranks on ONE GPU — RCCL refuses that, the
+    # device exchange does not need it (tests/test_gpu_tp_device.py). Never what the driver runs.
+    backend = os.environ.get("WOQ_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     workload = args.workload
     if workload == "auto":
         workload = "70b" if world > 1 or torch.cuda.device_count() > 1 else "7b"

@@ -16,9 +16,11 @@
  *  - `stream` is a hipStream_t passed as void* (0 = default stream). All work is asynchronous on
  *    that stream. The per-token calls (woq_linear with int4 blobs, fp32 activations and M <= 8, the
  *    woq_engine step) neither synchronise nor allocate and can be captured into a hipGraph; the
- *    prefill GEMM (M > 8), int8 blobs and 16-bit activations at M <= 8 take stream-ordered scratch
- *    (hipMallocAsync / hipFreeAsync on `stream`) per call, like the reference's per-call amalloc
- *    (bestla_weightonly_dispatcher.cpp:108-118,179); the engine's prompt pass owns its scratch.
+ *    prefill GEMM (M > 8), int8 blobs and 16-bit activations at M <= 8 need scratch: it comes from the
+ *    caller's workspace (woq_set_workspace, the reference's set_woq_workspace contract) when that has
+ *    room — then these calls do not allocate either and are capturable — and otherwise from
+ *    stream-ordered allocation (hipMallocAsync / hipFreeAsync on `stream`) per call, like the reference's
+ *    per-call amalloc (bestla_weightonly_dispatcher.cpp:108-118,179); the engine's prompt pass owns its scratch.
  *  - return value: 0 on success, non-zero on error; woq_last_error() returns a thread-local
  *    message that starts with "QBits:" like the reference's TORCH_CHECK strings
  *    (bestla_weightonly_dispatcher.cpp:289,368; qbits.cpp:35,150). The Python shim raises
@@ -90,6 +92,13 @@ WOQ_API int woq_read_header(const void* blob_dev, woq_blob_header* hdr_out, void
 WOQ_API int woq_blob_extract(const void* blob_dev, const woq_blob_header* hdr, int what, void* out_dev,
                              void* stream);
 
+/* replaces qbits.set_woq_workspace (qbits.cpp:142-144 -> bestla_weightonly_dispatcher.cpp:394-397): a raw pointer
+ * into caller-owned device memory that must outlive every later call; woq_linear carves its scratch from it (int8
+ * composite: M * N * 4 bytes; 16-bit activations at M <= 8: M * K * 4; M > 8: the packed activation planes,
+ * about 2 * Mpad * Kpad * (1 or 2 planes) + 8 * Mpad + 4 * Npad bytes). Process-wide like the reference's (calls from
+ * several host threads are not safe with it). NULL / 0 removes it. */
+WOQ_API int woq_set_workspace(void* workspace_dev, size_t bytes);
+
 /* ---- the hot call ------------------------------------------------------------------------------ */
 
 /* replaces qbits.woq_linear (qbits.cpp:113-140): out[M,N] = act[M,K] . W_deq[K,N] (+ bias).
@@ -157,6 +166,10 @@ WOQ_API int woq_engine_set_head(woq_engine* e, const void* embed_dev, int embed_
 WOQ_API int woq_engine_bind_io(woq_engine* e, void* token_dev, void* pos_dev, void* logits_dev, void* hidden_dev);
 /* device buffers the caller reads/writes between steps */
 WOQ_API void* woq_engine_token_ptr(woq_engine* e);  /* int32[1]: token fed to the next step */
+/* int32[max_ctx + 1]: a greedy step that fed position p leaves its new token in slot p, so a host that replays k
+ * steps back to back reads k tokens with ONE synchronisation (the reference's loop pays a host round trip per token,
+ * transformers/generation: greedy_search.py:148-150,374-377) */
+WOQ_API void* woq_engine_token_log_ptr(woq_engine* e);
 WOQ_API void* woq_engine_pos_ptr(woq_engine* e);    /* int32[1]: its position */
 WOQ_API void* woq_engine_logits_ptr(woq_engine* e); /* fp32[vocab] of the last step */
 WOQ_API void* woq_engine_hidden_ptr(woq_engine* e); /* fp32[hidden] residual stream (TP all-reduce target) */
@@ -188,6 +201,9 @@ WOQ_API int woq_engine_attn_grouped(woq_engine* e);
 /* KV cache base pointers (which: 0 = K, 1 = V), layout [sequence][layer][position][kv_head][head_dim] in kv_dtype:
  * inspection / tests, and the seam for an external cache manager. */
 WOQ_API void* woq_engine_kv_cache_ptr(woq_engine* e, int which);
+/* 1 when the decode step hands activations between its kernels as XQ limb blocks (csrc/woq_xq.h; every layer's blobs
+ * qualify, one GPU, WOQ_ENGINE_XQ != 0), 0 when it runs the fp32-activation kernels. */
+WOQ_API int woq_engine_uses_xq(woq_engine* e);
 /* capture one step into a hipGraph and replay it `n` times (greedy chaining). */
 WOQ_API int woq_engine_capture(woq_engine* e, int greedy, void* stream);
 WOQ_API int woq_engine_replay(woq_engine* e, int n, void* stream);

@@ -73,7 +73,8 @@ EXPORTS = [
     "woq_engine_time_gemv", "woq_engine_prefill", "woq_engine_prefill_logits_ptr", "woq_engine_kv_cache_ptr", "woq_engine_set_attn_splits", "woq_engine_attn_splits",
     "woq_engine_set_attn_grouped", "woq_engine_attn_grouped",
     "woq_comm_create", "woq_comm_handle", "woq_comm_connect", "woq_comm_allreduce_f32", "woq_comm_status",
-    "woq_comm_set_timeout_ms", "woq_comm_destroy", "woq_engine_set_comm",
+    "woq_comm_set_timeout_ms", "woq_comm_destroy", "woq_engine_set_comm", "woq_set_workspace", "woq_engine_uses_xq",
+    "woq_engine_token_log_ptr",
 ]
 
 _lib = None
@@ -137,6 +138,10 @@ def lib():
     L.woq_comm_destroy.argtypes = [vp]
     L.woq_comm_destroy.restype = None
     L.woq_engine_set_comm.argtypes = [vp, vp, ci]
+    L.woq_set_workspace.argtypes = [vp, cs]
+    L.woq_engine_uses_xq.argtypes = [vp]
+    L.woq_engine_token_log_ptr.restype = vp
+    L.woq_engine_token_log_ptr.argtypes = [vp]
     _lib = L
     return L
 

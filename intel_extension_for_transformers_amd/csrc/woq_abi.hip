@@ -14,6 +14,38 @@ std::string& last_error_ref() {
   return s;
 }
 
+namespace {
+struct Workspace {
+  unsigned char* base = nullptr;
+  size_t bytes = 0, used = 0;
+} g_ws;
+inline size_t ws_round(size_t b) { return (b + 255) & ~(size_t)255; }
+}  // namespace
+
+void* scratch_take(size_t bytes, hipStream_t st, bool* own) {
+  const size_t need = ws_round(bytes);
+  if (g_ws.base != nullptr && g_ws.used + need <= g_ws.bytes) {
+    void* p = g_ws.base + g_ws.used;
+    g_ws.used += need;
+    *own = false;
+    return p;
+  }
+  void* p = nullptr;
+  *own = true;
+  if (hipMallocAsync(&p, bytes, st) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+void scratch_release(void* p, size_t bytes, bool own, hipStream_t st) {
+  if (p == nullptr) return;
+  if (own)
+    hipFreeAsync(p, st);
+  else
+    g_ws.used -= ws_round(bytes);
+}
+
 struct GemvArgs;
 int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                             const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w,
@@ -53,6 +85,15 @@ static int linear_int4(const void* act, int act_dtype, int lda, const void* blob
                                  ld_res, 0, 1, st);
 }
 
+int woq_set_workspace(void* workspace_dev, size_t bytes) {
+  WOQ_TRY
+  WOQ_CHECK(workspace_dev != nullptr || bytes == 0, "QBits: null workspace with a size");
+  WOQ_CHECK(g_ws.used == 0, "QBits: workspace changed while a call is using it");
+  g_ws.base = (unsigned char*)workspace_dev;
+  g_ws.bytes = workspace_dev ? bytes : 0;
+  WOQ_END
+}
+
 int woq_linear(const void* act_dev, int act_dtype, int lda, const void* blob_dev, const woq_blob_header* hdr,
                const float* bias_dev, void* out_dev, int out_dtype, int ldo, int M, void* stream) {
   WOQ_TRY
@@ -78,14 +119,16 @@ int woq_linear(const void* act_dev, int act_dtype, int lda, const void* blob_dev
     woq_blob_header o, hi, lo;
     WOQ_CHECK(woq_int8_headers(&o, &hi, &lo, hdr->K, hdr->N, hdr->group, hdr->scale_type, hdr->compute_type,
                                hdr->off_zp != 0, hdr->off_shuffle != 0) == 0, "QBits: corrupt int8 header");
-    float* tmp = nullptr;
-    WOQ_HIP(hipMallocAsync((void**)&tmp, (size_t)M * hdr->N * sizeof(float), st));
+    bool own = false;
+    const size_t tmp_bytes = (size_t)M * hdr->N * sizeof(float);
+    float* tmp = (float*)scratch_take(tmp_bytes, st, &own);
+    WOQ_CHECK(tmp != nullptr, "QBits: scratch allocation failed");
     rc = linear_int4(act_dev, act_dtype, lda, (const uint8_t*)blob_dev + hdr->off_q, hi, nullptr, tmp, WOQ_F32,
                      hdr->N, M, nullptr, 0, st);
     if (rc == 0)
       rc = linear_int4(act_dev, act_dtype, lda, (const uint8_t*)blob_dev + hdr->off_scale, lo, bias_dev, out_dev,
                        out_dtype, ldo, M, tmp, hdr->N, st);
-    hipFreeAsync(tmp, st);
+    scratch_release(tmp, tmp_bytes, own, st);
   } else {
     rc = linear_int4(act_dev, act_dtype, lda, blob_dev, *hdr, bias_dev, out_dev, out_dtype, ldo, M, nullptr, 0, st);
   }

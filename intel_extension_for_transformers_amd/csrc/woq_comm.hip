@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void allreduce_ll_kernel(CommDev c, float* __r
 // on ties (a single-device argmax over the gathered row). Writes token and advances pos. One workgroup.
 __global__ __launch_bounds__(1024) void tp_greedy_kernel(CommDev c, const float* __restrict__ pmax,
                                                          const int32_t* __restrict__ pidx, int n, int vocab_offset,
-                                                         int32_t* __restrict__ token, int32_t* __restrict__ pos) {
+                                                         int32_t* __restrict__ token, int32_t* __restrict__ pos,
+                                                         int32_t* __restrict__ log) {
   __shared__ float bv[16];
   __shared__ int bi[16];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(1024) void tp_greedy_kernel(CommDev c, const float*
     }
   }
   token[0] = top_i;
+  if (log != nullptr) log[pos[0]] = top_i;
   pos[0] = pos[0] + 1;
   if (!ok) atomicOr(&c.ctl[2], 2u);
   atomicExch(&c.ctl[0], next_seq(seq));
@@ -210,10 +212,10 @@ int woq_comm_launch_allreduce(woq_comm* c, float* buf, size_t n, hipStream_t st)
 }
 
 int woq_comm_launch_greedy(woq_comm* c, const float* pmax, const int32_t* pidx, int n, int vocab_offset,
-                           int32_t* token, int32_t* pos, hipStream_t st) {
+                           int32_t* token, int32_t* pos, int32_t* log, hipStream_t st) {
   if (!c || !c->connected) return woq::fail("QBits: tensor-parallel communicator is not connected");
   hipLaunchKernelGGL(woq::tp_greedy_kernel, dim3(1), dim3(1024), 0, st, c->dev, pmax, pidx, n, vocab_offset, token,
-                     pos);
+                     pos, log);
   return 0;
 }
 

@@ -36,7 +36,8 @@ int launch_gemv_xq(const XqPtrs& xin, const void* blob, const woq_blob_header& h
 void launch_lm_head(const float* hidden_in, const float* norm_w, float eps, const void* W, int w_dtype, int hidden,
                     int vocab, float* logits, float* pmax, int32_t* pidx, hipStream_t st);
 void launch_argmax(const float* logits, int vocab, int32_t* token, int32_t* pos, hipStream_t st);
-void launch_argmax_pairs(const float* pmax, const int32_t* pidx, int n, int32_t* token, int32_t* pos, hipStream_t st);
+void launch_argmax_pairs(const float* pmax, const int32_t* pidx, int n, int32_t* token, int32_t* pos, int32_t* log,
+                         hipStream_t st);
 // prompt pass (woq_gemm_f16.hip, woq_prefill.hip)
 size_t gemm_f16_workspace_bytes(int M, int Kpad, int Npad, int planes);
 int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
@@ -55,7 +56,7 @@ void launch_gather_last(const float* h, int n_seq, int T, int hidden, float* dst
 // device-side tensor-parallel exchange (woq_comm.hip)
 int woq_comm_launch_allreduce(woq_comm* c, float* buf, size_t n, hipStream_t st);
 int woq_comm_launch_greedy(woq_comm* c, const float* pmax, const int32_t* pidx, int n, int vocab_offset,
-                           int32_t* token, int32_t* pos, hipStream_t st);
+                           int32_t* token, int32_t* pos, int32_t* log, hipStream_t st);
 
 using woq::XqPtrs;
 
@@ -95,6 +96,7 @@ struct woq_engine {
   int nt = 1;
   std::vector<void*> owned;  // everything hipMalloc'ed by create()
   // prompt pass: [n_seq * T] rows at a time; buffers grow on demand (never inside a captured graph)
+  int32_t* tok_log = nullptr;   // [max_ctx + 1]: tok_log[p] = greedy token produced by the step that fed position p
   float* am_val = nullptr;      // per-workgroup (max logit, index) pairs of the lm_head launch, for the greedy argmax
   int32_t* am_idx = nullptr;
   int window = 0;               // sliding-window attention (HF Mistral sliding_window), 0 = full causal
@@ -186,8 +188,8 @@ static int engine_head(woq_engine* e, int greedy, hipStream_t st) {
                  greedy ? e->am_val : nullptr, greedy ? e->am_idx : nullptr, st);
   if (greedy && e->comm && c.tp_size > 1)  // vocab-sharded head: one (max, global index) pair per rank
     return woq_comm_launch_greedy(e->comm, e->am_val, e->am_idx, (c.vocab + 15) / 16, e->vocab_offset, e->token,
-                                  e->pos, st);
-  if (greedy) launch_argmax_pairs(e->am_val, e->am_idx, (c.vocab + 15) / 16, e->token, e->pos, st);
+                                  e->pos, e->tok_log, st);
+  if (greedy) launch_argmax_pairs(e->am_val, e->am_idx, (c.vocab + 15) / 16, e->token, e->pos, e->tok_log, st);
   return 0;
 }
 
@@ -382,12 +384,14 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
   WOQ_CHECK(e->attn_splits <= 64, "QBits: attn_splits must be <= 64");
   e->window = cfg->reserved[2] > 0 ? cfg->reserved[2] : 0;
   WOQ_HIP(hipMalloc((void**)&e->attn_part, (size_t)cfg->heads * 64 * (cfg->head_dim + 2) * 4));  // room for 64 slices
+  WOQ_HIP(hipMalloc((void**)&e->tok_log, (size_t)(cfg->max_ctx + 1) * 4));
+  WOQ_HIP(hipMemset(e->tok_log, 0, (size_t)(cfg->max_ctx + 1) * 4));
   WOQ_HIP(hipMalloc((void**)&e->am_val, (size_t)((cfg->vocab + 15) / 16) * 4));
   WOQ_HIP(hipMalloc((void**)&e->am_idx, (size_t)((cfg->vocab + 15) / 16) * 4));
   WOQ_HIP(hipMalloc((void**)&e->pf_last, (size_t)e->max_batch * cfg->hidden * 4));
   WOQ_HIP(hipMalloc((void**)&e->pf_logits, (size_t)e->max_batch * cfg->vocab * 4));
   e->owned = {e->hidden, e->qkv, e->attn, e->act, e->logits, e->token, e->pos, e->kcache, e->vcache, e->pf_last,
-              e->pf_logits, e->attn_part, e->am_val, e->am_idx};
+              e->pf_logits, e->attn_part, e->am_val, e->am_idx, e->tok_log};
   {  // XQ vectors (woq_xq.h) for the three GEMV inputs of a layer
     const char* sw = getenv("WOQ_ENGINE_XQ");
     e->xq_enabled = !(sw && sw[0] == '0');
@@ -471,6 +475,7 @@ int woq_engine_bind_io(woq_engine* e, void* token_dev, void* pos_dev, void* logi
   WOQ_END
 }
 
+void* woq_engine_token_log_ptr(woq_engine* e) { return e ? e->tok_log : nullptr; }
 void* woq_engine_token_ptr(woq_engine* e) { return e->token; }
 void* woq_engine_pos_ptr(woq_engine* e) { return e->pos; }
 void* woq_engine_logits_ptr(woq_engine* e) { return e->logits; }
@@ -492,6 +497,8 @@ int woq_engine_set_comm(woq_engine* e, woq_comm* comm, int vocab_offset) {
   e->vocab_offset = vocab_offset;
   WOQ_END
 }
+
+int woq_engine_uses_xq(woq_engine* e) { return e && e->use_xq() ? 1 : 0; }
 
 int woq_engine_step(woq_engine* e, int greedy, void* stream) {
   WOQ_TRY

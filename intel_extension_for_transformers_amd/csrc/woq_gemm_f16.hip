@@ -620,10 +620,11 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   const size_t Mpad = (size_t)a.nb_m * FBM;
   const size_t total = gemm_f16_workspace_bytes(M, h.Kpad, h.Npad, planes);
   unsigned char* w = (unsigned char*)ws;
-  const bool own = w == nullptr;
-  if (own) {
-    hipError_t e = hipMallocAsync((void**)&w, total, st);
-    if (e != hipSuccess) return woq::fail(std::string("QBits: workspace allocation failed: ") + hipGetErrorString(e));
+  const bool mine = w == nullptr;  // no workspace passed in (the engine passes its own): take scratch
+  bool own = false;
+  if (mine) {
+    w = (unsigned char*)scratch_take(total, st, &own);
+    if (w == nullptr) return woq::fail("QBits: workspace allocation failed");
   }
   a.ap = (const _Float16*)w;
   a.rs = (const float*)(w + Mpad * h.Kpad * sizeof(_Float16) * planes);
@@ -666,7 +667,7 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   WOQ_F16_CASE(1, false)
   WOQ_F16_CASE(1, true)
 #undef WOQ_F16_CASE
-  if (own) hipFreeAsync(w, st);
+  if (mine) scratch_release(w, total, own, st);
   return rc;
 }
 

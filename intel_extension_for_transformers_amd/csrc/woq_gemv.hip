@@ -250,11 +250,14 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
   // 16-bit activations: widen them once (M x K elements, a few KiB at decode) and take the fp32 tile kernel, if the
   // call would qualify with fp32 rows
   float* widened = nullptr;
+  bool widened_own = false;
+  size_t widened_bytes = 0;
   if (!force_generic && act_dtype != WOQ_F32 && h.off_shuffle == 0 && (h.K & 3) == 0) {
     const int Kc = (int)h.K;
     if (gemv_tile_max_rows((const void*)(uintptr_t)16, WOQ_F32, Kc, h, norm_w, epi, out_dtype) > 0) {
-      if (hipMallocAsync((void**)&widened, (size_t)M * Kc * sizeof(float), st) != hipSuccess)
-        return woq::fail("QBits: activation staging allocation failed");
+      widened = (float*)scratch_take((size_t)M * Kc * sizeof(float), st, &widened_own);
+      if (widened == nullptr) return woq::fail("QBits: activation staging allocation failed");
+      widened_bytes = (size_t)M * Kc * sizeof(float);
       const size_t n = (size_t)M * Kc;
       hipLaunchKernelGGL(act_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                          (const uint16_t*)act, act_dtype, lda, M, (int)h.K, Kc, widened);
@@ -281,11 +284,11 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
                         : launch_gemv_generic(a_p, act_dtype, lda, mc, blob, h, bias, o_p, out_dtype, ldo, norm_w,
                                               eps, r_p, ld_res, epi, st);
     if (rc) {
-      if (widened) hipFreeAsync(widened, st);
+      scratch_release(widened, widened_bytes, widened_own, st);
       return rc;
     }
   }
-  if (widened) hipFreeAsync(widened, st);
+  scratch_release(widened, widened_bytes, widened_own, st);
   return 0;
 }
 

@@ -17,6 +17,16 @@ inline int fail(const std::string& msg) {
 }
 }  // namespace woq
 
+namespace woq {
+// Scratch for one call: from the caller's workspace (woq_set_workspace — the reference's set_woq_workspace contract,
+// qbits.cpp:142-144, bestla_weightonly_dispatcher.cpp:394-397: a raw pointer into a caller-owned tensor that outlives
+// every call) when it has room, which keeps the call allocation-free and capturable into a hipGraph; otherwise
+// stream-ordered allocation, like the reference's per-call amalloc (:108-118,179). Nested takes release in LIFO order.
+// Like the reference's global workspace pointer, not safe for concurrent calls from several host threads / streams.
+void* scratch_take(size_t bytes, hipStream_t st, bool* own);
+void scratch_release(void* p, size_t bytes, bool own, hipStream_t st);
+}  // namespace woq
+
 #define WOQ_TRY try {
 #define WOQ_END                                                \
   return 0;                                                    \

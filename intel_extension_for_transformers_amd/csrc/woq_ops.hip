@@ -431,9 +431,11 @@ __global__ __launch_bounds__(256) void lm_head_kernel(const float* __restrict__ 
 
 // greedy: token = argmax(logits) (lowest index on ties, like torch.argmax), pos += 1. One workgroup.
 // `cand` null: candidate i is logit i; else (logits[i], cand[i]) are the per-workgroup pairs lm_head_kernel left.
+// `log` (optional): log[position of the token that was just fed] = the new token, so a host that replays several steps
+// back to back can read them all afterwards instead of synchronising on every step.
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, const int32_t* __restrict__ cand,
                                                       int vocab, int32_t* __restrict__ token,
-                                                      int32_t* __restrict__ pos) {
+                                                      int32_t* __restrict__ pos, int32_t* __restrict__ log) {
   __shared__ float bv[16];
   __shared__ int bi[16];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -468,6 +470,7 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
         idx = bi[w];
       }
     token[0] = idx;
+    if (log != nullptr) log[pos[0]] = idx;
     pos[0] = pos[0] + 1;
   }
 }
@@ -557,12 +560,14 @@ void launch_lm_head(const float* hidden_in, const float* norm_w, float eps, cons
 }
 
 void launch_argmax(const float* logits, int vocab, int32_t* token, int32_t* pos, hipStream_t st) {
-  hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, logits, (const int32_t*)nullptr, vocab, token, pos);
+  hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, logits, (const int32_t*)nullptr, vocab, token, pos,
+                     (int32_t*)nullptr);
 }
 
 // greedy token from the (max, index) pairs of launch_lm_head
-void launch_argmax_pairs(const float* pmax, const int32_t* pidx, int n, int32_t* token, int32_t* pos, hipStream_t st) {
-  hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, pmax, pidx, n, token, pos);
+void launch_argmax_pairs(const float* pmax, const int32_t* pidx, int n, int32_t* token, int32_t* pos, int32_t* log,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, pmax, pidx, n, token, pos, log);
 }
 
 }  // namespace woq

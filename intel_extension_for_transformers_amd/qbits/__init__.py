@@ -194,9 +194,25 @@ def acquire_packed_weight_info(packw, acquire_type):
     return out
 
 
+_workspace = None  # the tensor whose memory the library points into (it must outlive every call: kept here)
+
+
 def set_woq_workspace(workspace):
-    """qbits.cpp:142-144. The HIP kernels need no host-managed scratch (activation staging is in LDS,
-    reductions in registers/LDS), so this only keeps the call site valid."""
+    """qbits.cpp:142-144 -> bestla_weightonly_dispatcher.cpp:394-397: a caller-owned tensor whose memory the library
+    uses as scratch from now on (a raw pointer; this module keeps the tensor alive). With it, the calls that need
+    scratch — int8 weights, 16-bit activations at M <= 8, the M > 8 GEMM's packed activations — allocate nothing and
+    can be captured into a graph; without it (or when it is too small for a call) they use stream-ordered allocation.
+    `None` or an empty tensor removes it. Like the reference's, one process-wide workspace: not for concurrent use
+    from several threads."""
+    global _workspace
+    if workspace is None or workspace.numel() == 0:
+        L.check(L.lib().woq_set_workspace(None, 0))
+        _workspace = None
+        return None
+    if not workspace.is_cuda or not workspace.is_contiguous():
+        raise RuntimeError("QBits: the workspace must be a contiguous tensor on the HIP device")
+    L.check(L.lib().woq_set_workspace(_ptr(workspace), workspace.numel() * workspace.element_size()))
+    _workspace = workspace
     return None
 
 

@@ -130,6 +130,15 @@ class WoqDecoderEngine:
             L.check(L.lib().woq_engine_replay(self._h, int(n), L.stream_ptr()))
         cur.wait_stream(self._stream)
 
+    def token_log(self):
+        """int32 view [max_ctx + 1] of the engine's token log: slot p = the greedy token of the step that fed position
+        p. After `replay(k)` from position p0 the k new tokens are token_log()[p0 : p0 + k] — one host read."""
+        return _device_view(L.lib().woq_engine_token_log_ptr(self._h), (self.cfg.max_ctx + 1,), self.device, "<i4")
+
+    def uses_xq(self):
+        """True when the decode step's kernels hand activations over as XQ limb blocks (csrc/woq_xq.h)."""
+        return bool(L.lib().woq_engine_uses_xq(self._h))
+
     def phase(self, layer, phase, greedy=True):
         L.check(L.lib().woq_engine_phase(self._h, int(layer), int(phase), int(greedy), L.stream_ptr()))
 

@@ -260,6 +260,8 @@ def _engine_generate(self, inputs=None, generation_config=None, **kwargs):
         except RuntimeError:  # not a Llama-class int4 model: the module path serves it
             self._woq_engine_off = True
             return hf_generate(inputs, generation_config=generation_config, **kwargs)
+    if max_new < 1:
+        return ids
     eos = opt("eos_token_id")
     eos = set() if eos is None else set(eos if isinstance(eos, (list, tuple)) else [eos])
     streamer = kwargs.get("streamer")
@@ -271,16 +273,27 @@ def _engine_generate(self, inputs=None, generation_config=None, **kwargs):
     eng.tune_attn_for(n_in + max_new)
     if max_new > 1 and not eng.captured:
         eng.capture(greedy=True)
-    out = []
-    for i in range(max_new):
-        t = int(eng.token.item())
-        out.append(t)
-        if streamer is not None:
-            streamer.put(torch.tensor([t]))
-        if t in eos:
-            break
-        if i + 1 < max_new:
-            eng.replay(1)
+    # Tokens are read back in bursts: the steps chain on the device and log their tokens (engine.token_log), so the
+    # host synchronises once per burst instead of once per token. A stop token is noticed at the end of its burst —
+    # the few steps run past it are discarded. With a streamer the burst is one token (latency first).
+    out = [int(eng.token.item())]  # the prompt pass's token
+    if streamer is not None:
+        streamer.put(torch.tensor(out))
+    burst = 1 if streamer is not None else 16
+    log = eng.token_log()
+    done = out[0] in eos
+    while not done and len(out) < max_new:
+        k = min(burst, max_new - len(out))
+        p0 = n_in + len(out) - 1  # position the next step feeds
+        eng.replay(k)
+        new = log[p0:p0 + k].tolist()
+        for t in new:
+            out.append(t)
+            if streamer is not None:
+                streamer.put(torch.tensor([t]))
+            if t in eos:
+                done = True
+                break
     if streamer is not None:
         streamer.end()
     return torch.cat([ids, torch.tensor([out], dtype=ids.dtype, device=ids.device)], dim=1)

@@ -548,3 +548,44 @@ def test_quantized_linear_vllm_return_convention(monkeypatch):
     monkeypatch.setenv("backend", "use_vllm")
     out, out_bias = lin(x)
     assert out_bias is None and torch.equal(out, plain)
+
+
+def test_set_woq_workspace_makes_scratch_calls_capturable():
+    """qbits.set_woq_workspace (reference qbits.cpp:142-144): with a caller-owned workspace the calls that need
+    scratch — 16-bit activations at small M, int8 weights, the M > 8 GEMM — allocate nothing, so they can be captured
+    into a graph (a hipMallocAsync inside a capture fails), and replaying the graph reproduces the eager results."""
+    from intel_extension_for_transformers_amd import qbits
+
+    K, N = 512, 768
+    g = torch.Generator(device="cuda").manual_seed(3)
+    w = torch.randn(N, K, generator=g, device="cuda") * 0.05
+    blob4 = qbits.quantize_to_packed_weight(w, True, 128, "fp32", "int4_clip", "fp32", False)
+    blob8 = qbits.quantize_to_packed_weight(w, True, 128, "fp32", "int8", "fp32", False)
+    e = torch.empty(0)
+    cases = [(blob4, torch.randn(2, K, generator=g, device="cuda").bfloat16(), "int4_clip"),   # widened activations
+             (blob8, torch.randn(3, K, generator=g, device="cuda"), "int8"),                  # int8 composite
+             (blob4, torch.randn(40, K, generator=g, device="cuda"), "int4_clip")]            # MFMA GEMM pack pass
+    eager = []
+    for blob, x, wt in cases:
+        out = torch.empty(x.shape[0], N, device="cuda", dtype=x.dtype)
+        qbits.woq_linear(x, blob, e, out, "fp32", wt, "fp32", False)
+        eager.append(out.clone())
+    ws = torch.empty(8 << 20, dtype=torch.uint8, device="cuda")
+    qbits.set_woq_workspace(ws)
+    try:
+        outs = [torch.empty_like(o) for o in eager]
+        for (blob, x, wt), out in zip(cases, outs):  # warm (lazy kernel attributes) outside the capture
+            qbits.woq_linear(x, blob, e, out, "fp32", wt, "fp32", False)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for (blob, x, wt), out in zip(cases, outs):
+                qbits.woq_linear(x, blob, e, out, "fp32", wt, "fp32", False)
+        for out in outs:
+            out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        for out, ref in zip(outs, eager):
+            assert torch.equal(out, ref)
+    finally:
+        qbits.set_woq_workspace(None)
