@@ -64,12 +64,21 @@ def _error(status, message):
     return JSONResponse({"object": "error", "message": message, "code": int(status)}, status_code=int(status))
 
 
+MAX_N = 8           # completions per request
+MAX_TOKENS = 8192   # new tokens per completion
+
+
 def _check_ranges(req):
     """Parameter ranges of textchat_api.py:56-102, same messages."""
     if req.max_tokens is not None and req.max_tokens <= 0:
         return "%s is less than the minimum of 1 - 'max_tokens'" % req.max_tokens
     if req.n is not None and req.n <= 0:
         return "%s is less than the minimum of 1 - 'n'" % req.n
+    # one engine serves every request in turn: bound what a single request can make the others wait for
+    if req.n is not None and req.n > MAX_N:
+        return "%s is greater than the maximum of %d - 'n'" % (req.n, MAX_N)
+    if req.max_tokens is not None and req.max_tokens > MAX_TOKENS:
+        return "%s is greater than the maximum of %d - 'max_tokens'" % (req.max_tokens, MAX_TOKENS)
     if req.temperature is not None and req.temperature < 0:
         return "%s is less than the minimum of 0 - 'temperature'" % req.temperature
     if req.temperature is not None and req.temperature > 2:
@@ -153,13 +162,49 @@ class TextChatAPIRouter(APIRouter):
         return text, ("length" if self._count(text) >= config.max_new_tokens else "stop")
 
     def _stream(self, prompt, config, stops):
-        """Text pieces until a stop string shows up (the piece is cut there)."""
-        with self._gpu:
-            gen, _link = self.get_chatbot().predict_stream(query=prompt, config=config)
-            if not isinstance(gen, types.GeneratorType):
-                gen = (gen,)
-            seen = ""
-            for piece in gen:
+        """Text pieces until a stop string shows up (the piece is cut there). The generation itself runs in a worker
+        thread that holds the engine lock only while it generates and hands pieces over a queue: a slow or vanished
+        client (this generator suspended between yields, or never resumed) cannot keep the one engine locked."""
+        import queue
+        import threading
+
+        pieces = queue.Queue(maxsize=256)
+        gone = threading.Event()  # the consumer stopped listening (disconnect, stop string, generator closed)
+        done = object()
+
+        def work():
+            try:
+                with self._gpu:
+                    gen, _link = self.get_chatbot().predict_stream(query=prompt, config=config)
+                    if not isinstance(gen, types.GeneratorType):
+                        gen = (gen,)
+                    for piece in gen:
+                        if gone.is_set():
+                            break
+                        while not gone.is_set():
+                            try:
+                                pieces.put(piece, timeout=0.25)
+                                break
+                            except queue.Full:
+                                continue
+                    if hasattr(gen, "close"):
+                        gen.close()
+                pieces.put(done, timeout=1.0)
+            except BaseException as ex:  # surfaced on the consumer side
+                try:
+                    pieces.put(ex, timeout=1.0)
+                except queue.Full:
+                    pass
+
+        threading.Thread(target=work, daemon=True).start()
+        seen = ""
+        try:
+            while True:
+                piece = pieces.get()
+                if piece is done:
+                    return
+                if isinstance(piece, BaseException):
+                    raise piece
                 if not isinstance(piece, str) or not piece:
                     continue
                 seen += piece
@@ -170,6 +215,8 @@ class TextChatAPIRouter(APIRouter):
                         yield keep
                     return
                 yield piece
+        finally:
+            gone.set()
 
 
 router = TextChatAPIRouter()

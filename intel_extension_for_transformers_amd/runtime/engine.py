@@ -342,7 +342,7 @@ def synth_llama_weights(engine, hidden, inter, heads, kv_heads, head_dim, layers
 # ---- fused decode engine from a quantised HF model (the `ipex.optimize_transformers` analogue) ---------------------
 def _signed_parts(mod):
     """QuantizedLinearQBits -> (q int8 [K,N] in [-8,7], scales fp32 [G,N], zp int8 [G,N] signed or None)."""
-    int_w, scales, zeros, g_idx = mod.recover_qparms()
+    int_w, scales, zeros, g_idx = mod.recover_qparms_kn()
     if g_idx is not None:
         raise RuntimeError("QBits: the fused decode engine does not take act-order (g_idx) layers")
     return (int_w - 8).to(torch.int8), scales, None if zeros is None else (zeros - 8).to(torch.int8)

@@ -145,11 +145,14 @@ class QuantizedLinearQBits(torch.nn.Linear):
         self._adopt(packw, bias)
 
     # ---- save path (reference modules.py:297-392) -----------------------------------------------------------------
-    def recover_qparms(self):
-        """blob -> (int_weight [K, N] unsigned 0..15 int8, scales fp32 [G, N], zeros unsigned int8 [G, N] or None,
-        g_idx int32 [K] or None). The reference dequantises and re-quantises with the stored scales
-        (modules.py:356-372) because BesTLA cannot hand the integers back; the WQH1 blob can, so the integers are
-        recovered exactly: q = dequant / scale + zp computed from the blob's own tensors."""
+    def recover_qparms_kn(self):
+        """blob -> (int_weight [K, N] int8: unsigned 0..15 for 4 bits, signed for 8; scales fp32 [G, N]; zeros [G, N]
+        in the same domain or None; g_idx int32 [K] = the GPTQ group id of every ORIGINAL row, or None) — the tensors
+        `set_weights_bias` takes, in its orientation, so that `set_weights_bias(*recover_qparms_kn(), q_config)` is the
+        identity (act-order included: the blob keeps rows regrouped and the converted shuffle; both are undone here
+        like the reference's recover_idx / recover_int_weight, modules.py:299-326,375-377).
+        The reference dequantises and re-quantises with the stored scales (:356-372) because BesTLA cannot hand the
+        integers back; the WQH1 blob can, so they are recovered exactly: q = dequant / scale + zp from its own tensors."""
         if self.weight_dtype in ("nf4", "fp4_e2m1", "fp4_e2m1_bnb", "fp8_e4m3", "fp8_e5m2"):
             raise NotImplementedError("QBits: float weight types (%s) have no integer export format" % self.weight_dtype)
         w = self.weight.data
@@ -158,7 +161,7 @@ class QuantizedLinearQBits(torch.nn.Linear):
         scales = info(9)
         asym = bool(int(info(11)[0]))
         zeros = info(10) if asym else None
-        g_idx = info(5) if int(info(4)[0]) else None
+        shuffle = info(5).to(torch.int64) if int(info(4)[0]) else None  # position j of the blob = original row shuffle[j]
         deq = torch.empty(k, n, dtype=torch.float32, device=w.device)
         qbits.dequantize_packed_weight(w, deq, False, self.compute_dtype, self.weight_dtype, self.scale_dtype)
         group = int(info(1)[0])
@@ -168,10 +171,31 @@ class QuantizedLinearQBits(torch.nn.Linear):
         q = torch.round(deq / safe)
         if zeros is not None:
             q = q + zeros[rows].float()
+        g_idx = None
+        if shuffle is not None:
+            g_idx = torch.empty(k, dtype=torch.int32, device=w.device)
+            g_idx[shuffle] = rows.to(torch.int32)  # recover_idx (:299-305)
+            q_orig = torch.empty_like(q)
+            q_orig[shuffle] = q                     # recover_int_weight (:307-326): back to the checkpoint's row order
+            q = q_orig
         if self.bits == 8:  # the reference un-biases only 4-bit integers (:349-352); int8 stays signed
             return q.clamp_(-128, 127).to(torch.int8), scales, zeros, g_idx
         int_weight = (q + 8).clamp_(0, 15).to(torch.int8)  # back to the unsigned domain (recover_qparms :349-352)
         return int_weight, scales, (zeros + 8 if zeros is not None else None), g_idx
+
+    def recover_qparms(self):
+        """The reference's 12-tuple, in its orientation (modules.py:378-392): (group_size, in_features, out_features,
+        desc_act, g_idx, weight_dtype, bits, scales_dtype, scales [N, G], zp, qzeros [N, G] | None, int_weight [N, K]).
+        4-bit integers and zero points are unsigned (:349-352), 8-bit zero points uint8 (:353-354)."""
+        int_weight, scales, zeros, g_idx = self.recover_qparms_kn()
+        k, n = int_weight.shape
+        group = int(qbits.acquire_packed_weight_info(self.weight.data, 1)[0])
+        qzeros = None
+        if zeros is not None:
+            qzeros = zeros if self.bits == 4 else (zeros.to(torch.int32) + 128).to(torch.uint8)
+        return (group, k, n, g_idx is not None, g_idx, self.weight_dtype, self.bits,
+                torch.float32 if self.scale_dtype == "fp32" else None, scales.t(), zeros is not None,
+                qzeros.t() if qzeros is not None else None, int_weight.t())
 
 
 _FLOAT_OUT = (torch.float32, torch.bfloat16, torch.float16)

@@ -26,7 +26,8 @@ from ..utils.config import (AutoRoundConfig, AwqConfig, GPTQConfig, ITREXQuantiz
 logger = logging.getLogger(__name__)
 
 QUANT_CONFIG = "quantize_config.json"  # reference utils/utility.py:34
-WEIGHTS_NAME = "model_woq.safetensors"
+WEIGHTS_NAME = "model.safetensors"          # what HF save_pretrained writes (the reference saves through it)
+LEGACY_WEIGHTS_NAME = "model_woq.safetensors"  # round-1 builds of this package
 _BY_METHOD = {"rtn": RtnConfig, "awq": AwqConfig, "teq": TeqConfig, "gptq": GPTQConfig, "autoround": AutoRoundConfig}
 
 
@@ -36,12 +37,28 @@ def _config_from_dict(d):
     return _BY_METHOD.get(method, RtnConfig).from_dict(d)
 
 
-def save_low_bit(self, save_directory, push_to_hub=False, **kwargs):
-    """reference modeling_auto.py:209-320 (`convert_model_to_public` :190-205 + `recover_export_model` :99-157):
-    every QuantizedLinearQBits is exported as `<name>.qweight / .scales / .qzeros / .g_idx / .bias` in the optimum
-    format that `unpack_weight` (utils.py:82-125) reads back; all other tensors are saved as they are."""
+def _parse_size(v):
+    if isinstance(v, (int, float)):
+        return int(v)
+    t = str(v).strip().upper()
+    for suf, mul in (("GIB", 2 ** 30), ("MIB", 2 ** 20), ("KIB", 2 ** 10), ("GB", 10 ** 9), ("MB", 10 ** 6), ("KB", 10 ** 3)):
+        if t.endswith(suf):
+            return int(float(t[:-len(suf)]) * mul)
+    return int(t)
+
+
+def save_low_bit(self, save_directory, push_to_hub=False, safe_serialization=True, max_shard_size="5GB", **kwargs):
+    """reference modeling_auto.py:209-320 (`convert_model_to_public` :190-205 + `recover_export_model` :99-157, then
+    HF `save_pretrained`): every QuantizedLinearQBits is exported as `<name>.qweight / .scales / .qzeros / .g_idx /
+    .bias` in the optimum format that `unpack_weight` (utils.py:82-125) reads back; all other tensors are saved as
+    they are. Files follow HF's layout, which is what the reference's directories look like: `model.safetensors`, or
+    `model-0000i-of-0000n.safetensors` + `model.safetensors.index.json` above `max_shard_size`;
+    `safe_serialization=False` writes `pytorch_model.bin`. Plus config.json, quantize_config.json and
+    all_checkpoint_keys.json (:289-292)."""
     if push_to_hub:
         raise RuntimeError("push_to_hub is not supported (no network)")
+    if kwargs:
+        logger.warning("save_low_bit: ignoring %s", sorted(kwargs))
     from safetensors.torch import save_file
 
     os.makedirs(save_directory, exist_ok=True)
@@ -49,7 +66,7 @@ def save_low_bit(self, save_directory, push_to_hub=False, **kwargs):
     quantized = set()
     for name, mod in self.named_modules():
         if isinstance(mod, QuantizedLinearQBits):
-            int_w, scales, zeros, g_idx = mod.recover_qparms()
+            int_w, scales, zeros, g_idx = mod.recover_qparms_kn()
             if mod.bits == 8:  # on disk 8-bit values live in the unsigned domain, q + 128 (utils.py:103-124 undoes it)
                 int_w = int_w.to(torch.int16) + 128
                 zeros = None if zeros is None else zeros.to(torch.int16) + 128
@@ -76,8 +93,32 @@ def save_low_bit(self, save_directory, push_to_hub=False, **kwargs):
         seen_ptr[ptr] = [key]
         tensors[key] = t.cpu().contiguous()
     aliases = {names[0]: names[1:] for names in seen_ptr.values() if len(names) > 1}
-    save_file(tensors, os.path.join(save_directory, WEIGHTS_NAME),
-              metadata={"format": "pt", "aliases": json.dumps(aliases), "quantized": json.dumps(sorted(quantized))})
+    meta = {"format": "pt", "aliases": json.dumps(aliases), "quantized": json.dumps(sorted(quantized))}
+    if not safe_serialization:
+        torch.save(tensors, os.path.join(save_directory, "pytorch_model.bin"))
+    else:
+        limit = _parse_size(max_shard_size)
+        shards, cur, cur_bytes = [], {}, 0
+        for key in sorted(tensors):
+            nbytes = tensors[key].numel() * tensors[key].element_size()
+            if cur and cur_bytes + nbytes > limit:
+                shards.append(cur)
+                cur, cur_bytes = {}, 0
+            cur[key] = tensors[key]
+            cur_bytes += nbytes
+        shards.append(cur)
+        if len(shards) == 1:
+            save_file(shards[0], os.path.join(save_directory, WEIGHTS_NAME), metadata=meta)
+        else:
+            weight_map, total = {}, 0
+            for i, shard in enumerate(shards):
+                fname = "model-%05d-of-%05d.safetensors" % (i + 1, len(shards))
+                save_file(shard, os.path.join(save_directory, fname), metadata=meta)
+                for key, t in shard.items():
+                    weight_map[key] = fname
+                    total += t.numel() * t.element_size()
+            with open(os.path.join(save_directory, WEIGHTS_NAME + ".index.json"), "w") as f:
+                json.dump({"metadata": {"total_size": total}, "weight_map": weight_map}, f, indent=2)
     self.config.save_pretrained(save_directory)
     qcfg = self.quantization_config
     qcfg.save_pretrained(save_directory)
@@ -152,15 +193,40 @@ def _load_packed(d, qcfg, tensors, quantized, aliases, device, awq_gemm=False):
     return _finish(model, qcfg)
 
 
+def _checkpoint_tensors(d):
+    """The weight files of an HF-layout directory, whichever of the standard forms it uses: sharded safetensors
+    (index json), one model.safetensors, pytorch_model.bin (sharded or not), or round 1's model_woq.safetensors."""
+    for index in (WEIGHTS_NAME + ".index.json", "pytorch_model.bin.index.json"):
+        path = os.path.join(d, index)
+        if os.path.isfile(path):
+            with open(path) as f:
+                files = sorted(set(json.load(f)["weight_map"].values()))
+            if index.startswith("pytorch_model"):
+                tensors = {}
+                for fn in files:
+                    tensors.update(torch.load(os.path.join(d, fn), map_location="cpu", weights_only=True))
+                return tensors, {}
+            return _read_safetensors([os.path.join(d, fn) for fn in files])
+    for fn in (WEIGHTS_NAME, LEGACY_WEIGHTS_NAME):
+        if os.path.isfile(os.path.join(d, fn)):
+            return _read_safetensors([os.path.join(d, fn)])
+    if os.path.isfile(os.path.join(d, "pytorch_model.bin")):
+        return torch.load(os.path.join(d, "pytorch_model.bin"), map_location="cpu", weights_only=True), {}
+    raise FileNotFoundError("QBits: no model.safetensors / pytorch_model.bin (or their index) in %s" % d)
+
+
 def load_low_bit(pretrained_model_name_or_path, device="cuda", **kwargs):
-    """reference modeling_auto.py:1311-1990: a directory written by `save_low_bit`."""
+    """reference modeling_auto.py:1311-1990: a directory written by `save_low_bit` — this package's or the
+    reference's (same HF file layout, same optimum tensor names: the packed linears are the keys ending in .qweight,
+    tied weights are re-tied from the config)."""
     d = str(pretrained_model_name_or_path)
     with open(os.path.join(d, QUANT_CONFIG)) as f:
         qcfg = _config_from_dict(json.load(f))
     qcfg.post_init_hip()
-    tensors, meta = _read_safetensors([os.path.join(d, WEIGHTS_NAME)])
+    tensors, meta = _checkpoint_tensors(d)
     aliases = json.loads(meta.get("aliases", "{}"))
-    quantized = json.loads(meta.get("quantized", "[]"))
+    quantized = json.loads(meta["quantized"]) if "quantized" in meta else sorted(
+        k[:-len(".qweight")] for k in tensors if k.endswith(".qweight"))
     return _load_packed(d, qcfg, tensors, quantized, aliases, device)
 
 

@@ -124,11 +124,15 @@ class ITREXQuantizationConfigMixin(_HFBase):
     def remove_redundant_parameters(self):
         for k in ("calib_dataloader", "dataset", "calib_func", "calib_iters", "calib_len", "double_quant_scale_dtype",
                   "use_double_quant", "mse_range", "scheme", "tokenizer", "use_ggml", "use_neural_speed", "use_quant",
-                  "layer_wise", "blocksize", "nsamples", "max_input_length", "static_groups", "lr", "minmax_lr",
+                  "layer_wise", "blocksize", "nsamples", "max_input_length", "lr", "minmax_lr",
                   "iters", "use_quant_input", "device", "calib_shuffle", "calib_padding", "example_inputs",
                   "excluded_precisions", "op_name_dict", "op_type_dict", "train_dataloader", "train_func",
                   "train_iters", "train_len", "train_padding", "train_shuffle", "train_batch_size"):
             self.__dict__.pop(k, None)
+        # the reference drops `static_groups` too (config.py:576); a TRUE value is kept here: together with desc_act
+        # it decides whether a saved checkpoint carries an activation order, and a reload must read it the same way
+        if not self.__dict__.get("static_groups", False):
+            self.__dict__.pop("static_groups", None)
 
     # ---- validators --------------------------------------------------------------------------------------------
     def _common_checks(self):

@@ -124,17 +124,30 @@ def test_set_weights_bias_and_recover(method, sym, desc_act):
     ref = orc.woq_linear(x, blob, bias.numpy())
     got = m(torch.from_numpy(x).cuda()).cpu().numpy()
     assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-6
-    iw, sc, zz, gi = m.recover_qparms()
-    assert np.array_equal(iw.cpu().numpy(), (q + 8).astype(np.int8))
+    # recover: the checkpoint-side tensors come back exactly, in the checkpoint's own row order and with the RAW
+    # g_idx (group id per row) — not the blob's regrouped rows / converted shuffle (reference recover_idx,
+    # recover_int_weight, modules.py:299-326) — so feeding them to set_weights_bias again is the identity
+    iw, sc, zz, gi = m.recover_qparms_kn()
+    assert np.array_equal(iw.cpu().numpy(), w_u)
     assert np.array_equal(sc.cpu().numpy(), s)
     if sym:
         assert zz is None
     else:
         assert np.array_equal(zz.cpu().numpy(), z_u)
     if desc_act:
-        assert np.array_equal(gi.cpu().numpy(), shuf.astype(np.int32))
+        assert np.array_equal(gi.cpu().numpy(), gidx)
     else:
         assert gi is None
+    m2 = QuantizedLinearQBits(K, N, True, compute_dtype="fp32", weight_dtype="int4_clip", bits=4, scale_dtype="fp32",
+                              blocksize=g, scheme=cfg.scheme)
+    m2.set_weights_bias(iw, sc, zz, gi if gi is not None else torch.empty(0, dtype=torch.int32), cfg, bias)
+    assert torch.equal(m2.weight.data, m.weight.data)  # byte-identical blob
+    # the reference's 12-tuple view of the same thing (modules.py:378-392), in ITS orientation
+    t = m.recover_qparms()
+    assert len(t) == 12 and t[0] == g and t[1] == K and t[2] == N and t[3] == desc_act and t[6] == 4 and t[9] == (not sym)
+    assert t[5] == "int4_clip" and t[7] == torch.float32
+    assert np.array_equal(t[8].cpu().numpy(), s.T) and np.array_equal(t[11].cpu().numpy(), w_u.T)
+    assert (t[10] is None) if sym else np.array_equal(t[10].cpu().numpy(), z_u.T)
 
 
 @pytest.mark.parametrize("group,sym,scale_dtype", [(128, True, "fp16"), (32, False, "fp32")])
@@ -589,3 +602,38 @@ def test_set_woq_workspace_makes_scratch_calls_capturable():
             assert torch.equal(out, ref)
     finally:
         qbits.set_woq_workspace(None)
+
+
+@pytest.mark.parametrize("layout", ["sharded", "bin"])
+def test_desc_act_checkpoint_save_load_round_trip(tmp_path, layout):
+    """An act-order GPTQ model (desc_act: rows regrouped at load, activations gathered by the kernels) survives
+    save_pretrained -> from_pretrained: recover_qparms hands back the RAW g_idx and the checkpoint's own row order
+    (reference recover_idx / recover_int_weight, modules.py:299-326), so the reload regroups once, not twice. The saved
+    directory uses HF's file layout (sharded safetensors + index, or pytorch_model.bin) like the reference's."""
+    import os
+
+    from intel_extension_for_transformers_amd.transformers import AutoModelForCausalLM
+
+    fp = _tiny_llama()
+    src = tmp_path / "gptq-src"
+    _write_hf_gptq_checkpoint(fp, str(src), 128, False, True)
+    model = AutoModelForCausalLM.from_pretrained(str(src))
+    ids = torch.tensor([[5, 17, 200, 3, 77, 140, 9, 31]], device="cuda")
+    with torch.no_grad():
+        want = model(ids).logits.float()
+    out = tmp_path / "resaved"
+    if layout == "sharded":
+        model.save_pretrained(str(out), max_shard_size="200KB")
+        assert os.path.isfile(out / "model.safetensors.index.json")
+        assert len([f for f in os.listdir(out) if f.startswith("model-") and f.endswith(".safetensors")]) > 1
+    else:
+        model.save_pretrained(str(out), safe_serialization=False)
+        assert os.path.isfile(out / "pytorch_model.bin")
+    assert os.path.isfile(out / "quantize_config.json")
+    again = AutoModelForCausalLM.from_pretrained(str(out))
+    with torch.no_grad():
+        got = again(ids).logits.float()
+    assert torch.equal(got, want)  # same integers, same scales, same shuffle -> the same blobs
+    for (na, ma), (nb, mb) in zip(model.named_modules(), again.named_modules()):
+        if hasattr(ma, "recover_qparms_kn"):
+            assert torch.equal(ma.weight.data, mb.weight.data), na
