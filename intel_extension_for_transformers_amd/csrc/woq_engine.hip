@@ -393,8 +393,11 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
   e->owned = {e->hidden, e->qkv, e->attn, e->act, e->logits, e->token, e->pos, e->kcache, e->vcache, e->pf_last,
               e->pf_logits, e->attn_part, e->am_val, e->am_idx, e->tok_log};
   {  // XQ vectors (woq_xq.h) for the three GEMV inputs of a layer
+    // WOQ_ENGINE_XQ=1 / 0 forces the choice. Default: by measurement (profiles/r02n_xq_by_shape.txt) — at hidden 4096
+    // the XQ hand-off wins (Llama-2-7B g128 sym 747-757 vs 737-740 tokens/s, g32 asym 652 vs 626), at hidden 8192 the
+    // second recombination per tile costs more than the staging it removes (Llama-2-70B 119-120 vs 125-127 tokens/s)
     const char* sw = getenv("WOQ_ENGINE_XQ");
-    e->xq_enabled = !(sw && sw[0] == '0');
+    e->xq_enabled = sw ? sw[0] != '0' : cfg->hidden <= 4096;
     const int attn_k = cfg->heads * cfg->head_dim;
     if ((cfg->hidden % 16) == 0 && (attn_k % 16) == 0 && (cfg->inter % 16) == 0) {
       void *bh = nullptr, *ba = nullptr, *bc = nullptr;

@@ -19,6 +19,11 @@ __all__ = [
 ]
 
 
+import os as _os
+
+_VERBOSE = _os.environ.get("QBITS_VERBOSE") is not None  # dispatcher_utils.hpp:51-58
+
+
 def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -144,9 +149,20 @@ def woq_linear(activation, weight, bias, output, compute_type, weight_type, scal
     if bias is not None and bias.numel() != 0:
         b = bias if bias.dtype == torch.float32 else bias.float()
         b = b.to(activation.device).contiguous()
+    verbose = _VERBOSE  # QBITS_VERBOSE, read once at import like the reference's static env_initer
+    if verbose:
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
     L.check(L.lib().woq_linear(_ptr(activation), L.torch_dtype_code(activation.dtype), activation.stride(0),
                                _ptr(weight), ctypes.byref(hdr), _ptr(b), _ptr(output),
                                L.torch_dtype_code(output.dtype), output.stride(0), m, L.stream_ptr()))
+    if verbose:  # the reference's per-call line (bestla_weightonly_dispatcher.cpp:180-188); the time is the DEVICE time
+        t1.record()  # of this call between two events on its stream (the call itself is asynchronous)
+        t1.synchronize()
+        print("QBits linear verbose\nm:%d n:%d k:%d weight_type:%s compute_type:%s blocksize:%d src_type:%s dst_type:%s "
+              "execute time:%.4fms" % (m, hdr.N, hdr.K, weight_type, compute_type, hdr.group,
+                                       str(activation.dtype).replace("torch.", ""),
+                                       str(output.dtype).replace("torch.", ""), t0.elapsed_time(t1)), flush=True)
 
 
 def _ascii(s):
