@@ -224,22 +224,6 @@ static int launch_gemv_generic(const void* act, int act_dtype, int lda, int M, c
   return 0;
 }
 
-// bf16 / fp16 activation rows -> packed fp32 rows [M][Kc] (Kc = K rounded up to 4): lets 16-bit activations ride
-// the fp32 tile kernel (every bf16 / fp16 value is an exact fp32, so nothing is lost)
-__global__ __launch_bounds__(256) void act_to_f32_kernel(const uint16_t* __restrict__ x, int dtype, int lda, int M,
-                                                         int K, int Kc, float* __restrict__ out) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)M * Kc) return;
-  const int m = (int)(idx / Kc), k = (int)(idx % Kc);
-  float v = 0.f;
-  if (k < K) {
-    const uint16_t b = x[(size_t)m * lda + k];
-    const float fb = bf16_bits_to_f32(b), fh = f16_bits_to_f32(b);
-    v = dtype == WOQ_BF16 ? fb : fh;
-  }
-  out[idx] = v;
-}
-
 // Shared by woq_linear and the decode engine: rows in chunks through the i8 tile kernel when the call qualifies,
 // through the generic kernel otherwise. `nt` is reserved (weight loads are always non-temporal).
 int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
@@ -247,25 +231,6 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
                             float eps, const float* residual, int ld_res, int epi, int nt, hipStream_t st) {
   (void)nt;
   static const bool force_generic = getenv("WOQ_GEMV_GENERIC") != nullptr;  // A/B switch for tests
-  // 16-bit activations: widen them once (M x K elements, a few KiB at decode) and take the fp32 tile kernel, if the
-  // call would qualify with fp32 rows
-  float* widened = nullptr;
-  bool widened_own = false;
-  size_t widened_bytes = 0;
-  if (!force_generic && act_dtype != WOQ_F32 && h.off_shuffle == 0 && (h.K & 3) == 0) {
-    const int Kc = (int)h.K;
-    if (gemv_tile_max_rows((const void*)(uintptr_t)16, WOQ_F32, Kc, h, norm_w, epi, out_dtype) > 0) {
-      widened = (float*)scratch_take((size_t)M * Kc * sizeof(float), st, &widened_own);
-      if (widened == nullptr) return woq::fail("QBits: activation staging allocation failed");
-      widened_bytes = (size_t)M * Kc * sizeof(float);
-      const size_t n = (size_t)M * Kc;
-      hipLaunchKernelGGL(act_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                         (const uint16_t*)act, act_dtype, lda, M, (int)h.K, Kc, widened);
-      act = widened;
-      act_dtype = WOQ_F32;
-      lda = Kc;
-    }
-  }
   const size_t esz_a = act_dtype == WOQ_F32 ? 4 : 2, esz_o = out_dtype == WOQ_F32 ? 4 : 2;
   int rows = force_generic ? 0 : gemv_tile_max_rows(act, act_dtype, lda, h, norm_w, epi, out_dtype);
   const bool tile = rows > 0;
@@ -283,12 +248,8 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
                                            r_p, ld_res, epi, st)
                         : launch_gemv_generic(a_p, act_dtype, lda, mc, blob, h, bias, o_p, out_dtype, ldo, norm_w,
                                               eps, r_p, ld_res, epi, st);
-    if (rc) {
-      scratch_release(widened, widened_bytes, widened_own, st);
-      return rc;
-    }
+    if (rc) return rc;
   }
-  scratch_release(widened, widened_bytes, widened_own, st);
   return 0;
 }
 

@@ -101,7 +101,7 @@ template <int TPW, int CB, int SMODE, bool ASYM, bool S32, bool M1>
 // register budget by workgroup size: 1024 threads -> 128 VGPRs (group-128 paths), 768 -> 168 (per-32 scales keep
 // 3 more registers per tile and twice the A fragments), 512 -> 256
 __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) void gemv_tile_kernel(
-    const u32x4* __restrict__ q, const void* __restrict__ scales, const float* __restrict__ x,
+    const u32x4* __restrict__ q, const void* __restrict__ scales, const void* __restrict__ x,
     const float* __restrict__ norm_w, int tiles_k, int K, int base_tiles, int rem_tiles, int n_groups, int tpg_shift,
     const uint8_t* __restrict__ zp, void* __restrict__ out, const float* __restrict__ bias, const float* residual,
     float eps, int N, int Mrows, int lda, int ldo, int ld_res, int out_dtype, int flags, int kt_off) {
@@ -140,19 +140,44 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
   if constexpr (M1) {
     const int n0 = silu ? (int)blockIdx.x * 16 : (int)blockIdx.x * CB * 16;
     const int nlim = silu ? (N >> 1) : N;
-    const rsrc_t rr = make_rsrc(residual ? residual + n0 : x, residual ? max(0, min(nlim - n0, CB * 16)) * 4 : 0);
+    const rsrc_t rr = make_rsrc(residual ? (const void*)(residual + n0) : x,
+                                residual ? max(0, min(nlim - n0, CB * 16)) * 4 : 0);
     e_res = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, min(tid, 63) * 4, 0, 0));
   }
 
   // ---- 0. row 0 of the activations (and the RMSNorm weight) first ----
-  const rsrc_t rx = make_rsrc(x + kbase, WOQ_SKIP(7) ? 0 : xlen * 4);
-  const rsrc_t rg = make_rsrc(norm ? norm_w + kbase : x, norm ? xlen * 4 : 0);
-  float4_t xv0[XJ], gv[XJ];
+  // The activation rows are fp32 (what the reference's boundary holds, modules.py:152-154) or — read natively, every
+  // fp16 / bf16 value is an exact fp32 — 16-bit (flags bits 2-3: 1 fp16, 2 bf16): 8-byte loads of the same four
+  // elements per lane, widened in registers.
+  const int xdt = (flags >> 2) & 3;
+  auto load_row = [&](size_t row_off, float4_t (&xv)[XJ]) {
+    if (xdt == 0) {
+      const rsrc_t rx = make_rsrc((const float*)x + row_off + kbase, WOQ_SKIP(7) ? 0 : xlen * 4);
 #pragma unroll
-  for (int j = 0; j < XJ; ++j) {
-    xv0[j] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, v16 + j * 1024, 0, 0));
+      for (int j = 0; j < XJ; ++j)
+        xv[j] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, v16 + j * 1024, 0, 0));
+    } else {
+      const rsrc_t rx = make_rsrc((const uint16_t*)x + row_off + kbase, WOQ_SKIP(7) ? 0 : xlen * 2);
+#pragma unroll
+      for (int j = 0; j < XJ; ++j) {
+        const uint2 r = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rx, lane * 8 + j * 512, 0, 0));
+        const uint16_t hb[4] = {(uint16_t)r.x, (uint16_t)(r.x >> 16), (uint16_t)r.y, (uint16_t)(r.y >> 16)};
+        float f[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float fb = bf16_bits_to_f32(hb[i]), fh = f16_bits_to_f32(hb[i]);
+          f[i] = xdt == 2 ? fb : fh;
+        }
+        xv[j] = (float4_t){f[0], f[1], f[2], f[3]};
+      }
+    }
+  };
+  const rsrc_t rg = make_rsrc(norm ? (const void*)(norm_w + kbase) : x, norm ? xlen * 4 : 0);
+  float4_t xv0[XJ], gv[XJ];
+  load_row(0, xv0);
+#pragma unroll
+  for (int j = 0; j < XJ; ++j)
     gv[j] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, v16 + j * 1024, 0, 0));
-  }
   WOQ_STAMP(1);
 
   // ---- 1. scales / zero points, then the first PF weight tiles ----
@@ -250,11 +275,8 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
   if (!WOQ_SKIP(5)) stage_row(0, xv0);
   if constexpr (!M1) {
     for (int m = 1; m < M; ++m) {  // further rows (small batches): loaded behind the weights
-      const rsrc_t rxm = make_rsrc(x + (size_t)m * lda + kbase, xlen * 4);
       float4_t xv[XJ];
-#pragma unroll
-      for (int j = 0; j < XJ; ++j)
-        xv[j] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rxm, v16 + j * 1024, 0, 0));
+      load_row((size_t)m * lda, xv);
       stage_row(m, xv);
     }
   }
@@ -479,7 +501,7 @@ struct TileLaunch {
   const void* q;
   const void* scales;
   const void* zp;
-  const float* x;
+  const void* x;
   const float* norm_w;
   int tiles_k, K, N, n_groups, tpg_shift, M, lda, ldo, ld_res, out_dtype, flags;
   void* out;
@@ -548,14 +570,14 @@ bool gemv_tile_geometry(int tiles_k, int cb, int smode, int& nw, int& tpw) {
   return nw <= (cb * tpw > 8 ? 8 : (smode == 1 ? 12 : 16));  // the kernel's __launch_bounds__
 }
 
-// largest M the tile kernel takes for this call (LDS budget), 0 if it is not covered: the kernel wants fp32,
-// 16-B aligned, unshuffled activation rows (what the decode engine feeds it and what the reference's qbits
-// boundary always holds, modules.py:152-154); anything else goes to the generic kernel in woq_gemv.hip.
+// largest M the tile kernel takes for this call (LDS budget), 0 if it is not covered: the kernel wants unshuffled
+// activation rows, fp32 and 16-B aligned (what the decode engine feeds it and what the reference's qbits boundary
+// always holds, modules.py:152-154) or fp16 / bf16 and 8-B aligned; anything else goes to the generic kernel in
+// woq_gemv.hip.
 int gemv_tile_max_rows(const void* act, int act_dtype, int lda, const woq_blob_header& h, const float* norm_w,
                        int epi, int out_dtype) {
-  if (h.weight_type != WOQ_W_INT4_CLIP || act_dtype != WOQ_F32 || h.off_shuffle != 0 || (h.K & 3) != 0 ||
-      (lda & 3) != 0 ||
-      (((uintptr_t)act) & 15) != 0 || (((uintptr_t)norm_w) & 15) != 0)
+  if (h.weight_type != WOQ_W_INT4_CLIP || h.off_shuffle != 0 || (h.K & 3) != 0 || (lda & 3) != 0 ||
+      (((uintptr_t)act) & (act_dtype == WOQ_F32 ? 15 : 7)) != 0 || (((uintptr_t)norm_w) & 15) != 0)
     return 0;
   const int tiles_k = h.Kpad / WOQ_TILE_K;
   const int cb = epi == 1 ? 2 : 1;
@@ -592,7 +614,7 @@ int launch_gemv_tile(const void* act, int act_dtype, int lda, int M, const void*
       ++a.tpg_shift;
     }
   }
-  a.x = (const float*)act;
+  a.x = act;
   a.lda = lda;
   a.M = M;
   a.out = out;
@@ -603,7 +625,8 @@ int launch_gemv_tile(const void* act, int act_dtype, int lda, int M, const void*
   a.norm_w = norm_w;
   a.eps = eps;
   a.residual = residual;
-  a.flags = (h.scale_type == WOQ_BF16 ? 1 : 0) | (epi == 1 ? 2 : 0);
+  a.flags = (h.scale_type == WOQ_BF16 ? 1 : 0) | (epi == 1 ? 2 : 0) |
+            (act_dtype == WOQ_F16 ? 4 : (act_dtype == WOQ_BF16 ? 8 : 0));
 #ifdef WOQ_PROBE
   a.flags |= ::g_probe_flags;
 #endif
@@ -613,7 +636,7 @@ int launch_gemv_tile(const void* act, int act_dtype, int lda, int M, const void*
   const int smode = (int)h.scale_mode;
   const bool asym = a.zp != nullptr, s32 = h.scale_type == WOQ_F32;
   const int chunks = gemv_tile_k_chunks(a.tiles_k, cb, smode, epi == 0 && !norm_w && out_dtype == WOQ_F32);
-  if (act_dtype != WOQ_F32 || M > TMAXM || chunks == 0)
+  if (M > TMAXM || chunks == 0)
     return woq::fail("QBits: shape not covered by the tile GEMV");
   a.grid = tiles_n / cb;
   const int per = (a.tiles_k + chunks - 1) / chunks;

@@ -139,7 +139,7 @@ def woq_linear(activation, weight, bias, output, compute_type, weight_type, scal
     hdr = header_of(weight)
     if activation.dim() != 2 or output.dim() != 2:
         raise RuntimeError("QBits: woq_linear expects 2-D activation and output")
-    if not activation.is_contiguous():
+    if activation.stride(1) != 1 or activation.stride(0) < activation.shape[1]:  # row-strided views go down as is
         activation = activation.contiguous()
     m, k = activation.shape
     if k != hdr.K or output.shape[0] != m or output.shape[1] != hdr.N:

@@ -80,7 +80,9 @@ class QuantizedLinearQBits(torch.nn.Linear):
         for d in shape:
             m *= int(d)
         x2 = x.reshape(m, x.shape[-1])
-        if x2.dtype != torch.float32:  # the reference boundary always holds fp32 activations (modules.py:152-154)
+        # the reference boundary always holds fp32 activations (modules.py:152-154); here fp16 / bf16 rows go down as
+        # they are — the kernels widen them in registers, which is the same exact conversion without the cast launch
+        if x2.dtype not in _FLOAT_OUT and x2.dtype != torch.float32:
             x2 = x2.float()
         elif not x2.is_contiguous():
             x2 = x2.contiguous()

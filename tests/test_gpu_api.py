@@ -575,7 +575,7 @@ def test_set_woq_workspace_makes_scratch_calls_capturable():
     blob4 = qbits.quantize_to_packed_weight(w, True, 128, "fp32", "int4_clip", "fp32", False)
     blob8 = qbits.quantize_to_packed_weight(w, True, 128, "fp32", "int8", "fp32", False)
     e = torch.empty(0)
-    cases = [(blob4, torch.randn(2, K, generator=g, device="cuda").bfloat16(), "int4_clip"),   # widened activations
+    cases = [(blob4, torch.randn(2, K, generator=g, device="cuda").bfloat16(), "int4_clip"),   # 16-bit rows (read natively, no scratch)
              (blob8, torch.randn(3, K, generator=g, device="cuda"), "int8"),                  # int8 composite
              (blob4, torch.randn(40, K, generator=g, device="cuda"), "int4_clip")]            # MFMA GEMM pack pass
     eager = []

@@ -154,6 +154,24 @@ def test_woq_linear_decode_dtypes(qbits, src_dt, dst_dt, M):
     assert np.abs(got - ref).max() <= tol
 
 
+@pytest.mark.parametrize("src_dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("K,group", [(640, 128), (11008, 128), (4096, 32)])
+def test_woq_linear_16bit_rows_read_natively(qbits, src_dt, K, group):
+    """16-bit activation rows go to the tile GEMV as they are (8-byte loads widened in registers): a K that is not a
+    multiple of the 1024-element staging step, a K that is (several slices), a strided view (lda > K), M up to 7
+    (two row chunks). Same bound as fp32 rows — the widening is exact."""
+    N, M = 256, 7
+    q, s, z, idx = _mk(K, N, group, True, False, seed=11)
+    blob = _gpu_blob(qbits, q, s, z, idx, group)
+    wide = (torch.rand(M, K + 64) - 0.4).to(DT[src_dt])
+    xt = wide[:, :K]
+    ref = orc.woq_linear(np.ascontiguousarray(xt.float().numpy()), orc.repack(q, s, z, _cvt(idx, K, group), group))
+    out = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    qbits.woq_linear(wide.cuda()[:, :K], blob, torch.empty(0), out, "fp32", "int4_clip", "fp32", True)
+    got = out.cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-6
+
+
 @pytest.mark.parametrize("blocksize,asym", [(128, False), (128, True), (-1, False), (32, True)])
 @pytest.mark.parametrize("add_bias", [True, False])
 def test_reference_unit_test_idiom(qbits, blocksize, asym, add_bias):
