@@ -76,9 +76,10 @@ int woq_device_count(void) {
 static int linear_int4(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                        const float* bias, void* out, int out_dtype, int ldo, int M, const float* residual, int ld_res,
                        hipStream_t st) {
-  static const bool gemm_as_gemv = getenv("WOQ_GEMM_AS_GEMV") != nullptr;  // A/B switch for tests
+  static const bool gemm_as_gemv = getenv("WOQ_GEMM_AS_GEMV") != nullptr;  // A/B switches for tests
+  static const bool gemv_as_gemm = getenv("WOQ_GEMV_AS_GEMM") != nullptr;
   // 4-bit table weights (nf4 / fp4): the generic fp32 kernel for every M (functional, untuned: rows in chunks of 4)
-  if (M > 8 && !gemm_as_gemv && !is_table_type(h.weight_type))
+  if ((M > 8 || gemv_as_gemm) && !gemm_as_gemv && !is_table_type(h.weight_type))
     return launch_gemm_f16(act, act_dtype, lda, blob, h, bias, out, out_dtype, ldo, M, nullptr, 0.f, residual, ld_res, 0,
                            nullptr, h.compute_type == WOQ_C_FP32 ? 1 : 0, st);
   return launch_gemv_from_header(act, act_dtype, lda, blob, h, bias, out, out_dtype, ldo, M, nullptr, 0.f, residual,

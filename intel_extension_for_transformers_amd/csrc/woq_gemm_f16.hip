@@ -62,7 +62,10 @@ struct GemmF16Args {
   int epi;                // 0 plain; 1 SiLU(gate) * up over interleaved gate / up column tiles -> N/2 output columns
 };
 
-constexpr int FBM = 128, FBN = 128;
+#ifndef WOQ_GEMM_HANDSCHED  // 1: the hand-scheduled K loop (woq_gemm_f16p.h) for NP = 1; 0: hipcc's schedule (A/B runs)
+#define WOQ_GEMM_HANDSCHED 1
+#endif
+constexpr int FBM = 128;
 constexpr int FTILE_BYTES = 128 * 128 * 2;
 
 __device__ __forceinline__ int fperm(int e) { return (e < 4) ? 2 * e : 2 * (e - 4) + 1; }
@@ -279,11 +282,11 @@ __global__ __launch_bounds__(256) void pack_f16_kernel(PackF16Args a) {
 // ---------------------------------------------------------------------------------------------------------------
 // GEMM
 // ---------------------------------------------------------------------------------------------------------------
-template <int SMODE, bool S32>
+template <int SMODE, bool S32, int CT>
 struct BRegs {  // one K step of one wave's weight operand, as loaded
-  u32x4 wv[2];
-  typename std::conditional<S32, float, uint32_t>::type sc[2][SMODE == 0 ? 1 : 2];
-  uint32_t zp[2][SMODE == 0 ? 1 : 2];
+  u32x4 wv[CT];
+  typename std::conditional<S32, float, uint32_t>::type sc[CT][SMODE == 0 ? 1 : 2];
+  uint32_t zp[CT][SMODE == 0 ? 1 : 2];
 };
 
 // 8 signed nibbles of one blob word -> 8 fp16 (q - zp) * r, order {0,2,4,6,1,3,5,7}
@@ -321,172 +324,10 @@ __device__ __forceinline__ void dq8s_hl(uint32_t w, h2 nlo, h2 nhi, h2 rh, h2 rl
   lo = __builtin_bit_cast(h8, ul);
 }
 
-// NP = 1: one fp16 product per fragment pair (compute_dtype bf16 / fp16 / int8). NP = 3: fp32-class — activations
-// and scaled weights both carried as hi + lo fp16 pairs (~22 bits each), A_hi B_hi + A_hi B_lo + A_lo B_hi
-// accumulated in the same fp32 fragments (the dropped A_lo B_lo term is 2^-22 of the product). Same data flow, same
-// per-group scale folding, so group-32 blobs cost what group-128 blobs cost. One workgroup per CU (the A stage is
-// 64 KiB: two planes).
-template <int SMODE, bool ASYM, bool S32, int NP = 1>
-__global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gemm_f16s_kernel(GemmF16Args a) {
-  constexpr int PLANES = NP == 1 ? 1 : 2;
-  constexpr int STAGE = FTILE_BYTES * PLANES;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char fsm[];  // 2 x 32 KiB A tiles
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i16 = lane & 15, kq = lane >> 4;
-
-  // XCD-aware placement: workgroup ids go round-robin over the 8 XCDs; each XCD walks its own sequence of
-  // 8 x 8 super-tiles, 64 consecutive local ids per super-tile
-  const int bid = (int)blockIdx.x;
-  const int sup = ((bid >> 3) >> 6) * 8 + (bid & 7), within = (bid >> 3) & 63;
-  if (sup >= a.n_sup) return;
-  const int mb = (sup / a.sup_n) * 8 + (within >> 3), nb = (sup % a.sup_n) * 8 + (within & 7);
-  if (mb >= a.nb_m || nb >= a.nb_n) return;
-  const int row0 = mb * FBM;
-  const int ct0 = nb * (FBN / 16) + wid * 2;  // this wave's first column tile
-
-  float4_t acc[8][2];
-#pragma unroll
-  for (int rt = 0; rt < 8; ++rt)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) acc[rt][c] = (float4_t){0.f, 0.f, 0.f, 0.f};
-
-  // ---- operand movers ----
-  const _Float16* a_tiles = a.ap + (size_t)mb * a.tiles_k * (STAGE / 2);
-  auto issue_a = [&](int kt, int buf) {  // 8 LDS-DMA pieces of 1 KiB per wave
-    const _Float16* src = a_tiles + (size_t)kt * (STAGE / 2) + (size_t)wid * (4096 * PLANES) + lane * 8;
-    unsigned char* dst = fsm + buf * STAGE + wid * (8192 * PLANES);
-    // the instruction offset advances the global AND the LDS address: four 1-KiB pieces per address / M0 setup
-#pragma unroll
-    for (int j = 0; j < 8 * PLANES; j += 4) {
-      const __attribute__((address_space(1))) void* g = (const __attribute__((address_space(1))) void*)(src + j * 512);
-      __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(dst + j * 1024);
-      __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
-      __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
-      __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
-    }
-  };
-  int tnc[2];
-  float icol[2];
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    tnc[c] = min(ct0 + c, a.tiles_n - 1);
-    icol[c] = 1.f / a.cs[tnc[c] * 16 + i16];  // exact: a power of two
-  }
-  const int lane_s = kq >> 1;  // group-32: which 32-k group of a 64-k half this lane quarter belongs to
-  auto load_b = [&](int kt, BRegs<SMODE, S32>& b) {
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      b.wv[c] = a.q[((size_t)tnc[c] * a.tiles_k + kt) * 64 + lane];
-      if constexpr (SMODE == 0) {
-        int g = (kt * 128) / a.group;
-        g = g >= a.n_groups ? a.n_groups - 1 : g;
-        const size_t si = ((size_t)tnc[c] * a.n_groups + g) * 16 + i16;
-        if constexpr (S32)
-          b.sc[c][0] = ((const float*)a.scales)[si];
-        else
-          b.sc[c][0] = ((const uint16_t*)a.scales)[si];
-        if constexpr (ASYM) b.zp[c][0] = a.zp[si];
-      } else {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const size_t si = ((((size_t)tnc[c] * a.tiles_k + kt) * 16 + i16) << 2) + 2 * h + lane_s;
-          if constexpr (S32)
-            b.sc[c][h] = ((const float*)a.scales)[si];
-          else
-            b.sc[c][h] = ((const uint16_t*)a.scales)[si];
-          if constexpr (ASYM) b.zp[c][h] = a.zp[si];
-        }
-      }
-    }
-  };
-  const bool sc_bf = a.scale_type == WOQ_BF16;
-  // A fragment of (64-k half h, part p) for row tile rt: chunk h*8 + kq*2 + p of row rt*16 + i16, slot = chunk ^ i16
-  int a_off[4];
-#pragma unroll
-  for (int hp = 0; hp < 4; ++hp) a_off[hp] = i16 * 256 + ((((hp >> 1) * 8 + kq * 2 + (hp & 1)) ^ i16) << 4);
-
-  auto compute = [&](int buf, const BRegs<SMODE, S32>& b) {
-    const unsigned char* at = fsm + buf * STAGE;
-    constexpr int NS = SMODE == 0 ? 1 : 2;
-    h2 r2[2][NS], r2l[2][NS], nlo[2][NS], nhi[2][NS];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        float sv;
-        if constexpr (S32) {
-          sv = b.sc[c][s];
-        } else {
-          const float fb = bf16_bits_to_f32((uint16_t)b.sc[c][s]), fh = f16_bits_to_f32((uint16_t)b.sc[c][s]);
-          sv = sc_bf ? fb : fh;
-        }
-        const float rf = sv * icol[c];
-        const _Float16 rr = (_Float16)rf;
-        r2[c][s] = (h2){rr, rr};
-        if constexpr (NP == 3) {
-          const _Float16 rl_ = (_Float16)(rf - (float)rr);
-          r2l[c][s] = (h2){rl_, rl_};
-        }
-        const float uz = ASYM ? (float)(b.zp[c][s] & 0xff) : 8.f;
-        const _Float16 l = (_Float16)(-(1024.f + uz)), hgh = (_Float16)(-(64.f + uz));
-        nlo[c][s] = (h2){l, l};
-        nhi[c][s] = (h2){hgh, hgh};
-      }
-    // (an explicit one-word read-ahead of the A fragments, pinned with sched_barrier, measured the same throughput at
-    // +40 VGPRs: with two workgroups per CU the other workgroup's waves already cover the ds_read latency)
-#pragma unroll
-    for (int hp = 0; hp < 4; ++hp) {
-      const int s = SMODE == 0 ? 0 : (hp >> 1);
-      h8 bfr[2], bfl[2];
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        if constexpr (NP == 3)
-          dq8s_hl(b.wv[c][hp], nlo[c][s], nhi[c][s], r2[c][s], r2l[c][s], bfr[c], bfl[c]);
-        else
-          bfr[c] = dq8s(b.wv[c][hp], nlo[c][s], nhi[c][s], r2[c][s]);
-      }
-#pragma unroll
-      for (int rt = 0; rt < 8; ++rt) {
-        const h8 af = *(const h8*)(at + rt * 4096 + a_off[hp]);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr[c], acc[rt][c], 0, 0, 0);
-        if constexpr (NP == 3) {
-          const h8 al = *(const h8*)(at + FTILE_BYTES + rt * 4096 + a_off[hp]);
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfl[c], acc[rt][c], 0, 0, 0);
-            acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bfr[c], acc[rt][c], 0, 0, 0);
-          }
-        }
-      }
-    }
-  };
-
-  // ---- K loop, two steps per trip (ping-pong register sets and LDS buffers; no register copies) ----
-  BRegs<SMODE, S32> b0, b1;
-  issue_a(0, 0);
-  load_b(0, b0);
-  const int last = a.tiles_k - 1;
-  for (int kt = 0; kt < a.tiles_k; kt += 2) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt has landed
-    __syncthreads();                                   // everyone's has; everyone is done reading the other buffer
-    issue_a(min(kt + 1, last), 1);
-    load_b(min(kt + 1, last), b1);
-    __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks these loads below the MFMAs, next to their first use
-    compute(0, b0);
-    if (kt + 1 >= a.tiles_k) break;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    issue_a(min(kt + 2, last), 0);
-    load_b(min(kt + 2, last), b0);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(1, b1);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still be writing LDS when the workgroup retires
-
-  // ---- epilogue. D: lane (column i16, rows 4*kq + j) of every 16 x 16 fragment ----
+// epilogue shared by the GEMM kernels. D: lane (column i16, rows 4*kq + j) of every 16 x 16 fragment
+template <int CT>
+__device__ __forceinline__ void gemm_epilogue(const GemmF16Args& a, float4_t (&acc)[8][CT], int row0, int ct0, int i16,
+                                              int kq) {
   const bool odd = (i16 & 1) != 0;
   const bool silu = a.epi == 1;
   const int n_out = silu ? (a.N >> 1) : a.N;
@@ -494,10 +335,10 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gemm_f16s_kernel(GemmF16
                        (((uintptr_t)a.out) & (a.out_dtype == WOQ_F32 ? 7 : 3)) == 0 && (((uintptr_t)a.residual) & 7) == 0;
   auto store_all = [&](auto put1, auto put2) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      if (silu && c == 1) continue;  // the up tile was consumed together with its gate tile
+    for (int c = 0; c < CT; ++c) {
+      if (silu && (c & 1)) continue;  // the up tile was consumed together with its gate tile
       const int n_in = (ct0 + c) * 16 + i16;                       // weight column
-      const int n = silu ? (ct0 >> 1) * 16 + i16 : n_in;           // output column
+      const int n = silu ? ((ct0 + c) >> 1) * 16 + i16 : n_in;     // output column
       const bool live = ct0 + c < a.tiles_n && n_in < a.N && n < n_out;
       const float csv = live ? a.cs[n_in] : 0.f;
       const float csu = (silu && live) ? a.cs[n_in + 16] : 0.f;
@@ -512,7 +353,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gemm_f16s_kernel(GemmF16
         for (int j = 0; j < 4; ++j) {
           v[j] = fmaf(acc[rt][c][j], rsv[j] * csv, bsv);
           if (silu) {
-            const float u = fmaf(acc[rt][1][j], rsv[j] * csu, bsu);
+            const float u = fmaf(acc[rt][(c | 1) < CT ? (c | 1) : c][j], rsv[j] * csu, bsu);
             v[j] = v[j] / (1.f + __expf(-v[j])) * u;
           }
         }
@@ -561,15 +402,239 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gemm_f16s_kernel(GemmF16
               });
 }
 
+// Everything the epilogue needs is read from the kernel-argument segment at the TOP of a GEMM kernel and kept in SGPRs
+// across the K loop (WOQ_PIN_EPILOGUE_ARGS there, WOQ_UNPIN_EPILOGUE_ARGS in front of gemm_epilogue). Left to itself
+// hipcc re-loads some of it behind the loop (s_load_dword ..., s[0:1], 0x50 for M) and recycles the segment pointer's
+// s0 with a v_readfirstlane three instructions later; in the first launches of a process (cold scalar cache) one wave
+// in a few hundred workgroups of the hand-scheduled kernel then saw a garbage M and stored nothing: 10 of 80 process
+// starts left output elements unwritten, 0 of 200 with the arguments pinned (tools/gemm_probe.hip, PROBE_CLEAR).
+#define WOQ_PIN_EPILOGUE_ARGS(a)                                                                                       \
+  int p_m = a.M, p_n = a.N, p_ldo = a.ldo, p_odt = a.out_dtype, p_ldr = a.ld_res, p_epi = a.epi, p_tn = a.tiles_n;     \
+  void* p_out = a.out;                                                                                                 \
+  const float *p_bias = a.bias, *p_res = a.residual, *p_rs = a.rs, *p_cs = a.cs;                                       \
+  asm volatile("" : "+s"(p_m), "+s"(p_n), "+s"(p_ldo), "+s"(p_odt), "+s"(p_ldr), "+s"(p_epi), "+s"(p_tn));             \
+  asm volatile("" : "+s"(p_out), "+s"(p_bias), "+s"(p_res), "+s"(p_rs), "+s"(p_cs));
+#define WOQ_UNPIN_EPILOGUE_ARGS(a)                                                                                     \
+  asm volatile("" : "+s"(p_m), "+s"(p_n), "+s"(p_ldo), "+s"(p_odt), "+s"(p_ldr), "+s"(p_epi), "+s"(p_tn));             \
+  asm volatile("" : "+s"(p_out), "+s"(p_bias), "+s"(p_res), "+s"(p_rs), "+s"(p_cs));                                   \
+  a.M = p_m, a.N = p_n, a.ldo = p_ldo, a.out_dtype = p_odt, a.ld_res = p_ldr, a.epi = p_epi, a.tiles_n = p_tn;         \
+  a.out = p_out, a.bias = p_bias, a.residual = p_res, a.rs = p_rs, a.cs = p_cs;
+
+// NP = 1: one fp16 product per fragment pair (compute_dtype bf16 / fp16 / int8). NP = 3: fp32-class — activations
+// and scaled weights both carried as hi + lo fp16 pairs (~22 bits each), A_hi B_hi + A_hi B_lo + A_lo B_hi
+// accumulated in the same fp32 fragments (the dropped A_lo B_lo term is 2^-22 of the product). Same data flow, same
+// per-group scale folding, so group-32 blobs cost what group-128 blobs cost. One workgroup per CU (the A stage is
+// 64 KiB: two planes).
+// CT = 16-column tiles per wave: the workgroup covers 128 rows x 64 CT columns.
+template <int SMODE, bool ASYM, bool S32, int NP = 1, int CT = 2>
+__global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gemm_f16s_kernel(GemmF16Args a) {
+  constexpr int PLANES = NP == 1 ? 1 : 2;
+  constexpr int FBN = 64 * CT;
+  constexpr int STAGE = FTILE_BYTES * PLANES;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char fsm[];  // 2 x 32 KiB A tiles
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, kq = lane >> 4;
+
+  // XCD-aware placement: workgroup ids go round-robin over the 8 XCDs; each XCD walks its own sequence of
+  // 8 x 8 super-tiles, 64 consecutive local ids per super-tile
+  const int bid = (int)blockIdx.x;
+  const int sup = ((bid >> 3) >> 6) * 8 + (bid & 7), within = (bid >> 3) & 63;
+  if (sup >= a.n_sup) return;
+  const int mb = (sup / a.sup_n) * 8 + (within >> 3), nb = (sup % a.sup_n) * 8 + (within & 7);
+  if (mb >= a.nb_m || nb >= a.nb_n) return;
+  const int row0 = mb * FBM;
+  const int ct0 = nb * (FBN / 16) + wid * CT;  // this wave's first column tile
+
+  float4_t acc[8][CT];
+#pragma unroll
+  for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[rt][c] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+  WOQ_PIN_EPILOGUE_ARGS(a)
+
+  // ---- operand movers ----
+  const _Float16* a_tiles = a.ap + (size_t)mb * a.tiles_k * (STAGE / 2);
+  // Every load of the K loop is issued from inline asm and waited for by hand (wait_loads below). With the builtins
+  // hipcc keeps its own count of what is in flight and, not knowing that the s_waitcnt at the top of a K step already
+  // retired the CURRENT step's operands, puts an s_waitcnt vmcnt(0) in front of their first use — after the NEXT
+  // step's loads have been issued, so every K step sat out a full load latency before its first MFMA.
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)fsm;
+  auto issue_a = [&](int kt, int buf) {  // 8 LDS-DMA pieces of 1 KiB per wave
+    const _Float16* src = a_tiles + (size_t)kt * (STAGE / 2) + (size_t)wid * (4096 * PLANES) + lane * 8;
+    const uint32_t dst = lds0 + buf * STAGE + wid * (8192 * PLANES);
+    // the instruction offset advances the global AND the LDS address: four 1-KiB pieces per address / M0 setup
+#pragma unroll
+    for (int j = 0; j < 8 * PLANES; j += 4) {
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, off\n\t"
+          "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+          "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+          "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src + j * 512), "s"(dst + j * 1024)
+          : "memory");
+    }
+  };
+  auto ld128 = [](u32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); };
+  auto ld32 = [](float& d, const void* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory"); };
+  auto ld16 = [](uint32_t& d, const void* p) { asm volatile("global_load_ushort %0, %1, off" : "=v"(d) : "v"(p) : "memory"); };
+  auto ld8 = [](uint32_t& d, const void* p) { asm volatile("global_load_ubyte %0, %1, off" : "=v"(d) : "v"(p) : "memory"); };
+  int tnc[CT];
+  float icol[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    tnc[c] = min(ct0 + c, a.tiles_n - 1);
+    icol[c] = 1.f / a.cs[tnc[c] * 16 + i16];  // exact: a power of two
+  }
+  const int lane_s = kq >> 1;  // group-32: which 32-k group of a 64-k half this lane quarter belongs to
+  auto load_b = [&](int kt, BRegs<SMODE, S32, CT>& b) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      ld128(b.wv[c], a.q + ((size_t)tnc[c] * a.tiles_k + kt) * 64 + lane);
+      if constexpr (SMODE == 0) {
+        int g = (kt * 128) / a.group;
+        g = g >= a.n_groups ? a.n_groups - 1 : g;
+        const size_t si = ((size_t)tnc[c] * a.n_groups + g) * 16 + i16;
+        if constexpr (S32)
+          ld32(b.sc[c][0], (const float*)a.scales + si);
+        else
+          ld16(b.sc[c][0], (const uint16_t*)a.scales + si);
+        if constexpr (ASYM) ld8(b.zp[c][0], a.zp + si);
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const size_t si = ((((size_t)tnc[c] * a.tiles_k + kt) * 16 + i16) << 2) + 2 * h + lane_s;
+          if constexpr (S32)
+            ld32(b.sc[c][h], (const float*)a.scales + si);
+          else
+            ld16(b.sc[c][h], (const uint16_t*)a.scales + si);
+          if constexpr (ASYM) ld8(b.zp[c][h], a.zp + si);
+        }
+      }
+    }
+  };
+  // everything in flight has landed (the loads of ONE K step are all that ever is); the "+v" ties make the register
+  // operands' first use depend on the wait
+  auto wait_loads = [&](BRegs<SMODE, S32, CT>& b) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      asm volatile("" : "+v"(b.wv[c]));
+#pragma unroll
+      for (int h = 0; h < (SMODE == 0 ? 1 : 2); ++h) {
+        asm volatile("" : "+v"(b.sc[c][h]));
+        if constexpr (ASYM) asm volatile("" : "+v"(b.zp[c][h]));
+      }
+    }
+  };
+  const bool sc_bf = a.scale_type == WOQ_BF16;
+  // A fragment of (64-k half h, part p) for row tile rt: chunk h*8 + kq*2 + p of row rt*16 + i16, slot = chunk ^ i16
+  int a_off[4];
+#pragma unroll
+  for (int hp = 0; hp < 4; ++hp) a_off[hp] = i16 * 256 + ((((hp >> 1) * 8 + kq * 2 + (hp & 1)) ^ i16) << 4);
+
+  auto compute = [&](int buf, const BRegs<SMODE, S32, CT>& b) {
+    const unsigned char* at = fsm + buf * STAGE;
+    constexpr int NS = SMODE == 0 ? 1 : 2;
+    h2 r2[CT][NS], r2l[CT][NS], nlo[CT][NS], nhi[CT][NS];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        float sv;
+        if constexpr (S32) {
+          sv = b.sc[c][s];
+        } else {
+          const float fb = bf16_bits_to_f32((uint16_t)b.sc[c][s]), fh = f16_bits_to_f32((uint16_t)b.sc[c][s]);
+          sv = sc_bf ? fb : fh;
+        }
+        const float rf = sv * icol[c];
+        const _Float16 rr = (_Float16)rf;
+        r2[c][s] = (h2){rr, rr};
+        if constexpr (NP == 3) {
+          const _Float16 rl_ = (_Float16)(rf - (float)rr);
+          r2l[c][s] = (h2){rl_, rl_};
+        }
+        const float uz = ASYM ? (float)(b.zp[c][s] & 0xff) : 8.f;
+        const _Float16 l = (_Float16)(-(1024.f + uz)), hgh = (_Float16)(-(64.f + uz));
+        nlo[c][s] = (h2){l, l};
+        nhi[c][s] = (h2){hgh, hgh};
+      }
+#pragma unroll
+    for (int hp = 0; hp < 4; ++hp) {
+      const int s = SMODE == 0 ? 0 : (hp >> 1);
+      h8 bfr[CT], bfl[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        if constexpr (NP == 3)
+          dq8s_hl(b.wv[c][hp], nlo[c][s], nhi[c][s], r2[c][s], r2l[c][s], bfr[c], bfl[c]);
+        else
+          bfr[c] = dq8s(b.wv[c][hp], nlo[c][s], nhi[c][s], r2[c][s]);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 8; ++rt) {
+        const h8 af = *(const h8*)(at + rt * 4096 + a_off[hp]);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr[c], acc[rt][c], 0, 0, 0);
+        if constexpr (NP == 3) {
+          const h8 al = *(const h8*)(at + FTILE_BYTES + rt * 4096 + a_off[hp]);
+#pragma unroll
+          for (int c = 0; c < CT; ++c) {
+            acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfl[c], acc[rt][c], 0, 0, 0);
+            acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bfr[c], acc[rt][c], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+
+  // ---- K loop, two steps per trip (ping-pong register sets and LDS buffers; no register copies) ----
+  BRegs<SMODE, S32, CT> b0, b1;
+  issue_a(0, 0);
+  load_b(0, b0);
+  const int last = a.tiles_k - 1;
+  for (int kt = 0; kt < a.tiles_k; kt += 2) {
+    wait_loads(b0);   // this wave's share of tile kt and its weight registers have landed
+    __syncthreads();  // everyone's has; everyone is done reading the other buffer
+    issue_a(min(kt + 1, last), 1);
+    load_b(min(kt + 1, last), b1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(0, b0);
+    if (kt + 1 >= a.tiles_k) break;
+    wait_loads(b1);
+    __syncthreads();
+    issue_a(min(kt + 2, last), 0);
+    load_b(min(kt + 2, last), b0);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1, b1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still be writing LDS when the workgroup retires
+
+  WOQ_UNPIN_EPILOGUE_ARGS(a)
+  gemm_epilogue<CT>(a, acc, row0, ct0, i16, kq);
+}
+
+#include "woq_gemm_f16p.h"
+
 template <int SMODE, bool ASYM, bool S32, int NP>
 static int launch_f16_t(GemmF16Args& a, hipStream_t st) {
-  auto kern = gemm_f16s_kernel<SMODE, ASYM, S32, NP>;
+  auto kern = gemm_f16s_kernel<SMODE, ASYM, S32, NP, 2>;
+#if WOQ_GEMM_HANDSCHED
+  if (NP == 1 && (a.tiles_k & 1) == 0)  // (its K loop runs two K steps per trip; odd tile counts keep the kernel above)
+    kern = S32 ? gemm_f16p_kernel<SMODE, ASYM, 2>
+               : (a.scale_type == WOQ_BF16 ? gemm_f16p_kernel<SMODE, ASYM, 1> : gemm_f16p_kernel<SMODE, ASYM, 0>);
+#endif
   constexpr int LDS = 2 * FTILE_BYTES * (NP == 1 ? 1 : 2);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const void* attr_set[3] = {nullptr, nullptr, nullptr};  // (the kernels this instantiation can pick)
+  if (attr_set[0] != (const void*)kern && attr_set[1] != (const void*)kern && attr_set[2] != (const void*)kern) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return woq::fail(std::string("QBits: hipFuncSetAttribute: ") + hipGetErrorString(e));
-    attr_set = true;
+    attr_set[attr_set[0] ? (attr_set[1] ? 2 : 1) : 0] = (const void*)kern;
   }
   const int n_sup8 = (a.n_sup + 7) / 8;
   hipLaunchKernelGGL(kern, dim3((unsigned)(n_sup8 * 8 * 64)), dim3(256), LDS, st, a);
@@ -606,7 +671,7 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   a.scale_type = (int)h.scale_type;
   a.M = M;
   a.nb_m = (M + FBM - 1) / FBM;
-  a.nb_n = (a.tiles_n * 16 + FBN - 1) / FBN;
+  a.nb_n = (a.tiles_n * 16 + 127) / 128;
   const int sup_m = (a.nb_m + 7) / 8;
   a.sup_n = (a.nb_n + 7) / 8;
   a.n_sup = sup_m * a.sup_n;
