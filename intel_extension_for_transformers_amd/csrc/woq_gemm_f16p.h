@@ -4,15 +4,18 @@
 //
 // Why. hipcc's schedule of gemm_f16s_kernel reads two A fragments, waits for them, issues four MFMAs, and repeats:
 // sixteen exposed LDS round trips per K step (SQ_WAIT_ANY 33 % of the wave cycles, matrix pipe 48 % busy,
-// profiles/r02t_gemm_counters.txt), and no source-level arrangement survived its scheduler. Here a K step is four asm
-// blocks, one per 32-k part: part p's sixteen MFMAs are interleaved with the eight ds_read_b128 of part p + 1's A
-// fragments (first half of the block, so that they have landed by its end) and the 26 VALU operations that dequantise
-// part p + 1's two weight fragments. The workgroup barrier sits once per K step between parts 2 and 3: behind it tile
-// kt + 1 is complete in the other LDS buffer (part 3 already prefetches from it) and every wave is done reading this
-// one, so the LDS-DMA of tile kt + 2 is issued from inside part 3's block, one piece after each of its last eight
-// MFMAs, a whole K step ahead of its use. Every block starts with s_waitcnt lgkmcnt(0) (the previous block's reads,
-// issued >= 8 MFMAs earlier); the only vmcnt wait is the one before the barrier, for loads issued a K step earlier.
-// Registers are allocated by the compiler (operands), the instruction order inside a block is fixed by hand.
+// profiles/r02t_gemm_counters.txt), and no source-level arrangement survived its scheduler. Here a K step is four
+// asm blocks, one per 32-k part: part p's sixteen MFMAs (eight row-tile pairs) are interleaved with the eight
+// ds_read_b128 of part p + 1's A fragments and the 26 VALU operations that dequantise part p + 1's two weight
+// fragments. The A fragments live in ONE set of eight registers: fragment i is refilled with the next part's right
+// after its two MFMAs have issued (hipcc's own schedule does the same), and the waits are counted (LDS returns in
+// order), so six or seven reads stay in flight. The workgroup barrier sits once per K step between parts 2 and 3:
+// behind it tile kt + 1 is complete in the other LDS buffer (part 3 already prefetches from it) and every wave is done
+// reading this one, so the LDS-DMA of tile kt + 2 is issued from inside part 3's block, one 1-KiB piece per row-tile
+// pair, a whole K step ahead of its use. The only vmcnt wait is the one before part 2, for loads issued a K step
+// earlier. Registers are allocated by the compiler (operands); the instruction order inside a block is fixed by hand.
+// gfx950, M = 8192 x K = 4096 x N = 22016, g128 sym: 1.16 ms under rocprofv3 against 1.40 for hipcc's schedule
+// (profiles/r02z_bench_kernel_stats.txt, r01m_prefill_kernel_stats.txt).
 #pragma once
 // (included inside namespace woq)
 
@@ -268,8 +271,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f16p_kernel(GemmF16Args a) {
   tie_b(B1);
   __syncthreads();
   prep(B0, F0);
-  __builtin_amdgcn_s_sleep(8);  // (see WOQ_KSTEP: no LDS read of a staged tile right behind the barrier)
-  __syncthreads();
   h8 af[8];
   uint32_t bq[2][CT][4];
 #pragma unroll
@@ -285,9 +286,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16p_kernel(GemmF16Args a) {
 
   // one K step on LDS buffer BUF: parts 0..2, the barrier, part 3 (which starts tile kt + 1 and refills BUF).
   // The vmcnt wait that retires tile kt + 1 sits one whole block BEFORE the barrier behind which the tile is first
-  // read: a ds_read issued within ~100 cycles of "vmcnt(0), s_barrier" still returned the old LDS bytes now and then
-  // (tools/prefill_stress.py: 299 of 300 repeats of a 3-row prompt pass differed from the first; none with the wait a
-  // block early, none with a 100-cycle pause behind the barrier) — the rule the guide gives for staged buffers.
+  // read (the guide's rule for staged buffers: read one phase after the wait that retires it, never in the same one);
+  // the loads it waits for were issued a K step earlier, so it costs nothing there.
 #define WOQ_KSTEP(BUF, BCUR, FCUR, BNXT, FNXT, KT)                                                                    \
   gemm_phase<BUF * STAGE, false>(acc, af, bfrag(0, 0), bfrag(0, 1), bq[1], a_ad[1], BCUR.wv[0][1], BCUR.wv[1][1], pk, \
                                  FCUR[0][0], FCUR[1][0], 0, nullptr, nullptr, 0, 0);                                  \

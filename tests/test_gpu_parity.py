@@ -319,6 +319,36 @@ def test_woq_linear_prefill_f16_operand_variants(qbits, K, N, group, asym, shuf,
     assert (np.abs(got - ref) <= 2e-3 * scale + out_eps * np.abs(ref) + 1e-5).all()
 
 
+@pytest.mark.parametrize("group,asym,scale_type", [(128, False, "fp16"), (32, True, "fp16"), (32, True, "fp32"),
+                                                   (128, True, "bf16"), (64, False, "fp32")])
+@pytest.mark.parametrize("M,K,N", [(9, 4096, 1152), (130, 1024, 1152), (130, 640, 256)])
+def test_woq_linear_prefill_stores_every_element_and_repeats(qbits, M, K, N, group, asym, scale_type):
+    """The hand-scheduled K loop (csrc/woq_gemm_f16p.h; K = 640 has an odd tile count and stays on hipcc's schedule):
+    the output is pre-filled with NaN before every launch, so an element a workgroup did not store is seen (that
+    happened on cold starts until the epilogue's arguments were pinned in SGPRs), every repeat is bit-identical, and
+    the values are the oracle's within the fp16-operand bound."""
+    q, s, z, idx = _mk(K, N, group, asym, False, seed=21)
+    e8, e32 = torch.empty(0, dtype=torch.int8), torch.empty(0, dtype=torch.int32)
+    blob = qbits.repack_quantized_weight(torch.from_numpy(q).cuda(), torch.from_numpy(s).cuda(),
+                                         e8 if z is None else torch.from_numpy(z).cuda(), e32, "int4_clip", scale_type,
+                                         "bf16", z is not None, group)
+    rng = np.random.default_rng(22)
+    x = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).cuda()
+    s_used = torch.from_numpy(s).to(DT[scale_type]).float().numpy()
+    ref = orc.woq_linear(x.cpu().numpy(), orc.repack(q, s_used, z, None, group), None)
+    first = None
+    for _ in range(12):
+        out = torch.full((M, N), float("nan"), device="cuda")
+        qbits.woq_linear(x, blob, torch.empty(0), out, "bf16", "int4_clip", scale_type, asym)
+        assert not torch.isnan(out).any(), "an output element was never stored"
+        if first is None:
+            first = out
+        else:
+            assert torch.equal(out, first)
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    assert (np.abs(first.cpu().numpy() - ref) <= 2e-3 * scale + 1e-5).all()
+
+
 def test_woq_linear_prefill_f16_strided_rows(qbits):
     """lda / ldo larger than K / N and not 16-byte multiples: the generic pack path and the scalar-store epilogue."""
     K, N, M, group = 384, 100, 70, 128
