@@ -94,8 +94,8 @@ WOQ_API int woq_blob_extract(const void* blob_dev, const woq_blob_header* hdr, i
 
 /* replaces qbits.set_woq_workspace (qbits.cpp:142-144 -> bestla_weightonly_dispatcher.cpp:394-397): a raw pointer
  * into caller-owned device memory that must outlive every later call; woq_linear carves its scratch from it (int8
- * composite: M * N * 4 bytes; 16-bit activations at M <= 8: M * K * 4; M > 8: the packed activation planes,
- * about 2 * Mpad * Kpad * (1 or 2 planes) + 8 * Mpad + 4 * Npad bytes). Process-wide like the reference's (calls from
+ * composite: M * N * 4 bytes; M > 8: the packed activation planes, about 2 * Mpad * Kpad * (1 or 2 planes) +
+ * 8 * Mpad + 4 * Npad bytes; fp16 / bf16 activation rows at M <= 8 are read natively and need none). Process-wide like the reference's (calls from
  * several host threads are not safe with it). NULL / 0 removes it. */
 WOQ_API int woq_set_workspace(void* workspace_dev, size_t bytes);
 
@@ -106,7 +106,8 @@ WOQ_API int woq_set_workspace(void* workspace_dev, size_t bytes);
  *   (alpha = 1, beta = bias ? 1 : 0, bestla_customop.hpp:22-40). Activation shuffle (g_idx) is
  *   applied when the blob carries indices (autograd/functions.py:52-57).
  * Kernel selection by M: M <= 8 decode GEMV (int8-MFMA inner product over exact fixed-point activation limbs,
- * csrc/woq_gemv_i8.hip; the generic fp32-VALU kernel for shuffled / table / fp8 blobs), M > 8 MFMA GEMM. */
+ * csrc/woq_gemv_i8.hip; the generic fp32-VALU kernel for shuffled / table / fp8 blobs), M > 8 MFMA GEMM
+ * (csrc/woq_gemm_f16.hip; its K loop for the one-product form is scheduled by hand, csrc/woq_gemm_f16p.h). */
 WOQ_API int woq_linear(const void* act_dev, int act_dtype, int lda, const void* blob_dev,
                        const woq_blob_header* hdr, const float* bias_dev, void* out_dev, int out_dtype, int ldo,
                        int M, void* stream);
