@@ -51,7 +51,9 @@ struct GemmF16Args {
   const uint8_t* zp;
   int K, N, tiles_k, tiles_n, n_groups, group, scale_type;
   const _Float16* ap;  // packed activation tiles [mb][kt][planes][128][16 slots][8] (planes: hi, and lo for NP == 3)
-  const float* rs;     // [Mpad] 2^e per row
+  const void* act_raw; // raw-A form (woq_gemm_f16p.h): the caller's row-major fp16 activations, no pack pass; else null
+  int lda;             // its row stride in elements
+  const float* rs;     // [Mpad] 2^e per row; null = all 1 (raw-A)
   const float* cs;     // [Npad] 2^E per column
   int M, nb_m, nb_n, sup_n, n_sup;
   void* out;
@@ -347,7 +349,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmF16Args& a, float4_t (&a
 #pragma unroll
       for (int rt = 0; rt < 8; ++rt) {
         const int mrow = row0 + rt * 16 + kq * 4;
-        const float4_t rsv = *(const float4_t*)(a.rs + mrow);  // rs is padded to the row block
+        const float4_t rsv = a.rs ? *(const float4_t*)(a.rs + mrow) : (float4_t){1.f, 1.f, 1.f, 1.f};  // padded to the row block
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -625,16 +627,28 @@ template <int SMODE, bool ASYM, bool S32, int NP>
 static int launch_f16_t(GemmF16Args& a, hipStream_t st) {
   auto kern = gemm_f16s_kernel<SMODE, ASYM, S32, NP, 2>;
 #if WOQ_GEMM_HANDSCHED
-  if (NP == 1 && (a.tiles_k & 1) == 0)  // (its K loop runs two K steps per trip; odd tile counts keep the kernel above)
-    kern = S32 ? gemm_f16p_kernel<SMODE, ASYM, 2>
-               : (a.scale_type == WOQ_BF16 ? gemm_f16p_kernel<SMODE, ASYM, 1> : gemm_f16p_kernel<SMODE, ASYM, 0>);
+  if (NP == 1 && (a.tiles_k & 1) == 0) {  // (its K loop runs two K steps per trip; odd tile counts keep the kernel above)
+    if (a.act_raw)
+      kern = S32 ? gemm_f16p_kernel<SMODE, ASYM, 2, true>
+                 : (a.scale_type == WOQ_BF16 ? gemm_f16p_kernel<SMODE, ASYM, 1, true>
+                                             : gemm_f16p_kernel<SMODE, ASYM, 0, true>);
+    else
+      kern = S32 ? gemm_f16p_kernel<SMODE, ASYM, 2>
+                 : (a.scale_type == WOQ_BF16 ? gemm_f16p_kernel<SMODE, ASYM, 1> : gemm_f16p_kernel<SMODE, ASYM, 0>);
+  }
 #endif
   constexpr int LDS = 2 * FTILE_BYTES * (NP == 1 ? 1 : 2);
-  static const void* attr_set[3] = {nullptr, nullptr, nullptr};  // (the kernels this instantiation can pick)
-  if (attr_set[0] != (const void*)kern && attr_set[1] != (const void*)kern && attr_set[2] != (const void*)kern) {
+  static const void* attr_set[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // (the kernels this instantiation can pick)
+  bool have = false;
+  int free_slot = 4;
+  for (int i = 4; i >= 0; --i) {
+    have = have || attr_set[i] == (const void*)kern;
+    if (attr_set[i] == nullptr) free_slot = i;
+  }
+  if (!have) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return woq::fail(std::string("QBits: hipFuncSetAttribute: ") + hipGetErrorString(e));
-    attr_set[attr_set[0] ? (attr_set[1] ? 2 : 1) : 0] = (const void*)kern;
+    attr_set[free_slot] = (const void*)kern;
   }
   const int n_sup8 = (a.n_sup + 7) / 8;
   hipLaunchKernelGGL(kern, dim3((unsigned)(n_sup8 * 8 * 64)), dim3(256), LDS, st, a);
@@ -695,6 +709,16 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   a.rs = (const float*)(w + Mpad * h.Kpad * sizeof(_Float16) * planes);
   a.cs = a.rs + Mpad;
 
+  // raw-A form: fp16 rows that need no gather, no RMSNorm and no rescale go to the hand-scheduled kernel as they are
+  // (the o_proj / down_proj calls of the prompt pass); only the column scales are computed here
+  static const bool raw_ok = !(getenv("WOQ_GEMM_RAW_A") && getenv("WOQ_GEMM_RAW_A")[0] == '0');
+  const bool raw = WOQ_GEMM_HANDSCHED && raw_ok && !fp32_class && act_dtype == WOQ_F16 && norm_w == nullptr &&
+                   h.off_shuffle == 0 && (h.K & 127) == 0 && ((h.Kpad / WOQ_TILE_K) & 1) == 0 && (lda & 7) == 0 &&
+                   (((uintptr_t)act) & 15) == 0 && (size_t)M * lda * 2 < ((size_t)1 << 32);
+  a.act_raw = raw ? act : nullptr;
+  a.lda = lda;
+  if (raw) a.rs = nullptr;
+
   PackF16Args p;
   p.planes = planes;
   p.x = act;
@@ -715,7 +739,7 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   p.n_groups = h.n_groups;
   p.tiles_k = a.tiles_k;
   p.Npad = h.Npad;
-  p.row_blocks = (int)Mpad;
+  p.row_blocks = raw ? 0 : (int)Mpad;  // raw-A: only the column-scale blocks run
   p.cs = (float*)a.cs;
   hipLaunchKernelGGL(pack_f16_kernel, dim3((unsigned)(p.row_blocks + (h.Npad + 255) / 256)), dim3(256), 0, st, p);
 

@@ -24,13 +24,35 @@
   "v_mfma_f32_16x16x32_f16 %[c" WOQ_S_(ci) "], %[a" WOQ_S_(ai) "], %[b" WOQ_S_(bi) "], %[c" WOQ_S_(ci) "]\n\t"
 // refill A fragment register i with the NEXT part's fragment (its two MFMAs of this part have been issued)
 #define WOQ_RD(i) "ds_read_b128 %[a" WOQ_S_(i) "], %[ad] offset:%[ob]+4096*" WOQ_S_(i) "\n\t"
-// dequantisation of fragment f, 13 operations: (w & mask) ^ magic -> + n -> * r   (see dq8s; bitop3 0x6c is
-// (src0 & src2) ^ src1)
-#define WOQ_D0(f) "v_lshrrev_b32 %[y" WOQ_S_(f) "], 8, %[w" WOQ_S_(f) "]\n\t"
+// dequantisation of fragment f: (w & mask) ^ magic -> + n -> * r   (see dq8s; bitop3 0x6c is (src0 & src2) ^ src1).
+// Two element orders. P (packed A tiles, whose 16-byte chunks hold k in the order 0 2 4 6 1 3 5 7): the word and the
+// word >> 8 give the pairs (n0 n4)(n1 n5)(n2 n6)(n3 n7), 13 operations. R (raw row-major A, k in natural order): two
+// byte permutes [B0 0 B1 0], [B2 0 B3 0] give (n0 n2)(n4 n6)(n1 n3)(n5 n7) = k (0 1)(2 3)(4 5)(6 7) — the blob keeps
+// k -> nibble 0 2 4 6 1 3 5 7 (include/woq_blob.h) — 14 operations.
+#define WOQ_DH_P(f) "v_lshrrev_b32 %[y" WOQ_S_(f) "], 8, %[w" WOQ_S_(f) "]\n\t"
+#define WOQ_DH_R(f)                                                                         \
+  "v_perm_b32 %[y" WOQ_S_(f) "], %[w" WOQ_S_(f) "], %[w" WOQ_S_(f) "], %[s1]\n\t"           \
+  "v_perm_b32 %[z" WOQ_S_(f) "], %[w" WOQ_S_(f) "], %[w" WOQ_S_(f) "], %[s2]\n\t"
 #define WOQ_DB(f, k, src, m, g) \
   "v_bitop3_b32 %[q" WOQ_S_(f) WOQ_S_(k) "], %[" src WOQ_S_(f) "], %[" g "], %[" m "] bitop3:0x6c\n\t"
+#define WOQ_DB_P0(f) WOQ_DB(f, 0, "w", "ml", "gl")
+#define WOQ_DB_P1(f) WOQ_DB(f, 1, "w", "mh", "gh")
+#define WOQ_DB_P2(f) WOQ_DB(f, 2, "y", "ml", "gl")
+#define WOQ_DB_P3(f) WOQ_DB(f, 3, "y", "mh", "gh")
+#define WOQ_DB_R0(f) WOQ_DB(f, 0, "y", "ml", "gl")
+#define WOQ_DB_R1(f) WOQ_DB(f, 1, "z", "ml", "gl")
+#define WOQ_DB_R2(f) WOQ_DB(f, 2, "y", "mh", "gh")
+#define WOQ_DB_R3(f) WOQ_DB(f, 3, "z", "mh", "gh")
 #define WOQ_DA(f, k, n) \
   "v_pk_add_f16 %[q" WOQ_S_(f) WOQ_S_(k) "], %[q" WOQ_S_(f) WOQ_S_(k) "], %[" n WOQ_S_(f) "] op_sel_hi:[1,0]\n\t"
+#define WOQ_DA_P0(f) WOQ_DA(f, 0, "nl")
+#define WOQ_DA_P1(f) WOQ_DA(f, 1, "nh")
+#define WOQ_DA_P2(f) WOQ_DA(f, 2, "nl")
+#define WOQ_DA_P3(f) WOQ_DA(f, 3, "nh")
+#define WOQ_DA_R0(f) WOQ_DA(f, 0, "nl")
+#define WOQ_DA_R1(f) WOQ_DA(f, 1, "nl")
+#define WOQ_DA_R2(f) WOQ_DA(f, 2, "nh")
+#define WOQ_DA_R3(f) WOQ_DA(f, 3, "nh")
 #define WOQ_DM(f, k) \
   "v_pk_mul_f16 %[q" WOQ_S_(f) WOQ_S_(k) "], %[q" WOQ_S_(f) WOQ_S_(k) "], %[r" WOQ_S_(f) "] op_sel_hi:[1,0]\n\t"
 #define WOQ_DMA0(g, off) "global_load_lds_dwordx4 %[gv], %[" g "] offset:" WOQ_S_(off) "\n\t"
@@ -40,23 +62,26 @@
 // previous block, i - 1 of this one — may still be in flight, so the count is 7 for pair 0 and 6 after), its two
 // MFMAs with the refill of fragment i - 1 between them, then three or four of the 26 VALU operations. X0 .. X7: the
 // LDS-DMA pieces in the part-3 block, nothing elsewhere.
-#define WOQ_PHASE_TEXT(X0, X1, X2, X3, X4, X5, X6, X7)                                                              \
-  WOQ_W7 WOQ_MF(0, 0, 0) WOQ_MF(1, 0, 1) X0 WOQ_D0(0) WOQ_D0(1) WOQ_DB(0, 0, "w", "ml", "gl")                       \
-  WOQ_W6 WOQ_MF(2, 1, 0) WOQ_RD(0) WOQ_MF(3, 1, 1) X1 WOQ_DB(0, 1, "w", "mh", "gh") WOQ_DB(0, 2, "y", "ml", "gl")   \
-      WOQ_DB(0, 3, "y", "mh", "gh")                                                                                 \
-  WOQ_W6 WOQ_MF(4, 2, 0) WOQ_RD(1) WOQ_MF(5, 2, 1) X2 WOQ_DB(1, 0, "w", "ml", "gl") WOQ_DB(1, 1, "w", "mh", "gh")   \
-      WOQ_DB(1, 2, "y", "ml", "gl")                                                                                 \
-  WOQ_W6 WOQ_MF(6, 3, 0) WOQ_RD(2) WOQ_MF(7, 3, 1) X3 WOQ_DB(1, 3, "y", "mh", "gh") WOQ_DA(0, 0, "nl")              \
-      WOQ_DA(0, 1, "nh")                                                                                            \
-  WOQ_W6 WOQ_MF(8, 4, 0) WOQ_RD(3) WOQ_MF(9, 4, 1) X4 WOQ_DA(0, 2, "nl") WOQ_DA(0, 3, "nh") WOQ_DA(1, 0, "nl")      \
-  WOQ_W6 WOQ_MF(10, 5, 0) WOQ_RD(4) WOQ_MF(11, 5, 1) X5 WOQ_DA(1, 1, "nh") WOQ_DA(1, 2, "nl") WOQ_DA(1, 3, "nh")    \
+#define WOQ_PHASE_TEXT(V, X0, X1, X2, X3, X4, X5, X6, X7)                                                           \
+  WOQ_W7 WOQ_MF(0, 0, 0) WOQ_MF(1, 0, 1) X0 WOQ_DH_##V(0) WOQ_DH_##V(1) WOQ_DB_##V##0(0)                            \
+  WOQ_W6 WOQ_MF(2, 1, 0) WOQ_RD(0) WOQ_MF(3, 1, 1) X1 WOQ_DB_##V##1(0) WOQ_DB_##V##2(0) WOQ_DB_##V##3(0)            \
+  WOQ_W6 WOQ_MF(4, 2, 0) WOQ_RD(1) WOQ_MF(5, 2, 1) X2 WOQ_DB_##V##0(1) WOQ_DB_##V##1(1) WOQ_DB_##V##2(1)            \
+  WOQ_W6 WOQ_MF(6, 3, 0) WOQ_RD(2) WOQ_MF(7, 3, 1) X3 WOQ_DB_##V##3(1) WOQ_DA_##V##0(0) WOQ_DA_##V##1(0)            \
+  WOQ_W6 WOQ_MF(8, 4, 0) WOQ_RD(3) WOQ_MF(9, 4, 1) X4 WOQ_DA_##V##2(0) WOQ_DA_##V##3(0) WOQ_DA_##V##0(1)            \
+  WOQ_W6 WOQ_MF(10, 5, 0) WOQ_RD(4) WOQ_MF(11, 5, 1) X5 WOQ_DA_##V##1(1) WOQ_DA_##V##2(1) WOQ_DA_##V##3(1)          \
   WOQ_W6 WOQ_MF(12, 6, 0) WOQ_RD(5) WOQ_MF(13, 6, 1) X6 WOQ_DM(0, 0) WOQ_DM(0, 1) WOQ_DM(0, 2) WOQ_DM(0, 3)         \
   WOQ_W6 WOQ_MF(14, 7, 0) WOQ_RD(6) WOQ_MF(15, 7, 1) X7 WOQ_DM(1, 0) WOQ_DM(1, 1) WOQ_DM(1, 2) WOQ_DM(1, 3)         \
       WOQ_RD(7)
+// one piece of a raw-A tile: its own lane offsets (row and swizzled chunk), the LDS address steps by 1 KiB in M0
+#define WOQ_DMAR(j) "global_load_lds_dwordx4 %[gr" WOQ_S_(j) "], %[g0]\n\ts_add_u32 m0, m0, 0x400\n\t"
 
 struct PhaseConst {  // loop-invariant operands of the dequantisation
   uint32_t ml, mh;   // nibble masks (SGPR)
   uint32_t gl, gh;   // magic words (VGPR: one constant-bus operand per VOP3)
+  uint32_t s1, s2;   // byte-permute selectors of the raw-A order (SGPR)
+};
+struct RawOffsets {  // raw-A: lane offset (row * lda * 2 + swizzled chunk * 16) of each of a wave's eight pieces
+  uint32_t v[8];
 };
 struct FragScale {  // per (column tile, scale slot): fp16 values in the low halves
   uint32_t r, nl, nh;
@@ -65,12 +90,13 @@ struct FragScale {  // per (column tile, scale slot): fp16 values in the low hal
 // one 32-k part. af: this part's A fragments on entry (possibly still in flight), the next part's on exit (in
 // flight), read from LDS address `ad` + immediate OB + 4096 rt; bc: this part's weight fragments; bn: the next
 // part's, dequantised here from the blob words w0 / w1.
-template <int OB, bool DMA>
+template <int OB, int DMA, bool RAW>  // DMA: 0 none, 1 this block carries the next-but-one tile's LDS-DMA
 __device__ __forceinline__ void gemm_phase(float4_t (&acc)[8][2], h8 (&af)[8], const u32x4& bc0, const u32x4& bc1,
                                            uint32_t (&bn)[2][4], uint32_t ad, uint32_t w0, uint32_t w1,
                                            const PhaseConst& k, const FragScale& f0, const FragScale& f1,
-                                           uint32_t gv, const void* g0, const void* g1, uint32_t m0a, uint32_t m0b) {
-  uint32_t y0, y1;
+                                           uint32_t gv, const void* g0, const void* g1, uint32_t m0a, uint32_t m0b,
+                                           const RawOffsets& ro) {
+  uint32_t y0, y1, z0, z1;
 #define WOQ_PHASE_OPERANDS                                                                                           \
   [c0] "+v"(acc[0][0]), [c1] "+v"(acc[0][1]), [c2] "+v"(acc[1][0]), [c3] "+v"(acc[1][1]), [c4] "+v"(acc[2][0]),      \
       [c5] "+v"(acc[2][1]), [c6] "+v"(acc[3][0]), [c7] "+v"(acc[3][1]), [c8] "+v"(acc[4][0]), [c9] "+v"(acc[4][1]),  \
@@ -80,26 +106,51 @@ __device__ __forceinline__ void gemm_phase(float4_t (&acc)[8][2], h8 (&af)[8], c
       [q00] "=&v"(bn[0][0]), [q01] "=&v"(bn[0][1]), [q02] "=&v"(bn[0][2]), [q03] "=&v"(bn[0][3]),                    \
       [q10] "=&v"(bn[1][0]), [q11] "=&v"(bn[1][1]), [q12] "=&v"(bn[1][2]), [q13] "=&v"(bn[1][3]), [y0] "=&v"(y0),    \
       [y1] "=&v"(y1)
-#define WOQ_PHASE_INPUTS                                                                                              \
-  [b0] "v"(bc0), [b1] "v"(bc1), [ad] "v"(ad), [ob] "n"(OB), [w0] "v"(w0), [w1] "v"(w1), [ml] "s"(k.ml), [mh] "s"(k.mh), [gl] "v"(k.gl), [gh] "v"(k.gh), [r0] "v"(f0.r), [nl0] "v"(f0.nl), \
-      [nh0] "v"(f0.nh), [r1] "v"(f1.r), [nl1] "v"(f1.nl), [nh1] "v"(f1.nh)
-  if constexpr (DMA) {
+#define WOQ_PHASE_INPUTS                                                                                             \
+  [b0] "v"(bc0), [b1] "v"(bc1), [ad] "v"(ad), [ob] "n"(OB), [w0] "v"(w0), [w1] "v"(w1), [ml] "s"(k.ml),             \
+      [mh] "s"(k.mh), [gl] "v"(k.gl), [gh] "v"(k.gh), [r0] "v"(f0.r), [nl0] "v"(f0.nl), [nh0] "v"(f0.nh),            \
+      [r1] "v"(f1.r), [nl1] "v"(f1.nl), [nh1] "v"(f1.nh)
+#define WOQ_RAW_OUT , [z0] "=&v"(z0), [z1] "=&v"(z1)
+#define WOQ_RAW_IN , [s1] "s"(k.s1), [s2] "s"(k.s2)
+  if constexpr (DMA == 1 && !RAW) {
     uint32_t keep;
     asm volatile("s_mov_b32 %[km], m0\n\t" WOQ_PHASE_TEXT(
-                     "s_mov_b32 m0, %[m0a]\n\ts_nop 0\n\t" WOQ_DMA0("g0", 0), WOQ_DMA0("g0", 1024), WOQ_DMA0("g0", 2048),
-                     WOQ_DMA0("g0", 3072), "s_mov_b32 m0, %[m0b]\n\ts_nop 0\n\t" WOQ_DMA0("g1", 0), WOQ_DMA0("g1", 1024),
-                     WOQ_DMA0("g1", 2048), WOQ_DMA0("g1", 3072)) "s_mov_b32 m0, %[km]"
+                     P, "s_mov_b32 m0, %[m0a]\n\ts_nop 0\n\t" WOQ_DMA0("g0", 0), WOQ_DMA0("g0", 1024),
+                     WOQ_DMA0("g0", 2048), WOQ_DMA0("g0", 3072), "s_mov_b32 m0, %[m0b]\n\ts_nop 0\n\t" WOQ_DMA0("g1", 0),
+                     WOQ_DMA0("g1", 1024), WOQ_DMA0("g1", 2048), WOQ_DMA0("g1", 3072)) "s_mov_b32 m0, %[km]"
                  : WOQ_PHASE_OPERANDS, [km] "=&s"(keep)
                  : WOQ_PHASE_INPUTS, [gv] "v"(gv), [g0] "s"(g0), [g1] "s"(g1), [m0a] "s"(m0a), [m0b] "s"(m0b)
                  : "memory");
+  } else if constexpr (DMA == 1 && RAW) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %[km], m0\n\t" WOQ_PHASE_TEXT(R, "s_mov_b32 m0, %[m0a]\n\ts_nop 0\n\t" WOQ_DMAR(0),
+                                                          WOQ_DMAR(1), WOQ_DMAR(2), WOQ_DMAR(3), WOQ_DMAR(4), WOQ_DMAR(5),
+                                                          WOQ_DMAR(6), WOQ_DMAR(7)) "s_mov_b32 m0, %[km]"
+                 : WOQ_PHASE_OPERANDS WOQ_RAW_OUT, [km] "=&s"(keep)
+                 : WOQ_PHASE_INPUTS WOQ_RAW_IN, [g0] "s"(g0), [m0a] "s"(m0a), [gr0] "v"(ro.v[0]), [gr1] "v"(ro.v[1]),
+                   [gr2] "v"(ro.v[2]), [gr3] "v"(ro.v[3]), [gr4] "v"(ro.v[4]), [gr5] "v"(ro.v[5]), [gr6] "v"(ro.v[6]),
+                   [gr7] "v"(ro.v[7])
+                 : "memory", "scc");
+  } else if constexpr (RAW) {
+    asm volatile(WOQ_PHASE_TEXT(R, "", "", "", "", "", "", "", "")
+                 : WOQ_PHASE_OPERANDS WOQ_RAW_OUT
+                 : WOQ_PHASE_INPUTS WOQ_RAW_IN
+                 : "memory");
   } else {
-    asm volatile(WOQ_PHASE_TEXT("", "", "", "", "", "", "", "") : WOQ_PHASE_OPERANDS : WOQ_PHASE_INPUTS : "memory");
+    asm volatile(WOQ_PHASE_TEXT(P, "", "", "", "", "", "", "", "") : WOQ_PHASE_OPERANDS : WOQ_PHASE_INPUTS : "memory");
   }
 #undef WOQ_PHASE_OPERANDS
 #undef WOQ_PHASE_INPUTS
+#undef WOQ_RAW_OUT
+#undef WOQ_RAW_IN
 }
 
-template <int SMODE, bool ASYM, int ST>  // ST: scale storage — 0 fp16, 1 bf16, 2 fp32
+// ST: scale storage — 0 fp16, 1 bf16, 2 fp32. RAW: the A operand is the caller's row-major fp16 matrix itself
+// (a.act_raw, a.lda; no pack pass, row scales all 1): every lane of an LDS-DMA piece fetches the 16-byte chunk that
+// belongs at its LDS position — row 4 j + lane / 16 of the wave's 32, chunk (lane % 16) ^ (row % 16) — so the tile
+// lands in the same swizzled image the packed tiles have; the k order inside a chunk is the natural one, which the
+// weight side answers with its R order (above).
+template <int SMODE, bool ASYM, int ST, bool RAW = false>
 __global__ __launch_bounds__(256, 2) void gemm_f16p_kernel(GemmF16Args a) {
   constexpr bool S32 = ST == 2;
   constexpr int CT = 2, STAGE = FTILE_BYTES, FBN = 128, NS = SMODE == 0 ? 1 : 2;
@@ -125,24 +176,43 @@ __global__ __launch_bounds__(256, 2) void gemm_f16p_kernel(GemmF16Args a) {
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)fsm;
   // Every address of the K loop is a wave-uniform 64-bit base (SGPR pair, advanced by scalar adds) plus a lane
   // offset that never changes (VGPR): no vector address arithmetic per K step.
-  const unsigned char* a_base = (const unsigned char*)(a.ap + (size_t)mb * a.tiles_k * (FTILE_BYTES / 2)) + wid * 8192;
+  const unsigned char* a_base =
+      RAW ? (const unsigned char*)a.act_raw
+          : (const unsigned char*)(a.ap + (size_t)mb * a.tiles_k * (FTILE_BYTES / 2)) + wid * 8192;
   const uint32_t lane16 = lane * 16;
   const uint32_t dma_dst = lds0 + wid * 8192;  // + buf * STAGE
-  auto a_src = [&](int kt) { return a_base + (size_t)kt * FTILE_BYTES; };
-  auto issue_a = [&](int kt, int buf) {  // the whole 8-KiB share of this wave at once (prologue only)
+  auto a_src = [&](int kt) { return a_base + (size_t)kt * (RAW ? 256 : FTILE_BYTES); };
+  RawOffsets ro;
 #pragma unroll
-    for (int j = 0; j < 8; j += 4) {
-      uint32_t keep;
-      asm volatile(
-          "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-          "global_load_lds_dwordx4 %1, %2\n\t"
-          "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-          "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-          "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
-          "s_mov_b32 m0, %0"
-          : "=&s"(keep)
-          : "v"(lane16), "s"(a_src(kt) + j * 1024), "s"(dma_dst + buf * STAGE + j * 1024)
-          : "memory");
+  for (int j = 0; j < 8; ++j) {
+    const int rl = wid * 32 + j * 4 + kq;  // row of the tile this lane fetches in piece j (rows past M: the last row)
+    ro.v[j] = RAW ? (uint32_t)min(row0 + rl, a.M - 1) * (uint32_t)(a.lda * 2) + (uint32_t)((i16 ^ (rl & 15)) << 4) : 0u;
+  }
+  auto issue_a = [&](int kt, int buf) {  // the whole 8-KiB share of this wave at once (prologue only)
+    if constexpr (RAW) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(ro.v[j]), "s"(a_src(kt)), "s"(dma_dst + buf * STAGE + j * 1024)
+                     : "memory");
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j += 4) {
+        uint32_t keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2\n\t"
+            "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+            "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+            "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(lane16), "s"(a_src(kt) + j * 1024), "s"(dma_dst + buf * STAGE + j * 1024)
+            : "memory");
+      }
     }
   };
   int tnc[CT], nexp[CT];
@@ -252,6 +322,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16p_kernel(GemmF16Args a) {
   };
   PhaseConst pk;
   pk.ml = 0x000f000fu, pk.mh = 0x00f000f0u, pk.gl = 0x64086408u, pk.gh = 0x54805480u;
+  pk.s1 = 0x0c010c00u, pk.s2 = 0x0c030c02u;  // bytes [B0 0 B1 0], [B2 0 B3 0] of the blob word
   asm volatile("" : "+v"(pk.gl), "+v"(pk.gh));  // keep the magic words in registers
   // A fragment of (64-k half h, part p) for row tile rt: chunk h*8 + kq*2 + p of row rt*16 + i16, slot = chunk ^ i16
   uint32_t a_ad[4];
@@ -278,7 +349,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f16p_kernel(GemmF16Args a) {
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
     auto both = [](uint32_t lo16) { return __builtin_bit_cast(h2, (lo16 & 0xffffu) * 0x10001u); };
-    const u32x4 t = __builtin_bit_cast(u32x4, dq8s(B0.wv[c][0], both(F0[c][0].nl), both(F0[c][0].nh), both(F0[c][0].r)));
+    u32x4 t = __builtin_bit_cast(u32x4, dq8s(B0.wv[c][0], both(F0[c][0].nl), both(F0[c][0].nh), both(F0[c][0].r)));
+    if constexpr (RAW) {  // dq8s gives nibbles (0 4)(1 5)(2 6)(3 7); the raw order wants (0 2)(4 6)(1 3)(5 7)
+      const uint32_t lo = 0x05040100u, hi = 0x07060302u;  // v_perm: low halves / high halves of two words
+      const u32x4 u = t;
+      t.x = __builtin_amdgcn_perm(u.z, u.x, lo);  // (n0 n2)
+      t.y = __builtin_amdgcn_perm(u.z, u.x, hi);  // (n4 n6)
+      t.z = __builtin_amdgcn_perm(u.w, u.y, lo);  // (n1 n3)
+      t.w = __builtin_amdgcn_perm(u.w, u.y, hi);  // (n5 n7)
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) bq[0][c][i] = t[i];
   }
@@ -289,22 +368,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f16p_kernel(GemmF16Args a) {
   // read (the guide's rule for staged buffers: read one phase after the wait that retires it, never in the same one);
   // the loads it waits for were issued a K step earlier, so it costs nothing there.
 #define WOQ_KSTEP(BUF, BCUR, FCUR, BNXT, FNXT, KT)                                                                    \
-  gemm_phase<BUF * STAGE, false>(acc, af, bfrag(0, 0), bfrag(0, 1), bq[1], a_ad[1], BCUR.wv[0][1], BCUR.wv[1][1], pk, \
-                                 FCUR[0][0], FCUR[1][0], 0, nullptr, nullptr, 0, 0);                                  \
-  gemm_phase<BUF * STAGE, false>(acc, af, bfrag(1, 0), bfrag(1, 1), bq[0], a_ad[2], BCUR.wv[0][2], BCUR.wv[1][2], pk, \
-                                 FCUR[0][NS - 1], FCUR[1][NS - 1], 0, nullptr, nullptr, 0, 0);                        \
+  gemm_phase<BUF * STAGE, 0, RAW>(acc, af, bfrag(0, 0), bfrag(0, 1), bq[1], a_ad[1], BCUR.wv[0][1], BCUR.wv[1][1], pk, \
+                                 FCUR[0][0], FCUR[1][0], 0, nullptr, nullptr, 0, 0, ro);                                  \
+  gemm_phase<BUF * STAGE, 0, RAW>(acc, af, bfrag(1, 0), bfrag(1, 1), bq[0], a_ad[2], BCUR.wv[0][2], BCUR.wv[1][2], pk, \
+                                 FCUR[0][NS - 1], FCUR[1][NS - 1], 0, nullptr, nullptr, 0, 0, ro);                        \
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* tile KT + 1 and its weights, issued a K step ago */             \
   tie_b(BNXT);                                                                                                        \
   prep(BNXT, FNXT);                                                                                                   \
-  gemm_phase<BUF * STAGE, false>(acc, af, bfrag(0, 0), bfrag(0, 1), bq[1], a_ad[3], BCUR.wv[0][3], BCUR.wv[1][3], pk, \
-                                 FCUR[0][NS - 1], FCUR[1][NS - 1], 0, nullptr, nullptr, 0, 0);                        \
+  gemm_phase<BUF * STAGE, 0, RAW>(acc, af, bfrag(0, 0), bfrag(0, 1), bq[1], a_ad[3], BCUR.wv[0][3], BCUR.wv[1][3], pk, \
+                                 FCUR[0][NS - 1], FCUR[1][NS - 1], 0, nullptr, nullptr, 0, 0, ro);                        \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* my reads of BUF are done */                                   \
   __syncthreads();                                                                                                    \
   load_b(min((KT) + 2, last), BCUR);                                                                                  \
-  gemm_phase<(1 - BUF) * STAGE, true>(acc, af, bfrag(1, 0), bfrag(1, 1), bq[0], a_ad[0], BNXT.wv[0][0], BNXT.wv[1][0], \
+  gemm_phase<(1 - BUF) * STAGE, 1, RAW>(acc, af, bfrag(1, 0), bfrag(1, 1), bq[0], a_ad[0], BNXT.wv[0][0], BNXT.wv[1][0], \
                                       pk, FNXT[0][0], FNXT[1][0], lane16, a_src(min((KT) + 2, last)), \
                                       a_src(min((KT) + 2, last)) + 4096, dma_dst + BUF * STAGE,       \
-                                      dma_dst + BUF * STAGE + 4096);
+                                      dma_dst + BUF * STAGE + 4096, ro);
 
   for (int kt = 0; kt < a.tiles_k; kt += 2) {  // tiles_k is even (launch_f16_t sends odd counts to gemm_f16s_kernel)
     WOQ_KSTEP(0, B0, F0, B1, F1, kt)

@@ -34,6 +34,16 @@ __global__ void fill_uniform(float* p, size_t n, unsigned seed, float lo, float 
   }
 }
 
+// x := fp16-representable values, xh := the same as fp16 (PROBE_ACT16: the activation rows go down as fp16)
+__global__ void to_f16(float* x, _Float16* xh, size_t n) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const _Float16 h = (_Float16)x[i];
+    xh[i] = h;
+    x[i] = (float)h;
+  }
+}
+
 // ref[r][n] = sum_k x[rows[r]][k] * w[k][n], fp32, one thread per (r, n)
 __global__ void ref_rows(const float* x, const float* w, const int* rows, int K, int N, float* ref) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
@@ -100,6 +110,14 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&out, (size_t)M * N * 4));
   fill_uniform<<<2048, 256>>>(w, (size_t)K * N, 11u, asym ? -0.02f : -0.03f, asym ? 0.04f : 0.03f);
   fill_uniform<<<2048, 256>>>(x, (size_t)M * K, 23u, -1.f, 1.f);
+  const bool act16 = getenv("PROBE_ACT16") != nullptr;
+  _Float16* xh = nullptr;
+  if (act16) {
+    CK(hipMalloc(&xh, (size_t)M * K * 2));
+    to_f16<<<2048, 256>>>(x, xh, (size_t)M * K);
+  }
+  const void* xin = act16 ? (const void*)xh : (const void*)x;
+  const int xdt = act16 ? WOQ_F16 : WOQ_F32;
   const int wt = WOQ_W_INT4_CLIP, sct = WOQ_F16, ct = c32 ? WOQ_C_FP32 : WOQ_C_BF16;
   const size_t bb = f_size(K, N, group, wt, sct, asym, 0);
   if (bb == 0) {
@@ -120,11 +138,11 @@ int main(int argc, char** argv) {
   std::vector<float> very_first;
   if (getenv("PROBE_FIRST")) {  // the process's very first launch of this GEMM, kept for comparison with a later one
     CK(hipMemset(out, 0xFF, (size_t)M * N * 4));
-    WQ(f_lin(x, WOQ_F32, K, blob, &hdr, nullptr, out, WOQ_F32, N, M, nullptr));
+    WQ(f_lin(xin, xdt, K, blob, &hdr, nullptr, out, WOQ_F32, N, M, nullptr));
     very_first.resize((size_t)M * N);
     CK(hipMemcpy(very_first.data(), out, (size_t)M * N * 4, hipMemcpyDeviceToHost));
   }
-  for (int i = 0; i < 3; ++i) WQ(f_lin(x, WOQ_F32, K, blob, &hdr, nullptr, out, WOQ_F32, N, M, nullptr));
+  for (int i = 0; i < 3; ++i) WQ(f_lin(xin, xdt, K, blob, &hdr, nullptr, out, WOQ_F32, N, M, nullptr));
   CK(hipDeviceSynchronize());
   if (!very_first.empty()) {
     std::vector<float> now((size_t)M * N);
@@ -145,7 +163,7 @@ int main(int argc, char** argv) {
   float best = 1e30f, total = 0.f;
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < reps; ++i) WQ(f_lin(x, WOQ_F32, K, blob, &hdr, nullptr, out, WOQ_F32, N, M, nullptr));
+    for (int i = 0; i < reps; ++i) WQ(f_lin(xin, xdt, K, blob, &hdr, nullptr, out, WOQ_F32, N, M, nullptr));
     CK(hipEventRecord(e1, nullptr));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -164,7 +182,7 @@ int main(int argc, char** argv) {
       std::vector<uint16_t> f16a((size_t)M * N), f16b((size_t)M * N);
       int badr = 0;
       for (int r = 0; r < R; ++r) {
-        WQ(f_lin(x, WOQ_F32, K, blob, &hdr, nullptr, out, WOQ_F16, N, M, nullptr));
+        WQ(f_lin(xin, xdt, K, blob, &hdr, nullptr, out, WOQ_F16, N, M, nullptr));
         CK(hipMemcpy(r == 0 ? f16a.data() : f16b.data(), out, (size_t)M * N * 2, hipMemcpyDeviceToHost));
         if (r && memcmp(f16a.data(), f16b.data(), (size_t)M * N * 2) != 0) ++badr;
       }
@@ -182,7 +200,7 @@ int main(int argc, char** argv) {
         CK(hipMemset(out, 0xFF, (size_t)M * N * 4));
         CK(hipDeviceSynchronize());
       }
-      WQ(f_lin(x, WOQ_F32, K, blob, &hdr, nullptr, out, WOQ_F32, N, M, nullptr));
+      WQ(f_lin(xin, xdt, K, blob, &hdr, nullptr, out, WOQ_F32, N, M, nullptr));
       CK(hipMemcpy(r == 0 ? first.data() : cur.data(), out, (size_t)M * N * 4, hipMemcpyDeviceToHost));
       if (getenv("PROBE_CLEAR")) {
         const std::vector<float>& v = r == 0 ? first : cur;
