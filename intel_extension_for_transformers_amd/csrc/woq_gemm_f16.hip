@@ -53,6 +53,7 @@ struct GemmF16Args {
   const _Float16* ap;  // packed activation tiles [mb][kt][planes][128][16 slots][8] (planes: hi, and lo for NP == 3)
   const void* act_raw; // raw-A form (woq_gemm_f16p.h): the caller's row-major fp16 activations, no pack pass; else null
   int lda;             // its row stride in elements
+  int ring;            // 1: half-tile ring form of the hand-scheduled kernel (packed tiles in the half-tile layout)
   const float* rs;     // [Mpad] 2^e per row; null = all 1 (raw-A)
   const float* cs;     // [Npad] 2^E per column
   int M, nb_m, nb_n, sup_n, n_sup;
@@ -71,6 +72,7 @@ constexpr int FBM = 128;
 constexpr int FTILE_BYTES = 128 * 128 * 2;
 
 __device__ __forceinline__ int fperm(int e) { return (e < 4) ? 2 * e : 2 * (e - 4) + 1; }
+__host__ __device__ inline int ht_swz(int row);  // chunk swizzle of the half-tile layout (woq_gemm_f16p.h)
 
 // ---------------------------------------------------------------------------------------------------------------
 // pack pass. Blocks [0, Mpad): one workgroup per activation row (row max / sum of squares, then convert and store).
@@ -78,6 +80,8 @@ __device__ __forceinline__ int fperm(int e) { return (e < 4) ? 2 * e : 2 * (e - 
 // ---------------------------------------------------------------------------------------------------------------
 struct PackF16Args {
   int planes;  // 1: fp16 plane; 2: hi + lo planes (x 2^-e = hi + lo to ~22 bits) for the three-product kernel
+  int half_tiles;  // 1: [M/128][K/64] half-tiles of 16 KiB, row = 8 chunks, chunk c of row r in slot c ^ ht_swz(r)
+                   // (the ring kernel of woq_gemm_f16p.h); 0: [M/128][K/128] tiles of 32 KiB, slot c ^ (r & 15)
   const void* x;
   int x_dtype, lda, M, Mpad, K, Kpad;
   const int32_t* shuffle;  // GPTQ act-order gather (converted g_idx) or null
@@ -127,6 +131,8 @@ __device__ __forceinline__ void pack_row(const PackF16Args& a, int r, float* red
   const int full = a.K >> 3;  // chunks that lie wholly inside K (modes 0 / 1 load only those)
   const size_t tile_halves = (size_t)128 * 128 * a.planes;  // one (row block, K step): planes x 32 KiB
   _Float16* dst_row = a.ap + (size_t)mb * (a.Kpad >> 7) * tile_halves + (size_t)rl * 128;
+  const bool ht = a.half_tiles != 0;  // planes == 1 there
+  _Float16* ht_row = a.ap + (size_t)mb * (a.Kpad >> 6) * 8192 + (size_t)rl * 64;
   const size_t base = (size_t)r * a.lda;
   const bool norm = a.norm_w != nullptr;
   constexpr int NI = CACHED ? NC : 1;
@@ -203,7 +209,8 @@ __device__ __forceinline__ void pack_row(const PackF16Args& a, int r, float* red
       hh[e8] = (_Float16)xs;
       ll[e8] = (_Float16)(xs - (float)hh[e8]);
     }
-    _Float16* dp = dst_row + (size_t)(c >> 4) * tile_halves + (size_t)(((c & 15) ^ (rl & 15)) << 3);
+    _Float16* dp = ht ? ht_row + (size_t)(c >> 3) * 8192 + (size_t)(((c & 7) ^ ht_swz(rl)) << 3)
+                      : dst_row + (size_t)(c >> 4) * tile_halves + (size_t)(((c & 15) ^ (rl & 15)) << 3);
     *(h8*)dp = hh;
     if (a.planes == 2) *(h8*)(dp + 128 * 128) = ll;
   };
@@ -246,8 +253,10 @@ __global__ __launch_bounds__(256) void pack_f16_kernel(PackF16Args a) {
     const int mb = r >> 7, rl = r & 127;
     const size_t tile_halves = (size_t)128 * 128 * a.planes;
     _Float16* dst_row = a.ap + (size_t)mb * (a.Kpad >> 7) * tile_halves + (size_t)rl * 128;
+    _Float16* ht_row = a.ap + (size_t)mb * (a.Kpad >> 6) * 8192 + (size_t)rl * 64;
     for (int c = tid; c < (a.Kpad >> 3); c += 256) {
-      _Float16* dp = dst_row + (size_t)(c >> 4) * tile_halves + (size_t)(((c & 15) ^ (rl & 15)) << 3);
+      _Float16* dp = a.half_tiles ? ht_row + (size_t)(c >> 3) * 8192 + (size_t)(((c & 7) ^ ht_swz(rl)) << 3)
+                                  : dst_row + (size_t)(c >> 4) * tile_halves + (size_t)(((c & 15) ^ (rl & 15)) << 3);
       *(u32x4*)dp = (u32x4){0, 0, 0, 0};
       if (a.planes == 2) *(u32x4*)(dp + 128 * 128) = (u32x4){0, 0, 0, 0};
     }
@@ -626,27 +635,35 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gemm_f16s_kernel(GemmF16
 template <int SMODE, bool ASYM, bool S32, int NP>
 static int launch_f16_t(GemmF16Args& a, hipStream_t st) {
   auto kern = gemm_f16s_kernel<SMODE, ASYM, S32, NP, 2>;
+  bool ring = false;
 #if WOQ_GEMM_HANDSCHED
   if (NP == 1 && (a.tiles_k & 1) == 0) {  // (its K loop runs two K steps per trip; odd tile counts keep the kernel above)
-    if (a.act_raw)
-      kern = S32 ? gemm_f16p_kernel<SMODE, ASYM, 2, true>
-                 : (a.scale_type == WOQ_BF16 ? gemm_f16p_kernel<SMODE, ASYM, 1, true>
-                                             : gemm_f16p_kernel<SMODE, ASYM, 0, true>);
-    else
-      kern = S32 ? gemm_f16p_kernel<SMODE, ASYM, 2>
-                 : (a.scale_type == WOQ_BF16 ? gemm_f16p_kernel<SMODE, ASYM, 1> : gemm_f16p_kernel<SMODE, ASYM, 0>);
+    // (the ring form needs <= 168 VGPRs for its third workgroup per CU; group-32 asymmetric blobs with fp32 scales do
+    // not fit without spills and stay on the two-tile form)
+    constexpr bool ring_fits = !(SMODE == 1 && ASYM && S32);
+    ring = a.ring != 0 && ring_fits;
+#define WOQ_PICK(RAW_, RING_)                                                                       \
+  (S32 ? gemm_f16p_kernel<SMODE, ASYM, 2, RAW_, RING_>                                              \
+       : (a.scale_type == WOQ_BF16 ? gemm_f16p_kernel<SMODE, ASYM, 1, RAW_, RING_>                  \
+                                   : gemm_f16p_kernel<SMODE, ASYM, 0, RAW_, RING_>))
+    if constexpr (ring_fits) {
+      if (ring) kern = a.act_raw ? WOQ_PICK(true, true) : WOQ_PICK(false, true);
+    }
+    if (!ring)
+      kern = a.act_raw ? WOQ_PICK(true, false) : WOQ_PICK(false, false);
+#undef WOQ_PICK
   }
 #endif
-  constexpr int LDS = 2 * FTILE_BYTES * (NP == 1 ? 1 : 2);
-  static const void* attr_set[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // (the kernels this instantiation can pick)
-  bool have = false;
-  int free_slot = 4;
-  for (int i = 4; i >= 0; --i) {
+  const int LDS = ring ? 3 * (FTILE_BYTES / 2) : 2 * FTILE_BYTES * (NP == 1 ? 1 : 2);
+  static const void* attr_set[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool have = false;  // (attr_set: the kernels this instantiation can pick)
+  int free_slot = 7;
+  for (int i = 7; i >= 0; --i) {
     have = have || attr_set[i] == (const void*)kern;
     if (attr_set[i] == nullptr) free_slot = i;
   }
   if (!have) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FTILE_BYTES * 2);
     if (e != hipSuccess) return woq::fail(std::string("QBits: hipFuncSetAttribute: ") + hipGetErrorString(e));
     attr_set[free_slot] = (const void*)kern;
   }
@@ -718,9 +735,13 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   a.act_raw = raw ? act : nullptr;
   a.lda = lda;
   if (raw) a.rs = nullptr;
+  static const bool ring_ok = !(getenv("WOQ_GEMM_RING") && getenv("WOQ_GEMM_RING")[0] == '0');
+  const bool ring_fits = !(h.scale_mode == 1 && a.zp != nullptr && h.scale_type == WOQ_F32);  // (launch_f16_t: VGPRs)
+  a.ring = (WOQ_GEMM_HANDSCHED && ring_ok && ring_fits && !fp32_class && ((h.Kpad / WOQ_TILE_K) & 1) == 0) ? 1 : 0;
 
   PackF16Args p;
   p.planes = planes;
+  p.half_tiles = a.ring;
   p.x = act;
   p.x_dtype = act_dtype;
   p.lda = lda;
