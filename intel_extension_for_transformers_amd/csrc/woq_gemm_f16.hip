@@ -28,7 +28,10 @@
 //  * epilogue: acc * 2^e[row] * 2^E[col] + bias, adjacent columns paired through DPP so stores are 4 (16-bit out)
 //    or 8 bytes wide.
 // Workgroup 128 x 128 (4 waves, wave w = all rows x columns [32w, 32w+32) -> 8 x 2 fragments = 64 accumulator VGPRs),
-// two LDS buffers of 32 KiB, two workgroups per CU. Workgroup ids are laid out XCD-aware: the 64 workgroups that
+// two LDS buffers of 32 KiB, two workgroups per CU — the kernel in THIS file (hipcc's instruction order; kept for the
+// fp32-class form and for odd K-tile counts). The one-product form normally runs the hand-scheduled K loop of
+// woq_gemm_f16p.h: same tiles and epilogue, 16-KiB half-tiles through a ring of three LDS slots, three workgroups
+// per CU, optionally fetching fp16 activation rows without a pack pass. Workgroup ids are laid out XCD-aware: the 64 workgroups that
 // share an XCD's L2 at a time form an 8 x 8 super-tile (8 A row blocks x 8 B column blocks re-used 8x each).
 // Measured alternatives (MI355X, M = 8192, gate/up shape, 849 TFLOP/s as built): 8 waves per workgroup sharing one
 // A tile (128 x 256, one workgroup per CU) 799; 4 column tiles per wave (128 accumulator VGPRs, one workgroup per CU)

@@ -14,8 +14,11 @@
 // reading this one, so the LDS-DMA of tile kt + 2 is issued from inside part 3's block, one 1-KiB piece per row-tile
 // pair, a whole K step ahead of its use. The only vmcnt wait is the one before part 2, for loads issued a K step
 // earlier. Registers are allocated by the compiler (operands); the instruction order inside a block is fixed by hand.
-// gfx950, M = 8192 x K = 4096 x N = 22016, g128 sym: 1.16 ms under rocprofv3 against 1.40 for hipcc's schedule
-// (profiles/r02z_bench_kernel_stats.txt, r01m_prefill_kernel_stats.txt).
+// Two further forms of the same loop, selected by the launcher: RAW (fp16 activation rows fetched straight from the
+// caller's matrix, no pack pass) and RING (the A operand in 16-KiB half-tiles through three LDS slots: three
+// workgroups per CU) — described at gemm_f16p_kernel below.
+// gfx950, M = 8192 x K = 4096 x N = 22016, g128 sym, rocprofv3 kernel time: hipcc's schedule 1.40 ms, this loop 1.16,
+// with the ring 1.10 = 0.54 of 2.5 PF (profiles/r01m_prefill_kernel_stats.txt, r02z_*, r02zz_bench_kernel_stats.txt).
 #pragma once
 // (included inside namespace woq)
 
