@@ -257,18 +257,27 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const _Float16* __
     // some position of the tile may exceed some query of the wave, or fall below some query's window
     const bool diag = t0 + AKT - 1 > start + q0 || (window > 0 && t0 < start + q0 + 32 - window);
     h8 pb[2][2];
+    if (diag) {  // wave-uniform: the mask work (compare + select per score) only on tiles that touch the diagonal or a
+                 // window edge — most tiles of a long prompt are wholly visible
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int qpos = start + q0 + rt * 16 + i16;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int tp = t0 + a * 16 + kq * 4 + j;
+            if (tp > qpos || (window > 0 && tp < qpos + 1 - window)) s[a][rt][j] = -INFINITY;
+          }
+      }
+    }
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-      const int qpos = start + q0 + rt * 16 + i16;
       float mx = -INFINITY;
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int tp = t0 + a * 16 + kq * 4 + j;
-          if (diag && (tp > qpos || (window > 0 && tp < qpos + 1 - window))) s[a][rt][j] = -INFINITY;
-          mx = fmaxf(mx, s[a][rt][j]);
-        }
+        for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[a][rt][j]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[rt], mx * sc);
