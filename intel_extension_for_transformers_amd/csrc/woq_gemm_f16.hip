@@ -232,36 +232,33 @@ __device__ __forceinline__ void pack_row(const PackF16Args& a, int r, float* red
 __global__ __launch_bounds__(256) void pack_f16_kernel(PackF16Args a) {
   __shared__ float red[8];
   const int tid = threadIdx.x;
-  if ((int)blockIdx.x >= a.row_blocks) {  // ---- column scales ----
-    const int n = ((int)blockIdx.x - a.row_blocks) * 256 + tid;
-    if (n >= a.Npad) return;
+  if ((int)blockIdx.x >= a.row_blocks) {  // ---- column scales: 32 columns per block, 8 threads per column ----
+    // (each thread takes every 8th scale group of its column, the eight partial maxima meet in LDS: one thread per
+    // column walking all groups was a 22-us chain of dependent misses when no activation rows ride along — the raw-A
+    // calls — and 86 groups at K = 11008)
+    __shared__ float cred[256];
+    const int col = ((int)blockIdx.x - a.row_blocks) * 32 + (tid & 31), slice = tid >> 5;
+    const int n = min(col, a.Npad - 1);
     const int tn = n >> 4, i16 = n & 15;
     float mx = 0.f;
-    // eight independent loads per trip (indices past the end repeat the last one): one load per trip made this the
-    // longest part of the launch when no activation rows ride along (22 us for the raw-A calls, 86 groups at K = 11008)
     if (a.scale_mode == 0) {
-      for (int g0 = 0; g0 < a.n_groups; g0 += 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          v[u] = load_f32(a.scales, ((size_t)tn * a.n_groups + min(g0 + u, a.n_groups - 1)) * 16 + i16, a.scale_type);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) mx = fmaxf(mx, fabsf(v[u]));
-      }
+      for (int g = slice; g < a.n_groups; g += 8)
+        mx = fmaxf(mx, fabsf(load_f32(a.scales, ((size_t)tn * a.n_groups + g) * 16 + i16, a.scale_type)));
     } else {
-      for (int kt0 = 0; kt0 < a.tiles_k; kt0 += 2) {
-        float v[8];
+      for (int kt = slice; kt < a.tiles_k; kt += 8)
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          v[u] = load_f32(a.scales, ((((size_t)tn * a.tiles_k + min(kt0 + (u >> 2), a.tiles_k - 1)) * 16 + i16) << 2) + (u & 3),
-                          a.scale_type);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) mx = fmaxf(mx, fabsf(v[u]));
-      }
+        for (int u = 0; u < 4; ++u)
+          mx = fmaxf(mx, fabsf(load_f32(a.scales, ((((size_t)tn * a.tiles_k + kt) * 16 + i16) << 2) + u, a.scale_type)));
     }
-    int e = 0;
-    if (mx > 0.f && mx < INFINITY) e = max(-120, min(120, __builtin_amdgcn_frexp_expf(mx)));  // mx < 2^e
-    a.cs[n] = ldexpf(1.f, e);
+    cred[tid] = mx;
+    __syncthreads();
+    if (slice == 0 && col < a.Npad) {
+#pragma unroll
+      for (int u = 1; u < 8; ++u) mx = fmaxf(mx, cred[u * 32 + tid]);
+      int e = 0;
+      if (mx > 0.f && mx < INFINITY) e = max(-120, min(120, __builtin_amdgcn_frexp_expf(mx)));  // mx < 2^e
+      a.cs[col] = ldexpf(1.f, e);
+    }
     return;
   }
   const int r = (int)blockIdx.x;
@@ -778,7 +775,7 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   p.Npad = h.Npad;
   p.row_blocks = raw ? 0 : (int)Mpad;  // raw-A: only the column-scale blocks run
   p.cs = (float*)a.cs;
-  hipLaunchKernelGGL(pack_f16_kernel, dim3((unsigned)(p.row_blocks + (h.Npad + 255) / 256)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(pack_f16_kernel, dim3((unsigned)(p.row_blocks + (h.Npad + 31) / 32)), dim3(256), 0, st, p);
 
   const bool asym = a.zp != nullptr;
   const int sm = (int)h.scale_mode;
