@@ -70,6 +70,10 @@ __device__ __forceinline__ uint32_t next_seq(uint32_t s) { return s + 1 == 0 ? 1
 // in-place sum over ranks of buf[0..n). grid = ceil(n / 1024) x 256 threads, 4 elements per thread (stride 256: every
 // store instruction of a wave covers 512 contiguous bytes of one peer's inbox).
 __global__ __launch_bounds__(256) void allreduce_ll_kernel(CommDev c, float* __restrict__ buf, uint32_t n) {
+  // the grid size is read HERE and kept in a register: left to itself hipcc loads it from the kernel-argument segment
+  // at the tail and recycles the segment pointer right behind the load (the pattern of DESIGN.md §3.3's trap)
+  uint32_t nblk = gridDim.x;
+  asm volatile("" : "+s"(nblk));
   const uint32_t seq = c.ctl[0];
   const int b = (int)(seq & 1u);
   const uint32_t i0 = blockIdx.x * 1024u + threadIdx.x;
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(256) void allreduce_ll_kernel(CommDev c, float* __r
   __syncthreads();
   if (threadIdx.x == 0) {
     // every workgroup read ctl[0] before it got here, so the last one to arrive may advance it
-    if (atomicAdd(&c.ctl[1], 1u) == gridDim.x - 1) {
+    if (atomicAdd(&c.ctl[1], 1u) == nblk - 1) {
       atomicExch(&c.ctl[1], 0u);
       atomicExch(&c.ctl[0], next_seq(seq));
     }
