@@ -115,11 +115,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
                                                           const float* __restrict__ cs, const float* __restrict__ sn,
                                                           int heads, int kv_heads, int window,
                                                           float* __restrict__ out, XqPtrs xo) {
-  // every kernel argument is in its register (and the scalar loads behind it retired) before anything else runs:
-  // hipcc otherwise reuses the argument-segment pointer as a VALU compare mask a few instructions behind a still
-  // outstanding s_load (the kernarg trap)
-  asm volatile("" : "+s"(qkv), "+s"(kcache), "+s"(vcache), "+s"(pos_p), "+s"(cs), "+s"(sn));
-  asm volatile("" : "+s"(heads), "+s"(kv_heads), "+s"(window), "+s"(out), "+s"(xo.limbs), "+s"(xo.u), "+s"(xo.sx));
   extern __shared__ __attribute__((aligned(16))) float sm[];
   typedef typename KvVec8<KV>::type kv8;
   constexpr int half = HD / 2;

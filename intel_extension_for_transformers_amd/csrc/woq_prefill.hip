@@ -366,9 +366,6 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const float* __re
                                                                const float* __restrict__ cs,
                                                                const float* __restrict__ sn, int heads, int kv_heads,
                                                                int window, float* __restrict__ part) {
-  // (arguments in registers, their scalar loads retired, before anything else: see attn_decode_kernel, woq_ops.hip)
-  asm volatile("" : "+s"(qkv), "+s"(kcache), "+s"(vcache), "+s"(pos_p), "+s"(cs), "+s"(sn));
-  asm volatile("" : "+s"(heads), "+s"(kv_heads), "+s"(window), "+s"(part));
   static_assert(HD == 128 && REP <= 16, "one 16-column MFMA tile of query heads, head_dim 128");
   static_assert(16 * (HD + 2) * 4 <= HD * DVRB, "the merge record of a wave reuses its V^T tile");
   constexpr int DC = HD / 32, DT = HD / 16, half = HD / 2;
