@@ -118,6 +118,16 @@ using namespace woq;
 
 static const XqPtrs kNoXq = {nullptr, nullptr, nullptr};
 
+// WOQ_ENGINE_SKIP=<bit mask>: leave launches out of the XQ decode step — timing experiments only (the step's results
+// are then meaningless). bit 0 qkv, 1 attention, 2 o_proj, 3 gate/up, 4 down_proj, 5 head.
+static int engine_skip_mask() {
+  static const int m = [] {
+    const char* s = getenv("WOQ_ENGINE_SKIP");
+    return s ? atoi(s) : 0;
+  }();
+  return m;
+}
+
 // one batch-1 projection over an XQ vector
 static int engine_gemv_xq(woq_engine* e, const XqPtrs& xin, const void* blob, const woq_blob_header& h, float* out,
                           const float* ssq_in, const float* residual, int epi, const XqPtrs& xo,
@@ -129,13 +139,19 @@ static int engine_gemv_xq(woq_engine* e, const XqPtrs& xin, const void* blob, co
 static int engine_attn_block_xq(woq_engine* e, int l, hipStream_t st) {
   const woq_engine_config& c = e->cfg;
   const woq_layer_weights& w = e->layers[l];
-  int rc = engine_gemv_xq(e, e->xq_hidden, w.qkv_blob, w.qkv_hdr, e->qkv, e->ssq_part, nullptr, 0, kNoXq, nullptr,
-                          nullptr, st);
+  const int skip = engine_skip_mask();
+  int rc = 0;
+  if (!(skip & 1))
+    rc = engine_gemv_xq(e, e->xq_hidden, w.qkv_blob, w.qkv_hdr, e->qkv, e->ssq_part, nullptr, 0, kNoXq, nullptr, nullptr,
+                        st);
   if (rc) return rc;
-  rc = launch_attn_decode(e->qkv, e->kcache + (size_t)l * e->kv_layer_bytes, e->vcache + (size_t)l * e->kv_layer_bytes,
-                          c.kv_dtype, e->pos, e->cs, e->sn, c.heads, c.kv_heads, c.head_dim, c.max_ctx, e->window,
-                          e->attn, e->attn_splits, e->attn_grouped, e->attn_part, e->xq_attn, st);
+  if (!(skip & 2))
+    rc = launch_attn_decode(e->qkv, e->kcache + (size_t)l * e->kv_layer_bytes,
+                            e->vcache + (size_t)l * e->kv_layer_bytes, c.kv_dtype, e->pos, e->cs, e->sn, c.heads,
+                            c.kv_heads, c.head_dim, c.max_ctx, e->window, e->attn, e->attn_splits, e->attn_grouped,
+                            e->attn_part, e->xq_attn, st);
   if (rc) return rc;
+  if (skip & 4) return 0;
   // hidden += attn . W_o ; the new hidden leaves as the MLP's XQ input (times ln2) with its sums of squares
   return engine_gemv_xq(e, e->xq_attn, w.o_blob, w.o_hdr, e->hidden, nullptr, e->hidden, 0, e->xq_hidden, w.ln2,
                         e->ssq_part, st);
@@ -144,9 +160,13 @@ static int engine_attn_block_xq(woq_engine* e, int l, hipStream_t st) {
 static int engine_mlp_block_xq(woq_engine* e, int l, hipStream_t st) {
   const woq_engine_config& c = e->cfg;
   const woq_layer_weights& w = e->layers[l];
-  int rc = engine_gemv_xq(e, e->xq_hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, e->ssq_part, nullptr, 1, e->xq_act,
-                          nullptr, nullptr, st);
+  const int skip = engine_skip_mask();
+  int rc = 0;
+  if (!(skip & 8))
+    rc = engine_gemv_xq(e, e->xq_hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, e->ssq_part, nullptr, 1, e->xq_act,
+                        nullptr, nullptr, st);
   if (rc) return rc;
+  if (skip & 16) return 0;
   const bool last = l + 1 == c.layers;  // the last layer's output feeds the head, which reads fp32
   return engine_gemv_xq(e, e->xq_act, w.down_blob, w.down_hdr, e->hidden, nullptr, e->hidden, 0,
                         last ? kNoXq : e->xq_hidden, last ? nullptr : e->layers[l + 1].ln1, last ? nullptr : e->ssq_part,
@@ -184,6 +204,7 @@ static int engine_mlp_block(woq_engine* e, int l, hipStream_t st) {
 
 static int engine_head(woq_engine* e, int greedy, hipStream_t st) {
   const woq_engine_config& c = e->cfg;
+  if (engine_skip_mask() & 32) return 0;
   launch_lm_head(e->hidden, e->final_norm, c.rms_eps, e->lm_head, e->lm_dtype, c.hidden, c.vocab, e->logits,
                  greedy ? e->am_val : nullptr, greedy ? e->am_idx : nullptr, st);
   if (greedy && e->comm && c.tp_size > 1)  // vocab-sharded head: one (max, global index) pair per rank

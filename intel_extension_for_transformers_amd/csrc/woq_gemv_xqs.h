@@ -1,0 +1,350 @@
+// woq_gemv_xqs.h — the batch-1 decode GEMV of the fused engine (round 3): int4 weights x an activation vector that
+// arrives in XQ form (woq_xq.h: balanced-digit limb blocks written by the producing kernel's epilogue).
+//
+// Arithmetic and parity definition: reference qbits.cpp:113-140, autograd/functions.py:41-63 — exact int8 x int8 ->
+// int32 sums on v_mfma_i32_16x16x64_i8, one fp32 recombination per 16-k block, group scale (and zero point) applied
+// per block, fp32 across blocks.
+//
+// What round 3 changed, and the measurement behind each change (tools/xq_probe.hip, profiles/r03b_xq_knockouts.txt):
+// the round-2 kernel with every load's descriptor emptied — no memory traffic at all — still took 5.0 us per qkv
+// launch, exactly what a load-only twin takes WITH the traffic, and its bare skeleton (no traffic, no arithmetic, no
+// epilogue) 3.6 us. The kernel was bound by its own instruction stream: ~300 instructions of per-wave set-up and ~50
+// per tile for 8 tiles of work, twelve waves per CU. So:
+//   * the weight requests are the first thing a wave does (their addresses need only the preloaded kernel arguments),
+//     and they move through a ROLLING WINDOW of D tiles — tile t + D is requested when tile t is consumed — so the
+//     arithmetic of a tile runs under the stream of the next ones instead of after the last byte;
+//   * balanced signed digits instead of offset-binary limbs (woq_xq.h): no ones row, no bias terms — the
+//     recombination of an MFMA result is 4 VALU instead of 9, and the A operand needs no ones block;
+//   * per-tile factors (block factors u, block sums sx, group scales, zero points) come from small wave-private LDS
+//     tables filled by ONE vector request each, instead of 16 cross-lane shuffles and 8 tiny global requests per
+//     column tile (as many trips through the address unit as the weight tiles themselves);
+//   * what only the 16 epilogue lanes need (residual, next norm weight, RMSNorm partials) is requested by wave 0 only,
+//     up front, so nothing in the serial tail waits on memory.
+#pragma once
+#include "woq_gemv_common.h"
+#include "woq_xq.h"
+
+#ifdef WOQ_XQS_STAMPS
+extern __device__ unsigned long long* g_xqs_probe;
+#define WOQ_XQS_STAMP(k)                                                              \
+  do {                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    if (g_xqs_probe && lane == 0) {                                                   \
+      unsigned long long* slot_ = g_xqs_probe + ((size_t)blockIdx.x * 16 + wid) * 16; \
+      slot_[(k)] = wall_clock64();                                                    \
+    }                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+  } while (0)
+#else
+#define WOQ_XQS_STAMP(k) \
+  do {                   \
+  } while (0)
+#endif
+
+// experiment switches of the probe build (tools/xq_probe.hip, -DWOQ_XQS_KNOBS): bits 4.. of `flags` knock out one
+// stage each by emptying its buffer descriptors or skipping its arithmetic. Nothing in the product build.
+#ifdef WOQ_XQS_KNOBS
+#define WOQ_XK(bit) (((flags) >> (bit)) & 1)
+#else
+#define WOQ_XK(bit) false
+#endif
+
+namespace woq {
+
+// wave-private LDS region: [zero block 256][limb strip TPW x 384][u 256][sx 256][scale slices][zero-point slices]
+template <int TPW, int CB, int SMODE, bool ASYM, bool S32>
+struct XqsLds {
+  static constexpr int ESZ = S32 ? 4 : 2;
+  static constexpr int STRIP = TPW * 384;
+  static constexpr int UTAB = 256;
+  static constexpr int SXTAB = ASYM ? 256 : 0;
+  static constexpr int SCB = (SMODE == 0 ? TPW * 16 : TPW * 64) * ESZ;  // one column tile's scale slice
+  static constexpr int ZPB = ASYM ? (SMODE == 0 ? TPW * 16 : TPW * 64) : 0;
+  static constexpr int O_STRIP = 256, O_U = O_STRIP + STRIP, O_SX = O_U + UTAB, O_SC = O_SX + SXTAB,
+                       O_ZP = O_SC + CB * SCB;
+  static constexpr int WAVE = O_ZP + CB * ZPB;
+  static_assert(WAVE % 16 == 0, "wave region must keep 16-byte alignment");
+  __host__ __device__ static constexpr size_t total(int nw) {
+    return (size_t)nw * WAVE + (size_t)nw * CB * 16 * 4 + 256;
+  }
+};
+
+__device__ __forceinline__ float xqs_swap32(float v) {
+  const uint32_t b = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+  return __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xqs_swap16(float v) {
+  const uint32_t b = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+  return __uint_as_float(r[1]);
+}
+// rows 4 e .. 4 e + 2 of the MFMA result = quarter e's three balanced digits against 16 q:
+// sum_k 16 q_k v_k = d0 + 2^8 d1 + 2^16 d2 (|d0 + 2^8 d1| < 2^27: exact in int32), rounded to fp32 twice at most
+__device__ __forceinline__ float digit_combine(const i32x4& d) {
+  return fmaf((float)d.z, 65536.f, (float)(d.x + (d.y << 8)));
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// flags: bit 0 scales are bf16 (else fp16; ignored for fp32 scales), bit 1 SiLU(gate)*up epilogue (CB == 2)
+// The first 14 argument dwords are preloaded into SGPRs (-amdgpu-kernarg-preload-count=14): everything the weight
+// requests need sits there.
+template <int TPW, int CB, int D, int SMODE, bool ASYM, bool S32>
+__global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_xqs_kernel(
+    const u32x4* __restrict__ q, const void* __restrict__ scales, const uint8_t* __restrict__ xlimbs,
+    const float* __restrict__ xu, int tiles_k, int kt_off, int base_tiles, int rem_tiles, int n_groups, int tpg_shift,
+    const uint8_t* __restrict__ zp, const float* __restrict__ xsx, float* __restrict__ out,
+    const float* __restrict__ bias, const float* residual, float eps, int N, int K, int flags,
+    const float* __restrict__ ssq_in, int n_ssq, XqPtrs xo, const float* __restrict__ next_norm_w,
+    float* __restrict__ ssq_out) {
+  typedef XqsLds<TPW, CB, SMODE, ASYM, S32> L;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int ESZ = L::ESZ;
+  constexpr int DD = D < TPW ? D : TPW;  // tiles requested before the first one is consumed
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = uni(tid >> 6);
+  const int nw = (int)blockDim.x >> 6;
+  WOQ_XQS_STAMP(0);
+  const int kt0 = kt_off + wid * base_tiles + min(wid, rem_tiles);
+  const int cnt = base_tiles + (wid < rem_tiles ? 1 : 0);
+  const int v16 = lane * 16;
+
+  // ---- 1. the first D weight tiles of the wave's slice: nothing is in front of them ----
+  u32x4 w[CB][TPW];
+  rsrc_t rq[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+    rq[cb] = make_rsrc(q + (size_t)((int)blockIdx.x * CB + cb) * tiles_k * 64,
+                       WOQ_XK(8) ? 0 : uni(min(kt0 + cnt, tiles_k) * 1024));
+#pragma unroll
+  for (int t = 0; t < DD; ++t)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+      w[cb][t] = __builtin_amdgcn_raw_buffer_load_b128(rq[cb], v16 + t * 1024, kt0 * 1024, AUX_NT);
+
+  // ---- 2. the small requests (L2-resident: written by the previous kernel, or shared by every workgroup) ----
+  constexpr int XP = (L::STRIP + 1023) / 1024;  // 1-KiB pieces per limb strip
+  u32x4 xl[XP];
+  {
+    const rsrc_t rl =
+        make_rsrc(xlimbs + (size_t)kt0 * 384, WOQ_XK(4) ? 0 : uni(max(0, min(cnt, tiles_k - kt0)) * 384));
+#pragma unroll
+    for (int j = 0; j < XP; ++j) xl[j] = __builtin_amdgcn_raw_buffer_load_b128(rl, v16 + j * 1024, 0, 0);
+  }
+  // block factors of the slice: lane L holds block kt0 * 8 + L (8 blocks per tile; reads past the slice return 0
+  // through the descriptor, so tiles past the slice end contribute exactly 0)
+  const int nblk = WOQ_XK(5) ? 0 : uni(max(0, min(cnt * 8, tiles_k * 8 - kt0 * 8)));
+  const rsrc_t ru = make_rsrc(xu + (size_t)kt0 * 8, nblk * 4);
+  const float uw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ru, lane * 4, 0, 0));
+  float sxw = 0.f;
+  if constexpr (ASYM) {
+    const rsrc_t rsx = make_rsrc(xsx + (size_t)kt0 * 8, nblk * 4);
+    sxw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, lane * 4, 0, 0));
+  }
+  // the wave's slice of scales (and zero points) of each column tile: one vector request per KiB
+  constexpr int NSP = (L::SCB + 1023) / 1024;
+  u32x4 sl[CB][NSP];
+  u32x4 zl[CB];
+  int g0 = 0;
+  if constexpr (SMODE == 0) g0 = min(kt0 >> tpg_shift, n_groups - 1);
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    const int tn = (int)blockIdx.x * CB + cb;
+    rsrc_t rs, rz;
+    if constexpr (SMODE == 0) {
+      rs = make_rsrc((const char*)scales + ((size_t)tn * n_groups + g0) * 16 * ESZ,
+                     WOQ_XK(5) ? 0 : uni((n_groups - g0) * 16 * ESZ));
+      rz = make_rsrc(zp + ((size_t)tn * n_groups + g0) * 16, uni((n_groups - g0) * 16));
+    } else {
+      const int left = uni(max(0, tiles_k - kt0));
+      rs = make_rsrc((const char*)scales + ((size_t)tn * tiles_k + kt0) * 64 * ESZ, WOQ_XK(5) ? 0 : left * 64 * ESZ);
+      rz = make_rsrc(zp + ((size_t)tn * tiles_k + kt0) * 64, left * 64);
+    }
+#pragma unroll
+    for (int j = 0; j < NSP; ++j) sl[cb][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, v16 + j * 1024, 0, 0);
+    if constexpr (ASYM) zl[cb] = __builtin_amdgcn_raw_buffer_load_b128(rz, v16, 0, 0);
+  }
+  // epilogue inputs (wave 0 runs the epilogue on its lanes 0..15): residual element, next norm weight, RMSNorm
+  // partials (256 per 16-B piece, only the pieces that exist) — requested now, used after the barrier
+  const bool silu = (flags & 2) != 0;
+  float e_res = 0.f, g_next = 1.f;
+  float4_t ssq_v[4];
+  if (wid == 0) {
+    const int n0 = (int)blockIdx.x * 16;
+    const int nlive = uni(max(0, min((silu ? (N >> 1) : N) - n0, 16)));
+    if (residual != nullptr && !WOQ_XK(5)) {
+      const rsrc_t rr = make_rsrc(residual + n0, nlive * 4);
+      e_res = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, min(lane, 15) * 4, 0, 0));
+    }
+    if (next_norm_w != nullptr && !WOQ_XK(5)) {
+      const rsrc_t rg = make_rsrc(next_norm_w + n0, nlive * 4);
+      g_next = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, min(lane, 15) * 4, 0, 0));
+    }
+    if (ssq_in != nullptr) {
+      const rsrc_t rs = make_rsrc(ssq_in, WOQ_XK(5) ? 0 : n_ssq * 4);
+      ssq_v[0] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, v16, 0, 0));
+#pragma unroll
+      for (int j = 1; j < 4; ++j) {
+        ssq_v[j] = float4_t{0.f, 0.f, 0.f, 0.f};
+        if (n_ssq > j * 256)
+          ssq_v[j] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, v16 + j * 1024, 0, 0));
+      }
+    }
+  }
+  WOQ_XQS_STAMP(1);
+
+  // ---- 3. park the small pieces in the wave's LDS region (wave-private, in-order LDS: no workgroup barrier) ----
+  unsigned char* wbase = smem_raw + (size_t)wid * L::WAVE;
+  float* slab = (float*)(smem_raw + (size_t)nw * L::WAVE);  // [nw][CB][16]
+  float* red = slab + nw * CB * 16;                          // [64]
+  ((uint32_t*)wbase)[lane] = 0u;
+#pragma unroll
+  for (int j = 0; j < XP; ++j)
+    if (v16 + j * 1024 < L::STRIP) *(u32x4*)(wbase + L::O_STRIP + v16 + j * 1024) = xl[j];  // past the slice: zeros
+  ((float*)(wbase + L::O_U))[lane] = uw;
+  if constexpr (ASYM) ((float*)(wbase + L::O_SX))[lane] = sxw;
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+    for (int j = 0; j < NSP; ++j)
+      if (v16 + j * 1024 < L::SCB) *(u32x4*)(wbase + L::O_SC + cb * L::SCB + v16 + j * 1024) = sl[cb][j];
+    if constexpr (ASYM)
+      if (v16 < L::ZPB) *(u32x4*)(wbase + L::O_ZP + cb * L::ZPB + v16) = zl[cb];
+  }
+  __builtin_amdgcn_wave_barrier();
+  // A-operand addresses: MFMA row r = lane & 15 -> quarter e = r >> 2, digit p = r & 3 (row 4 e + 3 stays zero);
+  // a row is live in lane quarter kq == e only, everything else reads the zero block
+  const int i16 = lane & 15, kq = lane >> 4;
+  const bool a_live = (i16 >> 2) == kq && (i16 & 3) != 3;
+  const unsigned char* a_base = a_live ? wbase + L::O_STRIP + kq * 48 + (i16 & 3) * 16 : wbase + kq * 16;
+  const int a_step_t = a_live ? 384 : 0, a_step_h = a_live ? 192 : 0;
+  const float* u_base = (const float*)(wbase + L::O_U) + kq;    // [t * 8 + h * 4]
+  const float* sx_base = (const float*)(wbase + L::O_SX) + kq;  // (ASYM)
+  const bool bf = (flags & 1) != 0;
+  const i32x4 izero = {0, 0, 0, 0};
+  float tot[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) tot[cb] = 0.f;
+  WOQ_XQS_STAMP(2);
+
+  // ---- 4. inner products: request tile t + D, consume tile t ----
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    if (t + DD < TPW) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+        w[cb][t + DD] = __builtin_amdgcn_raw_buffer_load_b128(rq[cb], v16 + (t + DD) * 1024, kt0 * 1024, AUX_NT);
+    }
+    const i32x4 a0 = *(const i32x4*)(a_base + t * a_step_t);
+    const i32x4 a1 = *(const i32x4*)(a_base + t * a_step_t + a_step_h);
+    const float u0 = u_base[t * 8], u1 = u_base[t * 8 + 4];
+    float s0 = 0.f, s1 = 0.f;
+    if constexpr (ASYM) s0 = sx_base[t * 8], s1 = sx_base[t * 8 + 4];
+    int gi = t;
+    if constexpr (SMODE == 0) gi = min((kt0 + t) >> tpg_shift, n_groups - 1) - g0;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      const u32x4 wv = w[cb][t];
+      if (WOQ_XK(6)) {  // probe: consume the tile, no arithmetic
+        tot[cb] += __uint_as_float((wv.x ^ wv.y) ^ (wv.z ^ wv.w));
+        continue;
+      }
+      const unsigned char* scp = wbase + L::O_SC + cb * L::SCB;
+      const unsigned char* zpp = wbase + L::O_ZP + cb * L::ZPB;
+      const i32x4 b0 = {(int)((wv.x << 4) & 0xf0f0f0f0u), (int)(wv.x & 0xf0f0f0f0u), (int)((wv.y << 4) & 0xf0f0f0f0u),
+                        (int)(wv.y & 0xf0f0f0f0u)};
+      const i32x4 b1 = {(int)((wv.z << 4) & 0xf0f0f0f0u), (int)(wv.z & 0xf0f0f0f0u), (int)((wv.w << 4) & 0xf0f0f0f0u),
+                        (int)(wv.w & 0xf0f0f0f0u)};
+      const i32x4 d0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, izero, 0, 0, 0);
+      const i32x4 d1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, izero, 0, 0, 0);
+      float f0 = digit_combine(d0), f1 = digit_combine(d1);
+      if constexpr (SMODE == 0) {
+        if constexpr (ASYM) {  // the weights carry 16 * q: the zero point enters as 16 * zp
+          const float z16 = -16.f * (float)((int)zpp[gi * 16 + i16] - 8);
+          f0 = fmaf(z16, s0, f0);
+          f1 = fmaf(z16, s1, f1);
+        }
+        float sc;
+        if constexpr (S32)
+          sc = *(const float*)(scp + (gi * 16 + i16) * 4);
+        else
+          sc = tscale16(*(const uint16_t*)(scp + (gi * 16 + i16) * 2), bf);
+        tot[cb] = fmaf(sc, fmaf(f0, u0, f1 * u1), tot[cb]);
+      } else {  // this lane quarter's 32-k group of each half: s = 2 h + (kq >> 1)
+        const int o = (t * 16 + i16) * 4 + (kq >> 1);
+        if constexpr (ASYM) {
+          f0 = fmaf(-16.f * (float)((int)zpp[o] - 8), s0, f0);
+          f1 = fmaf(-16.f * (float)((int)zpp[o + 2] - 8), s1, f1);
+        }
+        float sc0, sc1;
+        if constexpr (S32) {
+          sc0 = *(const float*)(scp + o * 4);
+          sc1 = *(const float*)(scp + (o + 2) * 4);
+        } else {
+          sc0 = tscale16(*(const uint16_t*)(scp + o * 2), bf);
+          sc1 = tscale16(*(const uint16_t*)(scp + (o + 2) * 2), bf);
+        }
+        tot[cb] = fmaf(sc0 * u0, f0, fmaf(sc1 * u1, f1, tot[cb]));
+      }
+    }
+    if (t == 0) WOQ_XQS_STAMP(3);
+    // memory requests stay in their iteration (that IS the window); ALU, MFMA and LDS work may move across
+    __builtin_amdgcn_sched_barrier(0x38f);
+  }
+  WOQ_XQS_STAMP(4);
+  if (WOQ_XK(7)) {  // probe: no cross-wave sum, no epilogue
+    if (lane < 16 && out) out[(int)blockIdx.x * 16 + lane] = tot[0] + tot[CB - 1];
+    return;
+  }
+  // the four lane quarters hold the four blocks' shares of each column
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    float v = tot[cb];
+    v += xqs_swap32(v);  // lanes 0..31: this lane + lane ^ 32
+    v += xqs_swap16(v);  // lanes 0..15: + lane ^ 16
+    if (lane < 16) slab[((size_t)wid * CB + cb) * 16 + lane] = v;
+  }
+  if (wid == 0 && ssq_in != nullptr) {
+    float4_t t4 = (ssq_v[0] + ssq_v[1]) + (ssq_v[2] + ssq_v[3]);
+    const float s = wave_sum_dpp((t4.x + t4.y) + (t4.z + t4.w));
+    if (lane == 0) red[0] = s;
+  }
+  __syncthreads();
+  WOQ_XQS_STAMP(5);
+
+  // ---- 5. finish (lanes 0..15 of wave 0): sum over waves, RMSNorm factor, bias, SiLU*mul, residual, store, XQ ----
+  if (tid < 16) {
+    float v = 0.f, up = 0.f;
+#pragma unroll 4
+    for (int w2 = 0; w2 < nw; ++w2) {
+      v += slab[((size_t)w2 * CB) * 16 + tid];
+      if constexpr (CB == 2) up += slab[((size_t)w2 * CB + 1) * 16 + tid];
+    }
+    const float inv = ssq_in != nullptr ? 1.0f / sqrtf(red[0] / (float)K + eps) : 1.f;  // HF LlamaRMSNorm
+    v *= inv;
+    const int n = (int)blockIdx.x * 16 + tid;  // CB == 1 or the SiLU pair: one 16-column output tile per workgroup
+    if (silu) {
+      up *= inv;
+      if (bias) {
+        v += bias[min(((int)blockIdx.x * 2) * 16 + tid, N - 1)];
+        up += bias[min(((int)blockIdx.x * 2 + 1) * 16 + tid, N - 1)];
+      }
+      v = v / (1.0f + __expf(-v)) * up;
+    } else if (bias) {
+      v += bias[min(n, N - 1)];
+    }
+    const bool live = n < (silu ? (N >> 1) : N);
+    v = live ? v + e_res : 0.f;
+    if (live && out) out[n] = v;
+    if (xo.limbs != nullptr) {  // this tile IS block blockIdx.x of the next kernel's activation vector
+      if (ssq_out != nullptr) {
+        const float ss = row16_sum(v * v);
+        if (tid == 0) ssq_out[blockIdx.x] = ss;
+      }
+      xq_emit16(v * g_next, xo, (int)blockIdx.x, tid);
+    }
+  }
+  WOQ_XQS_STAMP(6);
+}
+
+}  // namespace woq

@@ -10,14 +10,16 @@
 // Format, for K = 16 * nb values: block b = values [16 b, 16 b + 16) — exactly what one producer workgroup (one
 // 16-column output tile of the previous GEMV, or 16 lanes of the attention / embedding kernels) owns, so no
 // cross-workgroup reduction is needed:
-//   limbs [nb][3][16] int8 : 22-bit + sign offset-binary fixed point of y * 2^(21 - e_b), e_b = exponent of the
-//                            block's max |y|; rows hold b0 - 128, b1 - 128, b2 (same bytes gemv_tile_kernel stages)
+//   limbs [nb][3][16] int8 : BALANCED signed digits of v = round(y * 2^(21 - e_b)) (|v| <= 2^22), e_b = exponent of
+//                            the block's max |y|: v = s0 + 2^8 s1 + 2^16 s2 with s0, s1 in [-128, 127], s2 in
+//                            [-64, 64] (round 3; round 2 stored offset-binary bytes and needed a ones row in the MFMA
+//                            to take the offsets out again — 9 VALU per MFMA result instead of 4)
 //   u     [nb] fp32        : 2^(e_b - 25), undoes the block's fixed-point scale and the 16 * q weight bytes
-//   sx    [nb] fp32        : sum over the block of (Q - 2^22), the fixed-point activations' sum (zero-point term)
-// A block is one (64-k half, lane quarter) of the consumer's v_mfma_i32_16x16x64_i8: MFMA rows 4 e .. 4 e + 3 carry
-// quarter e's three limbs and its ones row and zeros elsewhere, so ONE MFMA per half returns the four blocks' sums
-// separately, one per lane quarter, each scaled by its own u (and, for group 32, its own weight scale). The error
-// bound tightens from max|x_slice| * 2^-22 to max|x_block| * 2^-22 per element.
+//   sx    [nb] fp32        : sum over the block of v, the fixed-point activations' sum (zero-point term)
+// A block is one (64-k half, lane quarter) of the consumer's v_mfma_i32_16x16x64_i8: MFMA rows 4 e .. 4 e + 2 carry
+// quarter e's three digits (row 4 e + 3 and the other quarters' k are zero), so ONE MFMA per half returns the four
+// blocks' digit sums separately, one per lane quarter, each scaled by its own u (and, for group 32, its own weight
+// scale). Element error <= max|x_block| * 2^-22. An all-zero buffer is a valid vector of zeros.
 // RMSNorm stays separable: the producer multiplies by the NEXT norm's weight before converting and leaves one partial
 // sum of squares of the raw values per block; the consumer adds them up in a fixed order.
 #pragma once
@@ -64,18 +66,23 @@ __device__ __forceinline__ int row16_sum_i32(int v) {
 }
 
 // Called by the 16 lanes of ONE DPP row (lanes 16 r .. 16 r + 15, all active), lane j = lane & 15 holding value
-// 16 * blk + j of the vector: writes block `blk`. Same conversion as gemv_tile_kernel's stage_row (fp32 sum with
-// 1.5 * 2^23: the mantissa IS round(y * 2^(21 - e)) + 2^22).
+// 16 * blk + j of the vector: writes block `blk`. Conversion as gemv_tile_kernel's stage_row (fp32 sum with
+// 1.5 * 2^23: the mantissa IS round(y * 2^(21 - e)) + 2^22), then three balanced digits.
 __device__ __forceinline__ void xq_emit16(float y, const XqPtrs& o, int blk, int j) {
   const float amax = row16_max(fabsf(y));
   int e = 0;
   if (amax > 0.f && amax < INFINITY) e = max(-100, min(100, __builtin_amdgcn_frexp_expf(amax)));
   const uint32_t Q = __float_as_uint(fmaf(y, ldexpf(1.f, 21 - e), 12582912.f));
+  const int v = (int)(Q & 0x7fffffu) - (1 << 22);
+  const int s0 = (int)((uint32_t)v << 24) >> 24;  // low byte, sign-extended
+  const int v1 = (v - s0) >> 8;
+  const int s1 = (int)((uint32_t)v1 << 24) >> 24;
+  const int s2 = (v1 - s1) >> 8;
   uint8_t* d = o.limbs + (size_t)blk * 48 + j;
-  d[0] = (uint8_t)((Q & 0xffu) ^ 0x80u);          // limb 0: b0 - 128
-  d[16] = (uint8_t)(((Q >> 8) & 0xffu) ^ 0x80u);  // limb 1: b1 - 128
-  d[32] = (uint8_t)((Q >> 16) & 0xffu);           // limb 2: b2 in [0, 127]
-  const int qs = row16_sum_i32((int)(Q & 0x7fffffu) - (1 << 22));
+  d[0] = (uint8_t)s0;
+  d[16] = (uint8_t)s1;
+  d[32] = (uint8_t)s2;
+  const int qs = row16_sum_i32(v);
   if (j == 0) {
     o.u[blk] = ldexpf(1.f, e - 25);
     o.sx[blk] = (float)qs;
