@@ -199,6 +199,17 @@ WOQ_API int woq_engine_attn_splits(woq_engine* e);
  * fp8 cache — silently the per-query-head slices otherwise). Default off. Same capture rule as attn_splits. */
 WOQ_API int woq_engine_set_attn_grouped(woq_engine* e, int on);
 WOQ_API int woq_engine_attn_grouped(woq_engine* e);
+/* decode step, XQ path: [RMSNorm + qkv GEMV] and [RoPE + KV append + attention] as ONE launch — the workgroup whose
+ * column strip completes a head's q / k / v runs that head's attention (csrc/woq_gemv_attn.hip). Applies to multi-head
+ * shapes (heads == kv_heads), head_dim 128, hidden 4096, one context slice, no sliding window; the two launches
+ * otherwise. Default on (WOQ_ENGINE_FUSE_ATTN=0 turns it off). Same capture rule as attn_splits.
+ * woq_engine_fuse_attn: 1 when the next step / capture will use it. */
+WOQ_API int woq_engine_set_fuse_attn(woq_engine* e, int on);
+WOQ_API int woq_engine_fuse_attn(woq_engine* e);
+/* sticky status of the fused launch's in-launch hand-off: 0 = every attention workgroup saw its head's q / k / v in
+ * time, 1 = one gave up after its bound (its outputs are then wrong); -1 = the read itself failed. Synchronises
+ * `stream`. */
+WOQ_API int woq_engine_fuse_status(woq_engine* e, void* stream);
 /* KV cache base pointers (which: 0 = K, 1 = V), layout [sequence][layer][position][kv_head][head_dim] in kv_dtype:
  * inspection / tests, and the seam for an external cache manager. */
 WOQ_API void* woq_engine_kv_cache_ptr(woq_engine* e, int which);

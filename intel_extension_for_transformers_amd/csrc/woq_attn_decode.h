@@ -1,0 +1,299 @@
+// woq_attn_decode.h — single-query (decode) attention of one head as a device function, shared by the standalone
+// launch (woq_ops.hip: attn_decode_kernel) and the fused qkv-GEMV + attention launch (woq_gemv_attn.hip).
+// Reference: stock HF eager attention over the KV cache run by PyTorch CPU ops.
+#pragma once
+#include "woq_device.h"
+#include "woq_xq.h"
+
+namespace woq {
+
+// Single-query attention for one new token: one workgroup (4 waves) per query head.
+//   qkv: fp32 [(heads + 2*kv_heads) * HD] un-rotated projections of the new token.
+//   RoPE is applied here to q and to the new k; rotated k and v are appended to the cache (by the first query
+//   head of each kv group) at position pos. kv caches: [max_ctx, kv_heads, HD] (fp16 | bf16 | e4m3). out fp32 [heads*HD].
+// Round 3 form — the launch is a latency chain (32 workgroups, a few dozen cached positions in the benchmark: 5.2 us
+// per layer, of which a lone thread's 128-step dot product for the new position and twelve LDS-crossbar shuffles were
+// more than a third), so the chain is what is cut:
+//   * every wave is its own flash-decoding slice: it rotates q itself (wave-private LDS copy, no workgroup barrier),
+//     owns the cached positions 64 i + 16 w + r (r < 16), and runs scores -> wave max -> exp / wave sum -> P.V over
+//     them with DPP reductions only; the 4 (max, sum, o[HD]) partials meet behind the launch's ONE barrier;
+//   * the new position's score is a wave-0 register dot product (the rotated q and k are already there), its
+//     probability rides in wave 0's list;
+//   * the first K rows and V rows of every wave depend only on `pos`: they are requested before anything else.
+// SPLIT (long contexts, flash-decoding across workgroups): gridDim.y workgroups per head, each over its own slice of
+// the cached positions (the last slice also takes the new position) -> un-normalised partial (o[HD], max, sum) per
+// (head, slice) in `out`; attn_combine_kernel merges them. A lone workgroup per head streams the cache at one CU's
+// ~10 B/clk, which is why contexts beyond a few thousand positions need the slices.
+// LDS (floats): [4][HD] q copies | [HD] new v | [4][HD] partial outputs | [8] (max, sum) | [4][spw] scores
+__host__ __device__ inline int attn_dec_spw(int span) { return ((span + 63) / 64) * 16 + 16; }
+__host__ __device__ inline size_t attn_dec_lds_floats(int HD, int span) {
+  return (size_t)9 * HD + 8 + 4 * (size_t)attn_dec_spw(span);
+}
+
+// Where q / k / v of the new token come from.
+//   AttnPlain  : fp32 array written by an earlier launch; every wave reads and rotates q itself (no barrier).
+//   AttnGranule: 8-byte {tag, fp32} granules that OTHER workgroups of the SAME launch are still writing with
+//                write-through agent-scope stores (woq_gemv_attn.hip). Wave 0 re-reads its six granules per lane until
+//                every tag is the expected one (cdna_hip_programming.md Guideline 16, form R2: the data is the flag —
+//                no fence, no separate flag that could overtake its payload), rotates, and shares q through LDS behind
+//                one workgroup barrier. The wait is bounded: after ~20 ms it raises *status and goes on.
+struct AttnPlain {
+  static constexpr bool granules = false;
+  const float* qkv;
+};
+struct AttnGranule {
+  static constexpr bool granules = true;
+  const unsigned long long* g;
+  unsigned int tag;
+  int* status;
+};
+
+// `h`: query head of this workgroup, `slice` / `n_slices`: its part of the cached positions (SPLIT), `sm`: LDS base
+template <typename KV, int HD, bool SPLIT, typename SRC>
+__device__ __forceinline__ void attn_decode_body(float* sm, int h, int slice, int n_slices, const SRC& src,
+                                                 KV* __restrict__ kcache,
+                                                 KV* __restrict__ vcache, const int32_t* __restrict__ pos_p,
+                                                 const float* __restrict__ cs, const float* __restrict__ sn,
+                                                 int heads, int kv_heads, int window, int spw,
+                                                 float* __restrict__ out, const XqPtrs& xo) {
+  typedef typename KvVec8<KV>::type kv8;
+  constexpr int half = HD / 2;
+  constexpr int DPL = HD / 4;   // dims per lane in the score phase (4 lanes per position)
+  constexpr int LPR = HD / 8;   // lanes per row in the P.V phase
+  constexpr int GP = 64 / LPR;  // positions per wave per P.V pass
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rep = heads / kv_heads, kh = h / rep;
+  const int apos = pos_p[0];  // absolute position of the new token = number of cached positions
+  // sliding window (HF Mistral `sliding_window`, 0 = none): the query sees positions [apos + 1 - window, apos]
+  const int w_lo = window > 0 ? max(0, apos + 1 - window) : 0;
+  int t_lo = w_lo, pos = apos - w_lo;  // this workgroup's cached slice is [t_lo, t_lo + pos)
+  bool incl_new = true;
+  if constexpr (SPLIT) {
+    const int ns = n_slices, sp = slice;
+    const int span = apos - w_lo;
+    const int chunk = (((span + ns - 1) / ns) + 63) & ~63;
+    t_lo = w_lo + min(sp * chunk, span);
+    pos = min(apos - t_lo, chunk);
+    incl_new = sp == ns - 1;
+  }
+  kcache += (size_t)t_lo * kv_heads * HD;
+  vcache += (size_t)t_lo * kv_heads * HD;
+  const int npos_abs = apos - t_lo;  // row of the new position relative to the re-based cache pointers
+  float* qw = sm + (SRC::granules ? 0 : wid * HD);  // rotated q (pre-scaled by 1/sqrt(HD)): wave-private | shared
+  float* vn = sm + 4 * HD;                 // new v, rounded to the cache dtype (wave 0 writes and reads it)
+  float* slab = sm + 5 * HD;               // [4][HD] partial outputs
+  float* ml = sm + 9 * HD;                 // [4] maxima, [4] sums
+  float* scw = sm + 9 * HD + 8 + wid * spw;  // this wave's scores / probabilities, list order
+  // this wave's cached positions: list index j <-> relative position 64 (j / 16) + 16 wid + (j % 16)
+  const int n_w = 16 * (pos >> 6) + max(0, min((pos & 63) - 16 * wid, 16));
+  const bool has_new = incl_new && wid == 0;
+  // ---- requests that depend on `pos` only: K rows of the first score pass, V rows of the first P.V pass ----
+  const int sub = lane & 3, r16 = lane >> 2;
+  const int g = lane / LPR, l8 = lane % LPR;
+  const int plast = max(pos - 1, 0);
+  kv8 kpre[DPL / 8];
+  {
+    const int tc = min(16 * wid + r16, plast);
+    const kv8* kp = (const kv8*)(kcache + ((size_t)tc * kv_heads + kh) * HD + sub * DPL);
+#pragma unroll
+    for (int j = 0; j < DPL / 8; ++j) kpre[j] = kp[j];
+  }
+  constexpr int VU = 16 / GP;  // P.V passes that cover one 16-position run
+  kv8 vpre[VU];
+#pragma unroll
+  for (int u = 0; u < VU; ++u) {
+    const int tc = min(16 * wid + g + u * GP, plast);
+    vpre[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
+  }
+  // ---- RoPE of q (every wave for itself | wave 0 for all); wave 0 also rotates k, rounds k / v and appends them ----
+  const float scale = 1.0f / sqrtf((float)HD);
+  float s_new = 0.f;
+  if (lane < half && (!SRC::granules || wid == 0)) {
+    const float c = cs[(size_t)apos * half + lane], s = sn[(size_t)apos * half + lane];
+    const size_t oq = (size_t)h * HD + lane, ok = (size_t)(heads + kh) * HD + lane,
+                 ov = (size_t)(heads + kv_heads + kh) * HD + lane;
+    float qa, qb, ka = 0.f, kb = 0.f, va = 0.f, vb = 0.f;
+    if constexpr (SRC::granules) {
+      const unsigned long long t0 = wall_clock64();
+      for (;;) {
+        const unsigned long long g0 = __hip_atomic_load(src.g + oq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long g1 = __hip_atomic_load(src.g + oq + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long g2 = __hip_atomic_load(src.g + ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long g3 = __hip_atomic_load(src.g + ok + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long g4 = __hip_atomic_load(src.g + ov, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long g5 = __hip_atomic_load(src.g + ov + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool good = (unsigned int)(g0 >> 32) == src.tag && (unsigned int)(g1 >> 32) == src.tag &&
+                          (unsigned int)(g2 >> 32) == src.tag && (unsigned int)(g3 >> 32) == src.tag &&
+                          (unsigned int)(g4 >> 32) == src.tag && (unsigned int)(g5 >> 32) == src.tag;
+        qa = __uint_as_float((unsigned int)g0), qb = __uint_as_float((unsigned int)g1);
+        ka = __uint_as_float((unsigned int)g2), kb = __uint_as_float((unsigned int)g3);
+        va = __uint_as_float((unsigned int)g4), vb = __uint_as_float((unsigned int)g5);
+        if (__all(good)) break;  // every participating lane of the wave saw its six tags
+        if (wall_clock64() - t0 > 2000000ull) {  // 20 ms at 100 MHz: a producer is missing — say so, do not hang
+          if (lane == 0) atomicExch(src.status, 1);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    } else {
+      qa = src.qkv[oq], qb = src.qkv[oq + half];
+      if (has_new) {
+        ka = src.qkv[ok], kb = src.qkv[ok + half];
+        va = src.qkv[ov], vb = src.qkv[ov + half];
+      }
+    }
+    const float ra = (qa * c - qb * s) * scale, rb = (qb * c + qa * s) * scale;
+    qw[lane] = ra;
+    qw[lane + half] = rb;
+    if (has_new) {
+      const KV ka_r = (KV)(ka * c - kb * s), kb_r = (KV)(kb * c + ka * s);
+      const KV va_r = (KV)va, vb_r = (KV)vb;
+      s_new = ra * (float)ka_r + rb * (float)kb_r;
+      vn[lane] = (float)va_r;
+      vn[lane + half] = (float)vb_r;
+      if (h % rep == 0) {
+        KV* kd = kcache + ((size_t)npos_abs * kv_heads + kh) * HD;
+        KV* vd = vcache + ((size_t)npos_abs * kv_heads + kh) * HD;
+        kd[lane] = ka_r;
+        kd[lane + half] = kb_r;
+        vd[lane] = va_r;
+        vd[lane + half] = vb_r;
+      }
+    }
+  }
+  if (has_new) s_new = wave_sum_dpp(s_new);
+  if constexpr (SRC::granules)
+    __syncthreads();  // q is wave 0's to give
+  else
+    __builtin_amdgcn_wave_barrier();
+  // ---- scores of this wave's cached positions ----
+  float qreg[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) qreg[i] = qw[sub * DPL + i];
+  float lmax = -INFINITY;
+  auto score = [&](int i, const kv8 (&kv)[DPL / 8]) {
+    const int t = 64 * i + 16 * wid + r16;
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < DPL / 8; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d = fmaf(qreg[j * 8 + e], (float)kv[j][e], d);
+    d += WOQ_DPP_F32(d, 0xB1);  // quad_perm xor 1
+    d += WOQ_DPP_F32(d, 0x4E);  // quad_perm xor 2: all four lanes of the position hold its score
+    if (t < pos) {
+      if (sub == 0) scw[16 * i + r16] = d;
+      lmax = fmaxf(lmax, d);
+    }
+  };
+  auto kload = [&](int i, kv8 (&kv)[DPL / 8]) {
+    const int tc = min(64 * i + 16 * wid + r16, plast);
+    const kv8* kp = (const kv8*)(kcache + ((size_t)tc * kv_heads + kh) * HD + sub * DPL);
+#pragma unroll
+    for (int j = 0; j < DPL / 8; ++j) kv[j] = kp[j];
+  };
+  const int n_it = (n_w + 15) >> 4;  // 16-position passes of this wave
+  if (n_it > 0) {
+    kv8 kb[DPL / 8];
+    if (n_it > 1) kload(1, kb);
+    score(0, kpre);
+    // rows of pass i + 1 are in flight while pass i is scored
+    for (int i = 1; i < n_it; i += 2) {
+      if (i + 1 < n_it) kload(i + 1, kpre);
+      score(i, kb);
+      if (i + 1 < n_it) {
+        if (i + 2 < n_it) kload(i + 2, kb);
+        score(i + 1, kpre);
+      }
+    }
+  }
+  if (has_new) {
+    if (lane == 0) scw[n_w] = s_new;
+    lmax = fmaxf(lmax, s_new);
+  }
+  const float m_w = wave_max_dpp(lmax);
+  const int n_l = n_w + (has_new ? 1 : 0);  // entries of this wave's list
+  __builtin_amdgcn_wave_barrier();
+  // ---- probabilities and their sum ----
+  float lsum = 0.f;
+  for (int j = lane; j < n_l; j += 64) {
+    const float p = __expf(scw[j] - m_w);
+    scw[j] = p;
+    lsum += p;
+  }
+  const float l_w = wave_sum_dpp(lsum);
+  __builtin_amdgcn_wave_barrier();
+  // ---- P.V over the wave's list: LPR lanes per row, GP rows per pass ----
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  auto vload = [&](int j, kv8& vv) {
+    const int tc = min(64 * (j >> 4) + 16 * wid + (j & 15), plast);
+    vv = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
+  };
+  auto pv = [&](int j, const kv8& vv) {
+    const float p = j < n_w ? scw[j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, (float)vv[i], acc[i]);
+  };
+  if (n_w > 0) {
+#pragma unroll
+    for (int u = 0; u < VU; ++u) pv(g + u * GP, vpre[u]);
+    for (int j0 = 16; j0 < n_w; j0 += 16) {  // later 16-position runs: all their rows requested, then consumed
+      kv8 vv[VU];
+#pragma unroll
+      for (int u = 0; u < VU; ++u) vload(j0 + g + u * GP, vv[u]);
+#pragma unroll
+      for (int u = 0; u < VU; ++u) pv(j0 + g + u * GP, vv[u]);
+    }
+  }
+  if (has_new && g == 0) {  // the new position
+    const float p = scw[n_w];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, vn[l8 * 8 + i], acc[i]);
+  }
+  // sum over the GP row groups: lane groups of LPR lanes -> lanes 0 .. LPR - 1
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float v = acc[i];
+    const uint32_t b32 = __float_as_uint(v);
+    v += __uint_as_float(__builtin_amdgcn_permlane32_swap(b32, b32, false, false)[1]);
+    const uint32_t b16 = __float_as_uint(v);
+    v += __uint_as_float(__builtin_amdgcn_permlane16_swap(b16, b16, false, false)[1]);
+    if constexpr (LPR == 8) v += WOQ_DPP_F32(v, 0x108);  // row_shl:8 — lane l += lane l + 8
+    acc[i] = v;
+  }
+  if (lane < LPR) {
+    float* dst = slab + wid * HD + l8 * 8;
+    *(float4_t*)dst = float4_t{acc[0], acc[1], acc[2], acc[3]};
+    *(float4_t*)(dst + 4) = float4_t{acc[4], acc[5], acc[6], acc[7]};
+  }
+  if (lane == 0) {
+    ml[wid] = m_w;
+    ml[4 + wid] = l_w;
+  }
+  __syncthreads();
+  // ---- merge the four waves' partials ----
+  if (tid < HD) {
+    const float m0 = ml[0], m1 = ml[1], m2 = ml[2], m3 = ml[3];
+    const float mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    const float e0 = m0 == -INFINITY ? 0.f : __expf(m0 - mx), e1 = m1 == -INFINITY ? 0.f : __expf(m1 - mx);
+    const float e2 = m2 == -INFINITY ? 0.f : __expf(m2 - mx), e3 = m3 == -INFINITY ? 0.f : __expf(m3 - mx);
+    const float o = (slab[tid] * e0 + slab[HD + tid] * e1) + (slab[2 * HD + tid] * e2 + slab[3 * HD + tid] * e3);
+    const float den = (ml[4] * e0 + ml[5] * e1) + (ml[6] * e2 + ml[7] * e3);
+    if constexpr (SPLIT) {
+      float* part = out + ((size_t)h * n_slices + slice) * (HD + 2);
+      part[tid] = o;
+      if (tid == 0) {
+        part[HD] = mx;
+        part[HD + 1] = den;
+      }
+    } else {
+      out[(size_t)h * HD + tid] = o / den;
+      // the o_proj GEMV's XQ input: tid < HD is a whole number of 16-lane rows, one block each
+      if (xo.limbs != nullptr) xq_emit16(o / den, xo, (h * HD + tid) >> 4, tid & 15);
+    }
+  }
+}
+
+}  // namespace woq

@@ -24,7 +24,7 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
                             const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w,
                             float eps, const float* residual, int ld_res, int epi, int nt, hipStream_t st);
 void launch_embed(const void* embed, int dtype, const int32_t* token, int hidden, float* out, const float* norm_w,
-                  const XqPtrs& xo, float* ssq_out, hipStream_t st);
+                  const XqPtrs& xo, float* ssq_out, unsigned int* step_seq, hipStream_t st);
 int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
                        const float* cs, const float* sn, int heads, int kv_heads, int D, int max_ctx, int window,
                        float* out, int splits, int grouped, float* part, const XqPtrs& xo, hipStream_t st);
@@ -33,6 +33,13 @@ bool gemv_xq_supported(const woq_blob_header& h, int epi);
 int launch_gemv_xq(const XqPtrs& xin, const void* blob, const woq_blob_header& h, const float* bias, float* out,
                    const float* ssq_in, float eps, const float* residual, int epi, const XqPtrs& xo,
                    const float* next_norm_w, float* ssq_out, hipStream_t st);
+// [RMSNorm + qkv GEMV] + [RoPE + KV append + attention] in one launch (woq_gemv_attn.hip)
+bool gemv_xq_attn_supported(const woq_blob_header& h, int heads, int kv_heads, int head_dim, int kv_dtype, int max_ctx,
+                            int window, int splits);
+int launch_gemv_xq_attn(const XqPtrs& xin, const void* blob, const woq_blob_header& h, unsigned long long* qkv_g,
+                        const float* ssq_in, float eps, const unsigned int* seq, int layer, int* status, void* kcache,
+                        void* vcache, int kv_dtype, const int32_t* pos, const float* cs, const float* sn, int heads,
+                        int kv_heads, int max_ctx, int window, float* attn_out, const XqPtrs& xq_attn, hipStream_t st);
 void launch_lm_head(const float* hidden_in, const float* norm_w, float eps, const void* W, int w_dtype, int hidden,
                     int vocab, float* logits, float* pmax, int32_t* pidx, hipStream_t st);
 void launch_argmax(const float* logits, int vocab, int32_t* token, int32_t* pos, hipStream_t st);
@@ -90,6 +97,12 @@ struct woq_engine {
   XqPtrs xq_hidden = {nullptr, nullptr, nullptr}, xq_attn = {nullptr, nullptr, nullptr},
          xq_act = {nullptr, nullptr, nullptr};
   float* ssq_part = nullptr;  // [hidden / 16] partial sums of squares of the residual stream
+  // fused qkv + attention launch (woq_gemv_attn.hip): {tag, fp32} granules of q | k | v, the step counter the tags are
+  // made of (advanced by the embedding kernel, the first of every step) and the sticky give-up flag
+  unsigned long long* qkv_g = nullptr;
+  unsigned int* step_seq = nullptr;
+  int* fuse_status = nullptr;
+  bool fuse_attn = true;             // qkv GEMV + attention in one launch where the shape allows (woq_gemv_attn.hip)
   bool use_xq() const { return xq_enabled && xq_shapes_ok && xq_hidden.limbs != nullptr && cfg.tp_size <= 1; }
   woq_comm* comm = nullptr;  // device-side exchange: all-reduce kernels inside the (capturable) decode step
   int vocab_offset = 0;      // first vocabulary row of this rank's lm_head shard
@@ -141,6 +154,19 @@ static int engine_attn_block_xq(woq_engine* e, int l, hipStream_t st) {
   const woq_layer_weights& w = e->layers[l];
   const int skip = engine_skip_mask();
   int rc = 0;
+  if (!(skip & 3) && e->fuse_attn && e->qkv_g != nullptr && !e->attn_grouped &&
+      gemv_xq_attn_supported(w.qkv_hdr, c.heads, c.kv_heads, c.head_dim, c.kv_dtype, c.max_ctx, e->window,
+                             e->attn_splits)) {
+    rc = launch_gemv_xq_attn(e->xq_hidden, w.qkv_blob, w.qkv_hdr, e->qkv_g, e->ssq_part, c.rms_eps, e->step_seq, l,
+                             e->fuse_status, e->kcache + (size_t)l * e->kv_layer_bytes,
+                             e->vcache + (size_t)l * e->kv_layer_bytes,
+                             c.kv_dtype, e->pos, e->cs, e->sn, c.heads, c.kv_heads, c.max_ctx, e->window, e->attn,
+                             e->xq_attn, st);
+    if (rc) return rc;
+    if (skip & 4) return 0;
+    return engine_gemv_xq(e, e->xq_attn, w.o_blob, w.o_hdr, e->hidden, nullptr, e->hidden, 0, e->xq_hidden, w.ln2,
+                          e->ssq_part, st);
+  }
   if (!(skip & 1))
     rc = engine_gemv_xq(e, e->xq_hidden, w.qkv_blob, w.qkv_hdr, e->qkv, e->ssq_part, nullptr, 0, kNoXq, nullptr, nullptr,
                         st);
@@ -244,7 +270,7 @@ static int engine_allreduce_rows(woq_engine* e, float* buf, size_t count, hipStr
 static void engine_embed(woq_engine* e, hipStream_t st) {
   const bool xq = e->use_xq();
   launch_embed(e->embed, e->embed_dtype, e->token, e->cfg.hidden, e->hidden, xq ? e->layers[0].ln1 : nullptr,
-               xq ? e->xq_hidden : kNoXq, xq ? e->ssq_part : nullptr, st);
+               xq ? e->xq_hidden : kNoXq, xq ? e->ssq_part : nullptr, e->step_seq, st);
 }
 
 static int engine_step_impl(woq_engine* e, int greedy, hipStream_t st) {
@@ -370,6 +396,27 @@ int woq_engine_set_attn_grouped(woq_engine* e, int on) {
   WOQ_END
 }
 int woq_engine_attn_grouped(woq_engine* e) { return e ? e->attn_grouped : 0; }
+int woq_engine_set_fuse_attn(woq_engine* e, int on) {
+  WOQ_TRY
+  WOQ_CHECK(e != nullptr, "QBits: null engine");
+  e->fuse_attn = on != 0;
+  WOQ_END
+}
+int woq_engine_fuse_status(woq_engine* e, void* stream) {
+  if (!e || !e->fuse_status) return 0;
+  int v = 0;
+  if (hipMemcpyAsync(&v, e->fuse_status, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -1;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+  return v;
+}
+int woq_engine_fuse_attn(woq_engine* e) {
+  if (!e || !e->fuse_attn || !e->use_xq() || e->qkv_g == nullptr || e->attn_grouped || e->layers.empty()) return 0;
+  const woq_engine_config& c = e->cfg;
+  return woq::gemv_xq_attn_supported(e->layers[0].qkv_hdr, c.heads, c.kv_heads, c.head_dim, c.kv_dtype, c.max_ctx,
+                                     e->window, e->attn_splits)
+             ? 1
+             : 0;
+}
 void* woq_engine_kv_cache_ptr(woq_engine* e, int which) { return e ? (which ? e->vcache : e->kcache) : nullptr; }
 
 int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
@@ -419,6 +466,8 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
     // second recombination per tile costs more than the staging it removes (Llama-2-70B 119-120 vs 125-127 tokens/s)
     const char* sw = getenv("WOQ_ENGINE_XQ");
     e->xq_enabled = sw ? sw[0] != '0' : cfg->hidden <= 4096;
+    const char* fa = getenv("WOQ_ENGINE_FUSE_ATTN");
+    e->fuse_attn = fa ? fa[0] != '0' : true;
     const int attn_k = cfg->heads * cfg->head_dim;
     if ((cfg->hidden % 16) == 0 && (attn_k % 16) == 0 && (cfg->inter % 16) == 0) {
       void *bh = nullptr, *ba = nullptr, *bc = nullptr;
@@ -426,6 +475,11 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
       WOQ_HIP(hipMalloc(&ba, xq_bytes(attn_k)));
       WOQ_HIP(hipMalloc(&bc, xq_bytes(cfg->inter)));
       WOQ_HIP(hipMalloc((void**)&e->ssq_part, (size_t)(cfg->hidden / 16) * 4));
+      WOQ_HIP(hipMalloc((void**)&e->qkv_g, (size_t)qkv_n * 8));
+      WOQ_HIP(hipMemset(e->qkv_g, 0, (size_t)qkv_n * 8));  // tag 0 is never a live tag
+      WOQ_HIP(hipMalloc((void**)&e->step_seq, 8));
+      WOQ_HIP(hipMemset(e->step_seq, 0, 8));
+      e->fuse_status = (int*)(e->step_seq + 1);
       WOQ_HIP(hipMemset(bh, 0, xq_bytes(cfg->hidden)));
       WOQ_HIP(hipMemset(ba, 0, xq_bytes(attn_k)));
       WOQ_HIP(hipMemset(bc, 0, xq_bytes(cfg->inter)));
@@ -433,7 +487,7 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
       e->xq_hidden = xq_carve(bh, cfg->hidden);
       e->xq_attn = xq_carve(ba, attn_k);
       e->xq_act = xq_carve(bc, cfg->inter);
-      for (void* p : {bh, ba, bc, (void*)e->ssq_part}) e->owned.push_back(p);
+      for (void* p : {bh, ba, bc, (void*)e->ssq_part, (void*)e->qkv_g, (void*)e->step_seq}) e->owned.push_back(p);
     }
   }
   *out = e;

@@ -1,0 +1,177 @@
+// woq_gemv_attn.hip — [RMSNorm + qkv GEMV] and [RoPE + KV append + single-query attention] of a decode step in ONE
+// launch (round 3). Reference path replaced: qbits.cpp:113-140 at M = 1 followed by stock HF eager attention on the CPU.
+//
+// Why. Inside the captured decode step every launch costs ~2 us before it does anything (tools/xq_probe.hip: an empty
+// kernel on the same grid, hipGraph replay: 1.7-2.4 us), and the batch-1 attention launch is a latency chain of 32
+// workgroups that costs 5.0 us per layer in place (profiles/r03g_skip_masks.txt) — most of it waiting for its own
+// first requests (position, cos / sin row, K / V rows) after the boundary. The qkv -> attention edge is the one edge of
+// the layer that is NOT all-to-all: head h needs only the 24 column strips that hold its q, k and v rows.
+// How. The grid is the GEMV's strips plus one attention workgroup per head at its END. An attention workgroup issues
+// everything that does not depend on this token's q / k / v at once (position, K / V rows of its first passes, cos /
+// sin), then its wave 0 re-reads the head's 384 {tag, value} granules until every tag is this (step, layer)'s; a strip
+// workgroup's epilogue writes its 16 outputs as such granules — one 8-byte write-through agent-scope store each, the
+// data is its own flag (cdna_hip_programming.md Guideline 16, form R2: no fence, no flag that can overtake its data).
+// Tags come from a device-side step counter (the step's first kernel advances it), so a replayed graph sees fresh
+// tags; the wait is bounded (~20 ms, then a sticky status word) and needs no dispatch order: strips never wait, and
+// 32 waiting workgroups cannot keep 768 strips off a chip that holds all of them at once.
+// A first form without resident attention workgroups — the strip that completes a head runs its attention — was
+// correct but slower than two launches (profiles/r03j_fused_attn_last_arriver_negative.txt).
+// Scope: multi-head attention shapes (heads == kv_heads), head_dim 128, K = 32 tiles at 8 per wave (4 waves),
+// one context slice, no sliding window; everything else keeps the two launches.
+#include <algorithm>
+#include <cstdlib>
+
+#include "woq_attn_decode.h"
+#include "woq_gemv_common.h"
+#include "woq_gemv_xqs.h"
+#include "woq_launch.h"
+#include "woq_xq.h"
+
+namespace woq {
+
+struct FusedAttnArgs {
+  const unsigned int* seq;  // device-side step counter (advanced by the step's first kernel): tag = seq << 6 | layer
+  int layer;
+  int* status;              // sticky: set when an attention workgroup gave up waiting
+  void* kcache;
+  void* vcache;
+  const int32_t* pos;
+  const float* cs;
+  const float* sn;
+  int heads, kv_heads, window, spw;
+  float* attn_out;
+  XqPtrs xq_attn;
+};
+
+constexpr int FUSED_TPW = 8, FUSED_D = 4;
+
+template <int SMODE, bool ASYM, bool S32, typename KV>
+__global__ __launch_bounds__(256) void gemv_xqs_attn_kernel(
+    const u32x4* __restrict__ q, const void* __restrict__ scales, const uint8_t* __restrict__ xlimbs,
+    const float* __restrict__ xu, int tiles_k, int kt_off, int base_tiles, int rem_tiles, int n_groups, int tpg_shift,
+    const uint8_t* __restrict__ zp, const float* __restrict__ xsx, unsigned long long* __restrict__ qkv_g,
+    const float* __restrict__ bias, float eps, int N, int K, int flags, const float* __restrict__ ssq_in, int n_ssq,
+    FusedAttnArgs fa) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const unsigned int tag = (fa.seq[0] << 6) | (unsigned int)fa.layer;
+  const int n_strips = N >> 4;
+  if ((int)blockIdx.x >= n_strips) {  // the attention workgroup of head blockIdx.x - n_strips
+    attn_decode_body<KV, 128, false>((float*)smem_raw, (int)blockIdx.x - n_strips, 0, 1,
+                                     AttnGranule{qkv_g, tag, fa.status}, (KV*)fa.kcache, (KV*)fa.vcache, fa.pos, fa.cs,
+                                     fa.sn, fa.heads, fa.kv_heads, fa.window, fa.spw, fa.attn_out, fa.xq_attn);
+    return;
+  }
+  const XqPtrs no_xq = {nullptr, nullptr, nullptr};
+  gemv_xqs_body<FUSED_TPW, 1, FUSED_D, SMODE, ASYM, S32, true>(
+      smem_raw, q, scales, xlimbs, xu, tiles_k, kt_off, base_tiles, rem_tiles, n_groups, tpg_shift, zp, xsx,
+      (float*)qkv_g, bias, nullptr, eps, N, K, flags, ssq_in, n_ssq, no_xq, nullptr, nullptr, tag);
+}
+
+// does the fused launch take this (blob, attention) combination?
+bool gemv_xq_attn_supported(const woq_blob_header& h, int heads, int kv_heads, int head_dim, int kv_dtype, int max_ctx,
+                            int window, int splits) {
+  if (h.weight_type != WOQ_W_INT4_CLIP || h.off_shuffle != 0 || h.K != h.Kpad || h.N != h.Npad) return false;
+  if (h.Kpad / WOQ_TILE_K != 4 * FUSED_TPW) return false;  // four waves of eight tiles
+  if (h.scale_mode == 0 && h.n_groups > 1) {
+    const int tpg = h.group / WOQ_TILE_K;
+    if (tpg < 1 || (tpg & (tpg - 1)) != 0) return false;
+  }
+  if (heads != kv_heads || head_dim != 128 || splits > 1 || window != 0) return false;
+  if (h.N != 3 * heads * head_dim) return false;
+  if (kv_dtype != WOQ_F16 && kv_dtype != WOQ_BF16 && kv_dtype != WOQ_FP8_E4M3) return false;
+  return attn_dec_lds_floats(128, max_ctx) * 4 <= 150 * 1024;
+}
+
+struct FusedLaunch {
+  const void* q;
+  const void* scales;
+  const void* zp;
+  XqPtrs xin;
+  int tiles_k, K, N, n_groups, tpg_shift, flags, n_ssq;
+  unsigned long long* out;
+  float eps;
+  const float* ssq_in;
+  FusedAttnArgs fa;
+  size_t lds;
+};
+
+template <int SMODE, bool ASYM, bool S32, typename KV>
+static int launch_fused_t(const FusedLaunch& a, hipStream_t st) {
+  auto kern = gemv_xqs_attn_kernel<SMODE, ASYM, S32, KV>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return woq::fail(std::string("QBits: hipFuncSetAttribute: ") + hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.N / 16 + a.fa.heads), dim3(256), a.lds, st, (const u32x4*)a.q, a.scales, a.xin.limbs, a.xin.u,
+                     a.tiles_k, 0, FUSED_TPW, 0, a.n_groups, a.tpg_shift, (const uint8_t*)a.zp, a.xin.sx, a.out,
+                     (const float*)nullptr, a.eps, a.N, a.K, a.flags, a.ssq_in, a.n_ssq, a.fa);
+  return 0;
+}
+
+template <typename KV>
+static int launch_fused_kv(const FusedLaunch& a, int smode, bool asym, bool s32, hipStream_t st) {
+#define WOQ_FA_CASE(SM, AS, S3) \
+  if (smode == SM && asym == AS && s32 == S3) return launch_fused_t<SM, AS, S3, KV>(a, st);
+  WOQ_FA_CASE(0, false, false)
+  WOQ_FA_CASE(0, false, true)
+  WOQ_FA_CASE(0, true, false)
+  WOQ_FA_CASE(0, true, true)
+  WOQ_FA_CASE(1, false, false)
+  WOQ_FA_CASE(1, false, true)
+  WOQ_FA_CASE(1, true, false)
+  WOQ_FA_CASE(1, true, true)
+#undef WOQ_FA_CASE
+  return woq::fail("QBits: bad fused qkv + attention configuration");
+}
+
+// qkv_g ({tag, fp32} granules [3 * heads * 128]) = xin . W_qkv_deq * rsqrt(mean(x^2) + eps); per head, as its granules
+// arrive: RoPE, KV append at *pos, attention over the cache -> attn_out (+ its XQ form).
+int launch_gemv_xq_attn(const XqPtrs& xin, const void* blob, const woq_blob_header& h, unsigned long long* qkv_g,
+                        const float* ssq_in, float eps, const unsigned int* seq, int layer, int* status, void* kcache,
+                        void* vcache, int kv_dtype, const int32_t* pos, const float* cs, const float* sn, int heads,
+                        int kv_heads, int max_ctx, int window, float* attn_out, const XqPtrs& xq_attn, hipStream_t st) {
+  FusedLaunch a;
+  const uint8_t* b = (const uint8_t*)blob;
+  a.q = b + h.off_q;
+  a.scales = b + h.off_scale;
+  a.zp = h.off_zp ? b + h.off_zp : nullptr;
+  a.xin = xin;
+  a.K = h.K;
+  a.N = h.N;
+  a.tiles_k = h.Kpad / WOQ_TILE_K;
+  a.n_groups = h.n_groups;
+  a.tpg_shift = 0;
+  if (h.scale_mode == 0 && h.n_groups > 1) {
+    int tpg = h.group / WOQ_TILE_K;
+    while (tpg > 1) {
+      tpg >>= 1;
+      ++a.tpg_shift;
+    }
+  }
+  a.flags = h.scale_type == WOQ_BF16 ? 1 : 0;
+  a.eps = eps;
+  a.n_ssq = h.K / 16;
+  a.ssq_in = ssq_in;
+  a.out = qkv_g;
+  const int smode = (int)h.scale_mode;
+  const bool asym = a.zp != nullptr, s32 = h.scale_type == WOQ_F32;
+  const int spw = attn_dec_spw(max_ctx);
+  a.fa = FusedAttnArgs{seq, layer, status, kcache, vcache, pos, cs, sn, heads, kv_heads, window, spw, attn_out, xq_attn};
+  const size_t lds_attn = attn_dec_lds_floats(128, max_ctx) * 4;
+  size_t lds_gemv = 0;
+  if (smode == 0)
+    lds_gemv = asym ? (s32 ? XqsLds<FUSED_TPW, 1, 0, true, true>::total(4) : XqsLds<FUSED_TPW, 1, 0, true, false>::total(4))
+                    : (s32 ? XqsLds<FUSED_TPW, 1, 0, false, true>::total(4) : XqsLds<FUSED_TPW, 1, 0, false, false>::total(4));
+  else
+    lds_gemv = asym ? (s32 ? XqsLds<FUSED_TPW, 1, 1, true, true>::total(4) : XqsLds<FUSED_TPW, 1, 1, true, false>::total(4))
+                    : (s32 ? XqsLds<FUSED_TPW, 1, 1, false, true>::total(4) : XqsLds<FUSED_TPW, 1, 1, false, false>::total(4));
+  a.lds = std::max(lds_attn, lds_gemv);
+  if (a.lds > 160 * 1024) return woq::fail("QBits: fused qkv + attention launch does not fit LDS");
+  if (kv_dtype == WOQ_F16) return launch_fused_kv<_Float16>(a, smode, asym, s32, st);
+  if (kv_dtype == WOQ_FP8_E4M3) return launch_fused_kv<Fp8>(a, smode, asym, s32, st);
+  return launch_fused_kv<__bf16>(a, smode, asym, s32, st);
+}
+
+}  // namespace woq

@@ -49,6 +49,12 @@ extern __device__ unsigned long long* g_xqs_probe;
 #define WOQ_XK(bit) false
 #endif
 
+// how many of the first D weight tiles a wave requests BEFORE its small (L2-resident) requests; the rest follow them.
+// Returns are in order, so whatever is in front of the limbs delays the first MFMA (tools/xq_probe.hip: A/B builds).
+#ifndef WOQ_XQS_PRE
+#define WOQ_XQS_PRE 2
+#endif
+
 namespace woq {
 
 // wave-private LDS region: [zero block 256][limb strip TPW x 384][u 256][sx 256][scale slices][zero-point slices]
@@ -86,19 +92,17 @@ __device__ __forceinline__ float digit_combine(const i32x4& d) {
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// flags: bit 0 scales are bf16 (else fp16; ignored for fp32 scales), bit 1 SiLU(gate)*up epilogue (CB == 2)
-// The first 14 argument dwords are preloaded into SGPRs (-amdgpu-kernarg-preload-count=14): everything the weight
-// requests need sits there.
-template <int TPW, int CB, int D, int SMODE, bool ASYM, bool S32>
-__global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_xqs_kernel(
-    const u32x4* __restrict__ q, const void* __restrict__ scales, const uint8_t* __restrict__ xlimbs,
-    const float* __restrict__ xu, int tiles_k, int kt_off, int base_tiles, int rem_tiles, int n_groups, int tpg_shift,
-    const uint8_t* __restrict__ zp, const float* __restrict__ xsx, float* __restrict__ out,
-    const float* __restrict__ bias, const float* residual, float eps, int N, int K, int flags,
-    const float* __restrict__ ssq_in, int n_ssq, XqPtrs xo, const float* __restrict__ next_norm_w,
-    float* __restrict__ ssq_out) {
+// FUSED (woq_gemv_attn.hip): the outputs are consumed by another workgroup of the SAME launch: `out` is then an array
+// of 8-byte {tag, fp32} granules, each written by ONE write-through agent-scope store (the data is its own flag).
+template <int TPW, int CB, int D, int SMODE, bool ASYM, bool S32, bool FUSED>
+__device__ __forceinline__ void gemv_xqs_body(
+    unsigned char* smem_raw, const u32x4* __restrict__ q, const void* __restrict__ scales,
+    const uint8_t* __restrict__ xlimbs, const float* __restrict__ xu, int tiles_k, int kt_off, int base_tiles,
+    int rem_tiles, int n_groups, int tpg_shift, const uint8_t* __restrict__ zp, const float* __restrict__ xsx,
+    float* __restrict__ out, const float* __restrict__ bias, const float* residual, float eps, int N, int K, int flags,
+    const float* __restrict__ ssq_in, int n_ssq, const XqPtrs& xo, const float* __restrict__ next_norm_w,
+    float* __restrict__ ssq_out, unsigned int fused_tag = 0u) {
   typedef XqsLds<TPW, CB, SMODE, ASYM, S32> L;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int ESZ = L::ESZ;
   constexpr int DD = D < TPW ? D : TPW;  // tiles requested before the first one is consumed
   const int tid = threadIdx.x, lane = tid & 63;
@@ -116,11 +120,13 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_xqs_kernel(
   for (int cb = 0; cb < CB; ++cb)
     rq[cb] = make_rsrc(q + (size_t)((int)blockIdx.x * CB + cb) * tiles_k * 64,
                        WOQ_XK(8) ? 0 : uni(min(kt0 + cnt, tiles_k) * 1024));
+  constexpr int PRE = WOQ_XQS_PRE < DD ? WOQ_XQS_PRE : DD;  // weight tiles requested in front of the small requests
 #pragma unroll
-  for (int t = 0; t < DD; ++t)
+  for (int t = 0; t < PRE; ++t)
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
       w[cb][t] = __builtin_amdgcn_raw_buffer_load_b128(rq[cb], v16 + t * 1024, kt0 * 1024, AUX_NT);
+  __builtin_amdgcn_sched_barrier(0);
 
   // ---- 2. the small requests (L2-resident: written by the previous kernel, or shared by every workgroup) ----
   constexpr int XP = (L::STRIP + 1023) / 1024;  // 1-KiB pieces per limb strip
@@ -191,6 +197,12 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_xqs_kernel(
       }
     }
   }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = PRE; t < DD; ++t)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+      w[cb][t] = __builtin_amdgcn_raw_buffer_load_b128(rq[cb], v16 + t * 1024, kt0 * 1024, AUX_NT);
   WOQ_XQS_STAMP(1);
 
   // ---- 3. park the small pieces in the wave's LDS region (wave-private, in-order LDS: no workgroup barrier) ----
@@ -335,7 +347,13 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_xqs_kernel(
     }
     const bool live = n < (silu ? (N >> 1) : N);
     v = live ? v + e_res : 0.f;
-    if (live && out) out[n] = v;
+    if (live && out) {
+      if constexpr (FUSED)
+        __hip_atomic_store((unsigned long long*)out + n, ((unsigned long long)fused_tag << 32) | __float_as_uint(v),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        out[n] = v;
+    }
     if (xo.limbs != nullptr) {  // this tile IS block blockIdx.x of the next kernel's activation vector
       if (ssq_out != nullptr) {
         const float ss = row16_sum(v * v);
@@ -345,6 +363,23 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_xqs_kernel(
     }
   }
   WOQ_XQS_STAMP(6);
+}
+
+// flags: bit 0 scales are bf16 (else fp16; ignored for fp32 scales), bit 1 SiLU(gate)*up epilogue (CB == 2)
+// The first 14 argument dwords are preloaded into SGPRs (-amdgpu-kernarg-preload-count=14): everything the weight
+// requests need sits there.
+template <int TPW, int CB, int D, int SMODE, bool ASYM, bool S32>
+__global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_xqs_kernel(
+    const u32x4* __restrict__ q, const void* __restrict__ scales, const uint8_t* __restrict__ xlimbs,
+    const float* __restrict__ xu, int tiles_k, int kt_off, int base_tiles, int rem_tiles, int n_groups, int tpg_shift,
+    const uint8_t* __restrict__ zp, const float* __restrict__ xsx, float* __restrict__ out,
+    const float* __restrict__ bias, const float* residual, float eps, int N, int K, int flags,
+    const float* __restrict__ ssq_in, int n_ssq, XqPtrs xo, const float* __restrict__ next_norm_w,
+    float* __restrict__ ssq_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  gemv_xqs_body<TPW, CB, D, SMODE, ASYM, S32, false>(smem_raw, q, scales, xlimbs, xu, tiles_k, kt_off, base_tiles,
+                                                      rem_tiles, n_groups, tpg_shift, zp, xsx, out, bias, residual, eps,
+                                                      N, K, flags, ssq_in, n_ssq, xo, next_norm_w, ssq_out);
 }
 
 }  // namespace woq

@@ -4,6 +4,7 @@
 // (LlamaRMSNorm, apply_rotary_pos_emb, SiLU*mul in LlamaMLP, GPT-2 gelu_new,
 // eager attention over the KV cache); ITREX contributes no code there. All are HBM/latency-bound
 // vector kernels: 16-byte loads, fp32 math, wave64 shuffles; no MFMA.
+#include "woq_attn_decode.h"
 #include "woq_device.h"
 #include "woq_launch.h"
 #include "woq_xq.h"
@@ -83,8 +84,9 @@ __global__ void gelu_kernel(const void* __restrict__ x, int dtype, size_t n, int
 // sums of squares — hidden % 16 == 0, so every 16-lane row is one whole block
 __global__ void embed_kernel(const void* __restrict__ embed, int dtype, const int32_t* __restrict__ token, int hidden,
                              float* __restrict__ out, const float* __restrict__ norm_w, XqPtrs xo,
-                             float* __restrict__ ssq_out) {
+                             float* __restrict__ ssq_out, unsigned int* __restrict__ step_seq) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && step_seq != nullptr) step_seq[0] = step_seq[0] + 1u;  // first kernel of a decode step: new tags
   if (i < hidden) {
     const float v = load_f32(embed, (size_t)token[0] * hidden + i, dtype);
     out[i] = v;
@@ -96,217 +98,19 @@ __global__ void embed_kernel(const void* __restrict__ embed, int dtype, const in
   }
 }
 
-// Single-query attention for one new token: one workgroup (4 waves) per query head.
-//   qkv: fp32 [(heads + 2*kv_heads) * HD] un-rotated projections of the new token.
-//   RoPE is applied here to q and to the new k; rotated k and v are appended to the cache (by the first query
-//   head of each kv group) at position pos. kv caches: [max_ctx, kv_heads, HD] (fp16 | bf16 | e4m3). out fp32 [heads*HD].
-// Three vectorised phases over the cached positions t < pos (the new position is taken from LDS, so no
-// workgroup ever reads a cache row another workgroup is writing):
-//   scores : 4 lanes per position (HD/4 dims each, 16-B loads), 16 positions per wave per iteration
-//   softmax: block max / sum over the LDS score row
-//   P.V    : HD/8 lanes per position (one 16-B load each), 4x unrolled, fp32 accumulate
-// SPLIT (long contexts, flash-decoding style): gridDim.y workgroups per head, each over its own slice of the cached
-// positions (the last slice also takes the new position) -> un-normalised partial (o[HD], max, sum) per (head,
-// slice) in `out`; attn_combine_kernel merges them. A lone workgroup per head streams the cache at one CU's
-// ~10 B/clk, which is why contexts beyond a few thousand positions need the slices.
 template <typename KV, int HD, bool SPLIT>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv, KV* __restrict__ kcache,
                                                           KV* __restrict__ vcache, const int32_t* __restrict__ pos_p,
                                                           const float* __restrict__ cs, const float* __restrict__ sn,
-                                                          int heads, int kv_heads, int window,
+                                                          int heads, int kv_heads, int window, int spw,
                                                           float* __restrict__ out, XqPtrs xo) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  typedef typename KvVec8<KV>::type kv8;
-  constexpr int half = HD / 2;
-  constexpr int DPL = HD / 4;   // dims per lane in the score phase
-  constexpr int LPR = HD / 8;   // lanes per row in the P.V phase
-  constexpr int GP = 64 / LPR;  // position groups per wave in the P.V phase
   // workgroup ids go round-robin over the 8 XCDs: give every XCD a run of consecutive heads, so that the query heads
   // sharing a kv head (GQA) share an L2 instead of pulling the same cache rows into several
   const int bx = (int)blockIdx.x;
   const int h = (heads & 7) == 0 ? (bx & 7) * (heads >> 3) + (bx >> 3) : bx;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int rep = heads / kv_heads, kh = h / rep;
-  const int apos = pos_p[0];  // absolute position of the new token = number of cached positions
-  // sliding window (HF Mistral `sliding_window`, 0 = none): the query sees positions [apos + 1 - window, apos]
-  const int w_lo = window > 0 ? max(0, apos + 1 - window) : 0;
-  int t_lo = w_lo, pos = apos - w_lo;  // this workgroup's cached slice is [t_lo, t_lo + pos)
-  bool incl_new = true;
-  if constexpr (SPLIT) {
-    const int ns = (int)gridDim.y, sp = (int)blockIdx.y;
-    const int span = apos - w_lo;
-    const int chunk = (((span + ns - 1) / ns) + 63) & ~63;
-    t_lo = w_lo + min(sp * chunk, span);
-    pos = min(apos - t_lo, chunk);
-    incl_new = sp == ns - 1;
-  }
-  kcache += (size_t)t_lo * kv_heads * HD;
-  vcache += (size_t)t_lo * kv_heads * HD;
-  const int npos_abs = apos - t_lo;  // row of the new position relative to the re-based cache pointers
-  float* qs = sm;                 // [HD] rotated q (pre-scaled by 1/sqrt(HD))
-  float* kn = qs + HD;            // [HD] rotated new k, rounded to the cache dtype
-  float* vn = kn + HD;            // [HD] new v, rounded to the cache dtype
-  float* redm = vn + HD;          // [8]
-  float* slab = redm + 8;         // [4 waves][GP][HD] partial outputs
-  float* sc = slab + 4 * GP * HD; // [pos + 1] scores / probabilities
-  const float scale = 1.0f / sqrtf((float)HD);
-  // The cache rows of the first score / P.V iteration depend only on `pos`: fetch them now, so that their HBM
-  // latency runs under the q/k/v read, the RoPE and the first barrier instead of after them.
-  const int sub = lane & 3;
-  const int g = lane / LPR, l8 = lane % LPR;
-  constexpr int TSTEP = 4 * GP;  // positions covered by the workgroup per P.V pass
-  const int plast = max(pos - 1, 0);
-  kv8 kpre[DPL / 8];
-  {
-    const int tc = min(wid * 16 + (lane >> 2), plast);
-    const kv8* kp = (const kv8*)(kcache + ((size_t)tc * kv_heads + kh) * HD + sub * DPL);
-#pragma unroll
-    for (int j = 0; j < DPL / 8; ++j) kpre[j] = kp[j];
-  }
-  kv8 vpre[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int tc = min(wid * GP + g + u * TSTEP, plast);
-    vpre[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
-  }
-  if (tid < half) {
-    const float c = cs[(size_t)apos * half + tid], s = sn[(size_t)apos * half + tid];
-    const float* q = qkv + (size_t)h * HD;
-    const float* k = qkv + (size_t)(heads + kh) * HD;
-    const float qa = q[tid], qb = q[tid + half], ka = k[tid], kb = k[tid + half];
-    qs[tid] = (qa * c - qb * s) * scale;
-    qs[tid + half] = (qb * c + qa * s) * scale;
-    kn[tid] = (float)(KV)(ka * c - kb * s);
-    kn[tid + half] = (float)(KV)(kb * c + ka * s);
-  } else if (tid >= 128 && tid < 128 + HD) {
-    vn[tid - 128] = (float)(KV)qkv[(size_t)(heads + kv_heads + kh) * HD + (tid - 128)];
-  }
-  __syncthreads();
-  if (h % rep == 0 && tid < HD && incl_new) {
-    kcache[((size_t)npos_abs * kv_heads + kh) * HD + tid] = (KV)kn[tid];
-    vcache[((size_t)npos_abs * kv_heads + kh) * HD + tid] = (KV)vn[tid];
-  }
-  // ---- scores for cached positions ----
-  float qreg[DPL];
-#pragma unroll
-  for (int i = 0; i < DPL; ++i) qreg[i] = qs[sub * DPL + i];
-  float lmax = -INFINITY;
-  auto score = [&](int t0, const kv8 (&kv)[DPL / 8]) {
-    const int t = t0 + (lane >> 2);
-    float d = 0.f;
-#pragma unroll
-    for (int j = 0; j < DPL / 8; ++j)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) d = fmaf(qreg[j * 8 + i], (float)kv[j][i], d);
-    d += __shfl_xor(d, 1, 64);
-    d += __shfl_xor(d, 2, 64);
-    if (t < pos) {
-      if (sub == 0) sc[t] = d;
-      lmax = fmaxf(lmax, d);
-    }
-  };
-  if (wid * 16 < pos) score(wid * 16, kpre);
-  {
-    // rows of iteration i+1 are in flight while iteration i is scored (a lone dependent load per iteration would
-    // expose the full HBM latency every 64 positions)
-    auto kload = [&](int t0, kv8 (&kv)[DPL / 8]) {
-      const int tc = min(t0 + (lane >> 2), max(pos - 1, 0));
-      const kv8* kp = (const kv8*)(kcache + ((size_t)tc * kv_heads + kh) * HD + sub * DPL);
-#pragma unroll
-      for (int j = 0; j < DPL / 8; ++j) kv[j] = kp[j];
-    };
-    kv8 ka[DPL / 8], kb[DPL / 8];
-    int t0 = wid * 16 + 64;
-    if (t0 < pos) kload(t0, ka);
-    for (; t0 < pos; t0 += 128) {
-      if (t0 + 64 < pos) kload(t0 + 64, kb);
-      score(t0, ka);
-      if (t0 + 64 < pos) {
-        if (t0 + 128 < pos) kload(t0 + 128, ka);
-        score(t0 + 64, kb);
-      }
-    }
-  }
-  if (tid == 0 && incl_new) {  // the new position, from LDS
-    float d = 0.f;
-    for (int i = 0; i < HD; ++i) d = fmaf(qs[i], kn[i], d);
-    sc[pos] = d;
-    lmax = fmaxf(lmax, d);
-  }
-  lmax = wave_max(lmax);
-  if (lane == 0) redm[wid] = lmax;
-  __syncthreads();
-  const float mx = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
-  float lsum = 0.f;
-  for (int t = tid; t < pos + (incl_new ? 1 : 0); t += 256) {
-    const float p = __expf(sc[t] - mx);
-    sc[t] = p;
-    lsum += p;
-  }
-  lsum = wave_sum(lsum);
-  if (lane == 0) redm[4 + wid] = lsum;
-  __syncthreads();
-  const float den = (redm[4] + redm[5]) + (redm[6] + redm[7]);
-  // ---- P.V ----
-  float acc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  auto pv = [&](int t0, const kv8 (&vv)[4]) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int t = t0 + u * TSTEP;
-      const float p = t < pos ? sc[min(t, pos - 1)] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, (float)vv[u][i], acc[i]);
-    }
-  };
-  if (wid * GP + g < pos) pv(wid * GP + g, vpre);
-  {
-    auto vload = [&](int t0, kv8 (&vv)[4]) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int tc = min(t0 + u * TSTEP, max(pos - 1, 0));
-        vv[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
-      }
-    };
-    kv8 va[4], vb[4];
-    int t0 = wid * GP + g + 4 * TSTEP;
-    if (t0 < pos) vload(t0, va);
-    for (; t0 < pos; t0 += 8 * TSTEP) {
-      if (t0 + 4 * TSTEP < pos) vload(t0 + 4 * TSTEP, vb);
-      pv(t0, va);
-      if (t0 + 4 * TSTEP < pos) {
-        if (t0 + 8 * TSTEP < pos) vload(t0 + 8 * TSTEP, va);
-        pv(t0 + 4 * TSTEP, vb);
-      }
-    }
-  }
-  if (wid == 0 && g == 0 && incl_new) {  // the new position
-    const float p = sc[pos];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, vn[l8 * 8 + i], acc[i]);
-  }
-  float* dst = slab + ((size_t)(wid * GP + g)) * HD + l8 * 8;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) dst[i] = acc[i];
-  __syncthreads();
-  if (tid < HD) {
-    float o = 0.f;
-#pragma unroll
-    for (int s2 = 0; s2 < 4 * GP; ++s2) o += slab[s2 * HD + tid];
-    if constexpr (SPLIT) {
-      float* part = out + ((size_t)h * gridDim.y + blockIdx.y) * (HD + 2);
-      part[tid] = o;
-      if (tid == 0) {
-        part[HD] = mx;
-        part[HD + 1] = den;
-      }
-    } else {
-      out[(size_t)h * HD + tid] = o / den;
-      // the o_proj GEMV's XQ input: tid < HD is a whole number of 16-lane rows, one block each
-      if (xo.limbs != nullptr) xq_emit16(o / den, xo, (h * HD + tid) >> 4, tid & 15);
-    }
-  }
+  attn_decode_body<KV, HD, SPLIT>(sm, h, (int)blockIdx.y, (int)gridDim.y, AttnPlain{qkv}, kcache, vcache, pos_p, cs,
+                                  sn, heads, kv_heads, window, spw, out, xo);
 }
 
 // merge the slices of attn_decode_kernel<SPLIT>: out[h][d] = sum_s o_s[d] e^(m_s - m) / sum_s l_s e^(m_s - m).
@@ -477,9 +281,9 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
 
 // ---- host launchers used by the engine ------------------------------------------------------------
 void launch_embed(const void* embed, int dtype, const int32_t* token, int hidden, float* out, const float* norm_w,
-                  const XqPtrs& xo, float* ssq_out, hipStream_t st) {
+                  const XqPtrs& xo, float* ssq_out, unsigned int* step_seq, hipStream_t st) {
   hipLaunchKernelGGL(embed_kernel, dim3((hidden + 255) / 256), dim3(256), 0, st, embed, dtype, token, hidden, out,
-                     norm_w, xo, ssq_out);
+                     norm_w, xo, ssq_out, step_seq);
 }
 
 bool launch_attn_decode_mfma(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
@@ -492,10 +296,10 @@ template <typename KV, int HD>
 static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int32_t* pos, const float* cs,
                          const float* sn, int heads, int kv_heads, int max_ctx, int window, float* out, int splits,
                          float* part, const XqPtrs& xo, hipStream_t st) {
-  constexpr int GP = 64 / (HD / 8);
   const int reach = window > 0 ? min(window, max_ctx) : max_ctx;  // positions a query can see
   const int span = splits > 1 ? ((((reach + splits - 1) / splits) + 63) & ~63) + 64 : reach;
-  const size_t lds = (size_t)(3 * HD + 8 + 4 * GP * HD + ((span + 4) & ~3)) * 4;
+  const int spw = attn_dec_spw(span);
+  const size_t lds = attn_dec_lds_floats(HD, span) * 4;
   if (lds > 160 * 1024) return woq::fail("QBits: max_ctx too large for the decode attention (raise attn_splits)");
   if (splits > 1) {
     auto k = attn_decode_kernel<KV, HD, true>;
@@ -505,7 +309,7 @@ static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int
       once = true;
     }
     hipLaunchKernelGGL(k, dim3(heads, splits), dim3(256), lds, st, qkv, (KV*)kcache, (KV*)vcache, pos, cs, sn, heads,
-                       kv_heads, window, part, XqPtrs{nullptr, nullptr, nullptr});
+                       kv_heads, window, spw, part, XqPtrs{nullptr, nullptr, nullptr});
     hipLaunchKernelGGL(attn_combine_kernel<HD>, dim3(heads), dim3(256), 0, st, part, splits, out, xo);
     return 0;
   }
@@ -516,7 +320,7 @@ static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int
     once = true;
   }
   hipLaunchKernelGGL(k, dim3(heads), dim3(256), lds, st, qkv, (KV*)kcache, (KV*)vcache, pos, cs, sn, heads, kv_heads,
-                     window, out, xo);
+                     window, spw, out, xo);
   return 0;
 }
 

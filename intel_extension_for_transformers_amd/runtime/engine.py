@@ -195,6 +195,20 @@ class WoqDecoderEngine:
             L.check(L.lib().woq_engine_set_attn_grouped(self._h, int(bool(on))))
             self.captured = False
 
+    def set_fuse_attn(self, on):
+        """Decode step: qkv GEMV + attention as one launch where the shape allows (csrc/woq_gemv_attn.hip; default
+        on). Invalidates a captured graph."""
+        L.check(L.lib().woq_engine_set_fuse_attn(self._h, int(bool(on))))
+        self.captured = False
+
+    def uses_fused_attn(self):
+        """True when the next step / capture runs the fused qkv + attention launch."""
+        return bool(L.lib().woq_engine_fuse_attn(self._h))
+
+    def fuse_status(self):
+        """0 = the fused launch's in-launch hand-offs all completed; 1 = an attention workgroup gave up waiting."""
+        return int(L.lib().woq_engine_fuse_status(self._h, L.stream_ptr()))
+
     def _grouped_applies(self):
         c = self.cfg
         return (c.head_dim == 128 and c.kv_heads > 0 and c.heads // c.kv_heads in (2, 4, 8)

@@ -176,3 +176,31 @@ def test_qbits_debug_switch_full_size(monkeypatch):
     assert torch.equal(out, fused)
     with pytest.raises(NotImplementedError):
         matmul_kbit(x, m.weight, None, out, "fp32", "int4_clip", "fp16", "asym", do_dequant=True)
+
+
+@pytest.mark.parametrize("kv_dtype", [torch.float16, torch.float8_e4m3fn])
+def test_fused_qkv_attention_launch_equals_two_launches(kv_dtype):
+    """csrc/woq_gemv_attn.hip: the decode step's qkv GEMV + attention as ONE launch (resident attention workgroups pick a head's q / k / v up as
+    tagged granules while the strips are still finishing) against the two launches, same engine, same cache contents: the arithmetic
+    is the same instruction stream on the same values, so logits and greedy tokens must be bit-identical — after a
+    200-token prompt pass (several passes of cached positions per wave), over eager steps and graph replays."""
+    eng, _, cfg = build_7b_shape(4, 128, False, kv_dtype=kv_dtype, max_ctx=512)
+    rng = np.random.default_rng(11)
+    prompt = rng.integers(0, cfg["vocab"], 200).tolist()
+    out = {}
+    for fused in (False, True):
+        eng.set_fuse_attn(fused)
+        assert eng.uses_fused_attn() == fused
+        eng.prefill(prompt, greedy=True)
+        logs = []
+        for _ in range(6):
+            eng.step(greedy=True)
+            logs.append(eng.logits.clone())
+        eng.capture(greedy=True)
+        eng.replay(20)
+        torch.cuda.synchronize()
+        logs.append(eng.logits.clone())
+        out[fused] = (torch.stack(logs), eng.token_log()[200:227].clone())
+    assert eng.fuse_status() == 0
+    assert torch.equal(out[True][0], out[False][0])
+    assert torch.equal(out[True][1], out[False][1])
