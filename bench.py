@@ -20,7 +20,8 @@ Which workload (`--workload auto`, the default):
     that the sweep's N = 1 value is the strong-scaling base; the 7B number rides along in `extra_configs`.
 
 Objects in the line: see DESIGN.md §6. roofline.achieved = algorithmic bytes per launch of the dominant kernel
-(woq::gemv_tile_kernel) / its average duration from HIP events on the launch stream around back-to-back passes.
+(woq::gemv_xqs_kernel) / its average duration from HIP events on the launch stream around back-to-back passes of the
+step's own launches; roofline.ceiling = the same launches as load-only twins / empty kernels, same run.
 """
 import argparse
 import gc
@@ -109,34 +110,61 @@ def timed(run, steps, warmup, fence):
     return time.perf_counter() - t0
 
 
-def gemv_roofline(eng, traffic=None):
-    ms, by, n_launch = eng.time_gemv(reps=4)
-    us = ms * 1e3 / (4 * n_launch)
-    achieved = (by / n_launch) / (us * 1e-6) / 1e9
-    return {
+def gemv_roofline(eng, traffic=None, ceiling=True):
+    """Dominant kernel: the batch-1 int4 GEMV. `achieved` = algorithmic bytes per launch / average launch duration from
+    HIP events on the launch stream around passes of the step's OWN four GEMV launches per layer (same kernels,
+    epilogues, XQ outputs and residual chaining as the captured step; back to back, so the boundaries a token pays are
+    inside). `ceiling`: the same launches with the arithmetic taken out, timed the same way in the same run — load-only
+    twins (what this launch structure reaches as a pure stream) and empty kernels (what its launches cost)."""
+    ms, by, n_launch = eng.time_gemv(reps=8)
+    us = ms * 1e3 / (8 * n_launch)
+    per_launch = by / n_launch
+    achieved = per_launch / (us * 1e-6) / 1e9
+    out = {
         "bound": "hbm",
-        "kernel": "woq::gemv_xq_kernel (int4 GEMV over XQ limb blocks, M=1, csrc/woq_gemv_xq.hip)" if eng.uses_xq()
+        "kernel": "woq::gemv_xqs_kernel (int4 GEMV over XQ digit blocks, M=1, csrc/woq_gemv_xqs.h)" if eng.uses_xq()
                   else "woq::gemv_tile_kernel (int4 GEMV, M=1, csrc/woq_gemv_i8.hip)",
         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
         "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBPS,
-        "traffic": traffic, "us_per_launch": us, "algorithmic_bytes_per_launch": by / n_launch,
+        "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,
+        "us_per_launch": us, "algorithmic_bytes_per_launch": per_launch,
         "launches_per_token": n_launch,
+        "timed": "HIP events on the launch stream around 8 replays of a captured pass of %d launches (the step's own "
+                 "kernel variants, chained as in the step; boundaries included)" % n_launch,
     }
+    if ceiling and eng.uses_xq():
+        us_twin = eng.time_twin(0, reps=8) * 1e3 / (8 * n_launch)
+        us_empty = eng.time_twin(1, reps=8) * 1e3 / (8 * n_launch)
+        out["ceiling"] = {
+            "load_only_twin_us_per_launch": us_twin,
+            "load_only_twin_gbps": per_launch / (us_twin * 1e-6) / 1e9,
+            "load_only_twin_frac": per_launch / (us_twin * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+            "empty_kernel_us_per_launch": us_empty,
+            "copy_ceiling_frac": HBM_COPY_GBPS / HBM_PEAK_GBPS,
+            "reading": "kernel %.3f of peak; the same four launches per layer as pure non-temporal streams %.3f; a "
+                       "float4 copy %.3f; an empty kernel on the same grids costs %.2f us of every launch"
+                       % (achieved / HBM_PEAK_GBPS, per_launch / (us_twin * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                          HBM_COPY_GBPS / HBM_PEAK_GBPS, us_empty),
+        }
+    return out
 
 
 def read_traffic():
-    """HBM bytes per dominant-kernel launch from the committed PMC pass (None if there is none)."""
+    """HBM bytes per dominant-kernel launch from the latest committed PMC pass (a separate rocprofv3 --pmc run: the
+    counters cannot be read inside the timed run). None if there is none."""
     pdir = os.path.join(ROOT, "profiles")
     best = None
     if os.path.isdir(pdir):
         for f in sorted(os.listdir(pdir)):
             if f.endswith("_pmc_traffic.json"):
-                best = os.path.join(pdir, f)
+                best = f
     if not best:
         return None
     try:
-        with open(best) as fh:
-            return float(json.load(fh)["hbm_bytes_per_launch"])
+        with open(os.path.join(pdir, best)) as fh:
+            return {"bytes": float(json.load(fh)["hbm_bytes_per_launch"]), "source": "profiles/" + best,
+                    "measured_in_this_run": False,
+                    "method": "rocprofv3 --pmc FETCH_SIZE pass of the same bench command, x2 gfx950 correction"}
     except Exception:
         return None
 
@@ -309,6 +337,72 @@ def parity_check(eng, cfg, tokens=(11, 20000, 317)):
     }
 
 
+def prefill_gemm_check(eng, cfg, M, layer=0, n_rows=64, time_reps=3):
+    """The prompt pass's GEMMs at the size they are measured at. For every projection of one layer: woq_linear with the
+    one-product (fp16-operand, hand-scheduled ring) kernel over M rows — fp32 rows for qkv / gate-up (the pack pass),
+    fp16 rows for o / down (the raw-A form) — and `n_rows` sampled rows (first / last row of the first, a middle and
+    the last 128-row tile, the rest random) against oracle.woq_linear on the same blob; bound 2e-3 * rowmax|ref|.
+    Also the dominant GEMM (gate/up) timed alone with HIP events on the launch stream."""
+    import ctypes
+
+    import numpy as np
+    import torch
+
+    from intel_extension_for_transformers_amd import _lib as L
+    from intel_extension_for_transformers_amd import qbits
+    from oracle import woq_oracle as orc
+
+    t0 = time.perf_counter()
+    orc.set_threads(orc.host_threads())
+    lt = eng.layer_tensors[layer]
+    rng = np.random.default_rng(77)
+    rows = sorted({0, 127, (M // 2) & ~127, ((M // 2) & ~127) + 127, M - 128, M - 1}
+                  | set(int(r) for r in rng.integers(0, M, n_rows)))[:max(n_rows, 6)]
+    res, worst = {}, 0.0
+    n_seq = max(1, M // 2048)
+    g = torch.Generator().manual_seed(4321)
+    eng.prefill(torch.randint(0, cfg["vocab"], (n_seq, M // n_seq), generator=g).cuda())  # rows for the timing below
+    gemm_ms, call_ms = eng.time_prefill_gemm(layer, M, reps=time_reps)
+    flops = 2.0 * M * cfg["hidden"] * 2 * cfg["inter"]
+    timing = {"gemm": "gate/up projection of layer %d in place, M=%d K=%d N=%d: woq::gemm_f16p_kernel (ring form, SiLU*mul "
+                      "epilogue)" % (layer, M, cfg["hidden"], 2 * cfg["inter"]),
+              "kernel_us": gemm_ms * 1e3, "kernel_tflops": flops / (gemm_ms * 1e-3) / 1e12,
+              "kernel_mfma_frac": flops / (gemm_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+              "call_us_with_pack_pass": call_ms * 1e3,
+              "timed": "HIP events on the launch stream right around the GEMM kernel's launch, %d calls after a warm-up "
+                       "one (woq_engine_time_prefill_gemm)" % time_reps}
+    for name, adt in (("qkv", torch.float32), ("o", torch.float16), ("gate_up", torch.float32), ("down", torch.float16)):
+        blob = lt[name]
+        hdr = qbits.header_of(blob)
+        hdr.compute_type = L.C_BF16  # the one-product MFMA form the prompt pass runs
+        g = torch.Generator(device="cuda").manual_seed(5)
+        x = torch.randn(M, hdr.K, generator=g, device="cuda", dtype=torch.float32).to(adt)
+        out = torch.empty(M, hdr.N, device="cuda", dtype=torch.float32)
+
+        def call():
+            L.check(L.lib().woq_linear(x.data_ptr(), L.torch_dtype_code(x.dtype), x.stride(0), blob.data_ptr(),
+                                       ctypes.byref(hdr), None, out.data_ptr(), L.torch_dtype_code(out.dtype),
+                                       out.stride(0), M, L.stream_ptr()))
+
+        call()
+        torch.cuda.synchronize()
+        got = out[rows].cpu().numpy()
+        ref = orc.woq_linear(x[rows].float().cpu().numpy(), blob.cpu().numpy().view(np.uint8))
+        rel = float((np.abs(got - ref).max(axis=1) / np.abs(ref).max(axis=1)).max())
+        res[name] = rel
+        worst = max(worst, rel)
+        if rel > 2e-3:
+            raise RuntimeError("prefill parity FAILED: %s GEMM at M=%d, worst row error %.3e of its row maximum" % (name, M, rel))
+        del x, out
+    return {
+        "checked": "layer %d's four GEMMs at M=%d through woq_linear's one-product MFMA form (fp32 rows: pack pass; "
+                   "fp16 rows: raw-A), %d sampled rows each vs oracle.woq_linear on the same blob"
+                   % (layer, M, len(rows)),
+        "worst_row_err_over_rowmax": worst, "per_gemm": res, "tol": "2e-3 * rowmax|ref| (fp16-operand products)",
+        "seconds": time.perf_counter() - t0,
+    }, timing
+
+
 # ---- the other BASELINE configurations (N = 1) ----------------------------------------------------------------------
 def decode_entry(name, cfg, eng, steps, warmup, group, asym, ctx_note, kv_bytes_per_token=0):
     import torch
@@ -373,6 +467,12 @@ def tp_point(args, cfg, rank, world, dist, steps, warmup, as_extra=False):
     from intel_extension_for_transformers_amd.runtime.tp import TPDecoder
 
     n_layers = args.layers if args.layers and not as_extra else cfg["layers"]
+    ranks_verified = None
+    if dist is not None:  # how many ranks actually answer a collective (not just the group's nominal size)
+        on = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        ones = torch.ones(1, dtype=torch.float32, device=on)
+        dist.all_reduce(ones)
+        ranks_verified = int(round(float(ones.item())))
     max_ctx = 1 << max(9, (args.prompt + warmup + steps + 8).bit_length())
     eng = build_engine(cfg, group=128, sym=True, max_ctx=max_ctx, tp_rank=rank, tp=world, layers=n_layers)
     transport, comm, dec = "none (one GPU)", None, None
@@ -436,7 +536,8 @@ def tp_point(args, cfg, rank, world, dist, steps, warmup, as_extra=False):
         "tokens_per_s": tok_s, "ms_per_token": elapsed * 1e3 / steps, "elapsed_s": elapsed,
         "algorithmic_weight_bytes_per_token_per_gpu": wbytes,
         "hbm_gbps_per_gpu": wbytes * tok_s / 1e9, "hbm_frac_per_gpu": wbytes * tok_s / 1e9 / HBM_PEAK_GBPS,
-        "rccl_ranks": world, "process_group_backend": dist.get_backend() if dist is not None else None, "allreduces_per_token": 2 * n_layers if world > 1 else 0,
+        "process_group_ranks": world, "process_group_backend": dist.get_backend() if dist is not None else None,
+        "rccl_ranks_verified": ranks_verified, "allreduces_per_token": 2 * n_layers if world > 1 else 0,
         "token_exchanges_per_token": 1 if world > 1 else 0, "allreduce_bytes": cfg["hidden"] * 4,
         "allreduce_transport": transport, "hipgraph": use_graph, "ranks_agree_on_token": agree,
     }
@@ -502,17 +603,29 @@ def main():
             out = dict(base, value=p["tokens_per_s"], ms_per_step=p["ms_per_token"], scaling="strong",
                        data="synthetic (random-init int4 weights of the Llama-2-70B shape, random prompt ids)",
                        config={"workload": p["workload"], "global_batch": 1, "parallelism": "tp%d" % world,
-                               "rccl_ranks": world, "allreduces_per_token": p["allreduces_per_token"],
+                               "process_group_ranks": world, "rccl_ranks_verified": p["rccl_ranks_verified"],
+                               "allreduces_per_token": p["allreduces_per_token"],
                                "token_exchanges_per_token": p["token_exchanges_per_token"],
                                "allreduce_bytes": p["allreduce_bytes"], "allreduce_transport": p["allreduce_transport"],
                                "hipgraph": p["hipgraph"], "visible_gpus": torch.cuda.device_count()},
                        hbm_gbps_per_gpu=p["hbm_gbps_per_gpu"], hbm_frac_of_peak_end_to_end=p["hbm_frac_per_gpu"],
                        roofline=dict(p["roofline_gemv"], traffic=None))
-            if world == 1 and not args.no_extra:  # first point of a sweep on a multi-GPU node: the 7B number rides along
+            out["note"] = ("`value` is Llama-2-70B at tensor-parallel degree %d: the strong-scaling curve of BASELINE "
+                           "configs[3] (the 7B batch-1 path of the metric's name does not shard, SURVEY.md §8(e))" % world)
+            if world == 1:
+                out["note"] += ("; this is the curve's N = 1 base on a multi-GPU node — the headline configuration "
+                                "(configs[1], Llama-2-7B, what BENCH_rNN.json's `value` is) rides along as `headline_7b`")
+            if world == 1 and not args.no_extra:  # first point of a sweep on a multi-GPU node: the 7B headline rides along
                 eng = build_engine(LLAMA2_7B, max_ctx=512)
                 feed_prompt(eng, LLAMA2_7B["vocab"], args.prompt)
-                out["extra_configs"] = [decode_entry("configs[1] Llama-2-7B int4 sym g128, batch-1 decode", LLAMA2_7B,
-                                                     eng, 64, 8, 128, False, "prompt %d" % args.prompt)]
+                e7 = decode_entry("configs[1] Llama-2-7B int4 sym g128, batch-1 decode", LLAMA2_7B, eng, args.steps,
+                                  args.warmup, 128, False, "prompt %d" % args.prompt)
+                out["headline_7b"] = {"value": e7["decode_tokens_per_s"], "unit": "tokens/s",
+                                      "ms_per_step": e7["ms_per_token"], "steps": args.steps, "warmup": args.warmup,
+                                      "workload": "Llama-2-7B int4 sym group_size=128 fp16 scales, batch=1 greedy "
+                                                  "decode, prompt %d (same as the one-GPU run's `value`)" % args.prompt,
+                                      "hbm_frac_of_peak_end_to_end": e7["hbm_frac_weights"],
+                                      "roofline": gemv_roofline(eng, read_traffic())}
                 del eng
                 free_gpu()
             print(json.dumps(out), flush=True)
@@ -560,7 +673,12 @@ def main():
     if want_prefill:
         out["prefill"] = prefill_measure(eng, cfg, args.prefill_seqs, args.prefill_len, label=", same int4 g128 weights")
     if not args.no_parity:
-        out["parity"] = parity_check(eng, cfg)
+        out["parity"] = {"decode": parity_check(eng, cfg)}
+        if want_prefill:
+            pp, timing = prefill_gemm_check(eng, cfg, args.prefill_seqs * args.prefill_len)
+            out["parity"]["prefill"] = pp
+            out["prefill"]["dominant_gemm"] = timing
+        out["fused_attention_launch"] = {"in_use": eng.uses_fused_attn(), "handoff_status": eng.fuse_status()}
     del eng
     free_gpu()
     if not args.no_extra:

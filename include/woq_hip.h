@@ -252,11 +252,24 @@ WOQ_API int woq_engine_set_comm(woq_engine* e, woq_comm* comm, int vocab_offset)
  * between them: phase 0 = embed + attention block up to o_proj partial, 1 = MLP block up to
  * down partial, 2 = head. layer ignored for phase 2. */
 WOQ_API int woq_engine_phase(woq_engine* e, int layer, int phase, int greedy, void* stream);
-/* time the dominant kernel (int4 GEMV) alone over all layers with HIP events on `stream`: `reps` passes over every
- * layer's 4 GEMVs launched back to back, one event pair around each pass; returns total ms, the algorithmic bytes of
- * one pass and its launch count (average launch duration = total_ms / (reps * launches_per_pass)). */
+/* time the dominant kernel (int4 GEMV) alone over all layers with HIP events on `stream`: one pass = every layer's 4
+ * GEMV launches in the forms the decode step uses (same kernels, epilogues, XQ outputs, residual chaining), captured
+ * into a hipGraph and replayed `reps` times between one event pair (after an untimed replay); returns total ms, the
+ * algorithmic bytes of one pass and its launch count (average launch duration = total_ms / (reps * launches_per_pass),
+ * boundaries included). Overwrites the residual stream / XQ vectors (the next step's embedding rewrites them). */
 WOQ_API int woq_engine_time_gemv(woq_engine* e, int reps, void* stream, float* total_ms, double* bytes_per_pass,
                                  int* launches_per_pass);
+/* the same four launches per layer with the arithmetic taken out, timed the same way (`reps` passes after a warm-up
+ * pass, total milliseconds): mode 0 = load-only twins (same grids, waves, K slices, non-temporal 16-byte requests over
+ * the engine's own blobs: what this launch structure reaches as a pure stream), mode 1 = empty kernels on the same
+ * grids (what the launches cost before they do anything). bench.py reports both as roofline.ceiling. */
+WOQ_API int woq_engine_time_twin(woq_engine* e, int mode, int reps, void* stream, float* total_ms);
+/* the prompt pass's dominant GEMM in place: the engine's own gate/up call of `layer` over n_rows rows of the residual
+ * stream a preceding woq_engine_prefill left (RMSNorm pack pass + MFMA GEMM + SiLU * mul epilogue), averaged over `reps`
+ * calls after a warm-up one: gemm_ms = the GEMM kernel alone (HIP events on the launch stream right around its launch),
+ * call_ms = pack pass + GEMM. */
+WOQ_API int woq_engine_time_prefill_gemm(woq_engine* e, int layer, int n_rows, int reps, void* stream, float* gemm_ms,
+                                         float* call_ms);
 
 #ifdef __cplusplus
 }

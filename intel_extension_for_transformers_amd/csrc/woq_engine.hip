@@ -40,6 +40,7 @@ int launch_gemv_xq_attn(const XqPtrs& xin, const void* blob, const woq_blob_head
                         const float* ssq_in, float eps, const unsigned int* seq, int layer, int* status, void* kcache,
                         void* vcache, int kv_dtype, const int32_t* pos, const float* cs, const float* sn, int heads,
                         int kv_heads, int max_ctx, int window, float* attn_out, const XqPtrs& xq_attn, hipStream_t st);
+int launch_gemv_twin(const void* blob, const woq_blob_header& h, int epi, int mode, unsigned int* sink, hipStream_t st);
 void launch_lm_head(const float* hidden_in, const float* norm_w, float eps, const void* W, int w_dtype, int hidden,
                     int vocab, float* logits, float* pmax, int32_t* pidx, hipStream_t st);
 void launch_argmax(const float* logits, int vocab, int32_t* token, int32_t* pos, hipStream_t st);
@@ -58,6 +59,7 @@ int launch_rope_append(_Float16* qkv, int n_seq, int T, int start, int heads, in
 int launch_attn_prefill(const _Float16* qkv, int n_seq, int T, int start, int heads, int kv_heads, int HD,
                         const void* kcache, const void* vcache, int kv_dtype, size_t seq_stride_elems, _Float16* out,
                         int window, hipStream_t st);
+void set_gemm_time_events(hipEvent_t before, hipEvent_t after);
 void launch_gather_last(const float* h, int n_seq, int T, int hidden, float* dst, hipStream_t st);
 }  // namespace woq
 // device-side tensor-parallel exchange (woq_comm.hip)
@@ -365,6 +367,37 @@ static int engine_prefill_impl(woq_engine* e, const int32_t* tokens, int n_seq, 
   return 0;
 }
 
+// one pass of `body` captured into a hipGraph and replayed `reps` times between two events on `st` (after one
+// untimed replay): what the launches cost inside the engine's own regime (captured, no host in the loop)
+template <typename F>
+static int time_captured(hipStream_t st, int reps, F body, float* total_ms) {
+  int rc = body();  // eager once: lazy kernel attributes outside of capture
+  if (rc) return rc;
+  WOQ_HIP(hipStreamSynchronize(st));
+  hipGraph_t g = nullptr;
+  hipGraphExec_t ge = nullptr;
+  WOQ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  rc = body();
+  hipError_t ce = hipStreamEndCapture(st, &g);
+  if (rc) return rc;
+  WOQ_HIP(ce);
+  WOQ_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  hipEvent_t ev0, ev1;
+  WOQ_HIP(hipEventCreate(&ev0));
+  WOQ_HIP(hipEventCreate(&ev1));
+  WOQ_HIP(hipGraphLaunch(ge, st));
+  WOQ_HIP(hipEventRecord(ev0, st));
+  for (int r = 0; r < reps; ++r) WOQ_HIP(hipGraphLaunch(ge, st));
+  WOQ_HIP(hipEventRecord(ev1, st));
+  WOQ_HIP(hipStreamSynchronize(st));
+  WOQ_HIP(hipEventElapsedTime(total_ms, ev0, ev1));
+  hipEventDestroy(ev0);
+  hipEventDestroy(ev1);
+  hipGraphExecDestroy(ge);
+  hipGraphDestroy(g);
+  return 0;
+}
+
 extern "C" {
 
 int woq_engine_prefill(woq_engine* e, const int32_t* tokens_dev, int n_seq, int T, int start_pos, int greedy,
@@ -648,13 +681,6 @@ int woq_engine_time_gemv(woq_engine* e, int reps, void* stream, float* total_ms,
   WOQ_CHECK(e && total_ms && bytes_per_pass && launches_per_pass, "QBits: null argument");
   hipStream_t st = (hipStream_t)stream;
   const woq_engine_config& c = e->cfg;
-  const int per_layer = 4;
-  const int n_launch = c.layers * per_layer;
-  // ONE event pair around each pass of n_launch back-to-back launches: the average launch duration then contains
-  // the kernel boundaries a token really pays, but not the ~1-2 us a per-launch event record adds to each interval
-  hipEvent_t ev0, ev1;
-  WOQ_HIP(hipEventCreate(&ev0));
-  WOQ_HIP(hipEventCreate(&ev1));
   double bytes = 0;
   for (int l = 0; l < c.layers; ++l) {
     const woq_layer_weights& w = e->layers[l];
@@ -666,24 +692,24 @@ int woq_engine_time_gemv(woq_engine* e, int reps, void* stream, float* total_ms,
                (h.off_zp ? (double)h.n_groups * h.N * 0.5 : 0.0);
     }
   }
-  double ms = 0;
-  for (int r = 0; r < reps; ++r) {
-    WOQ_HIP(hipEventRecord(ev0, st));
+  auto pass = [&]() -> int {
     for (int l = 0; l < c.layers; ++l) {
       const woq_layer_weights& w = e->layers[l];
       int rc;
-      if (e->use_xq()) {  // the same four launches in the form the step uses (outputs to scratch, no chaining)
+      if (e->use_xq()) {  // the step's own four GEMV launches: same kernels, epilogues, XQ outputs, residual chaining
+        const bool last = l + 1 == c.layers;
         if ((rc = engine_gemv_xq(e, e->xq_hidden, w.qkv_blob, w.qkv_hdr, e->qkv, e->ssq_part, nullptr, 0, kNoXq, nullptr,
                                  nullptr, st)) != 0)
           return rc;
-        if ((rc = engine_gemv_xq(e, e->xq_attn, w.o_blob, w.o_hdr, e->act, nullptr, nullptr, 0, kNoXq, nullptr, nullptr,
-                                 st)) != 0)
+        if ((rc = engine_gemv_xq(e, e->xq_attn, w.o_blob, w.o_hdr, e->hidden, nullptr, e->hidden, 0, e->xq_hidden, w.ln2,
+                                 e->ssq_part, st)) != 0)
           return rc;
-        if ((rc = engine_gemv_xq(e, e->xq_hidden, w.gate_up_blob, w.gate_up_hdr, e->act, e->ssq_part, nullptr, 1, kNoXq,
-                                 nullptr, nullptr, st)) != 0)
+        if ((rc = engine_gemv_xq(e, e->xq_hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, e->ssq_part, nullptr, 1,
+                                 e->xq_act, nullptr, nullptr, st)) != 0)
           return rc;
-        if ((rc = engine_gemv_xq(e, e->xq_act, w.down_blob, w.down_hdr, e->qkv, nullptr, nullptr, 0, kNoXq, nullptr,
-                                 nullptr, st)) != 0)
+        if ((rc = engine_gemv_xq(e, e->xq_act, w.down_blob, w.down_hdr, e->hidden, nullptr, e->hidden, 0,
+                                 last ? kNoXq : e->xq_hidden, last ? nullptr : e->layers[l + 1].ln1,
+                                 last ? nullptr : e->ssq_part, st)) != 0)
           return rc;
         continue;
       }
@@ -700,17 +726,74 @@ int woq_engine_time_gemv(woq_engine* e, int reps, void* stream, float* total_ms,
                                    c.hidden, 1, nullptr, 0.f, nullptr, 0, 0, e->nt, st);
       if (rc) return rc;
     }
-    WOQ_HIP(hipEventRecord(ev1, st));
-    WOQ_HIP(hipStreamSynchronize(st));
-    float t = 0.f;
-    WOQ_HIP(hipEventElapsedTime(&t, ev0, ev1));
-    ms += t;
-  }
-  hipEventDestroy(ev0);
-  hipEventDestroy(ev1);
-  *total_ms = (float)ms;
+    return 0;
+  };
+  const int rc = time_captured(st, reps, pass, total_ms);
+  if (rc) return rc;
   *bytes_per_pass = bytes;
-  *launches_per_pass = n_launch;
+  *launches_per_pass = c.layers * 4;
+  WOQ_END
+}
+
+// roofline.ceiling of bench.py: the decode step's four GEMV launches per layer with the arithmetic taken out — mode 0:
+// load-only twins (same grids, waves, K slices, non-temporal requests over the engine's own blobs), mode 1: empty
+// kernels on the same grids — timed like woq_engine_time_gemv (one event pair around each pass, back to back).
+int woq_engine_time_twin(woq_engine* e, int mode, int reps, void* stream, float* total_ms) {
+  WOQ_TRY
+  WOQ_CHECK(e && total_ms && (mode == 0 || mode == 1), "QBits: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned int* sink = (unsigned int*)e->am_idx;  // any device word; never written (the twins' store is unreachable)
+  auto pass = [&]() -> int {
+    for (int l = 0; l < e->cfg.layers; ++l) {
+      const woq_layer_weights& w = e->layers[l];
+      int rc;
+      if ((rc = launch_gemv_twin(w.qkv_blob, w.qkv_hdr, 0, mode, sink, st)) != 0) return rc;
+      if ((rc = launch_gemv_twin(w.o_blob, w.o_hdr, 0, mode, sink, st)) != 0) return rc;
+      if ((rc = launch_gemv_twin(w.gate_up_blob, w.gate_up_hdr, 1, mode, sink, st)) != 0) return rc;
+      if ((rc = launch_gemv_twin(w.down_blob, w.down_hdr, 0, mode, sink, st)) != 0) return rc;
+    }
+    return 0;
+  };
+  const int rc = time_captured(st, reps, pass, total_ms);
+  if (rc) return rc;
+  WOQ_END
+}
+
+// The prompt pass's dominant GEMM in place: the engine's own gate/up call of `layer` over n_seq * T rows (RMSNorm pack
+// pass + MFMA GEMM with the SiLU * mul epilogue into the fp16 activation buffer), `reps` times; gemm_ms = the GEMM
+// kernel alone (events right around its launch), call_ms = pack pass + GEMM. The residual stream must hold a prompt
+// pass's rows (call woq_engine_prefill with the same n_seq * T first).
+int woq_engine_time_prefill_gemm(woq_engine* e, int layer, int n_rows, int reps, void* stream, float* gemm_ms,
+                                 float* call_ms) {
+  WOQ_TRY
+  WOQ_CHECK(e && gemm_ms && call_ms && layer >= 0 && layer < e->cfg.layers && reps >= 1, "QBits: bad argument");
+  WOQ_CHECK((size_t)n_rows <= e->pf_rows && n_rows > 8, "QBits: run a prompt pass of at least n_rows rows first");
+  hipStream_t st = (hipStream_t)stream;
+  const woq_engine_config& c = e->cfg;
+  const woq_layer_weights& w = e->layers[layer];
+  hipEvent_t k0, k1, c0, c1;
+  WOQ_HIP(hipEventCreate(&k0));
+  WOQ_HIP(hipEventCreate(&k1));
+  WOQ_HIP(hipEventCreate(&c0));
+  WOQ_HIP(hipEventCreate(&c1));
+  double gsum = 0, csum = 0;
+  for (int r = 0; r <= reps; ++r) {  // pass 0 warms up
+    WOQ_HIP(hipEventRecord(c0, st));
+    set_gemm_time_events(k0, k1);
+    const int rc = launch_gemm_f16(e->pf_h, WOQ_F32, c.hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, e->pf_act, WOQ_F16,
+                                   c.inter, n_rows, w.ln2, c.rms_eps, nullptr, 0, 1, e->pf_ws, 0, st);
+    set_gemm_time_events(nullptr, nullptr);
+    if (rc) return rc;
+    WOQ_HIP(hipEventRecord(c1, st));
+    WOQ_HIP(hipStreamSynchronize(st));
+    float tk = 0.f, tc = 0.f;
+    WOQ_HIP(hipEventElapsedTime(&tk, k0, k1));
+    WOQ_HIP(hipEventElapsedTime(&tc, c0, c1));
+    if (r > 0) gsum += tk, csum += tc;
+  }
+  for (hipEvent_t ev : {k0, k1, c0, c1}) hipEventDestroy(ev);
+  *gemm_ms = (float)(gsum / reps);
+  *call_ms = (float)(csum / reps);
   WOQ_END
 }
 

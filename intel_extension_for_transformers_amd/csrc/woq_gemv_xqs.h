@@ -120,7 +120,9 @@ __device__ __forceinline__ void gemv_xqs_body(
   for (int cb = 0; cb < CB; ++cb)
     rq[cb] = make_rsrc(q + (size_t)((int)blockIdx.x * CB + cb) * tiles_k * 64,
                        WOQ_XK(8) ? 0 : uni(min(kt0 + cnt, tiles_k) * 1024));
-  constexpr int PRE = WOQ_XQS_PRE < DD ? WOQ_XQS_PRE : DD;  // weight tiles requested in front of the small requests
+  // weight tiles requested in front of the small requests: two for single column tiles, all D for the gate/up pairs
+  // (same-box A/B builds of tools/xq_probe.hip, profiles/r03i_xq_issue_order.txt)
+  constexpr int PRE = CB == 2 ? DD : (WOQ_XQS_PRE < DD ? WOQ_XQS_PRE : DD);
 #pragma unroll
   for (int t = 0; t < PRE; ++t)
 #pragma unroll

@@ -142,11 +142,37 @@ class WoqDecoderEngine:
     def phase(self, layer, phase, greedy=True):
         L.check(L.lib().woq_engine_phase(self._h, int(layer), int(phase), int(greedy), L.stream_ptr()))
 
+    def _on_own_stream(self, fn):
+        """Run `fn` with the engine's own stream current (captures are not allowed on the legacy default stream)."""
+        cur = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            out = fn()
+        cur.wait_stream(self._stream)
+        return out
+
     def time_gemv(self, reps=1):
         ms, by, n = ctypes.c_float(), ctypes.c_double(), ctypes.c_int()
-        L.check(L.lib().woq_engine_time_gemv(self._h, reps, L.stream_ptr(), ctypes.byref(ms), ctypes.byref(by),
-                                             ctypes.byref(n)))
+        self._on_own_stream(lambda: L.check(L.lib().woq_engine_time_gemv(
+            self._h, reps, L.stream_ptr(), ctypes.byref(ms), ctypes.byref(by), ctypes.byref(n))))
         return ms.value, by.value, n.value
+
+    def time_twin(self, mode, reps=1):
+        """Total ms of `reps` replays of a captured pass over every layer's 4 GEMV launches with the arithmetic taken
+        out: mode 0 = load-only twins over the engine's own blobs, mode 1 = empty kernels on the same grids (bench.py
+        roofline.ceiling)."""
+        ms = ctypes.c_float()
+        self._on_own_stream(lambda: L.check(L.lib().woq_engine_time_twin(
+            self._h, int(mode), int(reps), L.stream_ptr(), ctypes.byref(ms))))
+        return ms.value
+
+    def time_prefill_gemm(self, layer, n_rows, reps=3):
+        """(gemm_ms, call_ms) of the engine's own gate/up GEMM call over the `n_rows` rows a preceding prefill left in
+        the residual stream: the MFMA GEMM kernel alone, and pack pass + GEMM (bench.py prefill.dominant_gemm)."""
+        g, c = ctypes.c_float(), ctypes.c_float()
+        L.check(L.lib().woq_engine_time_prefill_gemm(self._h, int(layer), int(n_rows), int(reps), L.stream_ptr(),
+                                                     ctypes.byref(g), ctypes.byref(c)))
+        return g.value, c.value
 
     # ---- tensor parallel: host-driven collectives between sub-blocks (RCCL via torch.distributed) ----
     def step_tp(self, group=None, greedy=True):

@@ -204,3 +204,49 @@ def test_fused_qkv_attention_launch_equals_two_launches(kv_dtype):
     assert eng.fuse_status() == 0
     assert torch.equal(out[True][0], out[False][0])
     assert torch.equal(out[True][1], out[False][1])
+
+
+PREFILL_SHAPES = [("qkv", 4096, 12288), ("o", 4096, 4096), ("gate_up", 4096, 22016), ("down", 11008, 4096)]
+
+
+def _sampled_rows(M, n, rng):
+    """first / last row of the first, a middle and the last 128-row tile (the XCD-aware super-tile mapping and the
+    raw-A row clamp live at those edges), the rest random"""
+    mid = (M // 2) & ~127
+    fixed = {0, 127, mid, mid + 127, M - 128, M - 1}
+    return sorted(fixed | set(int(r) for r in rng.integers(0, M, n - len(fixed))))
+
+
+@pytest.mark.parametrize("name,K,N", PREFILL_SHAPES)
+@pytest.mark.parametrize("group,asym", [(128, False), (32, True)])
+@pytest.mark.parametrize("act_dtype", [torch.float32, torch.float16])
+def test_prefill_gemm_at_measured_size_vs_oracle(name, K, N, group, asym, act_dtype, M=8192):
+    """The prompt pass's one-product MFMA GEMM (compute "bf16": hand-scheduled ring kernel, 8 x 8 super-tile mapping
+    live from M = 1024, fp16 rows fetched raw) at the M the bench line measures, every Llama-2-7B projection, both
+    BASELINE quantisation variants: 64 sampled rows against oracle.woq_linear on the same blob. The reference's own
+    test compares at m = 256 (qbits_ut/test_weightonly.py:51-88); bound 2e-3 * rowmax (fp16-operand products)."""
+    from intel_extension_for_transformers_amd import qbits
+
+    rng = np.random.default_rng(K + N + group + M)
+    q, s, z = _host_qsz(rng, K, N, group, asym)
+    e8, e32 = torch.empty(0, dtype=torch.int8), torch.empty(0, dtype=torch.int32)
+    blob = qbits.repack_quantized_weight(torch.from_numpy(q).cuda(), torch.from_numpy(s).cuda(),
+                                         e8 if z is None else torch.from_numpy(z).cuda(), e32, "int4_clip", "fp16",
+                                         "bf16", asym, group)
+    g = torch.Generator(device="cuda").manual_seed(K + M)
+    x = torch.randn(M, K, generator=g, device="cuda", dtype=torch.float32).to(act_dtype)
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32)
+    qbits.woq_linear(x, blob, torch.empty(0), out, "bf16", "int4_clip", "fp16", asym)
+    torch.cuda.synchronize()
+    assert not torch.isnan(out).any(), "output elements left unwritten"
+    rows = _sampled_rows(M, 64, rng)
+    got = out[rows].cpu().numpy()
+    ref = orc.woq_linear(x[rows].float().cpu().numpy(), blob.cpu().numpy().view(np.uint8))
+    rel = (np.abs(got - ref).max(axis=1) / np.abs(ref).max(axis=1)).max()
+    assert rel <= 2e-3, (name, group, asym, str(act_dtype), float(rel))
+
+
+@pytest.mark.parametrize("group,asym", [(128, False), (32, True)])
+def test_prefill_gemm_qkv_at_32x2048_rows_vs_oracle(group, asym):
+    """BASELINE configs[2]'s prompt pass feeds its GEMMs M = 32 x 2048 = 65 536 rows: the qkv projection at that M."""
+    test_prefill_gemm_at_measured_size_vs_oracle("qkv", 4096, 12288, group, asym, torch.float32, M=65536)
