@@ -678,7 +678,7 @@ def main():
             pp, timing = prefill_gemm_check(eng, cfg, args.prefill_seqs * args.prefill_len)
             out["parity"]["prefill"] = pp
             out["prefill"]["dominant_gemm"] = timing
-        out["fused_attention_launch"] = {"in_use": eng.uses_fused_attn(), "handoff_status": eng.fuse_status()}
+        out["fused_attention_launch"] = {"in_use": eng.uses_fused_attn(), "engine_status": eng.status()}
     del eng
     free_gpu()
     if not args.no_extra:

@@ -206,10 +206,12 @@ WOQ_API int woq_engine_attn_grouped(woq_engine* e);
  * woq_engine_fuse_attn: 1 when the next step / capture will use it. */
 WOQ_API int woq_engine_set_fuse_attn(woq_engine* e, int on);
 WOQ_API int woq_engine_fuse_attn(woq_engine* e);
-/* sticky status of the fused launch's in-launch hand-off: 0 = every attention workgroup saw its head's q / k / v in
- * time, 1 = one gave up after its bound (its outputs are then wrong); -1 = the read itself failed. Synchronises
- * `stream`. */
-WOQ_API int woq_engine_fuse_status(woq_engine* e, void* stream);
+/* sticky device-side status of the decode step, 0 = fine; bit 0: an attention workgroup of the fused launch gave up
+ * waiting for its head's q / k / v after its bound (its outputs are then wrong); bit 1: a step started with its
+ * position at or beyond max_ctx — it ran at max_ctx - 1 instead (outputs meaningless, nothing written out of bounds;
+ * woq_engine_step / _replay cannot check a position that lives on the device); -1 = the read itself failed.
+ * Synchronises `stream`. */
+WOQ_API int woq_engine_status(woq_engine* e, void* stream);
 /* KV cache base pointers (which: 0 = K, 1 = V), layout [sequence][layer][position][kv_head][head_dim] in kv_dtype:
  * inspection / tests, and the seam for an external cache manager. */
 WOQ_API void* woq_engine_kv_cache_ptr(woq_engine* e, int which);

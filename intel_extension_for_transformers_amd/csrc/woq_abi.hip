@@ -5,6 +5,8 @@
 // parse_activation / parse_weight / parse_gemm_core). Here the "dispatcher" is a few integer
 // compares on the cached header: M <= 8 -> decode GEMV, else the MFMA GEMM (three-product fp32-class form for
 // compute_dtype fp32, single fp16 product for the reduced-precision compute modes).
+#include <mutex>
+
 #include "woq_device.h"
 #include "woq_launch.h"
 
@@ -18,18 +20,40 @@ namespace {
 struct Workspace {
   unsigned char* base = nullptr;
   size_t bytes = 0, used = 0;
+  hipStream_t last = nullptr;  // stream of the most recent taker: the slices are released at host return, while the
+  bool has_last = false;       // kernels that use them are still queued on that stream
+  hipEvent_t ev = nullptr;
+  std::mutex mu;
 } g_ws;
 inline size_t ws_round(size_t b) { return (b + 255) & ~(size_t)255; }
 }  // namespace
 
+// The workspace is handed out by a bump pointer and given back when the host call returns — safe only while every
+// user queues on ONE stream. A taker on a different stream first makes its stream wait for what the previous stream
+// has queued so far (an event), so two streams (or threads) share the scratch in turn instead of at once.
 void* scratch_take(size_t bytes, hipStream_t st, bool* own) {
   const size_t need = ws_round(bytes);
+  std::lock_guard<std::mutex> lock(g_ws.mu);
   if (g_ws.base != nullptr && g_ws.used + need <= g_ws.bytes) {
+    if (g_ws.has_last && g_ws.last != st && g_ws.used == 0) {
+      bool ordered = false;
+      if (g_ws.ev == nullptr && hipEventCreateWithFlags(&g_ws.ev, hipEventDisableTiming) != hipSuccess) g_ws.ev = nullptr;
+      if (g_ws.ev != nullptr && hipEventRecord(g_ws.ev, g_ws.last) == hipSuccess &&
+          hipStreamWaitEvent(st, g_ws.ev, 0) == hipSuccess)
+        ordered = true;
+      if (!ordered) {  // (e.g. the previous stream is capturing): fall through to a private allocation
+        (void)hipGetLastError();
+        goto private_alloc;
+      }
+    }
+    g_ws.last = st;
+    g_ws.has_last = true;
     void* p = g_ws.base + g_ws.used;
     g_ws.used += need;
     *own = false;
     return p;
   }
+private_alloc:
   void* p = nullptr;
   *own = true;
   if (hipMallocAsync(&p, bytes, st) != hipSuccess) {
@@ -40,10 +64,12 @@ void* scratch_take(size_t bytes, hipStream_t st, bool* own) {
 }
 void scratch_release(void* p, size_t bytes, bool own, hipStream_t st) {
   if (p == nullptr) return;
-  if (own)
+  if (own) {
     hipFreeAsync(p, st);
-  else
+  } else {
+    std::lock_guard<std::mutex> lock(g_ws.mu);
     g_ws.used -= ws_round(bytes);
+  }
 }
 
 struct GemvArgs;
@@ -89,9 +115,11 @@ static int linear_int4(const void* act, int act_dtype, int lda, const void* blob
 int woq_set_workspace(void* workspace_dev, size_t bytes) {
   WOQ_TRY
   WOQ_CHECK(workspace_dev != nullptr || bytes == 0, "QBits: null workspace with a size");
+  std::lock_guard<std::mutex> lock(g_ws.mu);
   WOQ_CHECK(g_ws.used == 0, "QBits: workspace changed while a call is using it");
   g_ws.base = (unsigned char*)workspace_dev;
   g_ws.bytes = workspace_dev ? bytes : 0;
+  g_ws.has_last = false;
   WOQ_END
 }
 

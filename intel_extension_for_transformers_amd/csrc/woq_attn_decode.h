@@ -99,6 +99,13 @@ __device__ __forceinline__ void attn_decode_body(float* sm, int h, int slice, in
 #pragma unroll
     for (int j = 0; j < DPL / 8; ++j) kpre[j] = kp[j];
   }
+  kv8 kb[DPL / 8];  // second score pass (positions 64 + 16 w + r): needs only `pos` as well
+  if (n_w > 16) {
+    const int tc = min(64 + 16 * wid + r16, plast);
+    const kv8* kp = (const kv8*)(kcache + ((size_t)tc * kv_heads + kh) * HD + sub * DPL);
+#pragma unroll
+    for (int j = 0; j < DPL / 8; ++j) kb[j] = kp[j];
+  }
   constexpr int VU = 16 / GP;  // P.V passes that cover one 16-position run
   kv8 vpre[VU];
 #pragma unroll
@@ -194,8 +201,6 @@ __device__ __forceinline__ void attn_decode_body(float* sm, int h, int slice, in
   };
   const int n_it = (n_w + 15) >> 4;  // 16-position passes of this wave
   if (n_it > 0) {
-    kv8 kb[DPL / 8];
-    if (n_it > 1) kload(1, kb);
     score(0, kpre);
     // rows of pass i + 1 are in flight while pass i is scored
     for (int i = 1; i < n_it; i += 2) {

@@ -65,7 +65,8 @@ __device__ __forceinline__ bool pull(const uint64_t* p, uint32_t tag, uint64_t t
     __builtin_amdgcn_s_sleep(1);
   }
 }
-__device__ __forceinline__ uint32_t next_seq(uint32_t s) { return s + 1 == 0 ? 1 : s + 1; }
+// 0 is never a live tag; on the wrap 0xffffffff (odd) -> 2 (even), so consecutive collectives still alternate buffers
+__device__ __forceinline__ uint32_t next_seq(uint32_t s) { return s + 1 == 0 ? 2 : s + 1; }
 
 // in-place sum over ranks of buf[0..n). grid = ceil(n / 1024) x 256 threads, 4 elements per thread (stride 256: every
 // store instruction of a wave covers 512 contiguous bytes of one peer's inbox).

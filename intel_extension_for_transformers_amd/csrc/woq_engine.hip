@@ -24,7 +24,8 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
                             const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w,
                             float eps, const float* residual, int ld_res, int epi, int nt, hipStream_t st);
 void launch_embed(const void* embed, int dtype, const int32_t* token, int hidden, float* out, const float* norm_w,
-                  const XqPtrs& xo, float* ssq_out, unsigned int* step_seq, hipStream_t st);
+                  const XqPtrs& xo, float* ssq_out, unsigned int* step_seq, int32_t* pos, int max_ctx, int* status,
+                  hipStream_t st);
 int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
                        const float* cs, const float* sn, int heads, int kv_heads, int D, int max_ctx, int window,
                        float* out, int splits, int grouped, float* part, const XqPtrs& xo, hipStream_t st);
@@ -272,7 +273,8 @@ static int engine_allreduce_rows(woq_engine* e, float* buf, size_t count, hipStr
 static void engine_embed(woq_engine* e, hipStream_t st) {
   const bool xq = e->use_xq();
   launch_embed(e->embed, e->embed_dtype, e->token, e->cfg.hidden, e->hidden, xq ? e->layers[0].ln1 : nullptr,
-               xq ? e->xq_hidden : kNoXq, xq ? e->ssq_part : nullptr, e->step_seq, st);
+               xq ? e->xq_hidden : kNoXq, xq ? e->ssq_part : nullptr, e->step_seq, e->pos, e->cfg.max_ctx, e->fuse_status,
+               st);
 }
 
 static int engine_step_impl(woq_engine* e, int greedy, hipStream_t st) {
@@ -435,7 +437,7 @@ int woq_engine_set_fuse_attn(woq_engine* e, int on) {
   e->fuse_attn = on != 0;
   WOQ_END
 }
-int woq_engine_fuse_status(woq_engine* e, void* stream) {
+int woq_engine_status(woq_engine* e, void* stream) {  // bit 0 hand-off give-up, bit 1 position clamp
   if (!e || !e->fuse_status) return 0;
   int v = 0;
   if (hipMemcpyAsync(&v, e->fuse_status, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -1;
@@ -491,8 +493,11 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
   WOQ_HIP(hipMalloc((void**)&e->am_idx, (size_t)((cfg->vocab + 15) / 16) * 4));
   WOQ_HIP(hipMalloc((void**)&e->pf_last, (size_t)e->max_batch * cfg->hidden * 4));
   WOQ_HIP(hipMalloc((void**)&e->pf_logits, (size_t)e->max_batch * cfg->vocab * 4));
+  WOQ_HIP(hipMalloc((void**)&e->step_seq, 8));  // step counter (hand-off tags) + sticky status word
+  WOQ_HIP(hipMemset(e->step_seq, 0, 8));
+  e->fuse_status = (int*)(e->step_seq + 1);
   e->owned = {e->hidden, e->qkv, e->attn, e->act, e->logits, e->token, e->pos, e->kcache, e->vcache, e->pf_last,
-              e->pf_logits, e->attn_part, e->am_val, e->am_idx, e->tok_log};
+              e->pf_logits, e->attn_part, e->am_val, e->am_idx, e->tok_log, e->step_seq};
   {  // XQ vectors (woq_xq.h) for the three GEMV inputs of a layer
     // WOQ_ENGINE_XQ=1 / 0 forces the choice. Default: by measurement (profiles/r02n_xq_by_shape.txt) — at hidden 4096
     // the XQ hand-off wins (Llama-2-7B g128 sym 747-757 vs 737-740 tokens/s, g32 asym 652 vs 626), at hidden 8192 the
@@ -510,9 +515,6 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
       WOQ_HIP(hipMalloc((void**)&e->ssq_part, (size_t)(cfg->hidden / 16) * 4));
       WOQ_HIP(hipMalloc((void**)&e->qkv_g, (size_t)qkv_n * 8));
       WOQ_HIP(hipMemset(e->qkv_g, 0, (size_t)qkv_n * 8));  // tag 0 is never a live tag
-      WOQ_HIP(hipMalloc((void**)&e->step_seq, 8));
-      WOQ_HIP(hipMemset(e->step_seq, 0, 8));
-      e->fuse_status = (int*)(e->step_seq + 1);
       WOQ_HIP(hipMemset(bh, 0, xq_bytes(cfg->hidden)));
       WOQ_HIP(hipMemset(ba, 0, xq_bytes(attn_k)));
       WOQ_HIP(hipMemset(bc, 0, xq_bytes(cfg->inter)));
@@ -520,7 +522,7 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
       e->xq_hidden = xq_carve(bh, cfg->hidden);
       e->xq_attn = xq_carve(ba, attn_k);
       e->xq_act = xq_carve(bc, cfg->inter);
-      for (void* p : {bh, ba, bc, (void*)e->ssq_part, (void*)e->qkv_g, (void*)e->step_seq}) e->owned.push_back(p);
+      for (void* p : {bh, ba, bc, (void*)e->ssq_part, (void*)e->qkv_g}) e->owned.push_back(p);
     }
   }
   *out = e;

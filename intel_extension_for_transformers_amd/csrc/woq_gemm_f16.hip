@@ -37,6 +37,7 @@
 // A tile (128 x 256, one workgroup per CU) 799; 4 column tiles per wave (128 accumulator VGPRs, one workgroup per CU)
 // 474; knock-outs of the built kernel: no dequantisation 1012, no A-tile DMA 997, no barrier 892 — i.e. ~17 % of
 // the time is the 14-VALU dequantisation, ~15 % the LDS-DMA issue / landing, ~5 % barrier skew.
+#include <mutex>
 #include <type_traits>
 
 #include "woq_device.h"
@@ -671,6 +672,8 @@ static int launch_f16_t(GemmF16Args& a, hipStream_t st) {
 #endif
   const int LDS = ring ? 3 * (FTILE_BYTES / 2) : 2 * FTILE_BYTES * (NP == 1 ? 1 : 2);
   static const void* attr_set[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  static std::mutex attr_mu;  // (host threads launching concurrently)
+  std::lock_guard<std::mutex> attr_lock(attr_mu);
   bool have = false;  // (attr_set: the kernels this instantiation can pick)
   int free_slot = 7;
   for (int i = 7; i >= 0; --i) {

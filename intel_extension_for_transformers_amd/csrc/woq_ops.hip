@@ -84,9 +84,18 @@ __global__ void gelu_kernel(const void* __restrict__ x, int dtype, size_t n, int
 // sums of squares — hidden % 16 == 0, so every 16-lane row is one whole block
 __global__ void embed_kernel(const void* __restrict__ embed, int dtype, const int32_t* __restrict__ token, int hidden,
                              float* __restrict__ out, const float* __restrict__ norm_w, XqPtrs xo,
-                             float* __restrict__ ssq_out, unsigned int* __restrict__ step_seq) {
+                             float* __restrict__ ssq_out, unsigned int* __restrict__ step_seq,
+                             int32_t* __restrict__ pos, int max_ctx, int* __restrict__ status) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0 && step_seq != nullptr) step_seq[0] = step_seq[0] + 1u;  // first kernel of a decode step: new tags
+  if (i == 0) {  // first kernel of a decode step
+    if (step_seq != nullptr) step_seq[0] = step_seq[0] + 1u;  // new hand-off tags
+    // the position lives on the device (greedy chaining advances it there): the KV cache, the RoPE tables and the token
+    // log are indexed by it unchecked, so a step that starts out of range is moved to the last slot and flagged
+    if (pos != nullptr && pos[0] >= max_ctx) {
+      pos[0] = max_ctx - 1;
+      if (status != nullptr) atomicOr(status, 2);
+    }
+  }
   if (i < hidden) {
     const float v = load_f32(embed, (size_t)token[0] * hidden + i, dtype);
     out[i] = v;
@@ -281,9 +290,10 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
 
 // ---- host launchers used by the engine ------------------------------------------------------------
 void launch_embed(const void* embed, int dtype, const int32_t* token, int hidden, float* out, const float* norm_w,
-                  const XqPtrs& xo, float* ssq_out, unsigned int* step_seq, hipStream_t st) {
+                  const XqPtrs& xo, float* ssq_out, unsigned int* step_seq, int32_t* pos, int max_ctx, int* status,
+                  hipStream_t st) {
   hipLaunchKernelGGL(embed_kernel, dim3((hidden + 255) / 256), dim3(256), 0, st, embed, dtype, token, hidden, out,
-                     norm_w, xo, ssq_out, step_seq);
+                     norm_w, xo, ssq_out, step_seq, pos, max_ctx, status);
 }
 
 bool launch_attn_decode_mfma(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,

@@ -168,7 +168,9 @@ class TextChatAPIRouter(APIRouter):
         import queue
         import threading
 
-        pieces = queue.Queue(maxsize=256)
+        # unbounded: the generation is already bounded by max_tokens, so the worker never blocks on a slow client and the
+        # engine lock is held for the generation only; `done` and an exception always get through
+        pieces = queue.Queue()
         gone = threading.Event()  # the consumer stopped listening (disconnect, stop string, generator closed)
         done = object()
 
@@ -181,26 +183,27 @@ class TextChatAPIRouter(APIRouter):
                     for piece in gen:
                         if gone.is_set():
                             break
-                        while not gone.is_set():
-                            try:
-                                pieces.put(piece, timeout=0.25)
-                                break
-                            except queue.Full:
-                                continue
+                        pieces.put(piece)
                     if hasattr(gen, "close"):
                         gen.close()
-                pieces.put(done, timeout=1.0)
+                pieces.put(done)
             except BaseException as ex:  # surfaced on the consumer side
-                try:
-                    pieces.put(ex, timeout=1.0)
-                except queue.Full:
-                    pass
+                pieces.put(ex)
 
-        threading.Thread(target=work, daemon=True).start()
+        worker = threading.Thread(target=work, daemon=True)
+        worker.start()
         seen = ""
         try:
             while True:
-                piece = pieces.get()
+                try:
+                    piece = pieces.get(timeout=1.0)
+                except queue.Empty:
+                    if worker.is_alive():
+                        continue
+                    try:  # the worker is gone: whatever it left is already in the queue
+                        piece = pieces.get_nowait()
+                    except queue.Empty:
+                        return
                 if piece is done:
                     return
                 if isinstance(piece, BaseException):

@@ -231,9 +231,11 @@ class WoqDecoderEngine:
         """True when the next step / capture runs the fused qkv + attention launch."""
         return bool(L.lib().woq_engine_fuse_attn(self._h))
 
-    def fuse_status(self):
-        """0 = the fused launch's in-launch hand-offs all completed; 1 = an attention workgroup gave up waiting."""
-        return int(L.lib().woq_engine_fuse_status(self._h, L.stream_ptr()))
+    def status(self):
+        """Sticky device-side status of the decode step, 0 = fine. bit 0: an attention workgroup of the fused launch
+        gave up waiting for its head's q / k / v; bit 1: a step found its position at or beyond max_ctx and ran at
+        max_ctx - 1 instead (its outputs are meaningless, memory was not touched out of bounds)."""
+        return int(L.lib().woq_engine_status(self._h, L.stream_ptr()))
 
     def _grouped_applies(self):
         c = self.cfg

@@ -155,6 +155,19 @@ class TPDecoder:
         self.vocab_offset = rank * ((vocab + world - 1) // world)
         if comm is not None:
             engine.bind_comm(comm, self.vocab_offset)
+        self._since_check = 0
+
+    CHECK_EVERY = 64  # device steps between two reads of the exchange's sticky status
+
+    def check_status(self):
+        """The device exchange never hangs: a peer that stays silent past the timeout contributes 0 and raises a
+        sticky status word — after which the ranks' hidden states and KV caches have diverged. Read it (one small
+        host synchronisation) and refuse to go on. Called at prompt-pass / capture / generation boundaries and every
+        CHECK_EVERY steps; call it yourself after a burst of `engine.replay`."""
+        self._since_check = 0
+        if self.comm is not None and self.comm.status() != 0:
+            raise RuntimeError("QBits: the tensor-parallel device exchange timed out on this rank (a peer stalled): "
+                               "the step's results are invalid; re-create the communicator or use the RCCL transport")
 
     def prefill(self, tokens, start_pos=0):
         """Prompt pass over this rank's shards: the engine's native prefill with the all-reduce seam bound to the
@@ -175,6 +188,7 @@ class TPDecoder:
                 local = e.prefill(tokens, start_pos=start_pos, greedy=False)
             finally:
                 e.unbind_allreduce()
+        self.check_status()
         nxt = greedy_token(local[0][:e.cfg.vocab], self.vocab, self.group)
         e.token.copy_(nxt.to(torch.int32).reshape(e.token.shape))
         e.pos.add_(1)  # prefill(greedy=False) left start + T - 1
@@ -186,6 +200,7 @@ class TPDecoder:
         if self.comm is None:
             raise RuntimeError("QBits: graph capture of a tensor-parallel step needs the device communicator")
         self.engine.capture(greedy=True)
+        self.check_status()
 
     def step(self, greedy=True, return_logits=True):
         """One token. greedy + return_logits=False is the production form: the next token is agreed from one
@@ -195,10 +210,15 @@ class TPDecoder:
 
         e = self.engine
         if self.comm is not None:
+            self._since_check += 1
+            if self._since_check >= self.CHECK_EVERY:
+                self.check_status()
             if greedy and not return_logits and e.captured:
                 e.replay(1)
                 return None
             e.step(greedy=greedy)  # all-reduces and, when greedy, the token exchange run inside the native step
+            if return_logits:
+                self.check_status()  # the host reads results here anyway
             return gather_logits(e.logits[:e.cfg.vocab], self.vocab, self.group) if return_logits else None
         e.step_tp(self.group, greedy=False)  # logits of this rank's vocab shard
         local = e.logits[:e.cfg.vocab]

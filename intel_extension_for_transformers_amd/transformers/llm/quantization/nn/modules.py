@@ -188,8 +188,12 @@ class QuantizedLinearQBits(torch.nn.Linear):
     def recover_qparms(self):
         """The reference's 12-tuple, in its orientation (modules.py:378-392): (group_size, in_features, out_features,
         desc_act, g_idx, weight_dtype, bits, scales_dtype, scales [N, G], zp, qzeros [N, G] | None, int_weight [N, K]).
-        4-bit integers and zero points are unsigned (:349-352), 8-bit zero points uint8 (:353-354)."""
+        Asymmetric 4-bit integers and zero points are unsigned (:349-352 adds 8 to the zero points only, and
+        quant_weight_w_scale adds the zero point to round(w / scale)); SYMMETRIC ones have no zero point there, so
+        the reference's int_weight is the signed round(w / scale) in [-8, 7]; 8-bit zero points uint8 (:353-354)."""
         int_weight, scales, zeros, g_idx = self.recover_qparms_kn()
+        if zeros is None and self.bits == 4:
+            int_weight = int_weight - 8  # recover_qparms_kn works in the unsigned domain throughout
         k, n = int_weight.shape
         group = int(qbits.acquire_packed_weight_info(self.weight.data, 1)[0])
         qzeros = None

@@ -290,7 +290,26 @@ def _engine_generate(self, inputs=None, generation_config=None, **kwargs):
     QuantizedLinearQBits modules) for everything else. Same return value as HF for the covered case: LongTensor
     [1, prompt + new]. The reference has no counterpart (its CPU path always runs the module-by-module loop); the
     precedent for swapping the loop after from_pretrained is ipex.optimize_transformers (docs/weightonlyquant.md:199)."""
-    hf_generate = self._woq_hf_generate
+    # reference greedy_search.py:148-150,374-377,408-409: config.token_latency (or model.token_latency) makes generate
+    # return (ids, latency_list), one wall-clock entry per generated token, the first one being the prompt pass
+    want_latency = bool(getattr(self.config, "token_latency", False) or getattr(self, "token_latency", False))
+    raw_hf_generate = self._woq_hf_generate
+
+    def hf_generate(*a, **kw):
+        """HF's loop over the quantised modules; with token_latency the whole call is timed and every new token
+        gets the average (HF's loop has no per-token hook without the reference's patched greedy_search)."""
+        if not want_latency:
+            return raw_hf_generate(*a, **kw)
+        import time
+
+        tic = time.time()
+        res = raw_hf_generate(*a, **kw)
+        torch.cuda.synchronize()
+        seq = res if torch.is_tensor(res) else res.sequences
+        n_prompt = ids.shape[1] if torch.is_tensor(ids) and ids.dim() == 2 else 0
+        n_new = max(int(seq.shape[1]) - int(n_prompt), 1)
+        return res, [(time.time() - tic) / n_new] * n_new
+
     ids = inputs if inputs is not None else kwargs.get("input_ids")
     gc = generation_config if generation_config is not None else self.generation_config
     opt = lambda k, d=None: kwargs[k] if k in kwargs else getattr(gc, k, d)  # noqa: E731
@@ -327,13 +346,17 @@ def _engine_generate(self, inputs=None, generation_config=None, **kwargs):
             self._woq_engine_off = True
             return hf_generate(inputs, generation_config=generation_config, **kwargs)
     if max_new < 1:
-        return ids
+        return (ids, []) if want_latency else ids
     eos = opt("eos_token_id")
     eos = set() if eos is None else set(eos if isinstance(eos, (list, tuple)) else [eos])
     streamer = kwargs.get("streamer")
     prompt = ids[0].tolist()
     if streamer is not None:
         streamer.put(ids.cpu())
+    import time
+
+    latency = []
+    tic = time.time()
     for s0 in range(0, n_in, 2048):
         eng.prefill(prompt[s0:s0 + 2048], start_pos=s0, greedy=True)
     eng.tune_attn_for(n_in + max_new)
@@ -342,7 +365,8 @@ def _engine_generate(self, inputs=None, generation_config=None, **kwargs):
     # Tokens are read back in bursts: the steps chain on the device and log their tokens (engine.token_log), so the
     # host synchronises once per burst instead of once per token. A stop token is noticed at the end of its burst —
     # the few steps run past it are discarded. With a streamer the burst is one token (latency first).
-    out = [int(eng.token.item())]  # the prompt pass's token
+    out = [int(eng.token.item())]  # the prompt pass's token (the .item() synchronises)
+    latency.append(time.time() - tic)
     if streamer is not None:
         streamer.put(torch.tensor(out))
     burst = 1 if streamer is not None else 16
@@ -351,9 +375,12 @@ def _engine_generate(self, inputs=None, generation_config=None, **kwargs):
     while not done and len(out) < max_new:
         k = min(burst, max_new - len(out))
         p0 = n_in + len(out) - 1  # position the next step feeds
+        tic = time.time()
         eng.replay(k)
-        new = log[p0:p0 + k].tolist()
+        new = log[p0:p0 + k].tolist()  # one host synchronisation per burst
+        per_token = (time.time() - tic) / k  # the burst's steps chain on the device: its tokens share the average
         for t in new:
+            latency.append(per_token)
             out.append(t)
             if streamer is not None:
                 streamer.put(torch.tensor([t]))
@@ -362,7 +389,8 @@ def _engine_generate(self, inputs=None, generation_config=None, **kwargs):
                 break
     if streamer is not None:
         streamer.end()
-    return torch.cat([ids, torch.tensor([out], dtype=ids.dtype, device=ids.device)], dim=1)
+    result = torch.cat([ids, torch.tensor([out], dtype=ids.dtype, device=ids.device)], dim=1)
+    return (result, latency[:len(out)]) if want_latency else result
 
 
 def _finish(model, qcfg):

@@ -146,7 +146,10 @@ def test_set_weights_bias_and_recover(method, sym, desc_act):
     t = m.recover_qparms()
     assert len(t) == 12 and t[0] == g and t[1] == K and t[2] == N and t[3] == desc_act and t[6] == 4 and t[9] == (not sym)
     assert t[5] == "int4_clip" and t[7] == torch.float32
-    assert np.array_equal(t[8].cpu().numpy(), s.T) and np.array_equal(t[11].cpu().numpy(), w_u.T)
+    assert np.array_equal(t[8].cpu().numpy(), s.T)
+    # symmetric: the reference's int_weight is the SIGNED round(w / scale) (no zero point to add, modules.py:356-372);
+    # asymmetric: unsigned (the +8 sits on the zero points, :349-352)
+    assert np.array_equal(t[11].cpu().numpy(), (w_u.astype(np.int16) - 8).T if sym else w_u.T)
     assert (t[10] is None) if sym else np.array_equal(t[10].cpu().numpy(), z_u.T)
 
 
@@ -176,6 +179,13 @@ def test_from_pretrained_llama_logits_generate_save_load(tmp_path, group, sym, s
     out = qmodel.generate(ids, max_new_tokens=8, do_sample=False)
     ref_out = twin.generate(ids, max_new_tokens=8, do_sample=False)
     assert torch.equal(out, ref_out)
+    # config.token_latency -> (ids, latency_list), one entry per generated token (reference greedy_search.py:148-150,
+    # 374-377,408-409; asserted by tests/CI/test_weight_only.py:173-183)
+    qmodel.config.token_latency = True
+    res = qmodel.generate(ids, max_new_tokens=8, do_sample=False)
+    qmodel.config.token_latency = False
+    assert len(res) == 2 and isinstance(res[1], list) and torch.equal(res[0], out)
+    assert len(res[1]) == out.shape[1] - ids.shape[1] and all(t > 0 for t in res[1])
     dst = tmp_path / "woq"
     qmodel.save_pretrained(str(dst))
     reloaded = AutoModelForCausalLM.from_pretrained(str(dst))

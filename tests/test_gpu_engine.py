@@ -408,3 +408,21 @@ def test_grouped_attention_long_slices_match_per_head_slices(rep, kv_dtype):
             e.step(greedy=False)
         la, lb = a.logits.cpu().numpy(), b.logits.cpu().numpy()
         assert np.abs(la - lb).max() <= 2e-3 * np.abs(lb).max() + 1e-4, j
+
+
+def test_step_beyond_max_ctx_is_flagged_and_stays_in_bounds():
+    """The position lives on the device (greedy chaining advances it there), so woq_engine_step / _replay cannot check
+    it: a step that starts at or beyond max_ctx runs at max_ctx - 1 instead and raises bit 1 of the sticky status —
+    no out-of-bounds KV-cache / RoPE-table / token-log access (round-2 ADVICE)."""
+    eng, _, cfg = _tiny(128, False, "fp16", max_ctx=16)
+    assert eng.status() == 0
+    eng.token.fill_(5)
+    eng.pos.fill_(14)
+    eng.capture(greedy=True)
+    eng.replay(1)   # position 14 -> 15: fine
+    assert eng.status() == 0 and int(eng.pos.item()) == 15
+    eng.replay(6)   # 15 is the last slot; the following steps start at 16 = max_ctx
+    torch.cuda.synchronize()
+    assert eng.status() & 2
+    assert int(eng.pos.item()) <= 16
+    assert torch.isfinite(eng.logits).all()

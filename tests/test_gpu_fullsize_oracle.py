@@ -201,7 +201,7 @@ def test_fused_qkv_attention_launch_equals_two_launches(kv_dtype):
         torch.cuda.synchronize()
         logs.append(eng.logits.clone())
         out[fused] = (torch.stack(logs), eng.token_log()[200:227].clone())
-    assert eng.fuse_status() == 0
+    assert eng.status() == 0
     assert torch.equal(out[True][0], out[False][0])
     assert torch.equal(out[True][1], out[False][1])
 

@@ -164,6 +164,28 @@ def test_generation_errors_surface_as_500_and_in_band_on_streams():
     assert ev[-1] == "[DONE]" and ev[-2] == {"text": "QBits: device lost", "error_code": 500}
 
 
+def test_slow_stream_consumer_still_sees_the_end_and_does_not_hold_the_engine():
+    """A client that reads slowly: the worker must not block on it (it would keep the engine lock for the whole
+    generation), and the end-of-stream marker must arrive however many pieces are still queued (round-2 ADVICE: a full
+    256-slot queue dropped the marker and the consumer waited forever)."""
+    import time
+
+    from intel_extension_for_transformers_amd.neural_chat.server.restful.textchat_api import router
+
+    bot = _Bot(reply=" ".join("w%d" % i for i in range(1000)))
+    create_app(bot)
+    gen = router._stream("p", None, [])
+    first = next(gen)
+    assert first == "w0 "
+    t0 = time.time()
+    while not router._gpu.acquire(blocking=False):  # the generation (1000 pieces) finishes without the consumer
+        assert time.time() - t0 < 5.0, "the worker is still holding the engine lock behind a slow consumer"
+        time.sleep(0.01)
+    router._gpu.release()
+    rest = list(gen)
+    assert len(rest) == 999 and rest[-1] == "w999"
+
+
 def test_deepspeed_fanout_is_refused():
     from intel_extension_for_transformers_amd.neural_chat.server.restful import TextChatAPIRouter
 
