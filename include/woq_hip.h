@@ -250,6 +250,13 @@ WOQ_API void woq_comm_destroy(woq_comm* c);
  * token id = vocab_offset + local argmax of this rank's lm_head rows), so woq_engine_capture / replay cover a whole
  * tensor-parallel token. The comm must outlive the engine's use of it. NULL = back to the callback / single GPU. */
 WOQ_API int woq_engine_set_comm(woq_engine* e, woq_comm* comm, int vocab_offset);
+/* tensor-parallel decode step with a bound device communicator. xq (default on, WOQ_TP_XQ=0 off): the ranks run the
+ * XQ decode kernels (csrc/woq_gemv_xqs.h) and the all-reduce kernel emits the next GEMV's XQ vector itself; off = the
+ * fp32-activation kernels. fused_push (default on, WOQ_TP_FUSED_PUSH=0 off; XQ path only): the row-parallel GEMVs
+ * (o_proj, down_proj) store their partial sums into the peers' inboxes from their own epilogue, so the fabric flight runs
+ * under the kernel boundary and the all-reduce kernel only pulls and sums; off = the all-reduce kernel pushes (the A/B
+ * twin; results are bit-identical). Takes effect at the next step / capture. */
+WOQ_API int woq_engine_set_tp_options(woq_engine* e, int xq, int fused_push);
 /* run only the kernels of one sub-block, for TP where the collective is issued by the host
  * between them: phase 0 = embed + attention block up to o_proj partial, 1 = MLP block up to
  * down partial, 2 = head. layer ignored for phase 2. */

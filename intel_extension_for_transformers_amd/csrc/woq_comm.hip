@@ -29,48 +29,22 @@
 #include "woq_device.h"
 #include "woq_launch.h"
 
-#define WOQ_COMM_MAX_WORLD 8
+#include "woq_comm_dev.h"
+#include "woq_xq.h"
 
 namespace woq {
 
-struct CommDev {
-  uint64_t* peer[WOQ_COMM_MAX_WORLD];  // inbox base of every rank (peer[rank] = the local one)
-  uint32_t* ctl;                       // [0] sequence number, [1] arrival ticket, [2] status (0 ok, else timeouts seen)
-  int rank, world;
-  uint32_t max_elems;
-  uint32_t timeout_ticks;              // wall_clock64 ticks (100 MHz)
-};
-
-__device__ __forceinline__ size_t ar_slot(const CommDev& c, int buf, int sender, uint32_t i) {
-  return ((size_t)buf * c.world + sender) * c.max_elems + i;
-}
-__device__ __forceinline__ size_t am_slot(const CommDev& c, int buf, int sender, int j) {
-  return (size_t)2 * c.world * c.max_elems + ((size_t)buf * c.world + sender) * 2 + j;
-}
-__device__ __forceinline__ void push(uint64_t* p, uint32_t payload, uint32_t tag) {
-  __hip_atomic_store(p, ((uint64_t)tag << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-// spin until the granule carries `tag`; false on timeout
-__device__ __forceinline__ bool pull(const uint64_t* p, uint32_t tag, uint64_t t0, uint32_t limit, uint32_t& payload) {
-  for (int spins = 1;; ++spins) {
-    const uint64_t g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if ((uint32_t)(g >> 32) == tag) {
-      payload = (uint32_t)g;
-      return true;
-    }
-    if ((spins & 31) == 0 && wall_clock64() - t0 > limit) {
-      payload = 0;
-      return false;
-    }
-    __builtin_amdgcn_s_sleep(1);
-  }
-}
-// 0 is never a live tag; on the wrap 0xffffffff (odd) -> 2 (even), so consecutive collectives still alternate buffers
-__device__ __forceinline__ uint32_t next_seq(uint32_t s) { return s + 1 == 0 ? 2 : s + 1; }
-
 // in-place sum over ranks of buf[0..n). grid = ceil(n / 1024) x 256 threads, 4 elements per thread (stride 256: every
 // store instruction of a wave covers 512 contiguous bytes of one peer's inbox).
-__global__ __launch_bounds__(256) void allreduce_ll_kernel(CommDev c, float* __restrict__ buf, uint32_t n) {
+//   PUSHED: this rank's contribution is already on its way — the kernel that produced `buf` stored it into the peers'
+//           inboxes from its own epilogue (woq_gemv_xqs.h: the 16 epilogue lanes of every column strip), so the fabric
+//           flight runs under the kernel boundary instead of after it; this kernel only pulls and sums.
+//   XQ:     the summed vector also leaves as the next GEMV's XQ input (woq_xq.h): times `norm_w`, per-block sums of
+//           squares of the raw sums in `ssq_out` — thread t holds 16 consecutive elements per DPP row for each j.
+template <bool PUSHED, bool XQ>
+__global__ __launch_bounds__(256) void allreduce_ll_kernel(CommDev c, float* __restrict__ buf, uint32_t n,
+                                                           const float* __restrict__ norm_w, XqPtrs xo,
+                                                           float* __restrict__ ssq_out) {
   // the grid size is read HERE and kept in a register: left to itself hipcc loads it from the kernel-argument segment
   // at the tail and recycles the segment pointer right behind the load (the pattern of DESIGN.md §3.3's trap)
   uint32_t nblk = gridDim.x;
@@ -84,12 +58,14 @@ __global__ __launch_bounds__(256) void allreduce_ll_kernel(CommDev c, float* __r
     const uint32_t i = i0 + j * 256u;
     mine[j] = i < n ? buf[i] : 0.f;
   }
-  for (int r = 0; r < c.world; ++r) {
-    if (r == c.rank) continue;
+  if constexpr (!PUSHED) {
+    for (int r = 0; r < c.world; ++r) {
+      if (r == c.rank) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t i = i0 + j * 256u;
-      if (i < n) push(c.peer[r] + ar_slot(c, b, c.rank, i), __float_as_uint(mine[j]), seq);
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t i = i0 + j * 256u;
+        if (i < n) push(c.peer[r] + ar_slot(c, b, c.rank, i), __float_as_uint(mine[j]), seq);
+      }
     }
   }
   const uint64_t t0 = wall_clock64();
@@ -113,6 +89,15 @@ __global__ __launch_bounds__(256) void allreduce_ll_kernel(CommDev c, float* __r
   for (int j = 0; j < 4; ++j) {
     const uint32_t i = i0 + j * 256u;
     if (i < n) buf[i] = acc[j];
+    if constexpr (XQ) {  // n is a multiple of 16 (checked by the launcher): whole DPP rows are live or dead together
+      if (i < n) {
+        if (ssq_out != nullptr) {
+          const float ss = row16_sum(acc[j] * acc[j]);
+          if ((i & 15u) == 0) ssq_out[i >> 4] = ss;
+        }
+        xq_emit16(norm_w != nullptr ? acc[j] * norm_w[i] : acc[j], xo, (int)(i >> 4), (int)(i & 15u));
+      }
+    }
   }
   if (!ok) atomicOr(&c.ctl[2], 1u);
   __syncthreads();
@@ -199,6 +184,7 @@ __global__ __launch_bounds__(1024) void tp_greedy_kernel(CommDev c, const float*
 
 struct woq_comm {
   woq::CommDev dev;
+  woq::CommDev* dev_copy = nullptr;  // the same record in device memory, for kernels that take it by pointer
   size_t inbox_bytes = 0;
   void* opened[WOQ_COMM_MAX_WORLD] = {};
   hipIpcMemHandle_t handle;
@@ -207,14 +193,43 @@ struct woq_comm {
 
 size_t woq_comm_max_elems(woq_comm* c) { return c ? c->dev.max_elems : 0; }
 
+static const woq::XqPtrs kCommNoXq = {nullptr, nullptr, nullptr};
+
 int woq_comm_launch_allreduce(woq_comm* c, float* buf, size_t n, hipStream_t st) {
   if (!c || !c->connected) return woq::fail("QBits: tensor-parallel communicator is not connected");
   if (n > c->dev.max_elems) return woq::fail("QBits: all-reduce larger than the communicator's inbox");
   if (c->dev.world == 1 || n == 0) return 0;
-  hipLaunchKernelGGL(woq::allreduce_ll_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, c->dev, buf,
-                     (uint32_t)n);
+  hipLaunchKernelGGL((woq::allreduce_ll_kernel<false, false>), dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st,
+                     c->dev, buf, (uint32_t)n, (const float*)nullptr, kCommNoXq, (float*)nullptr);
   return 0;
 }
+
+// the engine's form: `pushed` = the producing GEMV already stored this rank's contribution into the peers' inboxes
+// (woq_comm_dev_ptr), `xo` (optional) = the summed vector also as an XQ vector (times norm_w, sums of squares in ssq_out)
+int woq_comm_launch_allreduce_ex(woq_comm* c, float* buf, size_t n, int pushed, const float* norm_w,
+                                 const woq::XqPtrs& xo, float* ssq_out, hipStream_t st) {
+  if (!c || !c->connected) return woq::fail("QBits: tensor-parallel communicator is not connected");
+  if (n > c->dev.max_elems) return woq::fail("QBits: all-reduce larger than the communicator's inbox");
+  if (n == 0) return 0;
+  const bool xq = xo.limbs != nullptr;
+  if (xq && (n & 15) != 0) return woq::fail("QBits: an XQ-emitting all-reduce needs a multiple of 16 elements");
+  const dim3 grid((unsigned)((n + 1023) / 1024));
+#define WOQ_AR_CASE(P, X)                                                                                         \
+  if ((pushed != 0) == P && xq == X) {                                                                             \
+    hipLaunchKernelGGL((woq::allreduce_ll_kernel<P, X>), grid, dim3(256), 0, st, c->dev, buf, (uint32_t)n, norm_w, \
+                       xo, ssq_out);                                                                                \
+    return 0;                                                                                                      \
+  }
+  WOQ_AR_CASE(false, false)
+  WOQ_AR_CASE(false, true)
+  WOQ_AR_CASE(true, false)
+  WOQ_AR_CASE(true, true)
+#undef WOQ_AR_CASE
+  return 0;
+}
+
+// device-resident copy of the communicator record (peer inboxes, sequence word, rank / world), valid once connected
+const woq::CommDev* woq_comm_dev_ptr(woq_comm* c) { return c && c->connected ? c->dev_copy : nullptr; }
 
 int woq_comm_launch_greedy(woq_comm* c, const float* pmax, const int32_t* pidx, int n, int vocab_offset,
                            int32_t* token, int32_t* pos, int32_t* log, hipStream_t st) {
@@ -295,6 +310,8 @@ int woq_comm_connect(woq_comm* c, const void* handles, const int* peer_devices) 
     c->opened[r] = p;
     c->dev.peer[r] = (uint64_t*)p;
   }
+  if (c->dev_copy == nullptr) WOQ_HIP(hipMalloc((void**)&c->dev_copy, sizeof(woq::CommDev)));
+  WOQ_HIP(hipMemcpy(c->dev_copy, &c->dev, sizeof(woq::CommDev), hipMemcpyHostToDevice));
   c->connected = true;
   WOQ_END
 }
@@ -321,6 +338,8 @@ int woq_comm_set_timeout_ms(woq_comm* c, int ms) {
   WOQ_TRY
   WOQ_CHECK(c && ms >= 1 && ms <= 20000, "QBits: communicator timeout must be 1..20000 ms");
   c->dev.timeout_ticks = (uint32_t)ms * 100000u;
+  if (c->dev_copy != nullptr)
+    WOQ_HIP(hipMemcpy(c->dev_copy, &c->dev, sizeof(woq::CommDev), hipMemcpyHostToDevice));
   WOQ_END
 }
 
@@ -330,6 +349,7 @@ void woq_comm_destroy(woq_comm* c) {
     if (c->opened[r]) hipIpcCloseMemHandle(c->opened[r]);
   if (c->dev.peer[c->dev.rank]) hipFree(c->dev.peer[c->dev.rank]);
   if (c->dev.ctl) hipFree(c->dev.ctl);
+  if (c->dev_copy) hipFree(c->dev_copy);
   delete c;
 }
 

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "woq_comm_dev.h"
 #include "woq_device.h"
 #include "woq_launch.h"
 #include "woq_xq.h"
@@ -33,7 +34,7 @@ int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtyp
 bool gemv_xq_supported(const woq_blob_header& h, int epi);
 int launch_gemv_xq(const XqPtrs& xin, const void* blob, const woq_blob_header& h, const float* bias, float* out,
                    const float* ssq_in, float eps, const float* residual, int epi, const XqPtrs& xo,
-                   const float* next_norm_w, float* ssq_out, hipStream_t st);
+                   const float* next_norm_w, float* ssq_out, hipStream_t st, const CommDev* tp);
 // [RMSNorm + qkv GEMV] + [RoPE + KV append + attention] in one launch (woq_gemv_attn.hip)
 bool gemv_xq_attn_supported(const woq_blob_header& h, int heads, int kv_heads, int head_dim, int kv_dtype, int max_ctx,
                             int window, int splits);
@@ -65,6 +66,9 @@ void launch_gather_last(const float* h, int n_seq, int T, int hidden, float* dst
 }  // namespace woq
 // device-side tensor-parallel exchange (woq_comm.hip)
 int woq_comm_launch_allreduce(woq_comm* c, float* buf, size_t n, hipStream_t st);
+int woq_comm_launch_allreduce_ex(woq_comm* c, float* buf, size_t n, int pushed, const float* norm_w,
+                                 const woq::XqPtrs& xo, float* ssq_out, hipStream_t st);
+const woq::CommDev* woq_comm_dev_ptr(woq_comm* c);
 int woq_comm_launch_greedy(woq_comm* c, const float* pmax, const int32_t* pidx, int n, int vocab_offset,
                            int32_t* token, int32_t* pos, int32_t* log, hipStream_t st);
 
@@ -106,7 +110,14 @@ struct woq_engine {
   unsigned int* step_seq = nullptr;
   int* fuse_status = nullptr;
   bool fuse_attn = true;             // qkv GEMV + attention in one launch where the shape allows (woq_gemv_attn.hip)
-  bool use_xq() const { return xq_enabled && xq_shapes_ok && xq_hidden.limbs != nullptr && cfg.tp_size <= 1; }
+  // tensor parallel ranks take the XQ path when the exchange runs on the device (its all-reduce kernel then emits the
+  // next XQ vector itself); with a host-side transport they keep the fp32-activation kernels
+  bool tp_xq = true, tp_fused_push = true;
+  bool use_xq() const {
+    return xq_shapes_ok && xq_hidden.limbs != nullptr &&
+           (cfg.tp_size <= 1 ? xq_enabled : (tp_xq && comm != nullptr && allreduce == nullptr));
+  }
+  const woq::CommDev* tp_push() const;  // where the row-parallel GEMVs push their partial sums (null = nowhere)
   woq_comm* comm = nullptr;  // device-side exchange: all-reduce kernels inside the (capturable) decode step
   int vocab_offset = 0;      // first vocabulary row of this rank's lm_head shard
   int nt = 1;
@@ -132,6 +143,10 @@ struct woq_engine {
 
 using namespace woq;
 
+const woq::CommDev* woq_engine::tp_push() const {
+  return cfg.tp_size > 1 && comm != nullptr && tp_fused_push ? woq_comm_dev_ptr(comm) : nullptr;
+}
+
 static const XqPtrs kNoXq = {nullptr, nullptr, nullptr};
 
 // WOQ_ENGINE_SKIP=<bit mask>: leave launches out of the XQ decode step — timing experiments only (the step's results
@@ -147,8 +162,21 @@ static int engine_skip_mask() {
 // one batch-1 projection over an XQ vector
 static int engine_gemv_xq(woq_engine* e, const XqPtrs& xin, const void* blob, const woq_blob_header& h, float* out,
                           const float* ssq_in, const float* residual, int epi, const XqPtrs& xo,
-                          const float* next_norm_w, float* ssq_out, hipStream_t st) {
-  return launch_gemv_xq(xin, blob, h, nullptr, out, ssq_in, e->cfg.rms_eps, residual, epi, xo, next_norm_w, ssq_out, st);
+                          const float* next_norm_w, float* ssq_out, hipStream_t st, const CommDev* tp = nullptr) {
+  return launch_gemv_xq(xin, blob, h, nullptr, out, ssq_in, e->cfg.rms_eps, residual, epi, xo, next_norm_w, ssq_out, st,
+                        tp);
+}
+
+// The row-parallel projection that ends a sub-block (o_proj / down_proj), XQ path. One GPU: hidden += x . W, and the new
+// hidden leaves as the next GEMV's XQ input. Tensor parallel: hidden = this rank's partial sum (rank 0 carries the
+// residual), pushed into the peers' inboxes from the epilogue; the all-reduce that follows emits the XQ vector.
+static int engine_row_parallel_xq(woq_engine* e, const XqPtrs& xin, const void* blob, const woq_blob_header& h,
+                                  const XqPtrs& xo, const float* next_norm_w, float* ssq_out, hipStream_t st) {
+  const woq_engine_config& c = e->cfg;
+  if (c.tp_size <= 1)
+    return engine_gemv_xq(e, xin, blob, h, e->hidden, nullptr, e->hidden, 0, xo, next_norm_w, ssq_out, st);
+  return engine_gemv_xq(e, xin, blob, h, e->hidden, nullptr, c.tp_rank == 0 ? e->hidden : nullptr, 0, kNoXq, nullptr,
+                        nullptr, st, e->tp_push());
 }
 
 // XQ form of the two sub-blocks: the same five launches, activations handed over as limb blocks
@@ -167,8 +195,7 @@ static int engine_attn_block_xq(woq_engine* e, int l, hipStream_t st) {
                              e->xq_attn, st);
     if (rc) return rc;
     if (skip & 4) return 0;
-    return engine_gemv_xq(e, e->xq_attn, w.o_blob, w.o_hdr, e->hidden, nullptr, e->hidden, 0, e->xq_hidden, w.ln2,
-                          e->ssq_part, st);
+    return engine_row_parallel_xq(e, e->xq_attn, w.o_blob, w.o_hdr, e->xq_hidden, w.ln2, e->ssq_part, st);
   }
   if (!(skip & 1))
     rc = engine_gemv_xq(e, e->xq_hidden, w.qkv_blob, w.qkv_hdr, e->qkv, e->ssq_part, nullptr, 0, kNoXq, nullptr, nullptr,
@@ -182,8 +209,7 @@ static int engine_attn_block_xq(woq_engine* e, int l, hipStream_t st) {
   if (rc) return rc;
   if (skip & 4) return 0;
   // hidden += attn . W_o ; the new hidden leaves as the MLP's XQ input (times ln2) with its sums of squares
-  return engine_gemv_xq(e, e->xq_attn, w.o_blob, w.o_hdr, e->hidden, nullptr, e->hidden, 0, e->xq_hidden, w.ln2,
-                        e->ssq_part, st);
+  return engine_row_parallel_xq(e, e->xq_attn, w.o_blob, w.o_hdr, e->xq_hidden, w.ln2, e->ssq_part, st);
 }
 
 static int engine_mlp_block_xq(woq_engine* e, int l, hipStream_t st) {
@@ -197,9 +223,8 @@ static int engine_mlp_block_xq(woq_engine* e, int l, hipStream_t st) {
   if (rc) return rc;
   if (skip & 16) return 0;
   const bool last = l + 1 == c.layers;  // the last layer's output feeds the head, which reads fp32
-  return engine_gemv_xq(e, e->xq_act, w.down_blob, w.down_hdr, e->hidden, nullptr, e->hidden, 0,
-                        last ? kNoXq : e->xq_hidden, last ? nullptr : e->layers[l + 1].ln1, last ? nullptr : e->ssq_part,
-                        st);
+  return engine_row_parallel_xq(e, e->xq_act, w.down_blob, w.down_hdr, last ? kNoXq : e->xq_hidden,
+                                last ? nullptr : e->layers[l + 1].ln1, last ? nullptr : e->ssq_part, st);
 }
 
 static int engine_attn_block(woq_engine* e, int l, hipStream_t st) {
@@ -243,9 +268,21 @@ static int engine_head(woq_engine* e, int greedy, hipStream_t st) {
   return 0;
 }
 
-// sum of the row-parallel partials over the tensor-parallel ranks, in place on `buf`
-static int engine_allreduce(woq_engine* e, float* buf, size_t count, hipStream_t st) {
-  if (e->comm && e->cfg.tp_size > 1) return woq_comm_launch_allreduce(e->comm, buf, count, st);
+// sum of the row-parallel partials over the tensor-parallel ranks, in place on the residual stream, after sub-block
+// `which` (0 attention, 1 MLP) of layer l. XQ path: the producing GEMV already pushed this rank's share (tp_push) and
+// the summed vector leaves as the next GEMV's XQ input as well.
+static int engine_allreduce_after(woq_engine* e, int l, int which, hipStream_t st) {
+  const woq_engine_config& c = e->cfg;
+  if (c.tp_size <= 1) return 0;
+  if (e->comm && e->use_xq()) {
+    const bool last = which == 1 && l + 1 == c.layers;
+    const float* nw = which == 0 ? e->layers[l].ln2 : (last ? nullptr : e->layers[l + 1].ln1);
+    return woq_comm_launch_allreduce_ex(e->comm, e->hidden, (size_t)c.hidden, e->tp_push() != nullptr ? 1 : 0, nw,
+                                        last ? kNoXq : e->xq_hidden, last ? nullptr : e->ssq_part, st);
+  }
+  float* buf = e->hidden;
+  const size_t count = (size_t)c.hidden;
+  if (e->comm) return woq_comm_launch_allreduce(e->comm, buf, count, st);
   if (e->allreduce && e->allreduce(e->allreduce_user, buf, count, st) != 0)
     return woq::fail("QBits: tensor-parallel all-reduce callback failed");
   return 0;
@@ -283,10 +320,10 @@ static int engine_step_impl(woq_engine* e, int greedy, hipStream_t st) {
   for (int l = 0; l < c.layers; ++l) {
     int rc = engine_attn_block(e, l, st);
     if (rc) return rc;
-    if ((rc = engine_allreduce(e, e->hidden, (size_t)c.hidden, st)) != 0) return rc;
+    if ((rc = engine_allreduce_after(e, l, 0, st)) != 0) return rc;
     rc = engine_mlp_block(e, l, st);
     if (rc) return rc;
-    if ((rc = engine_allreduce(e, e->hidden, (size_t)c.hidden, st)) != 0) return rc;
+    if ((rc = engine_allreduce_after(e, l, 1, st)) != 0) return rc;
   }
   return engine_head(e, greedy, st);
 }
@@ -431,6 +468,13 @@ int woq_engine_set_attn_grouped(woq_engine* e, int on) {
   WOQ_END
 }
 int woq_engine_attn_grouped(woq_engine* e) { return e ? e->attn_grouped : 0; }
+int woq_engine_set_tp_options(woq_engine* e, int xq, int fused_push) {
+  WOQ_TRY
+  WOQ_CHECK(e != nullptr, "QBits: null engine");
+  e->tp_xq = xq != 0;
+  e->tp_fused_push = fused_push != 0;
+  WOQ_END
+}
 int woq_engine_set_fuse_attn(woq_engine* e, int on) {
   WOQ_TRY
   WOQ_CHECK(e != nullptr, "QBits: null engine");
@@ -506,6 +550,10 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
     e->xq_enabled = sw ? sw[0] != '0' : cfg->hidden <= 4096;
     const char* fa = getenv("WOQ_ENGINE_FUSE_ATTN");
     e->fuse_attn = fa ? fa[0] != '0' : true;
+    const char* tx = getenv("WOQ_TP_XQ");
+    e->tp_xq = tx ? tx[0] != '0' : true;
+    const char* tf = getenv("WOQ_TP_FUSED_PUSH");
+    e->tp_fused_push = tf ? tf[0] != '0' : true;
     const int attn_k = cfg->heads * cfg->head_dim;
     if ((cfg->hidden % 16) == 0 && (attn_k % 16) == 0 && (cfg->inter % 16) == 0) {
       void *bh = nullptr, *ba = nullptr, *bc = nullptr;

@@ -26,6 +26,7 @@ struct XqLaunch {
   XqPtrs xo;
   const float* next_norm_w;
   float* ssq_out;
+  const CommDev* tp;  // tensor parallel: push the outputs (partial sums) into the peers' inboxes from the epilogue
   int nw, grid, kt_begin, kt_count;
 };
 
@@ -50,7 +51,7 @@ static int launch_xq_t(const XqLaunch& a, hipStream_t st) {
   const int base = a.kt_count / a.nw, rem = a.kt_count % a.nw;
   hipLaunchKernelGGL(kern, dim3(a.grid), dim3(a.nw * 64), lds, st, (const u32x4*)a.q, a.scales, a.xin.limbs, a.xin.u,
                      a.tiles_k, a.kt_begin, base, rem, a.n_groups, a.tpg_shift, (const uint8_t*)a.zp, a.xin.sx, a.out,
-                     a.bias, a.residual, a.eps, a.N, a.K, a.flags, a.ssq_in, a.n_ssq, a.xo, a.next_norm_w, a.ssq_out);
+                     a.bias, a.residual, a.eps, a.N, a.K, a.flags, a.ssq_in, a.n_ssq, a.xo, a.next_norm_w, a.ssq_out, a.tp);
   return 0;
 }
 
@@ -110,7 +111,7 @@ bool gemv_xq_supported(const woq_blob_header& h, int epi) {
 // multiplying by next_norm_w (optional), with its per-block sums of squares in ssq_out (optional).
 int launch_gemv_xq(const XqPtrs& xin, const void* blob, const woq_blob_header& h, const float* bias, float* out,
                    const float* ssq_in, float eps, const float* residual, int epi, const XqPtrs& xo,
-                   const float* next_norm_w, float* ssq_out, hipStream_t st) {
+                   const float* next_norm_w, float* ssq_out, hipStream_t st, const CommDev* tp) {
   if (!gemv_xq_supported(h, epi)) return woq::fail("QBits: shape not covered by the XQ GEMV");
   XqLaunch a;
   const uint8_t* b = (const uint8_t*)blob;
@@ -156,6 +157,7 @@ int launch_gemv_xq(const XqPtrs& xin, const void* blob, const woq_blob_header& h
     a.residual = c == 0 ? residual : out;  // chunk c > 0 adds onto the previous chunk's output
     a.ssq_in = ssq_in;
     a.xo = last ? xo : XqPtrs{nullptr, nullptr, nullptr};
+    a.tp = last ? tp : nullptr;
     int rc;
     if (cb == 2)
       rc = tpw == 4 ? launch_xq_sm<4, 2>(a, smode, asym, s32, st) : launch_xq_sm<8, 2>(a, smode, asym, s32, st);
@@ -169,11 +171,11 @@ int launch_gemv_xq(const XqPtrs& xin, const void* blob, const woq_blob_header& h
 // ---- measurement twins (bench.py roofline.ceiling): what THIS launch structure reaches with the arithmetic taken out --
 // load-only twin: the same grid, waves, K slices and non-temporal 16-byte requests as the GEMV of this blob, nothing else
 template <int TPW, int CB>
-__global__ __launch_bounds__(1024) void gemv_stream_twin_kernel(const u32x4* __restrict__ q, int tiles_k,
+__global__ __launch_bounds__(1024) void gemv_stream_twin_kernel(const u32x4* __restrict__ q, int tiles_k, int kt_off,
                                                                 int base_tiles, int rem_tiles,
                                                                 unsigned int* __restrict__ sink) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int kt0 = wid * base_tiles + min(wid, rem_tiles);
+  const int kt0 = kt_off + wid * base_tiles + min(wid, rem_tiles);
   const int cnt = base_tiles + (wid < rem_tiles ? 1 : 0);
   u32x4 acc = {0, 0, 0, 0};
   u32x4 w[CB][TPW];
@@ -197,23 +199,30 @@ __global__ void gemv_empty_twin_kernel(unsigned int* __restrict__ sink) {
 // mode 0: load-only twin of the batch-1 GEMV of this blob; mode 1: an empty kernel on the same grid and block
 int launch_gemv_twin(const void* blob, const woq_blob_header& h, int epi, int mode, unsigned int* sink, hipStream_t st) {
   const int tiles_k = h.Kpad / WOQ_TILE_K, tiles_n = h.Npad / WOQ_TILE_N, cb = epi == 1 ? 2 : 1;
-  int nw, tpw;
-  if (!xq_geometry(tiles_k, cb, (int)h.scale_mode, nw, tpw)) return woq::fail("QBits: shape not covered by the XQ GEMV");
-  const int base = tiles_k / nw, rem = tiles_k % nw;
+  const int chunks = xq_k_chunks(tiles_k, cb, (int)h.scale_mode, epi == 0);
+  if (chunks == 0) return woq::fail("QBits: shape not covered by the XQ GEMV");
+  const int per = (tiles_k + chunks - 1) / chunks;
   const u32x4* q = (const u32x4*)((const uint8_t*)blob + h.off_q);
-  const dim3 grid(tiles_n / cb), block(nw * 64);
-  if (mode == 1) {
-    hipLaunchKernelGGL(gemv_empty_twin_kernel, grid, block, 0, st, sink);
-  } else if (cb == 2) {
-    if (tpw == 4)
-      hipLaunchKernelGGL((gemv_stream_twin_kernel<4, 2>), grid, block, 0, st, q, tiles_k, base, rem, sink);
-    else
-      hipLaunchKernelGGL((gemv_stream_twin_kernel<8, 2>), grid, block, 0, st, q, tiles_k, base, rem, sink);
-  } else {
-    if (tpw == 4)
-      hipLaunchKernelGGL((gemv_stream_twin_kernel<4, 1>), grid, block, 0, st, q, tiles_k, base, rem, sink);
-    else
-      hipLaunchKernelGGL((gemv_stream_twin_kernel<8, 1>), grid, block, 0, st, q, tiles_k, base, rem, sink);
+  for (int c = 0; c < chunks; ++c) {  // K ranges beyond one launch: the same chained launches as the GEMV
+    const int kt_begin = c * per, kt_count = std::min(per, tiles_k - kt_begin);
+    if (kt_count <= 0) break;
+    int nw, tpw;
+    if (!xq_geometry(kt_count, cb, (int)h.scale_mode, nw, tpw)) return woq::fail("QBits: shape not covered by the XQ GEMV");
+    const int base = kt_count / nw, rem = kt_count % nw;
+    const dim3 grid(tiles_n / cb), block(nw * 64);
+    if (mode == 1) {
+      hipLaunchKernelGGL(gemv_empty_twin_kernel, grid, block, 0, st, sink);
+    } else if (cb == 2) {
+      if (tpw == 4)
+        hipLaunchKernelGGL((gemv_stream_twin_kernel<4, 2>), grid, block, 0, st, q, tiles_k, kt_begin, base, rem, sink);
+      else
+        hipLaunchKernelGGL((gemv_stream_twin_kernel<8, 2>), grid, block, 0, st, q, tiles_k, kt_begin, base, rem, sink);
+    } else {
+      if (tpw == 4)
+        hipLaunchKernelGGL((gemv_stream_twin_kernel<4, 1>), grid, block, 0, st, q, tiles_k, kt_begin, base, rem, sink);
+      else
+        hipLaunchKernelGGL((gemv_stream_twin_kernel<8, 1>), grid, block, 0, st, q, tiles_k, kt_begin, base, rem, sink);
+    }
   }
   return 0;
 }

@@ -21,6 +21,7 @@
 //   * what only the 16 epilogue lanes need (residual, next norm weight, RMSNorm partials) is requested by wave 0 only,
 //     up front, so nothing in the serial tail waits on memory.
 #pragma once
+#include "woq_comm_dev.h"
 #include "woq_gemv_common.h"
 #include "woq_xq.h"
 
@@ -101,7 +102,7 @@ __device__ __forceinline__ void gemv_xqs_body(
     int rem_tiles, int n_groups, int tpg_shift, const uint8_t* __restrict__ zp, const float* __restrict__ xsx,
     float* __restrict__ out, const float* __restrict__ bias, const float* residual, float eps, int N, int K, int flags,
     const float* __restrict__ ssq_in, int n_ssq, const XqPtrs& xo, const float* __restrict__ next_norm_w,
-    float* __restrict__ ssq_out, unsigned int fused_tag = 0u) {
+    float* __restrict__ ssq_out, unsigned int fused_tag = 0u, const CommDev* __restrict__ tp = nullptr) {
   typedef XqsLds<TPW, CB, SMODE, ASYM, S32> L;
   constexpr int ESZ = L::ESZ;
   constexpr int DD = D < TPW ? D : TPW;  // tiles requested before the first one is consumed
@@ -349,6 +350,16 @@ __device__ __forceinline__ void gemv_xqs_body(
     }
     const bool live = n < (silu ? (N >> 1) : N);
     v = live ? v + e_res : 0.f;
+    if (tp != nullptr && live) {
+      // tensor parallel, row-parallel projection: this value is one rank's PARTIAL sum. Store it into every peer's
+      // inbox right here ({fp32, tag} granule, system scope — woq_comm.hip's protocol, tag = the sequence number of
+      // the all-reduce that follows): the fabric flight runs under the kernel boundary, the all-reduce kernel only
+      // pulls and sums (allreduce_ll_kernel<PUSHED>)
+      const unsigned int seq = tp->ctl[0];
+      const int world = tp->world, rank = tp->rank;
+      for (int r = 0; r < world; ++r)
+        if (r != rank) push(tp->peer[r] + ar_slot(*tp, (int)(seq & 1u), rank, (unsigned int)n), __float_as_uint(v), seq);
+    }
     if (live && out) {
       if constexpr (FUSED)
         __hip_atomic_store((unsigned long long*)out + n, ((unsigned long long)fused_tag << 32) | __float_as_uint(v),
@@ -377,11 +388,11 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_xqs_kernel(
     const uint8_t* __restrict__ zp, const float* __restrict__ xsx, float* __restrict__ out,
     const float* __restrict__ bias, const float* residual, float eps, int N, int K, int flags,
     const float* __restrict__ ssq_in, int n_ssq, XqPtrs xo, const float* __restrict__ next_norm_w,
-    float* __restrict__ ssq_out) {
+    float* __restrict__ ssq_out, const CommDev* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   gemv_xqs_body<TPW, CB, D, SMODE, ASYM, S32, false>(smem_raw, q, scales, xlimbs, xu, tiles_k, kt_off, base_tiles,
                                                       rem_tiles, n_groups, tpg_shift, zp, xsx, out, bias, residual, eps,
-                                                      N, K, flags, ssq_in, n_ssq, xo, next_norm_w, ssq_out);
+                                                      N, K, flags, ssq_in, n_ssq, xo, next_norm_w, ssq_out, 0u, tp);
 }
 
 }  // namespace woq

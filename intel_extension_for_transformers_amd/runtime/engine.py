@@ -221,6 +221,14 @@ class WoqDecoderEngine:
             L.check(L.lib().woq_engine_set_attn_grouped(self._h, int(bool(on))))
             self.captured = False
 
+    def set_tp_options(self, xq=True, fused_push=True):
+        """Tensor-parallel decode with a device communicator: `xq` = the XQ decode kernels with an XQ-emitting
+        all-reduce kernel (off: the fp32-activation kernels), `fused_push` = o_proj / down_proj push their partial sums
+        into the peers' inboxes from their own epilogue (off: the all-reduce kernel pushes; bit-identical results).
+        Invalidates a captured graph."""
+        L.check(L.lib().woq_engine_set_tp_options(self._h, int(bool(xq)), int(bool(fused_push))))
+        self.captured = False
+
     def set_fuse_attn(self, on):
         """Decode step: qkv GEMV + attention as one launch where the shape allows (csrc/woq_gemv_attn.hip; default
         on). Invalidates a captured graph."""

@@ -107,7 +107,37 @@ def _rank_main(rank, world, port, errfile):
 
         layers, embed, lm, norm = _full_model()
         oracle = _oracle(layers, embed, lm, norm)
+        # --- the XQ decode kernels under tensor parallelism (default): the row-parallel GEMVs push their partial sums
+        # into the peers' inboxes from their epilogue and the all-reduce kernel only pulls, sums and emits the next XQ
+        # vector — against the A/B twin where the all-reduce kernel pushes: bit-identical logits, eager and replayed
+        xa = _rank_engine(rank, world, layers, embed, lm, norm)
+        xb = _rank_engine(rank, world, layers, embed, lm, norm)
+        da, db = TPDecoder(xa, CFG["vocab"], comm=comm), TPDecoder(xb, CFG["vocab"], comm=comm)
+        xa.set_tp_options(xq=True, fused_push=True)
+        xb.set_tp_options(xq=True, fused_push=False)
+        assert xa.uses_xq() and xb.uses_xq()
+        for i, tok in enumerate([3, 17, 200, 5, 99]):
+            ref = oracle.forward_token(tok, i)
+            outs = []
+            for e, d in ((xa, da), (xb, db)):  # the two engines take turns on the one communicator
+                e.token.fill_(tok)
+                e.pos.fill_(i)
+                outs.append(d.step(greedy=True).cpu().numpy())
+            assert np.array_equal(outs[0], outs[1]), i
+            assert np.abs(outs[0] - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-4 and outs[0].argmax() == ref.argmax()
+        nxt, p = int(ref.argmax()), 5
+        da.capture()
+        for j in range(5):
+            da.step(greedy=True, return_logits=False)
+            ref = oracle.forward_token(nxt, p)
+            nxt, p = int(ref.argmax()), p + 1
+            assert int(xa.token.item()) == nxt and int(xa.pos.item()) == p, (j, int(xa.token.item()), nxt)
+        assert comm.status() == 0
+        oracle.reset()
+        del da, db, xa, xb
+        # --- the fp32-activation kernels (XQ off): device transport against the host-driven one, bit for bit
         eng = _rank_engine(rank, world, layers, embed, lm, norm)
+        eng.set_tp_options(xq=False, fused_push=False)
         dec = TPDecoder(eng, CFG["vocab"], comm=comm)
         host_eng = _rank_engine(rank, world, layers, embed, lm, norm)
         host = TPDecoder(host_eng, CFG["vocab"])  # host-driven transport (gloo all_reduce of the device buffer)

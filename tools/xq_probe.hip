@@ -109,7 +109,7 @@ static void launch_xqs(const woq::XqLaunch& a, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(a.grid), dim3(a.nw * 64), L::total(a.nw), st, (const u32x4*)a.q, a.scales, a.xin.limbs,
                      a.xin.u, a.tiles_k, a.kt_begin, base, rem, a.n_groups, a.tpg_shift, (const uint8_t*)a.zp, a.xin.sx,
                      a.out, a.bias, a.residual, a.eps, a.N, a.K, a.flags, a.ssq_in, a.n_ssq, a.xo, a.next_norm_w,
-                     a.ssq_out);
+                     a.ssq_out, (const woq::CommDev*)nullptr);
 }
 
 template <int TPW, int CB>
