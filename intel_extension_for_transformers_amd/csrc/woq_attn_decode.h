@@ -55,7 +55,8 @@ __device__ __forceinline__ void attn_decode_body(float* sm, int h, int slice, in
                                                  KV* __restrict__ vcache, const int32_t* __restrict__ pos_p,
                                                  const float* __restrict__ cs, const float* __restrict__ sn,
                                                  int heads, int kv_heads, int window, int spw,
-                                                 float* __restrict__ out, const XqPtrs& xo) {
+                                                 float* __restrict__ out, const XqPtrs& xo,
+                                                 const XqPub& pub = XqPub{nullptr, 0u}) {
   typedef typename KvVec8<KV>::type kv8;
   constexpr int half = HD / 2;
   constexpr int DPL = HD / 4;   // dims per lane in the score phase (4 lanes per position)
@@ -296,7 +297,12 @@ __device__ __forceinline__ void attn_decode_body(float* sm, int h, int slice, in
     } else {
       out[(size_t)h * HD + tid] = o / den;
       // the o_proj GEMV's XQ input: tid < HD is a whole number of 16-lane rows, one block each
-      if (xo.limbs != nullptr) xq_emit16(o / den, xo, (h * HD + tid) >> 4, tid & 15);
+      if (xo.limbs != nullptr) {
+        if (pub.flag != nullptr)  // an o_proj workgroup of the SAME launch may be waiting for this block
+          xq_emit16<true>(o / den, xo, (h * HD + tid) >> 4, tid & 15, pub);
+        else
+          xq_emit16<false>(o / den, xo, (h * HD + tid) >> 4, tid & 15, pub);
+      }
     }
   }
 }

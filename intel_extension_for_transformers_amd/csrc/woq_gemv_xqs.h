@@ -52,27 +52,33 @@ extern __device__ unsigned long long* g_xqs_probe;
 
 // how many of the first D weight tiles a wave requests BEFORE its small (L2-resident) requests; the rest follow them.
 // Returns are in order, so whatever is in front of the limbs delays the first MFMA (tools/xq_probe.hip: A/B builds).
+// polling interval of a wave that waits for its input blocks inside a chained launch, in units of 64 clocks: pollers
+// share the memory pipe with the streaming producers (MI355X_MICROARCH.md, polling-cost)
+#ifndef WOQ_CHAIN_SLEEP
+#define WOQ_CHAIN_SLEEP 8
+#endif
 #ifndef WOQ_XQS_PRE
 #define WOQ_XQS_PRE 2
 #endif
 
 namespace woq {
 
-// wave-private LDS region: [zero block 256][limb strip TPW x 384][u 256][sx 256][scale slices][zero-point slices]
+// LDS: [zero block 256, shared: every wave writes the same zeros before it reads them][per wave: limb strip TPW x 384 |
+// u | sx | scale slices | zero-point slices][slab nw x CB x 16 f32][64 f32 scratch]
 template <int TPW, int CB, int SMODE, bool ASYM, bool S32>
 struct XqsLds {
   static constexpr int ESZ = S32 ? 4 : 2;
   static constexpr int STRIP = TPW * 384;
-  static constexpr int UTAB = 256;
-  static constexpr int SXTAB = ASYM ? 256 : 0;
+  static constexpr int UTAB = ((TPW * 8 + 63) / 64) * 256;  // one fp32 per block of the slice
+  static constexpr int SXTAB = ASYM ? UTAB : 0;
   static constexpr int SCB = (SMODE == 0 ? TPW * 16 : TPW * 64) * ESZ;  // one column tile's scale slice
   static constexpr int ZPB = ASYM ? (SMODE == 0 ? TPW * 16 : TPW * 64) : 0;
-  static constexpr int O_STRIP = 256, O_U = O_STRIP + STRIP, O_SX = O_U + UTAB, O_SC = O_SX + SXTAB,
+  static constexpr int O_STRIP = 0, O_U = O_STRIP + STRIP, O_SX = O_U + UTAB, O_SC = O_SX + SXTAB,
                        O_ZP = O_SC + CB * SCB;
   static constexpr int WAVE = O_ZP + CB * ZPB;
   static_assert(WAVE % 16 == 0, "wave region must keep 16-byte alignment");
   __host__ __device__ static constexpr size_t total(int nw) {
-    return (size_t)nw * WAVE + (size_t)nw * CB * 16 * 4 + 256;
+    return 256 + (size_t)nw * WAVE + (size_t)nw * CB * 16 * 4 + 256;
   }
 };
 
@@ -93,22 +99,35 @@ __device__ __forceinline__ float digit_combine(const i32x4& d) {
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// In-launch chaining (woq_gemv_chain.hip): the input vector may still be in the making by workgroups of the SAME launch
+// (CHAIN_IN: every wave polls the flags of its K slice's blocks, bounded, and reads the blocks with agent-scope loads),
+// and the output vector may have a consumer there (out.flag != null: published block by block, woq_xq.h XqPub).
+struct XqsChain {
+  const unsigned int* in_flag;  // [K / 16] flags of the input vector's blocks
+  unsigned int in_tag;
+  XqPub out;
+  int* status;  // sticky give-up flag (bit 0)
+  int strip;    // this workgroup's column strip (pair) when the grid holds several roles; -1 = blockIdx.x
+};
+
 // FUSED (woq_gemv_attn.hip): the outputs are consumed by another workgroup of the SAME launch: `out` is then an array
 // of 8-byte {tag, fp32} granules, each written by ONE write-through agent-scope store (the data is its own flag).
-template <int TPW, int CB, int D, int SMODE, bool ASYM, bool S32, bool FUSED>
+template <int TPW, int CB, int D, int SMODE, bool ASYM, bool S32, bool FUSED, bool CHAIN_IN = false>
 __device__ __forceinline__ void gemv_xqs_body(
     unsigned char* smem_raw, const u32x4* __restrict__ q, const void* __restrict__ scales,
     const uint8_t* __restrict__ xlimbs, const float* __restrict__ xu, int tiles_k, int kt_off, int base_tiles,
     int rem_tiles, int n_groups, int tpg_shift, const uint8_t* __restrict__ zp, const float* __restrict__ xsx,
     float* __restrict__ out, const float* __restrict__ bias, const float* residual, float eps, int N, int K, int flags,
     const float* __restrict__ ssq_in, int n_ssq, const XqPtrs& xo, const float* __restrict__ next_norm_w,
-    float* __restrict__ ssq_out, unsigned int fused_tag = 0u, const CommDev* __restrict__ tp = nullptr) {
+    float* __restrict__ ssq_out, unsigned int fused_tag = 0u, const CommDev* __restrict__ tp = nullptr,
+    const XqsChain& chain = XqsChain{nullptr, 0u, XqPub{nullptr, 0u}, nullptr, -1}) {
   typedef XqsLds<TPW, CB, SMODE, ASYM, S32> L;
   constexpr int ESZ = L::ESZ;
   constexpr int DD = D < TPW ? D : TPW;  // tiles requested before the first one is consumed
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = uni(tid >> 6);
   const int nw = (int)blockDim.x >> 6;
+  const int bx = chain.strip >= 0 ? chain.strip : (int)blockIdx.x;
   WOQ_XQS_STAMP(0);
   const int kt0 = kt_off + wid * base_tiles + min(wid, rem_tiles);
   const int cnt = base_tiles + (wid < rem_tiles ? 1 : 0);
@@ -119,11 +138,11 @@ __device__ __forceinline__ void gemv_xqs_body(
   rsrc_t rq[CB];
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb)
-    rq[cb] = make_rsrc(q + (size_t)((int)blockIdx.x * CB + cb) * tiles_k * 64,
+    rq[cb] = make_rsrc(q + (size_t)(bx * CB + cb) * tiles_k * 64,
                        WOQ_XK(8) ? 0 : uni(min(kt0 + cnt, tiles_k) * 1024));
   // weight tiles requested in front of the small requests: two for single column tiles, all D for the gate/up pairs
   // (same-box A/B builds of tools/xq_probe.hip, profiles/r03i_xq_issue_order.txt)
-  constexpr int PRE = CB == 2 ? DD : (WOQ_XQS_PRE < DD ? WOQ_XQS_PRE : DD);
+  constexpr int PRE = (CB == 2 || CHAIN_IN) ? DD : (WOQ_XQS_PRE < DD ? WOQ_XQS_PRE : DD);
 #pragma unroll
   for (int t = 0; t < PRE; ++t)
 #pragma unroll
@@ -133,22 +152,48 @@ __device__ __forceinline__ void gemv_xqs_body(
 
   // ---- 2. the small requests (L2-resident: written by the previous kernel, or shared by every workgroup) ----
   constexpr int XP = (L::STRIP + 1023) / 1024;  // 1-KiB pieces per limb strip
+  constexpr int UL = (TPW * 8 + 63) / 64;       // block factors per lane (8 blocks per tile)
+  constexpr int AUX_IN = CHAIN_IN ? 16 : 0;     // sc1: agent-scope loads of data another workgroup just published
+  const int nblk = WOQ_XK(5) ? 0 : uni(max(0, min(cnt * 8, tiles_k * 8 - kt0 * 8)));
+  if constexpr (CHAIN_IN) {
+    // the blocks of this wave's K slice, one flag per lane and pass; the weight requests above are already in flight
+    const unsigned int* f = chain.in_flag + (size_t)kt0 * 8;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+      bool good = true;
+#pragma unroll
+      for (int j = 0; j < UL; ++j)
+        if (lane + 64 * j < nblk)
+          good = good && __hip_atomic_load(f + lane + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == chain.in_tag;
+      if (__all(good)) break;
+      if (wall_clock64() - t0 > 2000000ull) {  // 20 ms at 100 MHz: a producer is missing — say so, do not hang
+        if (lane == 0 && chain.status != nullptr) atomicOr(chain.status, 1);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(WOQ_CHAIN_SLEEP);
+    }
+  }
   u32x4 xl[XP];
   {
     const rsrc_t rl =
         make_rsrc(xlimbs + (size_t)kt0 * 384, WOQ_XK(4) ? 0 : uni(max(0, min(cnt, tiles_k - kt0)) * 384));
 #pragma unroll
-    for (int j = 0; j < XP; ++j) xl[j] = __builtin_amdgcn_raw_buffer_load_b128(rl, v16 + j * 1024, 0, 0);
+    for (int j = 0; j < XP; ++j) xl[j] = __builtin_amdgcn_raw_buffer_load_b128(rl, v16 + j * 1024, 0, AUX_IN);
   }
-  // block factors of the slice: lane L holds block kt0 * 8 + L (8 blocks per tile; reads past the slice return 0
-  // through the descriptor, so tiles past the slice end contribute exactly 0)
-  const int nblk = WOQ_XK(5) ? 0 : uni(max(0, min(cnt * 8, tiles_k * 8 - kt0 * 8)));
+  // block factors of the slice: lane L holds blocks kt0 * 8 + L (+ 64 ...) (8 blocks per tile; reads past the slice
+  // return 0 through the descriptor, so tiles past the slice end contribute exactly 0)
   const rsrc_t ru = make_rsrc(xu + (size_t)kt0 * 8, nblk * 4);
-  const float uw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ru, lane * 4, 0, 0));
-  float sxw = 0.f;
+  float uw[UL], sxw[UL];
+#pragma unroll
+  for (int j = 0; j < UL; ++j) {
+    uw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ru, (lane + 64 * j) * 4, 0, AUX_IN));
+    sxw[j] = 0.f;
+  }
   if constexpr (ASYM) {
     const rsrc_t rsx = make_rsrc(xsx + (size_t)kt0 * 8, nblk * 4);
-    sxw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, lane * 4, 0, 0));
+#pragma unroll
+    for (int j = 0; j < UL; ++j)
+      sxw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, (lane + 64 * j) * 4, 0, AUX_IN));
   }
   // the wave's slice of scales (and zero points) of each column tile: one vector request per KiB
   constexpr int NSP = (L::SCB + 1023) / 1024;
@@ -158,7 +203,7 @@ __device__ __forceinline__ void gemv_xqs_body(
   if constexpr (SMODE == 0) g0 = min(kt0 >> tpg_shift, n_groups - 1);
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
-    const int tn = (int)blockIdx.x * CB + cb;
+    const int tn = bx * CB + cb;
     rsrc_t rs, rz;
     if constexpr (SMODE == 0) {
       rs = make_rsrc((const char*)scales + ((size_t)tn * n_groups + g0) * 16 * ESZ,
@@ -179,7 +224,7 @@ __device__ __forceinline__ void gemv_xqs_body(
   float e_res = 0.f, g_next = 1.f;
   float4_t ssq_v[4];
   if (wid == 0) {
-    const int n0 = (int)blockIdx.x * 16;
+    const int n0 = bx * 16;
     const int nlive = uni(max(0, min((silu ? (N >> 1) : N) - n0, 16)));
     if (residual != nullptr && !WOQ_XK(5)) {
       const rsrc_t rr = make_rsrc(residual + n0, nlive * 4);
@@ -209,15 +254,19 @@ __device__ __forceinline__ void gemv_xqs_body(
   WOQ_XQS_STAMP(1);
 
   // ---- 3. park the small pieces in the wave's LDS region (wave-private, in-order LDS: no workgroup barrier) ----
-  unsigned char* wbase = smem_raw + (size_t)wid * L::WAVE;
-  float* slab = (float*)(smem_raw + (size_t)nw * L::WAVE);  // [nw][CB][16]
+  unsigned char* zero_blk = smem_raw;
+  unsigned char* wbase = smem_raw + 256 + (size_t)wid * L::WAVE;
+  float* slab = (float*)(smem_raw + 256 + (size_t)nw * L::WAVE);  // [nw][CB][16]
   float* red = slab + nw * CB * 16;                          // [64]
-  ((uint32_t*)wbase)[lane] = 0u;
+  ((uint32_t*)zero_blk)[lane] = 0u;
 #pragma unroll
   for (int j = 0; j < XP; ++j)
     if (v16 + j * 1024 < L::STRIP) *(u32x4*)(wbase + L::O_STRIP + v16 + j * 1024) = xl[j];  // past the slice: zeros
-  ((float*)(wbase + L::O_U))[lane] = uw;
-  if constexpr (ASYM) ((float*)(wbase + L::O_SX))[lane] = sxw;
+#pragma unroll
+  for (int j = 0; j < UL; ++j) {
+    ((float*)(wbase + L::O_U))[lane + 64 * j] = uw[j];
+    if constexpr (ASYM) ((float*)(wbase + L::O_SX))[lane + 64 * j] = sxw[j];
+  }
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
 #pragma unroll
@@ -231,7 +280,7 @@ __device__ __forceinline__ void gemv_xqs_body(
   // a row is live in lane quarter kq == e only, everything else reads the zero block
   const int i16 = lane & 15, kq = lane >> 4;
   const bool a_live = (i16 >> 2) == kq && (i16 & 3) != 3;
-  const unsigned char* a_base = a_live ? wbase + L::O_STRIP + kq * 48 + (i16 & 3) * 16 : wbase + kq * 16;
+  const unsigned char* a_base = a_live ? wbase + L::O_STRIP + kq * 48 + (i16 & 3) * 16 : zero_blk + kq * 16;
   const int a_step_t = a_live ? 384 : 0, a_step_h = a_live ? 192 : 0;
   const float* u_base = (const float*)(wbase + L::O_U) + kq;    // [t * 8 + h * 4]
   const float* sx_base = (const float*)(wbase + L::O_SX) + kq;  // (ASYM)
@@ -308,7 +357,7 @@ __device__ __forceinline__ void gemv_xqs_body(
   }
   WOQ_XQS_STAMP(4);
   if (WOQ_XK(7)) {  // probe: no cross-wave sum, no epilogue
-    if (lane < 16 && out) out[(int)blockIdx.x * 16 + lane] = tot[0] + tot[CB - 1];
+    if (lane < 16 && out) out[bx * 16 + lane] = tot[0] + tot[CB - 1];
     return;
   }
   // the four lane quarters hold the four blocks' shares of each column
@@ -337,12 +386,12 @@ __device__ __forceinline__ void gemv_xqs_body(
     }
     const float inv = ssq_in != nullptr ? 1.0f / sqrtf(red[0] / (float)K + eps) : 1.f;  // HF LlamaRMSNorm
     v *= inv;
-    const int n = (int)blockIdx.x * 16 + tid;  // CB == 1 or the SiLU pair: one 16-column output tile per workgroup
+    const int n = bx * 16 + tid;  // CB == 1 or the SiLU pair: one 16-column output tile per workgroup
     if (silu) {
       up *= inv;
       if (bias) {
-        v += bias[min(((int)blockIdx.x * 2) * 16 + tid, N - 1)];
-        up += bias[min(((int)blockIdx.x * 2 + 1) * 16 + tid, N - 1)];
+        v += bias[min((bx * 2) * 16 + tid, N - 1)];
+        up += bias[min((bx * 2 + 1) * 16 + tid, N - 1)];
       }
       v = v / (1.0f + __expf(-v)) * up;
     } else if (bias) {
@@ -368,11 +417,11 @@ __device__ __forceinline__ void gemv_xqs_body(
         out[n] = v;
     }
     if (xo.limbs != nullptr) {  // this tile IS block blockIdx.x of the next kernel's activation vector
-      if (ssq_out != nullptr) {
-        const float ss = row16_sum(v * v);
-        if (tid == 0) ssq_out[blockIdx.x] = ss;
-      }
-      xq_emit16(v * g_next, xo, (int)blockIdx.x, tid);
+      const float ss = ssq_out != nullptr ? row16_sum(v * v) : 0.f;
+      if (chain.out.flag != nullptr)
+        xq_emit16<true>(v * g_next, xo, bx, tid, chain.out, ssq_out, ss);
+      else
+        xq_emit16<false>(v * g_next, xo, bx, tid, chain.out, ssq_out, ss);
     }
   }
   WOQ_XQS_STAMP(6);

@@ -65,10 +65,23 @@ __device__ __forceinline__ int row16_sum_i32(int v) {
   return v + WOQ_DPP_I32(v, 0x140);
 }
 
+// In-launch hand-off of an XQ vector (round 3, the chained launches of woq_gemv_chain.hip): a consumer workgroup of the
+// SAME launch may be waiting for block `blk`. The producer then stores the block write-through (agent-scope stores
+// never stay in this XCD's L2 alone), drains them, and only then stores the block's flag word = the (step, vector) tag;
+// the consumer polls the flags of its K slice and reads the blocks with agent-scope loads afterwards
+// (cdna_hip_programming.md Guideline 16, form R1). flag == nullptr: plain stores, the consumer is a later launch.
+struct XqPub {
+  unsigned int* flag;  // [K / 16] one word per block, or null
+  unsigned int tag;    // never 0 (flags rest at 0 / at an older tag)
+};
+
 // Called by the 16 lanes of ONE DPP row (lanes 16 r .. 16 r + 15, all active), lane j = lane & 15 holding value
 // 16 * blk + j of the vector: writes block `blk`. Conversion as gemv_tile_kernel's stage_row (fp32 sum with
 // 1.5 * 2^23: the mantissa IS round(y * 2^(21 - e)) + 2^22), then three balanced digits.
-__device__ __forceinline__ void xq_emit16(float y, const XqPtrs& o, int blk, int j) {
+// ssq_out / ss (optional): the block's sum of squares of the raw values, published with the block.
+template <bool PUBLISH = false>
+__device__ __forceinline__ void xq_emit16(float y, const XqPtrs& o, int blk, int j, const XqPub& pub = XqPub{nullptr, 0u},
+                                          float* ssq_out = nullptr, float ss = 0.f) {
   const float amax = row16_max(fabsf(y));
   int e = 0;
   if (amax > 0.f && amax < INFINITY) e = max(-100, min(100, __builtin_amdgcn_frexp_expf(amax)));
@@ -79,13 +92,31 @@ __device__ __forceinline__ void xq_emit16(float y, const XqPtrs& o, int blk, int
   const int s1 = (int)((uint32_t)v1 << 24) >> 24;
   const int s2 = (v1 - s1) >> 8;
   uint8_t* d = o.limbs + (size_t)blk * 48 + j;
-  d[0] = (uint8_t)s0;
-  d[16] = (uint8_t)s1;
-  d[32] = (uint8_t)s2;
   const int qs = row16_sum_i32(v);
-  if (j == 0) {
-    o.u[blk] = ldexpf(1.f, e - 25);
-    o.sx[blk] = (float)qs;
+  if constexpr (PUBLISH) {
+    __hip_atomic_store(d, (uint8_t)s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d + 16, (uint8_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d + 32, (uint8_t)s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (j == 0) {
+      __hip_atomic_store((unsigned int*)(o.u + blk), __float_as_uint(ldexpf(1.f, e - 25)), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store((unsigned int*)(o.sx + blk), __float_as_uint((float)qs), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      if (ssq_out != nullptr)
+        __hip_atomic_store((unsigned int*)(ssq_out + blk), __float_as_uint(ss), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the block has landed (every storing lane is in this wave)
+    if (j == 0) __hip_atomic_store(pub.flag + blk, pub.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    d[0] = (uint8_t)s0;
+    d[16] = (uint8_t)s1;
+    d[32] = (uint8_t)s2;
+    if (j == 0) {
+      o.u[blk] = ldexpf(1.f, e - 25);
+      o.sx[blk] = (float)qs;
+      if (ssq_out != nullptr) ssq_out[blk] = ss;
+    }
   }
 }
 

@@ -221,6 +221,16 @@ class WoqDecoderEngine:
             L.check(L.lib().woq_engine_set_attn_grouped(self._h, int(bool(on))))
             self.captured = False
 
+    def set_chain(self, on):
+        """Decode step: each layer as two chained launches where the shape allows (csrc/woq_gemv_chain.hip; default on).
+        Invalidates a captured graph."""
+        L.check(L.lib().woq_engine_set_chain(self._h, int(bool(on))))
+        self.captured = False
+
+    def uses_chain(self):
+        """True when the next step / capture runs the chained layer launches."""
+        return bool(L.lib().woq_engine_chain(self._h))
+
     def set_tp_options(self, xq=True, fused_push=True):
         """Tensor-parallel decode with a device communicator: `xq` = the XQ decode kernels with an XQ-emitting
         all-reduce kernel (off: the fp32-activation kernels), `fused_push` = o_proj / down_proj push their partial sums
