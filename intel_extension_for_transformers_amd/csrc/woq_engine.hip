@@ -606,11 +606,12 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
   e->owned = {e->hidden, e->qkv, e->attn, e->act, e->logits, e->token, e->pos, e->kcache, e->vcache, e->pf_last,
               e->pf_logits, e->attn_part, e->am_val, e->am_idx, e->tok_log, e->step_seq};
   {  // XQ vectors (woq_xq.h) for the three GEMV inputs of a layer
-    // WOQ_ENGINE_XQ=1 / 0 forces the choice. Default: by measurement (profiles/r02n_xq_by_shape.txt) — at hidden 4096
-    // the XQ hand-off wins (Llama-2-7B g128 sym 747-757 vs 737-740 tokens/s, g32 asym 652 vs 626), at hidden 8192 the
-    // second recombination per tile costs more than the staging it removes (Llama-2-70B 119-120 vs 125-127 tokens/s)
+    // WOQ_ENGINE_XQ=0 turns the XQ hand-off off (the fp32-activation kernels). Round 2 picked by shape — at hidden 8192
+    // the second recombination per tile cost more than the staging it removed (Llama-2-70B 119-120 vs 125-127 tokens/s);
+    // with round 3's balanced digits and lean kernel the XQ path wins there too (129.1 vs 127.7 tokens/s, kernel 0.646
+    // vs 0.624 of 8 TB/s, profiles/r03z_70b_xq.txt), and on the tensor-parallel rank shapes (2.32 vs 2.52 ms per token)
     const char* sw = getenv("WOQ_ENGINE_XQ");
-    e->xq_enabled = sw ? sw[0] != '0' : cfg->hidden <= 4096;
+    e->xq_enabled = sw ? sw[0] != '0' : true;
     const char* fa = getenv("WOQ_ENGINE_FUSE_ATTN");
     e->fuse_attn = fa ? fa[0] != '0' : true;
     const char* ch = getenv("WOQ_ENGINE_CHAIN");
