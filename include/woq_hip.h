@@ -216,6 +216,19 @@ WOQ_API int woq_engine_fuse_attn(woq_engine* e);
  * Same capture rule as attn_splits. woq_engine_chain: 1 when the next step / capture will use it. */
 WOQ_API int woq_engine_set_chain(woq_engine* e, int on);
 WOQ_API int woq_engine_chain(woq_engine* e);
+/* decode step, XQ path: ALL layers of the step as one persistent launch (csrc/woq_persist.hip): one workgroup per CU,
+ * a loader wave streaming the token's weights HBM -> LDS ring without stopping at operator boundaries, eleven consumer
+ * waves doing the arithmetic, activation vectors handed between workgroups as tagged 8-byte granules (bounded waits,
+ * woq_engine_status bit 0). Scope: one GPU, unpadded int4 blobs with one scale layout, head_dim 128, one attention
+ * slice, no sliding window, activation vector + scales + a >= 64 KiB ring within 160 KiB of LDS; outside it the step keeps
+ * its launches. WOQ_ENGINE_PERSIST=1 or woq_engine_set_persist turn it on. Same capture rule as attn_splits.
+ * woq_engine_persist: 1 when the next step / capture will use it (0: woq_last_error says what is out of scope). */
+WOQ_API int woq_engine_set_persist(woq_engine* e, int on);
+WOQ_API int woq_engine_persist(woq_engine* e);
+/* diagnostics of the persistent launch: stamps_dev = device buffer of grid * layers * 4 * 32 uint64 that every later
+ * step fills with 100 MHz wall-clock stamps per (workgroup, projection) — csrc/woq_persist.hip PS_STAMP lists the
+ * slots — or NULL to turn them off; *grid / *ring_tiles (optional) report the launch geometry. */
+WOQ_API int woq_engine_persist_stamps(woq_engine* e, void* stamps_dev, int* grid, int* ring_tiles);
 /* sticky device-side status of the decode step, 0 = fine; bit 0: an attention workgroup of the fused launch gave up
  * waiting for its head's q / k / v after its bound (its outputs are then wrong); bit 1: a step started with its
  * position at or beyond max_ctx — it ran at max_ctx - 1 instead (outputs meaningless, nothing written out of bounds;

@@ -48,21 +48,41 @@ struct AttnGranule {
   int* status;
 };
 
+// Who runs the body. AttnWgEnv: a 256-thread workgroup of its own (the standalone and the fused launches) — thread ids
+// are the workgroup's, the two meeting points are workgroup barriers, the result leaves as fp32 (+ its XQ block).
+// The persistent token kernel (woq_persist.hip) runs the body on four of its consumer waves with its own environment:
+// sub-workgroup meeting points on an LDS counter (its loader wave never reaches an s_barrier) and tagged granules out.
+struct AttnWgEnv {
+  float* out;
+  XqPtrs xo;
+  XqPub pub;
+  __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
+  // value `idx` of the attention output; called by whole 16-lane rows (idx & 15 == lane & 15)
+  __device__ __forceinline__ void put(float v, int idx) const {
+    out[idx] = v;
+    if (xo.limbs != nullptr) {  // the o_proj GEMV's XQ input: one block per 16-lane row
+      if (pub.flag != nullptr)  // an o_proj workgroup of the SAME launch may be waiting for this block
+        xq_emit16<true>(v, xo, idx >> 4, idx & 15, pub);
+      else
+        xq_emit16<false>(v, xo, idx >> 4, idx & 15, pub);
+    }
+  }
+};
+
 // `h`: query head of this workgroup, `slice` / `n_slices`: its part of the cached positions (SPLIT), `sm`: LDS base
-template <typename KV, int HD, bool SPLIT, typename SRC>
-__device__ __forceinline__ void attn_decode_body(float* sm, int h, int slice, int n_slices, const SRC& src,
-                                                 KV* __restrict__ kcache,
-                                                 KV* __restrict__ vcache, const int32_t* __restrict__ pos_p,
-                                                 const float* __restrict__ cs, const float* __restrict__ sn,
-                                                 int heads, int kv_heads, int window, int spw,
-                                                 float* __restrict__ out, const XqPtrs& xo,
-                                                 const XqPub& pub = XqPub{nullptr, 0u}) {
+template <typename KV, int HD, bool SPLIT, typename SRC, typename ENV>
+__device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int n_slices, const SRC& src,
+                                                KV* __restrict__ kcache, KV* __restrict__ vcache,
+                                                const int32_t* __restrict__ pos_p, const float* __restrict__ cs,
+                                                const float* __restrict__ sn, int heads, int kv_heads, int window,
+                                                int spw, float* __restrict__ out, const ENV& env) {
   typedef typename KvVec8<KV>::type kv8;
   constexpr int half = HD / 2;
   constexpr int DPL = HD / 4;   // dims per lane in the score phase (4 lanes per position)
   constexpr int LPR = HD / 8;   // lanes per row in the P.V phase
   constexpr int GP = 64 / LPR;  // positions per wave per P.V pass
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = env.tid(), lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rep = heads / kv_heads, kh = h / rep;
   const int apos = pos_p[0];  // absolute position of the new token = number of cached positions
@@ -139,7 +159,7 @@ __device__ __forceinline__ void attn_decode_body(float* sm, int h, int slice, in
         va = __uint_as_float((unsigned int)g4), vb = __uint_as_float((unsigned int)g5);
         if (__all(good)) break;  // every participating lane of the wave saw its six tags
         if (wall_clock64() - t0 > 2000000ull) {  // 20 ms at 100 MHz: a producer is missing — say so, do not hang
-          if (lane == 0) atomicExch(src.status, 1);
+          if (lane == 0) atomicOr(src.status, 1);
           break;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -172,7 +192,7 @@ __device__ __forceinline__ void attn_decode_body(float* sm, int h, int slice, in
   }
   if (has_new) s_new = wave_sum_dpp(s_new);
   if constexpr (SRC::granules)
-    __syncthreads();  // q is wave 0's to give
+    env.sync();  // q is wave 0's to give
   else
     __builtin_amdgcn_wave_barrier();
   // ---- scores of this wave's cached positions ----
@@ -278,7 +298,7 @@ __device__ __forceinline__ void attn_decode_body(float* sm, int h, int slice, in
     ml[wid] = m_w;
     ml[4 + wid] = l_w;
   }
-  __syncthreads();
+  env.sync();
   // ---- merge the four waves' partials ----
   if (tid < HD) {
     const float m0 = ml[0], m1 = ml[1], m2 = ml[2], m3 = ml[3];
@@ -295,16 +315,20 @@ __device__ __forceinline__ void attn_decode_body(float* sm, int h, int slice, in
         part[HD + 1] = den;
       }
     } else {
-      out[(size_t)h * HD + tid] = o / den;
-      // the o_proj GEMV's XQ input: tid < HD is a whole number of 16-lane rows, one block each
-      if (xo.limbs != nullptr) {
-        if (pub.flag != nullptr)  // an o_proj workgroup of the SAME launch may be waiting for this block
-          xq_emit16<true>(o / den, xo, (h * HD + tid) >> 4, tid & 15, pub);
-        else
-          xq_emit16<false>(o / den, xo, (h * HD + tid) >> 4, tid & 15, pub);
-      }
+      env.put(o / den, h * HD + tid);  // tid < HD is a whole number of 16-lane rows
     }
   }
+}
+
+template <typename KV, int HD, bool SPLIT, typename SRC>
+__device__ __forceinline__ void attn_decode_body(float* sm, int h, int slice, int n_slices, const SRC& src,
+                                                 KV* __restrict__ kcache, KV* __restrict__ vcache,
+                                                 const int32_t* __restrict__ pos_p, const float* __restrict__ cs,
+                                                 const float* __restrict__ sn, int heads, int kv_heads, int window,
+                                                 int spw, float* __restrict__ out, const XqPtrs& xo,
+                                                 const XqPub& pub = XqPub{nullptr, 0u}) {
+  attn_decode_env<KV, HD, SPLIT>(sm, h, slice, n_slices, src, kcache, vcache, pos_p, cs, sn, heads, kv_heads, window,
+                                 spw, out, AttnWgEnv{out, xo, pub});
 }
 
 }  // namespace woq

@@ -18,6 +18,7 @@
 #include "woq_comm_dev.h"
 #include "woq_device.h"
 #include "woq_launch.h"
+#include "woq_persist.h"
 #include "woq_xq.h"
 
 namespace woq {
@@ -131,6 +132,12 @@ struct woq_engine {
   unsigned int* flag_attn = nullptr;  // [heads * head_dim / 16]
   unsigned int* flag_act = nullptr;   // [inter / 16]
   bool chain_ok(int l) const;
+  // all layers of the step as ONE persistent launch (woq_persist.hip): the weight stream runs through the operator
+  // boundaries. Built lazily at the first step (every layer must be set); null + persist_why when out of scope.
+  bool persist_on = false, persist_tried = false;
+  woq::Persist* persist = nullptr;
+  std::string persist_why;
+  woq::Persist* persist_get();
   // tensor parallel ranks take the XQ path when the exchange runs on the device (its all-reduce kernel then emits the
   // next XQ vector itself); with a host-side transport they keep the fp32-activation kernels
   bool tp_xq = true, tp_fused_push = true;
@@ -175,6 +182,24 @@ bool woq_engine::chain_ok(int l) const {
          !attn_grouped &&
          woq::chain_layer_supported(w.qkv_hdr, w.o_hdr, w.gate_up_hdr, w.down_hdr, c.heads, c.kv_heads, c.head_dim,
                                     c.kv_dtype, c.max_ctx, window, attn_splits);
+}
+
+woq::Persist* woq_engine::persist_get() {
+  if (!persist_on || !use_xq() || cfg.tp_size > 1 || qkv_g == nullptr || attn_grouped || attn_splits > 1 || window != 0)
+    return nullptr;
+  if (!persist_tried) {
+    persist_tried = true;
+    woq::PersistDesc d;
+    d.layers = cfg.layers, d.hidden = cfg.hidden, d.inter = cfg.inter, d.heads = cfg.heads, d.kv_heads = cfg.kv_heads;
+    d.head_dim = cfg.head_dim, d.kv_dtype = cfg.kv_dtype, d.max_ctx = cfg.max_ctx, d.window = window;
+    d.attn_splits = attn_splits, d.eps = cfg.rms_eps;
+    d.lw = layers.data();
+    d.kcache = kcache, d.vcache = vcache, d.kv_layer_bytes = kv_layer_bytes;
+    d.seq = step_seq, d.pos = pos, d.status = fuse_status, d.cs = cs, d.sn = sn;
+    d.x0 = xq_hidden, d.ssq0 = ssq_part, d.qkv_g = qkv_g, d.hidden_buf = hidden;
+    persist = woq::persist_create(d, &persist_why);
+  }
+  return persist;
 }
 
 static const XqPtrs kNoXq = {nullptr, nullptr, nullptr};
@@ -368,6 +393,12 @@ static void engine_embed(woq_engine* e, hipStream_t st) {
 static int engine_step_impl(woq_engine* e, int greedy, hipStream_t st) {
   const woq_engine_config& c = e->cfg;
   engine_embed(e, st);
+  if (woq::Persist* p = e->persist_get()) {  // embedding -> [all layers, one launch] -> head
+    woq::persist_rebind(p, e->pos, e->hidden);
+    const int rc = woq::persist_launch(p, st);
+    if (rc) return rc;
+    return engine_head(e, greedy, st);
+  }
   for (int l = 0; l < c.layers; ++l) {
     int rc;
     if (engine_skip_mask() == 0 && e->chain_ok(l)) {
@@ -531,6 +562,33 @@ int woq_engine_set_chain(woq_engine* e, int on) {
   WOQ_END
 }
 int woq_engine_chain(woq_engine* e) { return e && !e->layers.empty() && e->chain_ok(0) ? 1 : 0; }
+int woq_engine_set_persist(woq_engine* e, int on) {
+  WOQ_TRY
+  WOQ_CHECK(e != nullptr, "QBits: null engine");
+  e->persist_on = on != 0;  // takes effect at the next step / capture
+  WOQ_END
+}
+// 1 when the next step runs its layers as the persistent launch; 0 otherwise (woq_last_error() then says why, if the
+// model or device is outside its scope)
+int woq_engine_persist(woq_engine* e) {
+  if (!e || e->layers.empty()) return 0;
+  if (e->persist_get() != nullptr) return 1;
+  if (e->persist_on && e->persist_tried && !e->persist_why.empty())
+    woq::fail("QBits: persistent decode launch not used: " + e->persist_why);
+  return 0;
+}
+// diagnostics of the persistent launch: stamps_dev = device buffer of grid * layers * 4 * 32 uint64 (or null: off);
+// *grid / *ring_tiles (optional) report the launch's geometry. Fails when the persistent launch is not in use.
+int woq_engine_persist_stamps(woq_engine* e, void* stamps_dev, int* grid, int* ring_tiles) {
+  WOQ_TRY
+  WOQ_CHECK(e != nullptr, "QBits: null engine");
+  woq::Persist* p = e->persist_get();
+  WOQ_CHECK(p != nullptr, "QBits: the persistent decode launch is not in use");
+  woq::persist_set_stamps(p, (unsigned long long*)stamps_dev);
+  if (grid) *grid = woq::persist_grid(p);
+  if (ring_tiles) *ring_tiles = woq::persist_ring_tiles(p);
+  WOQ_END
+}
 int woq_engine_set_tp_options(woq_engine* e, int xq, int fused_push) {
   WOQ_TRY
   WOQ_CHECK(e != nullptr, "QBits: null engine");
@@ -617,6 +675,8 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
     const char* ch = getenv("WOQ_ENGINE_CHAIN");
     e->chain = ch ? ch[0] != '0' : false;
     e->chain_parts = ch && ch[0] == '2' ? 1 : (ch && ch[0] == '3' ? 2 : 3);
+    const char* pe = getenv("WOQ_ENGINE_PERSIST");
+    e->persist_on = pe ? pe[0] != '0' : false;
     const char* tx = getenv("WOQ_TP_XQ");
     e->tp_xq = tx ? tx[0] != '0' : true;
     const char* tf = getenv("WOQ_TP_FUSED_PUSH");
@@ -653,6 +713,7 @@ void woq_engine_destroy(woq_engine* e) {
   if (!e) return;
   if (e->exec) hipGraphExecDestroy(e->exec);
   if (e->graph) hipGraphDestroy(e->graph);
+  woq::persist_destroy(e->persist);
   for (void* p : e->owned) hipFree(p);
   for (void* p : {(void*)e->pf_h, (void*)e->pf_qkv, (void*)e->pf_attn, (void*)e->pf_act, e->pf_ws})
     if (p) hipFree(p);
@@ -676,6 +737,11 @@ int woq_engine_set_layer(woq_engine* e, int layer, const woq_layer_weights* w) {
             "QBits: gate_up blob shape mismatch (inter must be a multiple of 16)");
   WOQ_CHECK(w->down_hdr.K == c.inter && w->down_hdr.N == c.hidden, "QBits: down_proj blob shape mismatch");
   e->layers[layer] = *w;
+  if (e->persist_tried) {  // the plan holds the old layer's pointers
+    woq::persist_destroy(e->persist);
+    e->persist = nullptr;
+    e->persist_tried = false;
+  }
   e->xq_shapes_ok = e->xq_shapes_ok && gemv_xq_supported(w->qkv_hdr, 0) && gemv_xq_supported(w->o_hdr, 0) &&
                     gemv_xq_supported(w->gate_up_hdr, 1) && gemv_xq_supported(w->down_hdr, 0);
   WOQ_END

@@ -231,6 +231,30 @@ class WoqDecoderEngine:
         """True when the next step / capture runs the chained layer launches."""
         return bool(L.lib().woq_engine_chain(self._h))
 
+    def set_persist(self, on):
+        """Decode step: all layers as ONE persistent launch (csrc/woq_persist.hip) where the model fits its scope.
+        Invalidates a captured graph."""
+        L.check(L.lib().woq_engine_set_persist(self._h, int(bool(on))))
+        self.captured = False
+
+    def uses_persist(self):
+        """True when the next step / capture runs the persistent launch."""
+        return bool(L.lib().woq_engine_persist(self._h))
+
+    def persist_stamps(self, on=True):
+        """Diagnostics of the persistent launch: returns a uint64 tensor [grid, layers * 4, 32] that every later step
+        fills with 100 MHz wall-clock stamps per (workgroup, projection) (csrc/woq_persist.hip PS_STAMP), plus the
+        ring size in tiles; on=False turns the stamps off again."""
+        g, r = ctypes.c_int(), ctypes.c_int()
+        if not on:
+            L.check(L.lib().woq_engine_persist_stamps(self._h, None, ctypes.byref(g), ctypes.byref(r)))
+            self._stamps = None
+            return None, r.value
+        L.check(L.lib().woq_engine_persist_stamps(self._h, None, ctypes.byref(g), ctypes.byref(r)))
+        self._stamps = torch.zeros(g.value, int(self.cfg.layers) * 4, 32, dtype=torch.int64, device="cuda")
+        L.check(L.lib().woq_engine_persist_stamps(self._h, ctypes.c_void_p(self._stamps.data_ptr()), None, None))
+        return self._stamps, r.value
+
     def set_tp_options(self, xq=True, fused_push=True):
         """Tensor-parallel decode with a device communicator: `xq` = the XQ decode kernels with an XQ-emitting
         all-reduce kernel (off: the fp32-activation kernels), `fused_push` = o_proj / down_proj push their partial sums
