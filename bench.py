@@ -132,6 +132,18 @@ def gemv_roofline(eng, traffic=None, ceiling=True):
         "timed": "HIP events on the launch stream around 8 replays of a captured pass of %d launches (the step's own "
                  "kernel variants, chained as in the step; boundaries included)" % n_launch,
     }
+    # the four projections one at a time (the instantiations rocprofv3 lists separately): a pass of ONE projection per
+    # layer, back to back — each launch then starts behind a launch of its own kind, not behind its real predecessor
+    proj = {}
+    for bit, name in enumerate(("qkv", "o", "gate_up", "down")):
+        pms, pby, pn = eng.time_gemv(reps=8, mask=1 << bit)
+        pus = pms * 1e3 / (8 * pn)
+        proj[name] = {"us_per_launch": pus, "algorithmic_bytes_per_launch": pby / pn,
+                      "achieved": pby / pn / (pus * 1e-6) / 1e9, "frac": pby / pn / (pus * 1e-6) / 1e9 / HBM_PEAK_GBPS}
+    dom = max(proj, key=lambda k: proj[k]["us_per_launch"])
+    out["by_projection"] = dict(proj, dominant_by_time=dom,
+                                note="`achieved` above is the average over all four; the single instantiation with the "
+                                     "largest share of the step's time is `%s`" % dom)
     if ceiling and eng.uses_xq():
         us_twin = eng.time_twin(0, reps=8) * 1e3 / (8 * n_launch)
         us_empty = eng.time_twin(1, reps=8) * 1e3 / (8 * n_launch)
@@ -147,6 +159,29 @@ def gemv_roofline(eng, traffic=None, ceiling=True):
                           HBM_COPY_GBPS / HBM_PEAK_GBPS, us_empty),
         }
     return out
+
+
+def launch_structures(eng, cfg, args):
+    """The same decode, the other way of cutting it into launches that this tree carries: all layers as ONE persistent
+    launch (csrc/woq_persist.hip: loader wave + LDS ring + granule hand-offs). Same prompt, same number of timed steps,
+    measured in this run right after the headline. A built and measured NEGATIVE: kept in the line so that the claim
+    "the launch structure is not where the time is" is re-measured every run."""
+    import torch
+
+    eng.set_persist(True)
+    if not eng.uses_persist():
+        eng.set_persist(False)
+        return {"persistent_launch": None, "note": "outside the persistent launch's scope on this model / device"}
+    feed_prompt(eng, cfg["vocab"], args.prompt)
+    eng.capture(greedy=True)
+    el = timed(lambda n: eng.replay(n), args.steps, args.warmup, torch.cuda.synchronize)
+    status = eng.status()
+    eng.set_persist(False)
+    return {"persistent_launch": {"tokens_per_s": args.steps / el, "ms_per_step": el * 1e3 / args.steps,
+                                  "engine_status": status},
+            "note": "one launch for all layers instead of 4 per layer; correct (tests) and slower: with every weight "
+                    "prefetched into an LDS ring the layer is still five all-to-all hand-offs plus SIMD-issue-bound "
+                    "tile passes (DESIGN 3.2, profiles/r03ad_*)"}
 
 
 def read_traffic():
@@ -564,6 +599,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (configs[2], [3] single GPU, [4])")
     ap.add_argument("--no-70b", action="store_true", help="skip the 70B single-GPU point of extra_configs")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-structures", action="store_true", help="skip other_launch_structures (the persistent launch)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--host-allreduce", action="store_true", help="N > 1: force the RCCL host-driven transport")
     args = ap.parse_args()
@@ -659,6 +695,7 @@ def main():
 
     elapsed = timed(run, args.steps, args.warmup, torch.cuda.synchronize)
     tok_s = args.steps / elapsed
+    structures = launch_structures(eng, cfg, args) if use_graph and not args.no_structures else None
     qbytes = algorithmic_bytes_per_token(cfg)
     out = dict(base, value=tok_s, ms_per_step=elapsed * 1e3 / args.steps, scaling="weak",
                data="synthetic (random-init int4 weights of the Llama-2-7B shape, random prompt ids)",
@@ -670,6 +707,8 @@ def main():
                hbm_frac_of_peak_end_to_end=qbytes * tok_s / 1e9 / HBM_PEAK_GBPS,
                hbm_frac_of_measured_copy_ceiling_end_to_end=qbytes * tok_s / 1e9 / HBM_COPY_GBPS,
                roofline=gemv_roofline(eng, read_traffic()))
+    if structures is not None:
+        out["other_launch_structures"] = structures
     if want_prefill:
         out["prefill"] = prefill_measure(eng, cfg, args.prefill_seqs, args.prefill_len, label=", same int4 g128 weights")
     if not args.no_parity:

@@ -291,6 +291,10 @@ WOQ_API int woq_engine_phase(woq_engine* e, int layer, int phase, int greedy, vo
  * boundaries included). Overwrites the residual stream / XQ vectors (the next step's embedding rewrites them). */
 WOQ_API int woq_engine_time_gemv(woq_engine* e, int reps, void* stream, float* total_ms, double* bytes_per_pass,
                                  int* launches_per_pass);
+/* the same with a pass restricted to some of the layer's projections (mask bit 0 qkv, 1 o, 2 gate/up, 3 down): the
+ * per-instantiation numbers rocprofv3's kernel stats list separately (bench.py roofline.by_projection) */
+WOQ_API int woq_engine_time_gemv_mask(woq_engine* e, int mask, int reps, void* stream, float* total_ms,
+                                      double* bytes_per_pass, int* launches_per_pass);
 /* the same four launches per layer with the arithmetic taken out, timed the same way (`reps` passes after a warm-up
  * pass, total milliseconds): mode 0 = load-only twins (same grids, waves, K slices, non-temporal 16-byte requests over
  * the engine's own blobs: what this launch structure reaches as a pure stream), mode 1 = empty kernels on the same

@@ -863,10 +863,12 @@ int woq_engine_replay(woq_engine* e, int n, void* stream) {
   WOQ_END
 }
 
-int woq_engine_time_gemv(woq_engine* e, int reps, void* stream, float* total_ms, double* bytes_per_pass,
-                         int* launches_per_pass) {
+// mask: which of the layer's projections a pass launches (bit 0 qkv, 1 o, 2 gate/up, 3 down); bytes and launch count
+// are those of the selected ones
+int woq_engine_time_gemv_mask(woq_engine* e, int mask, int reps, void* stream, float* total_ms, double* bytes_per_pass,
+                              int* launches_per_pass) {
   WOQ_TRY
-  WOQ_CHECK(e && total_ms && bytes_per_pass && launches_per_pass, "QBits: null argument");
+  WOQ_CHECK(e && total_ms && bytes_per_pass && launches_per_pass && (mask & 15) != 0, "QBits: bad argument");
   hipStream_t st = (hipStream_t)stream;
   const woq_engine_config& c = e->cfg;
   double bytes = 0;
@@ -874,6 +876,7 @@ int woq_engine_time_gemv(woq_engine* e, int reps, void* stream, float* total_ms,
     const woq_layer_weights& w = e->layers[l];
     const woq_blob_header* hs[4] = {&w.qkv_hdr, &w.o_hdr, &w.gate_up_hdr, &w.down_hdr};
     for (int j = 0; j < 4; ++j) {
+      if (!((mask >> j) & 1)) continue;
       const woq_blob_header& h = *hs[j];
       // algorithmic bytes: int4 payload + scales (+ zero points), unpadded
       bytes += (double)h.K * h.N * 0.5 + (double)h.n_groups * h.N * (h.scale_type == WOQ_F32 ? 4 : 2) +
@@ -886,32 +889,36 @@ int woq_engine_time_gemv(woq_engine* e, int reps, void* stream, float* total_ms,
       int rc;
       if (e->use_xq()) {  // the step's own four GEMV launches: same kernels, epilogues, XQ outputs, residual chaining
         const bool last = l + 1 == c.layers;
-        if ((rc = engine_gemv_xq(e, e->xq_hidden, w.qkv_blob, w.qkv_hdr, e->qkv, e->ssq_part, nullptr, 0, kNoXq, nullptr,
-                                 nullptr, st)) != 0)
+        if ((mask & 1) && (rc = engine_gemv_xq(e, e->xq_hidden, w.qkv_blob, w.qkv_hdr, e->qkv, e->ssq_part, nullptr, 0,
+                                               kNoXq, nullptr, nullptr, st)) != 0)
           return rc;
-        if ((rc = engine_gemv_xq(e, e->xq_attn, w.o_blob, w.o_hdr, e->hidden, nullptr, e->hidden, 0, e->xq_hidden, w.ln2,
-                                 e->ssq_part, st)) != 0)
+        if ((mask & 2) && (rc = engine_gemv_xq(e, e->xq_attn, w.o_blob, w.o_hdr, e->hidden, nullptr, e->hidden, 0,
+                                               e->xq_hidden, w.ln2, e->ssq_part, st)) != 0)
           return rc;
-        if ((rc = engine_gemv_xq(e, e->xq_hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, e->ssq_part, nullptr, 1,
-                                 e->xq_act, nullptr, nullptr, st)) != 0)
+        if ((mask & 4) && (rc = engine_gemv_xq(e, e->xq_hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, e->ssq_part,
+                                               nullptr, 1, e->xq_act, nullptr, nullptr, st)) != 0)
           return rc;
-        if ((rc = engine_gemv_xq(e, e->xq_act, w.down_blob, w.down_hdr, e->hidden, nullptr, e->hidden, 0,
-                                 last ? kNoXq : e->xq_hidden, last ? nullptr : e->layers[l + 1].ln1,
-                                 last ? nullptr : e->ssq_part, st)) != 0)
+        if ((mask & 8) && (rc = engine_gemv_xq(e, e->xq_act, w.down_blob, w.down_hdr, e->hidden, nullptr, e->hidden, 0,
+                                               last ? kNoXq : e->xq_hidden, last ? nullptr : e->layers[l + 1].ln1,
+                                               last ? nullptr : e->ssq_part, st)) != 0)
           return rc;
         continue;
       }
-      rc = launch_gemv_from_header(e->hidden, WOQ_F32, c.hidden, w.qkv_blob, w.qkv_hdr, nullptr, e->qkv, WOQ_F32,
-                                   w.qkv_hdr.N, 1, w.ln1, c.rms_eps, nullptr, 0, 0, e->nt, st);
+      rc = (mask & 1) ? launch_gemv_from_header(e->hidden, WOQ_F32, c.hidden, w.qkv_blob, w.qkv_hdr, nullptr, e->qkv,
+                                                WOQ_F32, w.qkv_hdr.N, 1, w.ln1, c.rms_eps, nullptr, 0, 0, e->nt, st)
+                      : 0;
       if (rc) return rc;
-      rc = launch_gemv_from_header(e->attn, WOQ_F32, c.heads * c.head_dim, w.o_blob, w.o_hdr, nullptr, e->qkv,
-                                   WOQ_F32, c.hidden, 1, nullptr, 0.f, nullptr, 0, 0, e->nt, st);
+      rc = (mask & 2) ? launch_gemv_from_header(e->attn, WOQ_F32, c.heads * c.head_dim, w.o_blob, w.o_hdr, nullptr,
+                                                e->qkv, WOQ_F32, c.hidden, 1, nullptr, 0.f, nullptr, 0, 0, e->nt, st)
+                      : 0;
       if (rc) return rc;
-      rc = launch_gemv_from_header(e->hidden, WOQ_F32, c.hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, e->act,
-                                   WOQ_F32, c.inter, 1, w.ln2, c.rms_eps, nullptr, 0, 1, e->nt, st);
+      rc = (mask & 4) ? launch_gemv_from_header(e->hidden, WOQ_F32, c.hidden, w.gate_up_blob, w.gate_up_hdr, nullptr,
+                                                e->act, WOQ_F32, c.inter, 1, w.ln2, c.rms_eps, nullptr, 0, 1, e->nt, st)
+                      : 0;
       if (rc) return rc;
-      rc = launch_gemv_from_header(e->act, WOQ_F32, c.inter, w.down_blob, w.down_hdr, nullptr, e->qkv, WOQ_F32,
-                                   c.hidden, 1, nullptr, 0.f, nullptr, 0, 0, e->nt, st);
+      rc = (mask & 8) ? launch_gemv_from_header(e->act, WOQ_F32, c.inter, w.down_blob, w.down_hdr, nullptr, e->qkv,
+                                                WOQ_F32, c.hidden, 1, nullptr, 0.f, nullptr, 0, 0, e->nt, st)
+                      : 0;
       if (rc) return rc;
     }
     return 0;
@@ -919,8 +926,12 @@ int woq_engine_time_gemv(woq_engine* e, int reps, void* stream, float* total_ms,
   const int rc = time_captured(st, reps, pass, total_ms);
   if (rc) return rc;
   *bytes_per_pass = bytes;
-  *launches_per_pass = c.layers * 4;
+  *launches_per_pass = c.layers * __builtin_popcount(mask & 15);
   WOQ_END
+}
+int woq_engine_time_gemv(woq_engine* e, int reps, void* stream, float* total_ms, double* bytes_per_pass,
+                         int* launches_per_pass) {
+  return woq_engine_time_gemv_mask(e, 15, reps, stream, total_ms, bytes_per_pass, launches_per_pass);
 }
 
 // roofline.ceiling of bench.py: the decode step's four GEMV launches per layer with the arithmetic taken out — mode 0:

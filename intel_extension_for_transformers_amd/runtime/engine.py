@@ -151,10 +151,12 @@ class WoqDecoderEngine:
         cur.wait_stream(self._stream)
         return out
 
-    def time_gemv(self, reps=1):
+    def time_gemv(self, reps=1, mask=15):
+        """(total ms, algorithmic bytes per pass, launches per pass) of `reps` replays of a captured pass over every
+        layer's GEMV launches in the decode step's own forms; mask picks projections (bit 0 qkv, 1 o, 2 gate/up, 3 down)."""
         ms, by, n = ctypes.c_float(), ctypes.c_double(), ctypes.c_int()
-        self._on_own_stream(lambda: L.check(L.lib().woq_engine_time_gemv(
-            self._h, reps, L.stream_ptr(), ctypes.byref(ms), ctypes.byref(by), ctypes.byref(n))))
+        self._on_own_stream(lambda: L.check(L.lib().woq_engine_time_gemv_mask(
+            self._h, int(mask), reps, L.stream_ptr(), ctypes.byref(ms), ctypes.byref(by), ctypes.byref(n))))
         return ms.value, by.value, n.value
 
     def time_twin(self, mode, reps=1):
