@@ -1,4 +1,4 @@
-// woq_gemv_i8.hip — small-M (1..4 rows) int4 GEMV, the per-token hot kernel.
+// woq_gemv_i8.hip — small-M (1..8 rows, four per MFMA row set) int4 GEMV, the per-token hot kernel of the fp32-activation path.
 //
 // Arithmetic and parity definition (reference): qbits.cpp:113-140 -> bestla_weightonly_dispatcher.cpp:120-189
 // (per N-tile x K-block: unpack int4, apply scale / zero point, fp32 accumulate, epilogue
@@ -83,15 +83,19 @@ extern __device__ unsigned long long* g_probe;
 namespace woq {
 
 
-constexpr int TMAXM = 4;  // activation rows per launch: 4 MFMA rows (3 limbs + ones) per activation row
+constexpr int TSETM = 4;  // activation rows per MFMA row set: 4 MFMA rows (3 limbs + ones) per activation row
+constexpr int TMAXM = 8;  // activation rows per launch: two row sets over the SAME weight registers (round 3: rows
+                          // 5..8 used to be a second launch that streamed the weights again, 17-21 us against 10.9 at
+                          // M = 4 for the qkv shape — profiles/r03p)
 
 
-// LDS (dynamic, bytes): [nw zero blocks of 256][nw ones blocks of 256][nw strips: 3*M limb rows x (TPW*128 + 16)]
-//                       [slab nw x CB x 64 f32][sumsq nw x TMAXM f32]
+// LDS (dynamic, bytes): [nw zero blocks of 256][nw ones blocks of 256][nw strips: 3*min(M,4) limb rows x (TPW*128 + 16)]
+//                       [slab nrs x nw x CB x 64 f32][sumsq nrs x nw x 4 f32], nrs = row sets = ceil(M / 4)
 __host__ __device__ constexpr int tile_row_bytes(int TPW) { return TPW * 128 + 16; }  // +16 B: rows on distinct banks
 __host__ __device__ inline size_t tile_lds_bytes(int M, int nw, int TPW, int CB) {
-  return (size_t)nw * 512 + (size_t)nw * 3 * M * tile_row_bytes(TPW) + (size_t)nw * CB * 64 * 4 +
-         (size_t)nw * TMAXM * 4;
+  const int ms = M < TSETM ? M : TSETM, nrs = (M + TSETM - 1) / TSETM;
+  return (size_t)nw * 512 + (size_t)nw * 3 * ms * tile_row_bytes(TPW) + (size_t)nrs * nw * CB * 64 * 4 +
+         (size_t)nrs * nw * TSETM * 4;
 }
 
 
@@ -114,12 +118,14 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = (int)blockDim.x >> 6;
   const int M = M1 ? 1 : Mrows;
+  const int MS = M1 ? 1 : min(M, TSETM);          // rows of one set (the strip holds one set at a time)
+  const int nrs = M1 ? 1 : (M + TSETM - 1) / TSETM;  // row sets: each runs over the same weight registers
   unsigned char* zero_blk = smem_raw + wid * 256;             // this wave's 256 B of zeros
   unsigned char* ones_blk = smem_raw + nw * 256 + wid * 256;  // this wave's 256 B of int8 ones
   unsigned char* strips = smem_raw + nw * 512;
-  unsigned char* strip = strips + (size_t)wid * 3 * M * RB;  // this wave's [3*M][RB]
-  float* slab = (float*)(strips + (size_t)nw * 3 * M * RB);  // [nw][CB][64]
-  float* ssq = slab + nw * CB * 64;                           // [nw][TMAXM]
+  unsigned char* strip = strips + (size_t)wid * 3 * MS * RB;  // this wave's [3*MS][RB]
+  float* slab = (float*)(strips + (size_t)nw * 3 * MS * RB);  // [nrs][nw][CB][64]
+  float* ssq = slab + (size_t)nrs * nw * CB * 64;              // [nrs][nw][TSETM]
 
   // this wave's K tiles: balanced contiguous slice [kt0, kt0 + cnt), cnt <= TPW. Everything past the slice end
   // reads as zero through the descriptors' bounds, so tiles t >= cnt contribute exactly 0.
@@ -272,15 +278,28 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
       *(uint32_t*)(r0 + 2 * RB + j * 256) = ab2 | cd2;              // limb 2: b2 in [0, 127]
     }
   };
-  if (!WOQ_SKIP(5)) stage_row(0, xv0);
+#pragma unroll 1
+  for (int rs = 0; rs < nrs; ++rs) {  // row sets: rows 4 rs .. 4 rs + Mrs - 1 against the weight tiles in registers
+  const int Mrs = M1 ? 1 : min(TSETM, M - rs * TSETM);
+  // (the strip is wave-private and LDS executes one wave's accesses in order: the previous set's operand reads are
+  // behind us when this set's limbs are written; the barrier only pins the compiler)
+  __builtin_amdgcn_wave_barrier();
+  my_ss = 0.f, my_unsc = 0.f;
+  if (rs == 0) {
+    if (!WOQ_SKIP(5)) stage_row(0, xv0);
+  } else {
+    float4_t xv[XJ];
+    load_row((size_t)(rs * TSETM) * lda, xv);
+    stage_row(0, xv);
+  }
   if constexpr (!M1) {
-    for (int m = 1; m < M; ++m) {  // further rows (small batches): loaded behind the weights
+    for (int m = 1; m < Mrs; ++m) {  // further rows (small batches): loaded behind the weights
       float4_t xv[XJ];
-      load_row((size_t)m * lda, xv);
+      load_row((size_t)(rs * TSETM + m) * lda, xv);
       stage_row(m, xv);
     }
   }
-  if (lane < TMAXM) ssq[wid * TMAXM + lane] = my_ss;
+  if (lane < TSETM) ssq[((size_t)rs * nw + wid) * TSETM + lane] = my_ss;
   // the strip, zero and ones blocks are wave-private and LDS executes one wave's accesses in order: no barrier
   __builtin_amdgcn_wave_barrier();
   WOQ_STAMP(4);
@@ -293,7 +312,7 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
   // A rows: MFMA row r = lane & 15 -> activation row r >> 2, part r & 3 (limb 0..2 | ones). D: lane group kq
   // holds rows 4*kq .. 4*kq+3 = everything of activation row kq, for column lane & 15.
   const int a_m = i16 >> 2, a_part = i16 & 3;
-  const bool a_live = a_m < M;
+  const bool a_live = a_m < Mrs;
   const unsigned char* a_base = !a_live ? zero_blk + kq * 16
                                         : (a_part == 3 ? ones_blk + kq * 16
                                                        : strip + (size_t)(3 * a_m + a_part) * RB + kq * 16);
@@ -446,14 +465,15 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
   }
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
-    // slab layout [wave][cb][activation row = lane >> 4][16 columns]
-    if (!M1 || lane < 16) slab[((size_t)wid * CB + cb) * 64 + lane] = tot[cb] * unsc;
+    // slab layout [row set][wave][cb][activation row of the set = lane >> 4][16 columns]
+    if (!M1 || lane < 16) slab[(((size_t)rs * nw + wid) * CB + cb) * 64 + lane] = tot[cb] * unsc;
   }
   WOQ_STAMP(6);
   if (WOQ_SKIP(8)) {
     if (lane < 16 && wid == 0) ((float*)out)[(int)blockIdx.x * 16 + lane] = tot[0];
     return;
   }
+  }  // row sets
   __syncthreads();
   WOQ_STAMP(7);
 
@@ -463,13 +483,14 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
     const int e_i = idx & 15;
     const int e_m = M1 ? 0 : (idx >> 4) % M;
     const int e_cb = M1 ? (idx >> 4) : idx / (16 * M);
-    const int slot = e_m * 16 + e_i;
+    const int e_rs = e_m / TSETM, e_m4 = e_m % TSETM;  // row set, row inside it
+    const int slot = e_m4 * 16 + e_i;
     float v = 0.f, up = 0.f, sq = 0.f;
 #pragma unroll 4
     for (int w2 = 0; w2 < nw; ++w2) {
-      v += slab[((size_t)w2 * CB + e_cb) * 64 + slot];
-      if constexpr (CB == 2) up += slab[((size_t)w2 * CB + 1) * 64 + slot];
-      sq += ssq[w2 * TMAXM + e_m];
+      v += slab[(((size_t)e_rs * nw + w2) * CB + e_cb) * 64 + slot];
+      if constexpr (CB == 2) up += slab[(((size_t)e_rs * nw + w2) * CB + 1) * 64 + slot];
+      sq += ssq[((size_t)e_rs * nw + w2) * TSETM + e_m4];
     }
     const float inv = norm ? 1.0f / sqrtf(sq / (float)K + eps) : 1.f;  // HF LlamaRMSNorm
     v *= inv;
@@ -588,7 +609,12 @@ int gemv_tile_max_rows(const void* act, int act_dtype, int lda, const woq_blob_h
     const int tpg = h.group / WOQ_TILE_K;
     if (tpg < 1 || (tpg & (tpg - 1)) != 0) return 0;  // tiles per group must be a power of two
   }
-  int m = TMAXM;
+  static const int cap = [] {  // WOQ_TILE_MAXM=4: one row set per launch (the round-2 behaviour; same-box A/B runs)
+    const char* s = getenv("WOQ_TILE_MAXM");
+    const int v = s ? atoi(s) : TMAXM;
+    return v >= 1 && v <= TMAXM ? v : TMAXM;
+  }();
+  int m = cap;
   while (m > 0 && tile_lds_bytes(m, nw, tpw, cb) > 150 * 1024) --m;
   return m;
 }

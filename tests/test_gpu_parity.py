@@ -114,7 +114,7 @@ def test_packed_weight_info_roundtrip(qbits):
 
 
 @pytest.mark.parametrize("K,N,group,asym,shuf", CASES)
-@pytest.mark.parametrize("M", [1, 2, 3, 4, 7])
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_woq_linear_decode_vs_oracle(qbits, K, N, group, asym, shuf, M):
     """Decode GEMV (M <= 8) vs the parity definition (autograd/functions.py:41-63), fp32 in / fp32 out.
     Tolerance: |err| <= 2e-5 * sum_k |x_k w_k| bound, stated as 1e-4 * max|ref| + 1e-6 (fp32 accumulation in a
