@@ -20,6 +20,8 @@
 // Tiles entirely above a wave's causal diagonal are skipped by that wave; the workgroups with the most tiles are
 // scheduled first. One LDS buffer, two barriers per tile (a two-buffer, one-barrier variant measured 28 % slower:
 // 450 vs 353 us per layer at 4 x 2048 tokens — two workgroups per CU already overlap each other's staging). fp32 accumulation throughout; Q, K, V, P enter the MFMAs as fp16.
+#include <cstdlib>
+
 #include "woq_device.h"
 #include "woq_launch.h"
 
@@ -161,8 +163,23 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const _Float16* __
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, kq = lane >> 4;
-  const int qb = n_qblocks - 1 - (int)blockIdx.x;  // longest workgroups first
-  const int h = blockIdx.y, seq = blockIdx.z;
+  // Which (sequence, head, query block). 3-D grid: x = query block (longest first), y = head, z = sequence. 1-D grid
+  // (gridDim.y == 1, heads % 8 == 0): XCD-aware — workgroup ids go round-robin over the 8 XCDs, so id & 7 is the XCD;
+  // XCD x takes heads [x heads / 8, (x + 1) heads / 8) of every sequence and walks their query blocks one head after the
+  // other. The query blocks of a head (and the query heads of a kv group) then share ONE L2: with the 3-D order a
+  // head's 16 blocks ran on all eight XCDs and every L2 had to hold every active head's K / V (4 x 2048 tokens x 32
+  // heads = 134 MB per layer, re-read 8.5 times on average: the launch ran at the fabric's ~3.4 TB/s, not on its MFMAs).
+  int qb, h, seq;
+  if (gridDim.y == 1) {
+    const int L = (int)blockIdx.x, xcd = L & 7, r = L >> 3;
+    const int hp = heads >> 3, g = r / n_qblocks;
+    qb = n_qblocks - 1 - r % n_qblocks;
+    h = xcd * hp + g % hp;
+    seq = g / hp;
+  } else {
+    qb = n_qblocks - 1 - (int)blockIdx.x;  // longest workgroups first
+    h = blockIdx.y, seq = blockIdx.z;
+  }
   const int kh = h / (heads / kv_heads);
   const int nslots = heads + 2 * kv_heads;
   const int q0 = qb * AQB + wid * 32;  // this wave's first query row (within the chunk)
@@ -634,8 +651,15 @@ static int launch_attn_prefill_t(const _Float16* qkv, int n_seq, int T, int star
                                  int window, hipStream_t st) {
   auto k = attn_prefill_kernel<KVD, HD>;
   const int nqb = (T + AQB - 1) / AQB;
-  hipLaunchKernelGGL(k, dim3((unsigned)nqb, (unsigned)heads, (unsigned)n_seq), dim3(256), attn_lds_bytes<HD>(), st, qkv,
-                     T, start, heads, kv_heads, kcache, vcache, seq_stride_elems, out, nqb, window);
+  static const bool xcd_map = [] {  // WOQ_ATTN_XCD=0: the 3-D order (same-box A/B runs)
+    const char* e = getenv("WOQ_ATTN_XCD");
+    return !(e && e[0] == '0');
+  }();
+  const long long total = (long long)nqb * heads * n_seq;
+  const dim3 grid = (xcd_map && (heads & 7) == 0 && total < (1ll << 31)) ? dim3((unsigned)total)
+                                                                        : dim3((unsigned)nqb, (unsigned)heads, (unsigned)n_seq);
+  hipLaunchKernelGGL(k, grid, dim3(256), attn_lds_bytes<HD>(), st, qkv, T, start, heads, kv_heads, kcache, vcache,
+                     seq_stride_elems, out, nqb, window);
   return 0;
 }
 
