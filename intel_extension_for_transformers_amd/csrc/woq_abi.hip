@@ -78,7 +78,7 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
                             float eps, const float* residual, int ld_res, int epi, int nt, hipStream_t st);
 int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                     const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w, float eps,
-                    const float* residual, int ld_res, int epi, void* ws, int fp32_class, hipStream_t st);
+                    const float* residual, int ld_res, int epi, void* ws, int fp32_class, hipStream_t st, const void* fp8_lo = nullptr, uint32_t fp8_type = 0);
 int launch_gemv_fp8(const void* act, int act_dtype, int lda, const void* hi_blob, const woq_blob_header& hi,
                     const void* lo_q, uint32_t fp8_type, const float* bias, void* out, int out_dtype, int ldo, int M,
                     hipStream_t st);
@@ -104,8 +104,10 @@ static int linear_int4(const void* act, int act_dtype, int lda, const void* blob
                        hipStream_t st) {
   static const bool gemm_as_gemv = getenv("WOQ_GEMM_AS_GEMV") != nullptr;  // A/B switches for tests
   static const bool gemv_as_gemm = getenv("WOQ_GEMV_AS_GEMM") != nullptr;
-  // 4-bit table weights (nf4 / fp4): the generic fp32 kernel for every M (functional, untuned: rows in chunks of 4)
-  if ((M > 8 || gemv_as_gemm) && !gemm_as_gemv && !is_table_type(h.weight_type))
+  // 4-bit table weights (nf4 / fp4): M <= 8 the generic fp32 kernel (rows in chunks of 4); above, the MFMA GEMM over a
+  // pre-dequantised fragment image of the weight (woq_gemm_f16.hip: deq_frag_kernel + gemm_f16frag_kernel)
+  static const bool table_generic = getenv("WOQ_TABLE_GENERIC") != nullptr;  // A/B switch: the round-2 behaviour
+  if ((M > 8 || gemv_as_gemm) && !gemm_as_gemv && !(is_table_type(h.weight_type) && (table_generic || M <= 8)))
     return launch_gemm_f16(act, act_dtype, lda, blob, h, bias, out, out_dtype, ldo, M, nullptr, 0.f, residual, ld_res, 0,
                            nullptr, h.compute_type == WOQ_C_FP32 ? 1 : 0, st);
   return launch_gemv_from_header(act, act_dtype, lda, blob, h, bias, out, out_dtype, ldo, M, nullptr, 0.f, residual,
@@ -140,8 +142,13 @@ int woq_linear(const void* act_dev, int act_dtype, int lda, const void* blob_dev
                               hdr->compute_type, hdr->off_shuffle != 0) == 0, "QBits: corrupt fp8 header");
     const uint8_t* bhi = (const uint8_t*)blob_dev + hdr->off_q;
     const uint8_t* blo = (const uint8_t*)blob_dev + hdr->off_scale;
-    rc = launch_gemv_fp8(act_dev, act_dtype, lda, bhi, hi, blo + lo.off_q, hdr->weight_type, bias_dev, out_dev,
-                         out_dtype, ldo, M, st);
+    static const bool fp8_generic = getenv("WOQ_TABLE_GENERIC") != nullptr;  // A/B switch: the round-2 behaviour
+    if (M > 8 && !fp8_generic)  // the MFMA GEMM over a pre-dequantised fragment image (woq_gemm_f16.hip)
+      rc = launch_gemm_f16(act_dev, act_dtype, lda, bhi, hi, bias_dev, out_dev, out_dtype, ldo, M, nullptr, 0.f, nullptr, 0,
+                           0, nullptr, hdr->compute_type == WOQ_C_FP32 ? 1 : 0, st, blo + lo.off_q, hdr->weight_type);
+    else
+      rc = launch_gemv_fp8(act_dev, act_dtype, lda, bhi, hi, blo + lo.off_q, hdr->weight_type, bias_dev, out_dev,
+                           out_dtype, ldo, M, st);
   } else if (hdr->weight_type == WOQ_W_INT8) {
     // (q8 - zp8) s = (hi - zhi) 16s + (lo - zlo) s: two int4 linears on the same activations (woq_blob.h); the
     // first goes to an fp32 scratch, the second adds it (and the bias) and stores the caller's dtype

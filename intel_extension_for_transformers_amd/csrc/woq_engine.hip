@@ -68,7 +68,7 @@ void launch_argmax_pairs(const float* pmax, const int32_t* pidx, int n, int32_t*
 size_t gemm_f16_workspace_bytes(int M, int Kpad, int Npad, int planes);
 int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                     const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w, float eps,
-                    const float* residual, int ld_res, int epi, void* ws, int fp32_class, hipStream_t st);
+                    const float* residual, int ld_res, int epi, void* ws, int fp32_class, hipStream_t st, const void* fp8_lo = nullptr, uint32_t fp8_type = 0);
 void launch_embed_rows(const void* embed, int dtype, const int32_t* tokens, int M, int hidden, float* out,
                        hipStream_t st);
 int launch_rope_append(_Float16* qkv, int n_seq, int T, int start, int heads, int kv_heads, int HD, const float* cs,

@@ -69,6 +69,9 @@ struct GemmF16Args {
   const float* residual;  // fp32 [M][ld_res] added in the epilogue (may alias `out`), or null
   int ld_res;
   int epi;                // 0 plain; 1 SiLU(gate) * up over interleaved gate / up column tiles -> N/2 output columns
+  // float weight types (nf4 / fp4 tables): the B operand pre-dequantised by deq_frag_kernel into the MFMA fragment
+  // image [column tile][K tile][4 fragments][planes][64 lanes] x 16 B (planes: hi, and lo for the fp32-class form)
+  const u32x4* bfrag;
 };
 
 #ifndef WOQ_GEMM_HANDSCHED  // 1: the hand-scheduled K loop (woq_gemm_f16p.h) for NP = 1; 0: hipcc's schedule (A/B runs)
@@ -646,6 +649,207 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gemm_f16s_kernel(GemmF16
   gemm_epilogue<CT>(a, acc, row0, ct0, i16, kq);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// float weight types at M > 8 (round 3). nf4 / fp4 weights are w = table[code] * scale: no integer identity turns the
+// code into an fp16 in two VALU, and a 16-entry lookup per weight inside the K loop would cost more than the MFMAs it
+// feeds. So the dequantisation is a PRE-PASS (deq_frag_kernel: blob -> fp16 MFMA fragments, scaled by the same
+// power-of-two column factors as the int4 path, hi + lo planes for compute_dtype fp32) and the GEMM reads finished
+// fragments: 16 B per lane per fragment, no VALU on the B side at all. Costs one pass over the weight (25 MB in,
+// 100-200 MB out for a 4096 x 12288 projection, ~50 us) per call; before it these types ran the generic fp32 GEMV kernel
+// at every M: 64 ms for 2048 rows of that projection (3.2 TFLOP/s, tools/wtypes_bench.py).
+// ---------------------------------------------------------------------------------------------------------------
+struct DeqFragArgs {
+  const u32x4* q;
+  const u32x4* q_lo;  // fp8 weight types: the low-nibble plane (code = hi nibble << 4 | lo nibble ^ 8), else null
+  const void* scales;
+  int scale_type, scale_mode, n_groups, group, tiles_k, tiles_n, planes;
+  uint32_t weight_type;
+  const float* cs;  // [Npad] 2^E per column (pack pass)
+  u32x4* out;
+};
+
+__global__ __launch_bounds__(256) void deq_frag_kernel(DeqFragArgs a) {
+  __shared__ float lut_s[256];  // table types: 16 values; fp8: all 256 codes
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool fp8 = a.q_lo != nullptr;
+  if (fp8)
+    lut_s[tid] = fp8_code_value(a.weight_type, tid);
+  else if (tid < 16)
+    lut_s[tid] = lut_value(a.weight_type, tid);
+  __syncthreads();
+  const size_t tile = (size_t)blockIdx.x * 4 + (tid >> 6);  // (column tile, K tile), K fastest
+  if (tile >= (size_t)a.tiles_n * a.tiles_k) return;
+  const int tn = (int)(tile / a.tiles_k), kt = (int)(tile % a.tiles_k);
+  const int i16 = lane & 15, kq = lane >> 4;
+  const u32x4 wv = a.q[tile * 64 + lane];
+  u32x4 wl = {0u, 0u, 0u, 0u};
+  if (fp8) wl = a.q_lo[tile * 64 + lane];
+  const float icol = 1.f / a.cs[tn * 16 + i16];  // exact: a power of two
+#pragma unroll
+  for (int hp = 0; hp < 4; ++hp) {
+    size_t si;
+    if (a.scale_mode == 0) {
+      int g = (kt * 128) / a.group;
+      g = g >= a.n_groups ? a.n_groups - 1 : g;
+      si = ((size_t)tn * a.n_groups + g) * 16 + i16;
+    } else {
+      si = ((((size_t)tn * a.tiles_k + kt) * 16 + i16) << 2) + 2 * (hp >> 1) + (kq >> 1);
+    }
+    const float r = load_f32(a.scales, si, a.scale_type) * icol;
+    // element e of the fragment = nibble {0,4,1,5,2,6,3,7}[e] of the word: the order dq8s leaves its eight values in
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      uint32_t c0 = (wv[hp] >> (4 * pr)) & 0xfu, c1 = (wv[hp] >> (4 * pr + 16)) & 0xfu;
+      if (fp8) {
+        c0 = (c0 << 4) | (((wl[hp] >> (4 * pr)) & 0xfu) ^ 8u);
+        c1 = (c1 << 4) | (((wl[hp] >> (4 * pr + 16)) & 0xfu) ^ 8u);
+      }
+      const float w0 = lut_s[c0] * r, w1 = lut_s[c1] * r;
+      const _Float16 h0 = (_Float16)w0, h1 = (_Float16)w1;
+      hi[pr] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+      const _Float16 l0 = (_Float16)(w0 - (float)h0), l1 = (_Float16)(w1 - (float)h1);
+      lo[pr] = (uint32_t)__builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
+    }
+    u32x4* dst = a.out + ((tile * 4 + hp) * a.planes) * 64 + lane;
+    dst[0] = (u32x4){hi[0], hi[1], hi[2], hi[3]};
+    if (a.planes == 2) dst[64] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+  }
+}
+
+template <int NP, int CT = 2>
+__global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gemm_f16frag_kernel(GemmF16Args a) {
+  constexpr int PLANES = NP == 1 ? 1 : 2;
+  constexpr int FBN = 64 * CT;
+  constexpr int STAGE = FTILE_BYTES * PLANES;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char fsm[];  // 2 x 32 KiB A tiles (x planes)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int bid = (int)blockIdx.x;  // XCD-aware 8 x 8 super-tiles, as gemm_f16s_kernel
+  const int sup = ((bid >> 3) >> 6) * 8 + (bid & 7), within = (bid >> 3) & 63;
+  if (sup >= a.n_sup) return;
+  const int mb = (sup / a.sup_n) * 8 + (within >> 3), nb = (sup % a.sup_n) * 8 + (within & 7);
+  if (mb >= a.nb_m || nb >= a.nb_n) return;
+  const int row0 = mb * FBM;
+  const int ct0 = nb * (FBN / 16) + wid * CT;
+  float4_t acc[8][CT];
+#pragma unroll
+  for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[rt][c] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  const _Float16* a_tiles = a.ap + (size_t)mb * a.tiles_k * (STAGE / 2);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)fsm;
+  auto issue_a = [&](int kt, int buf) {  // 8 LDS-DMA pieces of 1 KiB per wave and plane
+    const _Float16* src = a_tiles + (size_t)kt * (STAGE / 2) + (size_t)wid * (4096 * PLANES) + lane * 8;
+    const uint32_t dst = lds0 + buf * STAGE + wid * (8192 * PLANES);
+#pragma unroll
+    for (int j = 0; j < 2 * PLANES; ++j) {
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, off\n\t"
+          "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+          "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+          "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src + j * 2048), "s"(dst + j * 4096)
+          : "memory");
+    }
+  };
+  int tnc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) tnc[c] = min(ct0 + c, a.tiles_n - 1);
+  struct Frags {
+    u32x4 f[CT][4][PLANES];
+  };
+  auto load_b = [&](int kt, Frags& b) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int hp = 0; hp < 4; ++hp)
+#pragma unroll
+        for (int p = 0; p < PLANES; ++p)
+          asm volatile("global_load_dwordx4 %0, %1, off"
+                       : "=v"(b.f[c][hp][p])
+                       : "v"(a.bfrag + ((((size_t)tnc[c] * a.tiles_k + kt) * 4 + hp) * PLANES + p) * 64 + lane)
+                       : "memory");
+  };
+  auto wait_loads = [&](Frags& b) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int hp = 0; hp < 4; ++hp)
+#pragma unroll
+        for (int p = 0; p < PLANES; ++p) asm volatile("" : "+v"(b.f[c][hp][p]));
+  };
+  int a_off[4];
+#pragma unroll
+  for (int hp = 0; hp < 4; ++hp) a_off[hp] = i16 * 256 + ((((hp >> 1) * 8 + kq * 2 + (hp & 1)) ^ i16) << 4);
+  auto compute = [&](int buf, const Frags& b) {
+    const unsigned char* at = fsm + buf * STAGE;
+#pragma unroll
+    for (int hp = 0; hp < 4; ++hp) {
+#pragma unroll
+      for (int rt = 0; rt < 8; ++rt) {
+        const h8 af = *(const h8*)(at + rt * 4096 + a_off[hp]);
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+          acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, __builtin_bit_cast(h8, b.f[c][hp][0]), acc[rt][c], 0, 0, 0);
+        if constexpr (NP == 3) {
+          const h8 al = *(const h8*)(at + FTILE_BYTES + rt * 4096 + a_off[hp]);
+#pragma unroll
+          for (int c = 0; c < CT; ++c) {
+            acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, __builtin_bit_cast(h8, b.f[c][hp][PLANES - 1]), acc[rt][c], 0, 0, 0);
+            acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, __builtin_bit_cast(h8, b.f[c][hp][0]), acc[rt][c], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+  Frags b0, b1;
+  issue_a(0, 0);
+  load_b(0, b0);
+  const int last = a.tiles_k - 1;
+  for (int kt = 0; kt < a.tiles_k; kt += 2) {
+    wait_loads(b0);
+    __syncthreads();
+    issue_a(min(kt + 1, last), 1);
+    load_b(min(kt + 1, last), b1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(0, b0);
+    if (kt + 1 >= a.tiles_k) break;
+    wait_loads(b1);
+    __syncthreads();
+    issue_a(min(kt + 2, last), 0);
+    load_b(min(kt + 2, last), b0);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1, b1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  gemm_epilogue<CT>(a, acc, row0, ct0, i16, kq);
+}
+
+template <int NP>
+static int launch_f16frag_t(GemmF16Args& a, hipStream_t st) {
+  auto kern = gemm_f16frag_kernel<NP, 2>;
+  static bool attr_set = false;
+  static std::mutex attr_mu;
+  {
+    std::lock_guard<std::mutex> attr_lock(attr_mu);
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FTILE_BYTES * 2);
+      if (e != hipSuccess) return woq::fail(std::string("QBits: hipFuncSetAttribute: ") + hipGetErrorString(e));
+      attr_set = true;
+    }
+  }
+  const int n_sup8 = (a.n_sup + 7) / 8;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(n_sup8 * 8 * 64)), dim3(256), 2 * FTILE_BYTES * (NP == 1 ? 1 : 2), st, a);
+  return 0;
+}
+
 #include "woq_gemm_f16p.h"
 
 template <int SMODE, bool ASYM, bool S32, int NP>
@@ -702,7 +906,8 @@ size_t gemm_f16_workspace_bytes(int M, int Kpad, int Npad, int planes) {
 // residual / epi: see GemmF16Args; fp32_class: the three-product hi + lo form (compute_dtype fp32).
 int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                     const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w, float eps,
-                    const float* residual, int ld_res, int epi, void* ws, int fp32_class, hipStream_t st) {
+                    const float* residual, int ld_res, int epi, void* ws, int fp32_class, hipStream_t st,
+                    const void* fp8_lo, uint32_t fp8_type) {
   const int planes = fp32_class ? 2 : 1;
   if (epi == 1 && (((h.Npad / WOQ_TILE_N) & 1) != 0 || (h.N & 31) != 0))
     return woq::fail("QBits: the SiLU*mul epilogue needs whole gate / up column-tile pairs");
@@ -732,7 +937,14 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   a.ld_res = ld_res;
   a.epi = epi;
   const size_t Mpad = (size_t)a.nb_m * FBM;
-  const size_t total = gemm_f16_workspace_bytes(M, h.Kpad, h.Npad, planes);
+  // float weight types (4-bit tables; fp8 as two nibble planes, `h` = the high plane's header): B pre-dequantised into
+  // MFMA fragments
+  const bool frag = is_table_type(h.weight_type) || fp8_lo != nullptr;
+  const size_t frag_bytes = frag ? (size_t)a.tiles_n * a.tiles_k * 4 * planes * 1024 : 0;
+  const size_t base_bytes = (gemm_f16_workspace_bytes(M, h.Kpad, h.Npad, planes) + 255) & ~(size_t)255;
+  const size_t total = base_bytes + frag_bytes;
+  if (frag && (ws != nullptr || epi != 0 || h.off_zp != 0))
+    return woq::fail("QBits: table weight types go through woq_linear (no fused epilogue, no zero points)");
   unsigned char* w = (unsigned char*)ws;
   const bool mine = w == nullptr;  // no workspace passed in (the engine passes its own): take scratch
   bool own = false;
@@ -743,11 +955,12 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   a.ap = (const _Float16*)w;
   a.rs = (const float*)(w + Mpad * h.Kpad * sizeof(_Float16) * planes);
   a.cs = a.rs + Mpad;
+  a.bfrag = frag ? (const u32x4*)(w + base_bytes) : nullptr;
 
   // raw-A form: fp16 rows that need no gather, no RMSNorm and no rescale go to the hand-scheduled kernel as they are
   // (the o_proj / down_proj calls of the prompt pass); only the column scales are computed here
   static const bool raw_ok = !(getenv("WOQ_GEMM_RAW_A") && getenv("WOQ_GEMM_RAW_A")[0] == '0');
-  const bool raw = WOQ_GEMM_HANDSCHED && raw_ok && !fp32_class && act_dtype == WOQ_F16 && norm_w == nullptr &&
+  const bool raw = WOQ_GEMM_HANDSCHED && raw_ok && !frag && !fp32_class && act_dtype == WOQ_F16 && norm_w == nullptr &&
                    h.off_shuffle == 0 && (h.K & 127) == 0 && ((h.Kpad / WOQ_TILE_K) & 1) == 0 && (lda & 7) == 0 &&
                    (((uintptr_t)act) & 15) == 0 && (size_t)M * lda * 2 < ((size_t)1 << 32);
   a.act_raw = raw ? act : nullptr;
@@ -755,7 +968,7 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   if (raw) a.rs = nullptr;
   static const bool ring_ok = !(getenv("WOQ_GEMM_RING") && getenv("WOQ_GEMM_RING")[0] == '0');
   const bool ring_fits = !(h.scale_mode == 1 && a.zp != nullptr && h.scale_type == WOQ_F32);  // (launch_f16_t: VGPRs)
-  a.ring = (WOQ_GEMM_HANDSCHED && ring_ok && ring_fits && !fp32_class && ((h.Kpad / WOQ_TILE_K) & 1) == 0) ? 1 : 0;
+  a.ring = (WOQ_GEMM_HANDSCHED && ring_ok && ring_fits && !frag && !fp32_class && ((h.Kpad / WOQ_TILE_K) & 1) == 0) ? 1 : 0;
 
   PackF16Args p;
   p.planes = planes;
@@ -787,6 +1000,15 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   const int sm = (int)h.scale_mode;
   const bool s32 = h.scale_type == WOQ_F32;
   int rc = 1;
+  if (frag) {
+    DeqFragArgs d;
+    d.q = a.q, d.q_lo = (const u32x4*)fp8_lo, d.scales = a.scales, d.scale_type = a.scale_type, d.scale_mode = sm, d.n_groups = h.n_groups;
+    d.group = h.group, d.tiles_k = a.tiles_k, d.tiles_n = a.tiles_n, d.planes = planes, d.weight_type = fp8_lo ? fp8_type : h.weight_type;
+    d.cs = a.cs, d.out = (u32x4*)a.bfrag;
+    const size_t tiles = (size_t)a.tiles_n * a.tiles_k;
+    hipLaunchKernelGGL(deq_frag_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, d);
+    rc = fp32_class ? launch_f16frag_t<3>(a, st) : launch_f16frag_t<1>(a, st);
+  } else {
 #define WOQ_F16_CASE(SM, AS)                                                                   \
   if (sm == SM && asym == AS)                                                                   \
     rc = fp32_class ? (s32 ? launch_f16_t<SM, AS, true, 3>(a, st) : launch_f16_t<SM, AS, false, 3>(a, st))  \
@@ -796,6 +1018,7 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   WOQ_F16_CASE(1, false)
   WOQ_F16_CASE(1, true)
 #undef WOQ_F16_CASE
+  }
   if (g_gemm_ev1) hipEventRecord(g_gemm_ev1, st);
   if (mine) scratch_release(w, total, own, st);
   return rc;

@@ -595,12 +595,14 @@ TABLE_TYPES = {"nf4": orc.W_NF4, "fp4_e2m1": orc.W_FP4_E2M1, "fp4_e2m1_bnb": orc
 
 
 @pytest.mark.parametrize("wname", sorted(TABLE_TYPES))
-@pytest.mark.parametrize("K,N,group", [(512, 1024, 128), (256, 48, 32), (160, 24, 64), (512, 64, -1)])
+@pytest.mark.parametrize("K,N,group", [(512, 1024, 128), (256, 48, 32), (160, 24, 64), (512, 64, -1), (384, 272, 128)])
 def test_table_weight_types_quantize_dequant_linear(qbits, wname, K, N, group):
     """w = table[code] * scale. quantize_to_packed_weight == the oracle's nearest-entry RTN + repack byte for byte
-    (rounding rule parity-unpinned); dequantisation bit-exact; woq_linear at decode and at prefill row
-    counts (the generic fp32 kernel serves every M for these types) within fp32 summation error of
-    dequantise -> matmul -> + bias; asym is rejected like the reference does for float weight types."""
+    (rounding rule parity-unpinned); dequantisation bit-exact; woq_linear at decode row counts (the
+    generic fp32 kernel) and at prefill row counts (round 3: the MFMA GEMM over a pre-dequantised fragment image of the
+    weight, hi + lo fp16 planes for compute fp32 — one and several row blocks, even and odd K-tile counts, ragged N)
+    within fp32 summation error of dequantise -> matmul -> + bias; asym is rejected like the reference does for float
+    weight types."""
     wt = TABLE_TYPES[wname]
     rng = np.random.default_rng(41)
     w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)  # nn.Linear layout
@@ -614,7 +616,7 @@ def test_table_weight_types_quantize_dequant_linear(qbits, wname, K, N, group):
     assert np.array_equal(deq.cpu().numpy(), want)
     assert "".join(chr(c) for c in qbits.acquire_packed_weight_info(blob, 6).tolist()) == wname
     bias = rng.random(N, dtype=np.float32)
-    for M in (1, 3, 37):
+    for M in (1, 3, 37, 300):
         x = rng.standard_normal((M, K)).astype(np.float32)
         ref = orc.woq_linear(x, ref_blob, bias)
         out = torch.zeros(M, N, device="cuda")
@@ -622,6 +624,13 @@ def test_table_weight_types_quantize_dequant_linear(qbits, wname, K, N, group):
                          False)
         mag = np.abs(x) @ np.abs(want)
         assert (np.abs(out.cpu().numpy() - ref) <= 2e-6 * mag + 1e-5).all()
+    # reduced-precision compute (one fp16 product per operand pair), 16-bit rows in, 16-bit out
+    blob16 = qbits.quantize_to_packed_weight(torch.from_numpy(w).cuda(), True, group, "bf16", wname, "fp32", False)
+    x = torch.from_numpy(rng.standard_normal((150, K)).astype(np.float32)).cuda().half()
+    out16 = torch.zeros(150, N, device="cuda", dtype=torch.float16)
+    qbits.woq_linear(x, blob16, torch.from_numpy(bias).cuda(), out16, "bf16", wname, "fp32", False)
+    ref = orc.woq_linear(x.float().cpu().numpy(), ref_blob, bias)
+    assert (np.abs(out16.float().cpu().numpy() - ref) <= 2e-3 * np.abs(ref).max(axis=1, keepdims=True) + 1e-3).all()
     with pytest.raises(RuntimeError, match="symmetric"):
         qbits.quantize_to_packed_weight(torch.from_numpy(w).cuda(), True, group, "fp32", wname, "fp32", True)
 
@@ -662,7 +671,8 @@ def test_fp8_weight_types_quantize_dequant_linear(qbits, wname, sname, K, N, gro
     # relative error of the grid: half a ulp of a 3- / 2-bit mantissa on the group's scale (twice that with e8m0)
     assert np.abs(want - w.T).max() <= (2.0 ** -4 if wt == orc.W_FP8_E4M3 else 2.0 ** -3) * np.abs(w).max() * (2 if e8 else 1)
     bias = rng.random(N, dtype=np.float32)
-    for M, adt in ((1, torch.float32), (3, torch.float32), (37, torch.float32), (5, torch.bfloat16)):
+    for M, adt in ((1, torch.float32), (3, torch.float32), (37, torch.float32), (5, torch.bfloat16),
+                   (260, torch.float32)):  # 37 / 260 rows: the MFMA GEMM over the pre-dequantised fragment image
         x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(adt)
         xf = x.float().numpy()
         ref = orc.woq_linear(xf, ref_blob, bias)
