@@ -3,7 +3,7 @@
 // woq_linear replaces qbits.woq_linear (qbits/qbits.cpp:113-140) and the string-driven template
 // selection under it (bestla_weightonly_dispatcher.cpp:230-382: parse_launcher / parse_store /
 // parse_activation / parse_weight / parse_gemm_core). Here the "dispatcher" is a few integer
-// compares on the cached header: M <= 8 -> decode GEMV, else the MFMA GEMM (three-product fp32-class form for
+// compares on the cached header: M <= 16 (int4; 8 for the float weight types) -> decode GEMV, else the MFMA GEMM (three-product fp32-class form for
 // compute_dtype fp32, single fp16 product for the reduced-precision compute modes).
 #include <mutex>
 
@@ -96,7 +96,7 @@ int woq_device_count(void) {
   return n;
 }
 
-// one int4 blob: M <= 8 -> decode GEMV, else the MFMA GEMM (woq_gemm_f16.hip): one fp16 product per operand pair for
+// one int4 blob: M <= 16 -> decode GEMV, else the MFMA GEMM (woq_gemm_f16.hip): one fp16 product per operand pair for
 // the reduced-precision compute modes, the three-product hi + lo form for compute_dtype fp32.
 // `residual` (fp32 [M][ld_res]) is added.
 static int linear_int4(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
@@ -107,7 +107,16 @@ static int linear_int4(const void* act, int act_dtype, int lda, const void* blob
   // 4-bit table weights (nf4 / fp4): M <= 8 the generic fp32 kernel (rows in chunks of 4); above, the MFMA GEMM over a
   // pre-dequantised fragment image of the weight (woq_gemm_f16.hip: deq_frag_kernel + gemm_f16frag_kernel)
   static const bool table_generic = getenv("WOQ_TABLE_GENERIC") != nullptr;  // A/B switch: the round-2 behaviour
-  if ((M > 8 || gemv_as_gemm) && !gemm_as_gemv && !(is_table_type(h.weight_type) && (table_generic || M <= 8)))
+  // int4: up to 16 rows stay on the decode GEMV (four MFMA row sets over one pass of the weights, woq_gemv_i8.hip): the
+  // MFMA GEMM has one 128-row block and a third of the chip's workgroups there (53-93 us at M = 16 for the Llama-2-7B
+  // projections against 14-44 us). WOQ_GEMV_MAX_ROWS=8 gives the round-2 seam back (same-box A/B runs).
+  static const int gemv_rows = [] {
+    const char* e = getenv("WOQ_GEMV_MAX_ROWS");
+    const int v = e ? atoi(e) : 16;
+    return v >= 1 && v <= 16 ? v : 16;
+  }();
+  const int seam = is_table_type(h.weight_type) ? 8 : gemv_rows;
+  if ((M > seam || gemv_as_gemm) && !gemm_as_gemv && !(is_table_type(h.weight_type) && (table_generic || M <= 8)))
     return launch_gemm_f16(act, act_dtype, lda, blob, h, bias, out, out_dtype, ldo, M, nullptr, 0.f, residual, ld_res, 0,
                            nullptr, h.compute_type == WOQ_C_FP32 ? 1 : 0, st);
   return launch_gemv_from_header(act, act_dtype, lda, blob, h, bias, out, out_dtype, ldo, M, nullptr, 0.f, residual,

@@ -1,4 +1,4 @@
-// woq_gemv_i8.hip — small-M (1..8 rows, four per MFMA row set) int4 GEMV, the per-token hot kernel of the fp32-activation path.
+// woq_gemv_i8.hip — small-M (1..16 rows, four per MFMA row set) int4 GEMV, the per-token hot kernel of the fp32-activation path.
 //
 // Arithmetic and parity definition (reference): qbits.cpp:113-140 -> bestla_weightonly_dispatcher.cpp:120-189
 // (per N-tile x K-block: unpack int4, apply scale / zero point, fp32 accumulate, epilogue
@@ -84,9 +84,9 @@ namespace woq {
 
 
 constexpr int TSETM = 4;  // activation rows per MFMA row set: 4 MFMA rows (3 limbs + ones) per activation row
-constexpr int TMAXM = 8;  // activation rows per launch: two row sets over the SAME weight registers (round 3: rows
-                          // 5..8 used to be a second launch that streamed the weights again, 17-21 us against 10.9 at
-                          // M = 4 for the qkv shape — profiles/r03p)
+constexpr int TMAXM = 16;  // activation rows per launch: up to four row sets over the SAME weight registers (round 3:
+                           // rows 5..8 used to be a second launch that streamed the weights again, 17-21 us against
+                           // 10.9 at M = 4 for the qkv shape — profiles/r03p; rows 9..16 used to go to the MFMA GEMM)
 
 
 // LDS (dynamic, bytes): [nw zero blocks of 256][nw ones blocks of 256][nw strips: 3*min(M,4) limb rows x (TPW*128 + 16)]

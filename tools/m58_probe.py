@@ -17,7 +17,7 @@ for name, K, N in shapes:
         q = torch.randint(-8, 8, (K, N), dtype=torch.int8, device="cuda")
         s = torch.rand(K // 128, N, device="cuda") * 0.01
         blobs.append(qbits.repack_quantized_weight(q, s, e8, e32, "int4_clip", "fp16", "bf16", False, 128))
-    for M in (4, 5, 8, 16):
+    for M in (4, 5, 8, 9, 12, 16, 17):
         x = torch.randn(M, K, device="cuda")
         out = torch.empty(M, N, device="cuda")
         for b in blobs:
