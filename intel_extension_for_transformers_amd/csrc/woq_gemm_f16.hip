@@ -37,6 +37,7 @@
 // A tile (128 x 256, one workgroup per CU) 799; 4 column tiles per wave (128 accumulator VGPRs, one workgroup per CU)
 // 474; knock-outs of the built kernel: no dequantisation 1012, no A-tile DMA 997, no barrier 892 — i.e. ~17 % of
 // the time is the 14-VALU dequantisation, ~15 % the LDS-DMA issue / landing, ~5 % barrier skew.
+#include <algorithm>
 #include <mutex>
 #include <type_traits>
 
@@ -72,6 +73,11 @@ struct GemmF16Args {
   // float weight types (nf4 / fp4 tables): the B operand pre-dequantised by deq_frag_kernel into the MFMA fragment
   // image [column tile][K tile][4 fragments][planes][64 lanes] x 16 B (planes: hi, and lo for the fp32-class form)
   const u32x4* bfrag;
+  // split-K (few-row calls that would leave most CUs without a workgroup): blockIdx.y = K slice of kper tiles; every
+  // slice leaves its scaled fp32 partial sums in part[z][M][ldp], splitk_reduce_kernel finishes (0 = no split)
+  int kper;
+  float* part;
+  int ldp;
 };
 
 #ifndef WOQ_GEMM_HANDSCHED  // 1: the hand-scheduled K loop (woq_gemm_f16p.h) for NP = 1; 0: hipcc's schedule (A/B runs)
@@ -625,17 +631,20 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gemm_f16s_kernel(GemmF16
 
   // ---- K loop, two steps per trip (ping-pong register sets and LDS buffers; no register copies) ----
   BRegs<SMODE, S32, CT> b0, b1;
-  issue_a(0, 0);
-  load_b(0, b0);
-  const int last = a.tiles_k - 1;
-  for (int kt = 0; kt < a.tiles_k; kt += 2) {
+  // this workgroup's K tiles: all of them, or slice blockIdx.y of a split call
+  const int kt_lo = a.kper > 0 ? (int)blockIdx.y * a.kper : 0;
+  const int kt_hi = a.kper > 0 ? min(a.tiles_k, kt_lo + a.kper) : a.tiles_k;
+  issue_a(kt_lo, 0);
+  load_b(kt_lo, b0);
+  const int last = kt_hi - 1;
+  for (int kt = kt_lo; kt < kt_hi; kt += 2) {
     wait_loads(b0);   // this wave's share of tile kt and its weight registers have landed
     __syncthreads();  // everyone's has; everyone is done reading the other buffer
     issue_a(min(kt + 1, last), 1);
     load_b(min(kt + 1, last), b1);
     __builtin_amdgcn_sched_barrier(0);
     compute(0, b0);
-    if (kt + 1 >= a.tiles_k) break;
+    if (kt + 1 >= kt_hi) break;
     wait_loads(b1);
     __syncthreads();
     issue_a(min(kt + 2, last), 0);
@@ -646,7 +655,47 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gemm_f16s_kernel(GemmF16
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still be writing LDS when the workgroup retires
 
   WOQ_UNPIN_EPILOGUE_ARGS(a)
+  if (a.kper > 0) {  // a K slice: scaled fp32 partial sums only; bias, SiLU * mul, residual and the cast come after the sum
+    a.out = a.part + (size_t)blockIdx.y * a.M * a.ldp;
+    a.out_dtype = WOQ_F32;
+    a.ldo = a.ldp;
+    a.bias = nullptr;
+    a.residual = nullptr;
+    a.epi = 0;
+  }
   gemm_epilogue<CT>(a, acc, row0, ct0, i16, kq);
+}
+
+// out[m][n] = sum over the K slices (+ bias, SiLU(gate) * up over interleaved column tiles, + residual), cast
+struct SplitKArgs {
+  const float* part;
+  int nz, M, N, ldp, epi;
+  const float* bias;
+  const float* residual;
+  int ld_res;
+  void* out;
+  int out_dtype, ldo;
+};
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitKArgs a) {
+  const int n_out = a.epi == 1 ? (a.N >> 1) : a.N;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)a.M * n_out) return;
+  const int m = (int)(idx / n_out), n = (int)(idx % n_out);
+  const int n_in = a.epi == 1 ? ((n >> 4) * 2) * 16 + (n & 15) : n;
+  float v = 0.f, u = 0.f;
+  for (int z = 0; z < a.nz; ++z) {  // fixed order: the result does not depend on which slice finished first
+    const float* row = a.part + ((size_t)z * a.M + m) * a.ldp;
+    v += row[n_in];
+    if (a.epi == 1) u += row[n_in + 16];
+  }
+  if (a.bias) {
+    v += a.bias[n_in];
+    if (a.epi == 1) u += a.bias[n_in + 16];
+  }
+  if (a.epi == 1) v = v / (1.f + __expf(-v)) * u;
+  if (a.residual) v += a.residual[(size_t)m * a.ld_res + n];
+  if (a.out_dtype == WOQ_F16) v = fminf(fmaxf(v, -65504.f), 65504.f);
+  store_f32(a.out, (size_t)m * a.ldo + n, a.out_dtype, v);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -857,7 +906,7 @@ static int launch_f16_t(GemmF16Args& a, hipStream_t st) {
   auto kern = gemm_f16s_kernel<SMODE, ASYM, S32, NP, 2>;
   bool ring = false;
 #if WOQ_GEMM_HANDSCHED
-  if (NP == 1 && (a.tiles_k & 1) == 0) {  // (its K loop runs two K steps per trip; odd tile counts keep the kernel above)
+  if (NP == 1 && (a.tiles_k & 1) == 0 && a.kper == 0) {  // (K slices run the kernel above: its K loop takes a range)  // (its K loop runs two K steps per trip; odd tile counts keep the kernel above)
     // (the ring form needs <= 168 VGPRs for its third workgroup per CU; group-32 asymmetric blobs with fp32 scales do
     // not fit without spills and stay on the two-tile form)
     constexpr bool ring_fits = !(SMODE == 1 && ASYM && S32);
@@ -890,14 +939,19 @@ static int launch_f16_t(GemmF16Args& a, hipStream_t st) {
     attr_set[free_slot] = (const void*)kern;
   }
   const int n_sup8 = (a.n_sup + 7) / 8;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(n_sup8 * 8 * 64)), dim3(256), LDS, st, a);
+  const unsigned nz = a.kper > 0 ? (unsigned)((a.tiles_k + a.kper - 1) / a.kper) : 1u;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(n_sup8 * 8 * 64), nz), dim3(256), LDS, st, a);
   return 0;
 }
 
 // Workspace bytes for an [M, K] x [K, N] call (activation tiles + row scales + column scales).
+// (+ SPLITK_WS for the partial sums of a split-K call: slices x rows x columns <= 512 / workgroups x 128 x 128 floats
+// per workgroup of the unsplit grid, i.e. <= 34 MiB whatever the shape; a fixed 40 MiB keeps the caller's sizing simple)
+constexpr size_t SPLITK_WS = (size_t)40 << 20;
 size_t gemm_f16_workspace_bytes(int M, int Kpad, int Npad, int planes) {
   const size_t Mpad = ((size_t)M + FBM - 1) / FBM * FBM;
-  return Mpad * Kpad * sizeof(_Float16) * planes + Mpad * sizeof(float) + (size_t)Npad * sizeof(float);
+  const size_t base = Mpad * Kpad * sizeof(_Float16) * planes + Mpad * sizeof(float) + (size_t)Npad * sizeof(float);
+  return ((base + 255) & ~(size_t)255) + SPLITK_WS;
 }
 
 // out[M,N] = act[M,K] . W_deq (+ bias) with fp16 operands. `ws` = caller workspace of gemm_f16_workspace_bytes or
@@ -941,8 +995,28 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   // MFMA fragments
   const bool frag = is_table_type(h.weight_type) || fp8_lo != nullptr;
   const size_t frag_bytes = frag ? (size_t)a.tiles_n * a.tiles_k * 4 * planes * 1024 : 0;
-  const size_t base_bytes = (gemm_f16_workspace_bytes(M, h.Kpad, h.Npad, planes) + 255) & ~(size_t)255;
-  const size_t total = base_bytes + frag_bytes;
+  const size_t base_bytes = gemm_f16_workspace_bytes(M, h.Kpad, h.Npad, planes) - SPLITK_WS;  // (a multiple of 256)
+  // split-K: a call of one or two row blocks launches a few dozen workgroups on 256 CUs (M = 64: o / down 32, qkv 96,
+  // gate / up 172 — 43-93 us per call); K slices bring the grid to ~512 workgroups, one round at two per CU. Each
+  // slice keeps >= 4 K tiles, an even count.
+  static const bool split_ok = !(getenv("WOQ_GEMM_SPLITK") && getenv("WOQ_GEMM_SPLITK")[0] == '0');
+  int kper = 0, nz = 1;
+  {
+    const int wgs = a.nb_m * a.nb_n;
+    // (measured on the Llama-2-7B prompt pass, 32 layers: 32 / 64 / 128 tokens 8.9 -> 5.6, 9.1 -> 6.0, 9.4 -> 6.6 ms;
+    // at 512 tokens slicing the 128-workgroup o / down calls LOSES 10 %: the slices run the compiler-scheduled kernel
+    // and pay the partials' round trip, so beyond one row block only really small grids are sliced)
+    if (split_ok && !frag && wgs <= (a.nb_m == 1 ? 256 : 64) && a.tiles_k >= 8) {
+      int want = std::min(16, std::max(2, 512 / wgs));
+      kper = std::max(4, ((a.tiles_k + want - 1) / want + 1) & ~1);
+      nz = (a.tiles_k + kper - 1) / kper;
+      if (nz < 2) kper = 0, nz = 1;
+    }
+  }
+  const int ldp = (h.Npad + 31) & ~31;
+  size_t part_bytes = kper ? (size_t)nz * M * ldp * sizeof(float) : 0;
+  if (part_bytes > SPLITK_WS) kper = 0, nz = 1, part_bytes = 0;  // (cannot happen: see SPLITK_WS)
+  const size_t total = base_bytes + frag_bytes + part_bytes;  // [tiles | row scales | column scales][fragments][partials]
   if (frag && (ws != nullptr || epi != 0 || h.off_zp != 0))
     return woq::fail("QBits: table weight types go through woq_linear (no fused epilogue, no zero points)");
   unsigned char* w = (unsigned char*)ws;
@@ -956,11 +1030,14 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   a.rs = (const float*)(w + Mpad * h.Kpad * sizeof(_Float16) * planes);
   a.cs = a.rs + Mpad;
   a.bfrag = frag ? (const u32x4*)(w + base_bytes) : nullptr;
+  a.kper = kper;
+  a.part = kper ? (float*)(w + base_bytes + frag_bytes) : nullptr;
+  a.ldp = ldp;
 
   // raw-A form: fp16 rows that need no gather, no RMSNorm and no rescale go to the hand-scheduled kernel as they are
   // (the o_proj / down_proj calls of the prompt pass); only the column scales are computed here
   static const bool raw_ok = !(getenv("WOQ_GEMM_RAW_A") && getenv("WOQ_GEMM_RAW_A")[0] == '0');
-  const bool raw = WOQ_GEMM_HANDSCHED && raw_ok && !frag && !fp32_class && act_dtype == WOQ_F16 && norm_w == nullptr &&
+  const bool raw = WOQ_GEMM_HANDSCHED && raw_ok && !frag && !kper && !fp32_class && act_dtype == WOQ_F16 && norm_w == nullptr &&
                    h.off_shuffle == 0 && (h.K & 127) == 0 && ((h.Kpad / WOQ_TILE_K) & 1) == 0 && (lda & 7) == 0 &&
                    (((uintptr_t)act) & 15) == 0 && (size_t)M * lda * 2 < ((size_t)1 << 32);
   a.act_raw = raw ? act : nullptr;
@@ -968,7 +1045,7 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   if (raw) a.rs = nullptr;
   static const bool ring_ok = !(getenv("WOQ_GEMM_RING") && getenv("WOQ_GEMM_RING")[0] == '0');
   const bool ring_fits = !(h.scale_mode == 1 && a.zp != nullptr && h.scale_type == WOQ_F32);  // (launch_f16_t: VGPRs)
-  a.ring = (WOQ_GEMM_HANDSCHED && ring_ok && ring_fits && !frag && !fp32_class && ((h.Kpad / WOQ_TILE_K) & 1) == 0) ? 1 : 0;
+  a.ring = (WOQ_GEMM_HANDSCHED && ring_ok && ring_fits && !frag && !kper && !fp32_class && ((h.Kpad / WOQ_TILE_K) & 1) == 0) ? 1 : 0;
 
   PackF16Args p;
   p.planes = planes;
@@ -1018,6 +1095,13 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   WOQ_F16_CASE(1, false)
   WOQ_F16_CASE(1, true)
 #undef WOQ_F16_CASE
+  }
+  if (rc == 0 && kper) {
+    SplitKArgs r;
+    r.part = a.part, r.nz = nz, r.M = M, r.N = h.N, r.ldp = ldp, r.epi = epi, r.bias = bias, r.residual = residual;
+    r.ld_res = ld_res, r.out = out, r.out_dtype = out_dtype, r.ldo = ldo;
+    const size_t elems = (size_t)M * (epi == 1 ? (h.N >> 1) : h.N);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, r);
   }
   if (g_gemm_ev1) hipEventRecord(g_gemm_ev1, st);
   if (mine) scratch_release(w, total, own, st);

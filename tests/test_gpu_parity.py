@@ -260,11 +260,14 @@ def test_errors_are_runtime_errors(qbits):
 
 
 @pytest.mark.parametrize("K,N,group,asym", [(512, 1024, 128, False), (512, 1024, 128, True), (256, 48, 32, True),
-                                            (160, 24, 64, True), (384, 200, -1, False), (1024, 4096, 256, False)])
-@pytest.mark.parametrize("M", [9, 130, 256])
+                                            (160, 24, 64, True), (384, 200, -1, False), (1024, 4096, 256, False),
+                                            (2048, 520, 32, True)])
+@pytest.mark.parametrize("M", [9, 40, 130, 256])
 @pytest.mark.parametrize("compute", ["fp32", "bf16"])
 def test_woq_linear_prefill_gemm_vs_oracle(qbits, K, N, group, asym, M, compute):
-    """MFMA GEMM path (M > 8, csrc/woq_gemm_f16.hip) vs the parity definition, ragged M / N / K included.
+    """MFMA GEMM path (M > 16, csrc/woq_gemm_f16.hip; 9 rows: the decode GEMV's third row set) vs the parity definition,
+    ragged M / N / K included. The K >= 1024 shapes at these row counts launch few workgroups and run as K slices
+    (split-K: scaled fp32 partials per slice, summed in a fixed order by splitk_reduce_kernel with the bias).
     compute_dtype fp32: activations and scaled weights as hi + lo fp16 pairs (~22 bits each), three products per
     pair -> fp32-class, stated bound 2e-5 * sum|x||w| expressed as 1e-4 * max|ref| + 1e-5. compute_dtype bf16: one plane,
     activation rounded to fp16 (2^-11 relative): stated bound 2e-3 * max|ref| (the reference's own criterion for
