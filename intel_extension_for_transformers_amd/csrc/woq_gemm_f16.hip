@@ -787,6 +787,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gemm_f16frag_kernel(Gemm
   for (int rt = 0; rt < 8; ++rt)
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[rt][c] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  WOQ_PIN_EPILOGUE_ARGS(a)
   const _Float16* a_tiles = a.ap + (size_t)mb * a.tiles_k * (STAGE / 2);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)fsm;
   auto issue_a = [&](int kt, int buf) {  // 8 LDS-DMA pieces of 1 KiB per wave and plane
@@ -878,6 +879,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gemm_f16frag_kernel(Gemm
     compute(1, b1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WOQ_UNPIN_EPILOGUE_ARGS(a)
   gemm_epilogue<CT>(a, acc, row0, ct0, i16, kq);
 }
 

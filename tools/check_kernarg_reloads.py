@@ -23,7 +23,7 @@ def compile_isa(out):
 def check(isa_path):
     text = open(isa_path).read()
     problems, kernels = [], 0
-    for m in re.finditer(r"^(_ZN3woq16gemm_f16[ps]_kernel\w+):.*?\n(.*?)s_endpgm", text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN3woq(?:16gemm_f16[ps]|19gemm_f16frag)_kernel\w+):.*?\n(.*?)s_endpgm", text, re.S | re.M):
         name, body = m.group(1), m.group(2)
         lines = [l.strip() for l in body.splitlines() if l.strip() and not l.strip().startswith(";")]
         loop_labels = [i for i, l in enumerate(lines) if re.match(r"\.LBB\d+_\d+:", l)]
