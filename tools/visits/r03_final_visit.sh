@@ -1,7 +1,7 @@
 #!/bin/bash
 # full measurement visit: the driver's bench command, its rocprofv3 kernel trace, the PMC traffic pass
 set -u
-TAG=${1:-r03am}; OUT=gpurun_out/$TAG; mkdir -p $OUT
+TAG=${1:-r03ar}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -3 $OUT/bench.err
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-extra --no-parity > $OUT/bench_prof.json 2> $OUT/rocprof.err; echo "rocprof rc=$?"
