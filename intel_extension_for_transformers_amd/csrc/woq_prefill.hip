@@ -152,7 +152,8 @@ template <int KVD, int HD>
 __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const _Float16* __restrict__ qkv, int T, int start,
                                                               int heads, int kv_heads, const void* __restrict__ kcache,
                                                               const void* __restrict__ vcache, size_t seq_stride_elems,
-                                                              _Float16* __restrict__ out, int n_qblocks, int window) {
+                                                              _Float16* __restrict__ out, int n_qblocks, int window,
+                                                              int prio) {
   constexpr int CPR = HD / 8;   // 16-B chunks per K row
   constexpr int DC = HD / 32;   // 32-wide d chunks of the QK^T contraction
   constexpr int DT = HD / 16;   // 16-wide d tiles of the output
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const _Float16* __
     if (window > 0 && t0 + AKT - 1 < start + q0 + 1 - window) continue;  // wholly below this wave's windows
 
     // ---- S^T = K Q^T ----
+    if (prio) __builtin_amdgcn_s_setprio(1);  // MFMA phases outrank the other workgroup's softmax on the same SIMD
     float4_t s[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -270,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const _Float16* __
         for (int rt = 0; rt < 2; ++rt) s[a][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[rt][c], s[a][rt], 0, 0, 0);
       }
     }
+    if (prio) __builtin_amdgcn_s_setprio(0);
     // ---- causal mask + online softmax (query = lane column i16, positions 16a + 4kq + j) ----
     // some position of the tile may exceed some query of the wave, or fall below some query's window
     const bool diag = t0 + AKT - 1 > start + q0 || (window > 0 && t0 < start + q0 + 32 - window);
@@ -320,6 +323,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const _Float16* __
       }
     }
     // ---- O^T += V^T P^T ----
+    if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -333,6 +337,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const _Float16* __
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) o[dt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[b][rt], o[dt][rt], 0, 0, 0);
       }
+    if (prio) __builtin_amdgcn_s_setprio(0);
   }
   // ---- finish: divide by the row sums, store fp16 [M][heads * HD] ----
 #pragma unroll
@@ -658,8 +663,15 @@ static int launch_attn_prefill_t(const _Float16* qkv, int n_seq, int T, int star
   const long long total = (long long)nqb * heads * n_seq;
   const dim3 grid = (xcd_map && (heads & 7) == 0 && total < (1ll << 31)) ? dim3((unsigned)total)
                                                                         : dim3((unsigned)nqb, (unsigned)heads, (unsigned)n_seq);
+  // s_setprio 1 around the two MFMA phases of a tile: the MFMAs of one workgroup outrank the softmax VALU of the other
+  // workgroup on the same SIMD, so the two fall into alternating phases instead of queueing behind each other. Same
+  // box, 8 layers at 4 x 2048: 24.42 -> 24.30 ms (attention -5 %, profiles/r03as); WOQ_ATTN_PRIO=0 turns it off.
+  static const int prio = [] {
+    const char* e = getenv("WOQ_ATTN_PRIO");
+    return e ? atoi(e) : 1;
+  }();
   hipLaunchKernelGGL(k, grid, dim3(256), attn_lds_bytes<HD>(), st, qkv, T, start, heads, kv_heads, kcache, vcache,
-                     seq_stride_elems, out, nqb, window);
+                     seq_stride_elems, out, nqb, window, prio);
   return 0;
 }
 
