@@ -372,7 +372,7 @@ def parity_check(eng, cfg, tokens=(11, 20000, 317)):
     }
 
 
-def prefill_gemm_check(eng, cfg, M, layer=0, n_rows=64, time_reps=3):
+def prefill_gemm_check(eng, cfg, M, layer=0, n_rows=64, time_reps=5):
     """The prompt pass's GEMMs at the size they are measured at. For every projection of one layer: woq_linear with the
     one-product (fp16-operand, hand-scheduled ring) kernel over M rows — fp32 rows for qkv / gate-up (the pack pass),
     fp16 rows for o / down (the raw-A form) — and `n_rows` sampled rows (first / last row of the first, a middle and
@@ -404,7 +404,7 @@ def prefill_gemm_check(eng, cfg, M, layer=0, n_rows=64, time_reps=3):
               "kernel_us": gemm_ms * 1e3, "kernel_tflops": flops / (gemm_ms * 1e-3) / 1e12,
               "kernel_mfma_frac": flops / (gemm_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
               "call_us_with_pack_pass": call_ms * 1e3,
-              "timed": "HIP events on the launch stream right around the GEMM kernel's launch, %d calls after a warm-up "
+              "timed": "HIP events on the launch stream right around the GEMM kernel's launch, median of %d calls after a warm-up "
                        "one (woq_engine_time_prefill_gemm)" % time_reps}
     for name, adt in (("qkv", torch.float32), ("o", torch.float16), ("gate_up", torch.float32), ("down", torch.float16)):
         blob = lt[name]

@@ -301,7 +301,7 @@ WOQ_API int woq_engine_time_gemv_mask(woq_engine* e, int mask, int reps, void* s
  * grids (what the launches cost before they do anything). bench.py reports both as roofline.ceiling. */
 WOQ_API int woq_engine_time_twin(woq_engine* e, int mode, int reps, void* stream, float* total_ms);
 /* the prompt pass's dominant GEMM in place: the engine's own gate/up call of `layer` over n_rows rows of the residual
- * stream a preceding woq_engine_prefill left (RMSNorm pack pass + MFMA GEMM + SiLU * mul epilogue), averaged over `reps`
+ * stream a preceding woq_engine_prefill left (RMSNorm pack pass + MFMA GEMM + SiLU * mul epilogue), the MEDIAN of `reps`
  * calls after a warm-up one: gemm_ms = the GEMM kernel alone (HIP events on the launch stream right around its launch),
  * call_ms = pack pass + GEMM. */
 WOQ_API int woq_engine_time_prefill_gemm(woq_engine* e, int layer, int n_rows, int reps, void* stream, float* gemm_ms,

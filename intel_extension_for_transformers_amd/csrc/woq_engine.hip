@@ -975,7 +975,7 @@ int woq_engine_time_prefill_gemm(woq_engine* e, int layer, int n_rows, int reps,
   WOQ_HIP(hipEventCreate(&k1));
   WOQ_HIP(hipEventCreate(&c0));
   WOQ_HIP(hipEventCreate(&c1));
-  double gsum = 0, csum = 0;
+  std::vector<std::pair<float, float>> samples;  // (kernel, call) per timed pass
   for (int r = 0; r <= reps; ++r) {  // pass 0 warms up
     WOQ_HIP(hipEventRecord(c0, st));
     set_gemm_time_events(k0, k1);
@@ -988,11 +988,14 @@ int woq_engine_time_prefill_gemm(woq_engine* e, int layer, int n_rows, int reps,
     float tk = 0.f, tc = 0.f;
     WOQ_HIP(hipEventElapsedTime(&tk, k0, k1));
     WOQ_HIP(hipEventElapsedTime(&tc, c0, c1));
-    if (r > 0) gsum += tk, csum += tc;
+    if (r > 0) samples.emplace_back(tk, tc);
   }
   for (hipEvent_t ev : {k0, k1, c0, c1}) hipEventDestroy(ev);
-  *gemm_ms = (float)(gsum / reps);
-  *call_ms = (float)(csum / reps);
+  // the MEDIAN pass: one visit of the round caught a single 6 ms pass among ~1.1 ms ones (a box hiccup; the rerun was
+  // clean) and the mean of three reported 0.10 of peak for a 0.54 kernel
+  std::sort(samples.begin(), samples.end());
+  *gemm_ms = samples[samples.size() / 2].first;
+  *call_ms = samples[samples.size() / 2].second;
   WOQ_END
 }
 
