@@ -325,15 +325,13 @@ def cpu_baseline(cfg, budget_s=10.0):
 
 
 # ---- parity of the measured model against the oracle ----------------------------------------------------------------
-def parity_check(eng, cfg, tokens=(11, 20000, 317)):
-    """Logits of the measured engine (all layers, its own synthetic weights) against oracle.LlamaOracle on the SAME
-    blobs (fused q|k|v and interleaved gate/up layouts read by the oracle's own dequantiser): north_star's
-    "logits max-abs" at the full BASELINE size. The oracle is the checker only."""
+def oracle_of(eng, cfg, window=0):
+    """oracle.LlamaOracle over the ENGINE'S OWN blobs (fused q|k|v and interleaved gate/up layouts, read by the oracle's
+    own dequantiser), norm weights, embedding and lm_head. Checker only."""
     import numpy as np
 
     from oracle import woq_oracle as orc
 
-    t0 = time.perf_counter()
     orc.set_threads(orc.host_threads())
     host = lambda t: t.detach().cpu().numpy()  # noqa: E731
     layers = []
@@ -344,8 +342,70 @@ def parity_check(eng, cfg, tokens=(11, 20000, 317)):
                            ln1=host(lt["ln1"]), ln2=host(lt["ln2"])))
     ht = eng.head_tensors
     ocfg = dict(heads=cfg["heads"], kv_heads=cfg["kv_heads"], head_dim=cfg["head_dim"], eps=float(eng.cfg.rms_eps),
-                theta=float(eng.cfg.rope_theta))
-    oracle = orc.LlamaOracle(ocfg, host(ht["embed"].float()), layers, host(ht["norm"]), host(ht["lm_head"].float()))
+                theta=float(eng.cfg.rope_theta), window=window)
+    return orc.LlamaOracle(ocfg, host(ht["embed"].float()), layers, host(ht["norm"]), host(ht["lm_head"].float()))
+
+
+def prefill_attention_check(cfg, n_seq, T, seqs=None):
+    """The prompt pass's ATTENTION at the geometry it is measured at: a 2-layer twin of the timed
+    engine — same hidden / heads / kv heads / head_dim, hence the same `attn_prefill_kernel` grid, XCD-aware work order
+    and query-block count per (sequence, head); `inter` and the vocabulary cut to 512 so the CPU oracle stays cheap —
+    runs the SAME n_seq x T prompt pass; layer 1's K and V rows at EVERY position (functions of layer 0's attention
+    output at every query row) and the last-position logits of the first and last sequence are compared with
+    oracle.LlamaOracle.forward_prompt on the engine's own blobs. Two layers because with one the logits would depend
+    on a single query row. Bounds: rows 5e-3 * max|row tensor| (+ half an fp16 ulp), logits 1e-2 * max|logit| + 1e-3."""
+    import numpy as np
+    import torch
+
+    t0 = time.perf_counter()
+    twin = dict(cfg, inter=512, vocab=512, layers=2)
+    eng = build_engine(twin, max_ctx=T, max_batch=n_seq, seed=4242)
+    g = torch.Generator().manual_seed(99)
+    prompts = torch.randint(0, twin["vocab"], (n_seq, T), generator=g)
+    got = eng.prefill(prompts.cuda(), greedy=True).cpu().numpy().copy()
+    oracle = oracle_of(eng, twin)
+    res = {}
+    for seq in (seqs if seqs is not None else sorted({0, n_seq - 1})):
+        oracle.reset()
+        ref = oracle.forward_prompt(prompts[seq].tolist())
+        rows = 0.0
+        for which, rc in (("k", oracle.k[1]), ("v", oracle.v[1])):
+            c = eng.kv_cache(which)[seq, 1, :T].float().cpu().numpy()
+            err = np.abs(c - rc)
+            scale = float(np.abs(rc).max())
+            if (err > 5e-3 * scale + 2.0 ** -11 * np.abs(rc)).any():
+                p, hd, d = (int(v) for v in np.argwhere(err > 5e-3 * scale + 2.0 ** -11 * np.abs(rc))[0])
+                raise RuntimeError("prefill attention parity FAILED: layer-1 %s row of sequence %d, position %d, head %d, "
+                                   "d %d: %.3e of the tensor's maximum" % (which, seq, p, hd, d, float(err.max()) / scale))
+            rows = max(rows, float(err.max()) / scale)
+        lerr = float(np.abs(got[seq] - ref).max()) / float(np.abs(ref).max())
+        if lerr > 1e-2 or int(got[seq].argmax()) != int(ref.argmax()):
+            raise RuntimeError("prefill attention parity FAILED: logits of sequence %d off by %.3e of the largest" % (seq, lerr))
+        res["sequence_%d" % seq] = {"layer1_kv_rows_worst_over_max": rows, "logits_max_abs_over_max_logit": lerr}
+    del eng
+    free_gpu()
+    return {
+        "checked": "2-layer twin of the timed engine (hidden %d, %d / %d heads x %d; inter 512, vocab 512), the same %d x %d "
+                   "prompt pass: layer 1's K / V rows at all %d positions x %d kv heads and the last-position logits of "
+                   "sequences %s vs oracle.LlamaOracle.forward_prompt on the twin's own blobs"
+                   % (cfg["hidden"], cfg["heads"], cfg["kv_heads"], cfg["head_dim"], n_seq, T, T, cfg["kv_heads"],
+                      sorted(int(k.split("_")[1]) for k in res)),
+        "per_sequence": res, "greedy_tokens_equal": True,
+        "tol": "rows 5e-3 * max + fp16 half-ulp; logits 1e-2 * max|logit| (fp16-operand GEMMs, fp16 q/k/v between kernels)",
+        "seconds": time.perf_counter() - t0,
+    }
+
+
+def parity_check(eng, cfg, tokens=(11, 20000, 317)):
+    """Logits of the measured engine (all layers, its own synthetic weights) against oracle.LlamaOracle on the SAME
+    blobs (fused q|k|v and interleaved gate/up layouts read by the oracle's own dequantiser): north_star's
+    "logits max-abs" at the full BASELINE size. The oracle is the checker only."""
+    import numpy as np
+
+    from oracle import woq_oracle as orc
+
+    t0 = time.perf_counter()
+    oracle = oracle_of(eng, cfg)
     worst_abs, worst_rel, same = 0.0, 0.0, True
     for i, t in enumerate(tokens):
         eng.token.fill_(int(t))
@@ -720,6 +780,8 @@ def main():
         out["fused_attention_launch"] = {"in_use": eng.uses_fused_attn(), "engine_status": eng.status()}
     del eng
     free_gpu()
+    if not args.no_parity and want_prefill:
+        out["parity"]["prefill"]["attention"] = prefill_attention_check(cfg, args.prefill_seqs, args.prefill_len)
     if not args.no_extra:
         out["extra_configs"] = extra_configs(args)
     if cpu is not None:

@@ -235,6 +235,9 @@ WOQ_API int woq_engine_persist_stamps(woq_engine* e, void* stamps_dev, int* grid
  * woq_engine_step / _replay cannot check a position that lives on the device); -1 = the read itself failed.
  * Synchronises `stream`. */
 WOQ_API int woq_engine_status(woq_engine* e, void* stream);
+/* resets the sticky status to 0 (stream-ordered): a caller that read a non-zero status, changed what caused it
+ * (e.g. woq_engine_set_fuse_attn(e, 0)) and re-runs the request starts from a clean word. */
+WOQ_API int woq_engine_clear_status(woq_engine* e, void* stream);
 /* KV cache base pointers (which: 0 = K, 1 = V), layout [sequence][layer][position][kv_head][head_dim] in kv_dtype:
  * inspection / tests, and the seam for an external cache manager. */
 WOQ_API void* woq_engine_kv_cache_ptr(woq_engine* e, int which);

@@ -30,12 +30,16 @@ inline size_t ws_round(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // The workspace is handed out by a bump pointer and given back when the host call returns — safe only while every
 // user queues on ONE stream. A taker on a different stream first makes its stream wait for what the previous stream
-// has queued so far (an event), so two streams (or threads) share the scratch in turn instead of at once.
+// has queued so far (an event), so two streams (or threads) share the scratch in turn instead of at once. While slices
+// of ANOTHER stream are still out (used != 0: a concurrent host thread on its own stream) the bump pointer cannot be
+// shared — releases would come back out of order and `last` names one stream only — so such a taker gets a private
+// stream-ordered allocation. Takers on the SAME stream may interleave freely: their kernels run in stream order.
 void* scratch_take(size_t bytes, hipStream_t st, bool* own) {
   const size_t need = ws_round(bytes);
   std::lock_guard<std::mutex> lock(g_ws.mu);
   if (g_ws.base != nullptr && g_ws.used + need <= g_ws.bytes) {
-    if (g_ws.has_last && g_ws.last != st && g_ws.used == 0) {
+    if (g_ws.has_last && g_ws.last != st && g_ws.used != 0) goto private_alloc;
+    if (g_ws.has_last && g_ws.last != st) {
       bool ordered = false;
       if (g_ws.ev == nullptr && hipEventCreateWithFlags(&g_ws.ev, hipEventDisableTiming) != hipSuccess) g_ws.ev = nullptr;
       if (g_ws.ev != nullptr && hipEventRecord(g_ws.ev, g_ws.last) == hipSuccess &&

@@ -132,6 +132,10 @@ struct woq_engine {
   unsigned int* flag_attn = nullptr;  // [heads * head_dim / 16]
   unsigned int* flag_act = nullptr;   // [inter / 16]
   bool chain_ok(int l) const;
+  // in-launch hand-off tags are (step counter << 6) | layer (woq_gemv_attn.hip, the chained and persistent launches):
+  // beyond 64 layers the layer bits would run into the counter and a stale granule could pass for a fresh one, so
+  // deeper models keep the separate launches
+  bool tags_ok() const { return cfg.layers <= 64; }
   // all layers of the step as ONE persistent launch (woq_persist.hip): the weight stream runs through the operator
   // boundaries. Built lazily at the first step (every layer must be set); null + persist_why when out of scope.
   bool persist_on = false, persist_tried = false;
@@ -179,13 +183,14 @@ bool woq_engine::chain_ok(int l) const {
   const woq_engine_config& c = cfg;
   const woq_layer_weights& w = layers[l];
   return chain && fuse_attn && use_xq() && c.tp_size <= 1 && qkv_g != nullptr && flag_attn != nullptr &&
-         !attn_grouped &&
+         !attn_grouped && tags_ok() &&
          woq::chain_layer_supported(w.qkv_hdr, w.o_hdr, w.gate_up_hdr, w.down_hdr, c.heads, c.kv_heads, c.head_dim,
                                     c.kv_dtype, c.max_ctx, window, attn_splits);
 }
 
 woq::Persist* woq_engine::persist_get() {
-  if (!persist_on || !use_xq() || cfg.tp_size > 1 || qkv_g == nullptr || attn_grouped || attn_splits > 1 || window != 0)
+  if (!persist_on || !use_xq() || cfg.tp_size > 1 || qkv_g == nullptr || attn_grouped || attn_splits > 1 || window != 0 ||
+      !tags_ok())
     return nullptr;
   if (!persist_tried) {
     persist_tried = true;
@@ -240,7 +245,7 @@ static int engine_attn_block_xq(woq_engine* e, int l, hipStream_t st) {
   const woq_layer_weights& w = e->layers[l];
   const int skip = engine_skip_mask();
   int rc = 0;
-  if (!(skip & 3) && e->fuse_attn && e->qkv_g != nullptr && !e->attn_grouped &&
+  if (!(skip & 3) && e->fuse_attn && e->qkv_g != nullptr && !e->attn_grouped && e->tags_ok() &&
       gemv_xq_attn_supported(w.qkv_hdr, c.heads, c.kv_heads, c.head_dim, c.kv_dtype, c.max_ctx, e->window,
                              e->attn_splits)) {
     rc = launch_gemv_xq_attn(e->xq_hidden, w.qkv_blob, w.qkv_hdr, e->qkv_g, e->ssq_part, c.rms_eps, e->step_seq, l,
@@ -609,8 +614,15 @@ int woq_engine_status(woq_engine* e, void* stream) {  // bit 0 hand-off give-up,
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
   return v;
 }
+int woq_engine_clear_status(woq_engine* e, void* stream) {
+  WOQ_TRY
+  WOQ_CHECK(e, "QBits: null engine");
+  if (e->fuse_status) WOQ_HIP(hipMemsetAsync(e->fuse_status, 0, 4, (hipStream_t)stream));
+  WOQ_END
+}
 int woq_engine_fuse_attn(woq_engine* e) {
-  if (!e || !e->fuse_attn || !e->use_xq() || e->qkv_g == nullptr || e->attn_grouped || e->layers.empty()) return 0;
+  if (!e || !e->fuse_attn || !e->use_xq() || e->qkv_g == nullptr || e->attn_grouped || e->layers.empty() || !e->tags_ok())
+    return 0;
   const woq_engine_config& c = e->cfg;
   return woq::gemv_xq_attn_supported(e->layers[0].qkv_hdr, c.heads, c.kv_heads, c.head_dim, c.kv_dtype, c.max_ctx,
                                      e->window, e->attn_splits)

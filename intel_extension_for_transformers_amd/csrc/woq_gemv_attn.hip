@@ -79,7 +79,11 @@ bool gemv_xq_attn_supported(const woq_blob_header& h, int heads, int kv_heads, i
   if (heads != kv_heads || head_dim != 128 || splits > 1 || window != 0) return false;
   if (h.N != 3 * heads * head_dim) return false;
   if (kv_dtype != WOQ_F16 && kv_dtype != WOQ_BF16 && kv_dtype != WOQ_FP8_E4M3) return false;
-  return attn_dec_lds_floats(128, max_ctx) * 4 <= 150 * 1024;
+  // every workgroup of the launch gets max(attention LDS, GEMV LDS): the 768 strip workgroups (three per CU, four on
+  // the CUs that also hold an attention workgroup) inherit the attention's score buffer, which grows with max_ctx.
+  // Up to 38 KiB (max_ctx 8192) four workgroups still share a CU's 160 KiB; beyond that the strips would lose
+  // occupancy to a buffer they never touch, so such engines keep the two launches.
+  return attn_dec_lds_floats(128, max_ctx) * 4 <= 38 * 1024;
 }
 
 struct FusedLaunch {

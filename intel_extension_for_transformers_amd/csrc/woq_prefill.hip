@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const _Float16* __
   // head's 16 blocks ran on all eight XCDs and every L2 had to hold every active head's K / V (4 x 2048 tokens x 32
   // heads = 134 MB per layer, re-read 8.5 times on average: the launch ran at the fabric's ~3.4 TB/s, not on its MFMAs).
   int qb, h, seq;
-  if (gridDim.y == 1) {
+  if (gridDim.y == 1 && (heads & 7) == 0) {  // a 3-D grid with heads % 8 == 0 has gridDim.y >= 8; heads == 1 is 3-D too
     const int L = (int)blockIdx.x, xcd = L & 7, r = L >> 3;
     const int hp = heads >> 3, g = r / n_qblocks;
     qb = n_qblocks - 1 - r % n_qblocks;

@@ -281,6 +281,10 @@ class WoqDecoderEngine:
         max_ctx - 1 instead (its outputs are meaningless, memory was not touched out of bounds)."""
         return int(L.lib().woq_engine_status(self._h, L.stream_ptr()))
 
+    def clear_status(self):
+        """Reset the sticky status (after the caller dealt with what it reported)."""
+        L.check(L.lib().woq_engine_clear_status(self._h, L.stream_ptr()))
+
     def _grouped_applies(self):
         c = self.cfg
         return (c.head_dim == 128 and c.kv_heads > 0 and c.heads // c.kv_heads in (2, 4, 8)

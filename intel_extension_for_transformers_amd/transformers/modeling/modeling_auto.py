@@ -355,38 +355,66 @@ def _engine_generate(self, inputs=None, generation_config=None, **kwargs):
         streamer.put(ids.cpu())
     import time
 
-    latency = []
-    tic = time.time()
-    for s0 in range(0, n_in, 2048):
-        eng.prefill(prompt[s0:s0 + 2048], start_pos=s0, greedy=True)
-    eng.tune_attn_for(n_in + max_new)
-    if max_new > 1 and not eng.captured:
-        eng.capture(greedy=True)
-    # Tokens are read back in bursts: the steps chain on the device and log their tokens (engine.token_log), so the
-    # host synchronises once per burst instead of once per token. A stop token is noticed at the end of its burst —
-    # the few steps run past it are discarded. With a streamer the burst is one token (latency first).
-    out = [int(eng.token.item())]  # the prompt pass's token (the .item() synchronises)
-    latency.append(time.time() - tic)
-    if streamer is not None:
-        streamer.put(torch.tensor(out))
-    burst = 1 if streamer is not None else 16
-    log = eng.token_log()
-    done = out[0] in eos
-    while not done and len(out) < max_new:
-        k = min(burst, max_new - len(out))
-        p0 = n_in + len(out) - 1  # position the next step feeds
+    def run_once():
+        """prompt pass + chained decode steps; returns (tokens, per-token latency)."""
+        latency = []
         tic = time.time()
-        eng.replay(k)
-        new = log[p0:p0 + k].tolist()  # one host synchronisation per burst
-        per_token = (time.time() - tic) / k  # the burst's steps chain on the device: its tokens share the average
-        for t in new:
-            latency.append(per_token)
-            out.append(t)
+        for s0 in range(0, n_in, 2048):
+            eng.prefill(prompt[s0:s0 + 2048], start_pos=s0, greedy=True)
+        eng.tune_attn_for(n_in + max_new)
+        if max_new > 1 and not eng.captured:
+            eng.capture(greedy=True)
+        # Tokens are read back in bursts: the steps chain on the device and log their tokens (engine.token_log), so the
+        # host synchronises once per burst instead of once per token. A stop token is noticed at the end of its burst —
+        # the few steps run past it are discarded. With a streamer the burst is one token (latency first).
+        out = [int(eng.token.item())]  # the prompt pass's token (the .item() synchronises)
+        latency.append(time.time() - tic)
+        if streamer is not None:
+            streamer.put(torch.tensor(out))
+        burst = 1 if streamer is not None else 16
+        log = eng.token_log()
+        done = out[0] in eos
+        while not done and len(out) < max_new:
+            k = min(burst, max_new - len(out))
+            p0 = n_in + len(out) - 1  # position the next step feeds
+            tic = time.time()
+            eng.replay(k)
+            new = log[p0:p0 + k].tolist()  # one host synchronisation per burst
+            per_token = (time.time() - tic) / k  # the burst's steps chain on the device: its tokens share the average
+            for t in new:
+                latency.append(per_token)
+                out.append(t)
+                if streamer is not None:
+                    streamer.put(torch.tensor([t]))
+                if t in eos:
+                    done = True
+                    break
+        return out, latency
+
+    out, latency = run_once()
+    # The decode step reports what it cannot raise from the device through a sticky status word; the host has just
+    # synchronised on the last burst, so one more 4-byte read is free. bit 0: an attention workgroup of the fused
+    # qkv + attention launch gave up waiting for its head's q / k / v (GPU preempted / shared / under a debugger for
+    # longer than the hand-off's 20 ms bound) and went on with stale values — the tokens since then and the KV rows of
+    # those positions are wrong. bit 1: a step ran at or beyond max_ctx. Neither may come back as a normal result.
+    st = eng.status()
+    if st != 0:
+        eng.clear_status()
+        if st & 1:
+            eng.set_fuse_attn(False)  # the two-launch form has no in-launch wait; the prompt pass rewrites the cache
+            logger.warning("QBits: the fused qkv + attention launch timed out waiting for a hand-off (engine status %d); "
+                           "the engine falls back to separate launches", st)
+        if st < 0 or (st & ~1) or streamer is not None:
             if streamer is not None:
-                streamer.put(torch.tensor([t]))
-            if t in eos:
-                done = True
-                break
+                streamer.end()
+            raise RuntimeError("QBits: the decode engine reported status %d (bit 0: in-launch hand-off timed out, "
+                               "bit 1: position beyond max_ctx)%s" % (st, "; tokens already streamed are not reliable"
+                                                                     if streamer is not None else ""))
+        out, latency = run_once()  # same request, separate launches
+        st = eng.status()
+        if st != 0:
+            eng.clear_status()
+            raise RuntimeError("QBits: the decode engine reported status %d on the retry" % st)
     if streamer is not None:
         streamer.end()
     result = torch.cat([ids, torch.tensor([out], dtype=ids.dtype, device=ids.device)], dim=1)

@@ -591,6 +591,48 @@ def attn_decode(q, kcache, vcache):
     return out
 
 
+def linear_rows(x, blob):
+    """Many-row form of `woq_linear` for prompt-sized inputs: dequantise -> matmul (autograd/functions.py:41-63, the
+    reference's own definition), the contraction in fp64 through BLAS so that thousands of rows cost seconds. int4
+    blobs without an activation shuffle only (what the decoder composition uses)."""
+    w = dequantize_blob(blob).astype(np.float64)
+    return (np.asarray(x, np.float64) @ w).astype(np.float32)
+
+
+def attn_prompt(q, kcache, vcache, start, window=0, qblock=512):
+    """Causal (optionally sliding-window) attention of T query rows over a cache — HF `eager_attention_forward` +
+    `repeat_kv` semantics: scores q.k / sqrt(D), softmax, P.V; query i sits at position start + i
+    and sees positions max(0, p - window + 1) .. p. q [T, heads, D]; caches [start + T, kv_heads, D] -> [T, heads, D].
+    fp64 throughout (the many-row twin of orc_attn_decode)."""
+    q = np.asarray(q, np.float64)
+    T, H, D = q.shape
+    KV = kcache.shape[1]
+    rep = H // KV
+    ctx = kcache.shape[0]
+    out = np.empty((T, H, D), np.float32)
+    scale = 1.0 / np.sqrt(float(D))
+    kpos = np.arange(ctx)[None, :]
+    for kh in range(KV):
+        kk = np.ascontiguousarray(kcache[:, kh, :], np.float64)
+        vv = np.ascontiguousarray(vcache[:, kh, :], np.float64)
+        for hh in range(kh * rep, (kh + 1) * rep):
+            for r0 in range(0, T, qblock):
+                r1 = min(T, r0 + qblock)
+                hi = start + r1  # positions beyond the block's last query are never visible
+                lo = max(0, start + r0 - window + 1) if window else 0
+                s = (q[r0:r1, hh, :] @ kk[lo:hi].T) * scale
+                qp = (start + np.arange(r0, r1))[:, None]
+                vis = kpos[:, lo:hi] <= qp
+                if window:
+                    vis &= kpos[:, lo:hi] > qp - window
+                s = np.where(vis, s, -np.inf)
+                s -= s.max(axis=1, keepdims=True)
+                p = np.exp(s)
+                p /= p.sum(axis=1, keepdims=True)
+                out[r0:r1, hh, :] = (p @ vv[lo:hi]).astype(np.float32)
+    return out
+
+
 # ---- whole-decoder composition (Llama-class), fp32, used for logits parity ---------------------
 class LlamaOracle:
     """fp32 CPU decoder built from the oracle ops, on the SAME (q, scale, zp) blobs as the GPU.
@@ -651,3 +693,42 @@ class LlamaOracle:
             h = h + woq_linear(silu_mul(g, u), ly["down"])
         x = rmsnorm(h, self.norm, c["eps"])
         return (x.astype(np.float64) @ self.lm_head.astype(np.float64).T).astype(np.float32)[0]
+
+    def forward_prompt(self, tokens, start_pos=0, all_logits=False):
+        """`forward_token` over a whole prompt (or one chunk of it, at positions start_pos ..) in many-row form: the
+        same composition, linears through `linear_rows`, attention through `attn_prompt` over this oracle's cache
+        (which it extends, so `forward_token` / further chunks continue from it). Returns the last position's logits
+        (all positions' with all_logits)."""
+        c = self.cfg
+        H, KV, D = c["heads"], c["kv_heads"], c["head_dim"]
+        tokens = [int(t) for t in tokens]
+        T = len(tokens)
+        pos = np.arange(start_pos, start_pos + T, dtype=np.int32)
+        h = self.embed[tokens].astype(np.float32)
+        for li, ly in enumerate(self.layers):
+            assert self.k[li].shape[0] == start_pos, "chunks must arrive in order"
+            x = rmsnorm(h, ly["ln1"], c["eps"])
+            if "qkv" in ly:
+                qkv = linear_rows(x, ly["qkv"])
+                q, k, v = qkv[:, :H * D], qkv[:, H * D:(H + KV) * D], qkv[:, (H + KV) * D:]
+            else:
+                q, k, v = (linear_rows(x, ly[n]) for n in ("q", "k", "v"))
+            q = rope(q.reshape(T, H, D), pos, c["theta"])
+            k = rope(k.reshape(T, KV, D), pos, c["theta"])
+            self.k[li] = np.concatenate([self.k[li], k], 0)
+            self.v[li] = np.concatenate([self.v[li], np.ascontiguousarray(v).reshape(T, KV, D)], 0)
+            a = attn_prompt(q, self.k[li], self.v[li], start_pos, c.get("window", 0)).reshape(T, H * D)
+            h = h + linear_rows(a, ly["o"])
+            x = rmsnorm(h, ly["ln2"], c["eps"])
+            if "gate_up" in ly:
+                gu = linear_rows(x, ly["gate_up"]).reshape(T, -1, 2, 16)
+                g = np.ascontiguousarray(gu[:, :, 0, :]).reshape(T, -1)
+                u = np.ascontiguousarray(gu[:, :, 1, :]).reshape(T, -1)
+            else:
+                g, u = linear_rows(x, ly["gate"]), linear_rows(x, ly["up"])
+            h = h + linear_rows(silu_mul(g, u), ly["down"])
+        if not all_logits:
+            h = h[-1:]
+        x = rmsnorm(h, self.norm, c["eps"])
+        lg = (x.astype(np.float64) @ self.lm_head.astype(np.float64).T).astype(np.float32)
+        return lg if all_logits else lg[0]

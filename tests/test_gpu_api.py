@@ -381,6 +381,45 @@ def test_model_generate_is_engine_backed_for_greedy(tmp_path):
     assert samp.shape == (1, ids.shape[1] + 4)
 
 
+def test_generate_reads_the_engine_status_and_retries_or_raises():
+    """the fused qkv + attention launch reports a timed-out in-launch hand-off (and a position
+    clamp) through the engine's sticky status word only. `generate` reads it once after the last burst: hand-off
+    time-out -> the engine drops to separate launches and the request is re-run (same tokens as a clean run); with a
+    streamer, or for any other bit, RuntimeError — never a silent wrong result. The status itself: a step beyond
+    max_ctx sets bit 1, `clear_status` resets it."""
+    from intel_extension_for_transformers_amd.transformers import AutoModelForCausalLM, RtnConfig
+
+    fp = _tiny_llama()
+    q = AutoModelForCausalLM.from_pretrained(copy.deepcopy(fp), quantization_config=RtnConfig(
+        bits=4, group_size=32, compute_dtype="fp32", scale_dtype="fp32"), device_map="cuda")
+    ids = torch.tensor([[5, 9, 33, 2, 71]], device="cuda")
+    clean = q.generate(ids, max_new_tokens=12, do_sample=False)
+    eng = q.woq_engine
+    assert eng.status() == 0
+    real = eng.status
+    seen = {"n": 0}
+
+    def flaky():
+        seen["n"] += 1
+        return 1 if seen["n"] == 1 else real()
+
+    eng.status = flaky
+    again = q.generate(ids, max_new_tokens=12, do_sample=False)
+    assert torch.equal(again, clean) and seen["n"] == 2 and not eng.uses_fused_attn()
+    eng.status = lambda: 2
+    with pytest.raises(RuntimeError, match="status 2"):
+        q.generate(ids, max_new_tokens=12, do_sample=False)
+    eng.status = real
+    # the real word: a step at max_ctx is clamped and says so; clear_status resets it
+    eng.token.fill_(3)
+    eng.pos.fill_(eng.cfg.max_ctx + 4)
+    eng.step(greedy=True)
+    assert eng.status() == 2
+    eng.clear_status()
+    assert eng.status() == 0
+    assert torch.equal(q.generate(ids, max_new_tokens=12, do_sample=False), clean)
+
+
 def _write_hf_gptq_checkpoint(fp, d, group, sym, desc_act, shards=2, seed=0):
     """A Hugging Face GPTQ checkpoint directory (AutoGPTQ tensor names / packing) synthesised from a tiny fp model with
     the oracle's RTN per (act-ordered) group: qweight int32 [K/8, N] in ORIGINAL row order, g_idx [K], qzeros storing

@@ -1,0 +1,189 @@
+"""Attention parity at the geometry the prompt pass and the long-context decode are MEASURED at.
+
+`attn_prefill_kernel` takes an XCD-aware 1-D work order whenever heads % 8 == 0 (csrc/woq_prefill.hip); the small
+models of tests/test_gpu_engine.py (2 / 4 heads, <= 200 tokens) never enter it. Here: 32 query heads x head_dim 128,
+several query blocks x several sequences, chunked passes with start_pos > 0, grouped-query 32 / 8 heads, the sliding
+window and the fp8 cache — all against `oracle.LlamaOracle` (fp32 CPU restatement, HF attention semantics, SURVEY §8
+a17) on the SAME (q, scale, zp). `inter` is 512 and the vocabulary 512 so the oracle stays cheap: the attention
+geometry (hidden 4096 = 32 x 128) is the measured one.
+
+Two layers, not one: with a single layer the last-position logits depend on ONE query row. Layer 1's K / V rows are
+functions of layer 0's attention output at EVERY position, so comparing layer 1's cache over all positions with the
+oracle's covers every query block of every checked sequence; the logits then cover layer 1's last row.
+
+Stated tolerances (fp16-operand GEMMs + fp16 q / k / v / attention output between kernels, fp32 oracle):
+  K / V rows : max|gpu - oracle| <= 5e-3 * max|oracle| (+ half an fp16 / bf16 ulp of storage); fp8 cache: 2^-4 relative
+  logits     : max|gpu - oracle| <= 1e-2 * max|logit| + 1e-3 (tests/test_gpu_engine.py PF_TOL), greedy token equal
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import woq_oracle as orc
+
+pytestmark = pytest.mark.gpu
+PF_TOL = 1e-2
+KV_TOL = 5e-3
+
+
+def build_attention_geometry(kv_heads=32, window=0, kv_dtype=torch.float16, max_ctx=2304, max_batch=1, layers=2, seed=21,
+                             group=128, asym=False, inter=512, vocab=512):
+    """hidden 4096 = 32 heads x 128 with a narrow MLP / vocabulary; engine + oracle over the same host-made tensors."""
+    from intel_extension_for_transformers_amd import qbits
+    from intel_extension_for_transformers_amd.runtime import WoqDecoderEngine, fuse_gate_up
+    from tests.test_gpu_fullsize_oracle import _gpu_pack, _host_qsz
+
+    cfg = dict(hidden=4096, inter=inter, heads=32, kv_heads=kv_heads, head_dim=128, layers=layers, vocab=vocab, eps=1e-5,
+               theta=10000.0, window=window)
+    rng = np.random.default_rng(seed)
+    H, I, NH, KV, D = cfg["hidden"], cfg["inter"], cfg["heads"], cfg["kv_heads"], cfg["head_dim"]
+    eng = WoqDecoderEngine(H, I, NH, KV, D, layers, vocab, max_ctx=max_ctx, rms_eps=cfg["eps"], rope_theta=cfg["theta"],
+                           kv_dtype=kv_dtype, max_batch=max_batch, sliding_window=window)
+    tt = torch.from_numpy
+    lys = []
+    for l in range(layers):
+        parts = {n: _host_qsz(rng, k, nn, group, asym)
+                 for n, (k, nn) in dict(q=(H, NH * D), k=(H, KV * D), v=(H, KV * D), o=(NH * D, H), gate=(H, I),
+                                        up=(H, I), down=(I, H)).items()}
+        ly = {n: orc.repack(q, s, z, None, group, scale_type=orc.F16) for n, (q, s, z) in parts.items()}
+        cat = lambda i: np.concatenate([parts["q"][i], parts["k"][i], parts["v"][i]], 1)  # noqa: E731
+        qkv = _gpu_pack(qbits, cat(0), cat(1), cat(2) if asym else None, group)
+        o = _gpu_pack(qbits, *parts["o"], group)
+        fz = fuse_gate_up(tt(parts["gate"][2]), tt(parts["up"][2])).numpy() if asym else None
+        gu = _gpu_pack(qbits, fuse_gate_up(tt(parts["gate"][0]), tt(parts["up"][0])).numpy(),
+                       fuse_gate_up(tt(parts["gate"][1]), tt(parts["up"][1])).numpy(), fz, group)
+        down = _gpu_pack(qbits, *parts["down"], group)
+        ly["ln1"] = (1 + 0.05 * rng.standard_normal(H)).astype(np.float32)
+        ly["ln2"] = (1 + 0.05 * rng.standard_normal(H)).astype(np.float32)
+        eng.set_layer(l, qkv, o, gu, down, tt(ly["ln1"]), tt(ly["ln2"]))
+        lys.append(ly)
+    embed = tt((rng.standard_normal((vocab, H)) * 0.5).astype(np.float32)).half()
+    lm = tt((rng.standard_normal((vocab, H)) * 0.02).astype(np.float32)).half()
+    norm = (1 + 0.05 * rng.standard_normal(H)).astype(np.float32)
+    eng.set_head(embed, tt(norm), lm)
+    return eng, orc.LlamaOracle(cfg, embed.float().numpy(), lys, norm, lm.float().numpy()), cfg
+
+
+def check_cache_rows(eng, oracle, seq, T, layer=1, tol=KV_TOL, rel_storage=2.0 ** -11):
+    """Layer `layer`'s K and V rows of sequence `seq`, ALL positions and heads, against the oracle's cache."""
+    worst = 0.0
+    for which, ref in (("k", oracle.k[layer]), ("v", oracle.v[layer])):
+        got = eng.kv_cache(which)[seq, layer, :T].float().cpu().numpy()
+        ref = ref[:T]
+        scale = float(np.abs(ref).max())
+        err = np.abs(got - ref)
+        bound = tol * scale + rel_storage * np.abs(ref)
+        bad = err > bound
+        assert not bad.any(), "%s cache, sequence %d: %d elements off, first at (pos, head, d) = %s, worst %.3e of max" % (
+            which, seq, int(bad.sum()), tuple(np.argwhere(bad)[0]), float(err.max()) / scale)
+        worst = max(worst, float(err.max()) / scale)
+    return worst
+
+
+def test_prefill_attention_4x2048_32_heads_vs_oracle():
+    """(i) n_seq = 4 x T = 2048 at the Llama-2-7B attention geometry — 16 query blocks x 32 heads x 4 sequences through
+    the XCD-aware work order — then (iii) ONE DECODE STEP over the 2048 cached positions in the sliced regime."""
+    n_seq, T = 4, 2048
+    eng, oracle, cfg = build_attention_geometry(max_ctx=2304, max_batch=n_seq)
+    rng = np.random.default_rng(31)
+    prompts = rng.integers(0, cfg["vocab"], (n_seq, T))
+    got = eng.prefill(prompts, greedy=True).cpu().numpy().copy()
+    for seq in (3, 0):  # sequence 0 last: the oracle's cache then belongs to the sequence the decode step continues
+        oracle.reset()
+        ref = oracle.forward_prompt(prompts[seq])
+        w = check_cache_rows(eng, oracle, seq, T)
+        err = float(np.abs(got[seq] - ref).max())
+        print("sequence %d: cache rows worst %.2e of max, logits %.2e of max" % (seq, w, err / np.abs(ref).max()))
+        assert err <= PF_TOL * np.abs(ref).max() + 1e-3
+        assert int(got[seq].argmax()) == int(ref.argmax())
+        # rows of two heads on different XCDs (heads 0 and 17 -> XCDs 0 and 4) at the positions the verdict names
+        for which, orc_c in (("k", oracle.k[1]), ("v", oracle.v[1])):
+            c = eng.kv_cache(which)[seq, 1].float().cpu().numpy()
+            for p in (0, 127, 1024, 2047):
+                for hd in (0, 17):
+                    assert np.abs(c[p, hd] - orc_c[p, hd]).max() <= KV_TOL * np.abs(orc_c).max() + 1e-3
+    # (iii) the next token of sequence 0 at position 2048: context slices + combine (tune_attn_for picks the regime)
+    eng.tune_attn_for(T + 1)
+    assert L_splits(eng) > 1
+    nxt = int(ref.argmax())
+    assert int(eng.token.item()) == nxt and int(eng.pos.item()) == T
+    eng.step(greedy=True)
+    refd = oracle.forward_token(nxt, T)
+    g = eng.logits.cpu().numpy()
+    derr = float(np.abs(g - refd).max())
+    print("decode step at 2048 cached positions: logits %.2e of max" % (derr / np.abs(refd).max()))
+    assert derr <= PF_TOL * np.abs(refd).max() + 1e-3  # the cache it reads came from the fp16-operand prompt pass
+    assert int(g.argmax()) == int(refd.argmax())
+    assert eng.status() == 0
+
+
+@pytest.mark.parametrize("ctx", [300, 520])
+def test_decode_step_sliced_regime_7b_attention_geometry_vs_oracle(ctx):
+    """(iii) decode steps past LONG_CTX at the 7B attention geometry: `ctx` prompt tokens, then 3 greedy steps in the
+    regime `tune_attn_for` picks (context slices per head + combine), each against the oracle."""
+    eng, oracle, cfg = build_attention_geometry(max_ctx=640)
+    rng = np.random.default_rng(ctx)
+    prompt = rng.integers(0, cfg["vocab"], ctx).tolist()
+    got = eng.prefill(prompt, greedy=True)[0].cpu().numpy().copy()
+    ref = oracle.forward_prompt(prompt)
+    assert np.abs(got - ref).max() <= PF_TOL * np.abs(ref).max() + 1e-3
+    eng.tune_attn_for(ctx + 3)
+    assert L_splits(eng) > 1
+    nxt = int(ref.argmax())
+    for j in range(3):
+        assert int(eng.token.item()) == nxt
+        eng.step(greedy=True)
+        ref = oracle.forward_token(nxt, ctx + j)
+        g = eng.logits.cpu().numpy()
+        assert np.abs(g - ref).max() <= PF_TOL * np.abs(ref).max() + 1e-3, (j, np.abs(g - ref).max())
+        nxt = int(ref.argmax())
+    assert eng.status() == 0
+
+
+def L_splits(eng):
+    from intel_extension_for_transformers_amd import _lib as L
+
+    return int(L.lib().woq_engine_attn_splits(eng._h))
+
+
+@pytest.mark.parametrize("kv_dtype", [torch.float8_e4m3fn, torch.float16])
+def test_mistral_geometry_chunked_8k_window_vs_oracle(kv_dtype):
+    """(ii) Mistral attention geometry — 32 query / 8 kv heads, sliding window 4096, fp8 (and fp16) cache — as the
+    benchmark runs it: 8192 tokens in 4 chunks of 2048 with start_pos > 0, against the fp32-cache oracle and against the
+    same engine's one-shot pass; then decode steps at 8192 cached positions (grouped-query matrix-core slices).
+    fp8 bound: the cache rounds K / V to 3-bit significands (2^-4 relative per element); logits within 6e-2 of the
+    largest (tests/test_gpu_engine.py::test_fp8_kv_cache_prefill_and_decode), cache rows 2^-4 |x| + KV_TOL * max."""
+    T, C, W = 8192, 2048, 4096
+    fp8 = kv_dtype == torch.float8_e4m3fn
+    eng, oracle, cfg = build_attention_geometry(kv_heads=8, window=W, kv_dtype=kv_dtype, max_ctx=T + 64)
+    rng = np.random.default_rng(41)
+    prompt = rng.integers(0, cfg["vocab"], T)
+    for s0 in range(0, T, C):
+        lg = eng.prefill(prompt[s0:s0 + C].tolist(), start_pos=s0, greedy=True)
+    chunked = lg[0].cpu().numpy().copy()
+    kc = eng.kv_cache("k")[0, 1, :T].float().cpu().numpy().copy()
+    for s0 in range(0, T, C):
+        ref = oracle.forward_prompt(prompt[s0:s0 + C], start_pos=s0)
+    ltol = 6e-2 if fp8 else PF_TOL
+    w = check_cache_rows(eng, oracle, 0, T, tol=KV_TOL * (4 if fp8 else 1), rel_storage=2.0 ** -4 if fp8 else 2.0 ** -11)
+    err = float(np.abs(chunked - ref).max())
+    print("mistral geometry, %s cache: rows worst %.2e of max, logits %.2e of max" % (kv_dtype, w, err / np.abs(ref).max()))
+    assert err <= ltol * np.abs(ref).max() + 1e-3
+    if not fp8:
+        assert int(chunked.argmax()) == int(ref.argmax())
+    # decode at 8192 cached positions, regime as generate() picks it; the oracle continues on its own cache
+    eng.tune_attn_for(T + 3)
+    nxt = int(eng.token.item())
+    for j in range(2):
+        eng.step(greedy=True)
+        refd = oracle.forward_token(nxt, T + j)
+        g = eng.logits.cpu().numpy()
+        assert np.abs(g - refd).max() <= ltol * np.abs(refd).max() + 1e-3, (j, np.abs(g - refd).max())
+        nxt = int(eng.token.item())
+    assert eng.status() == 0
+    # one-shot pass over the same tokens: same cache rows up to the rounding of identical arithmetic
+    one = eng.prefill(prompt.tolist(), greedy=True)[0].cpu().numpy()
+    k1 = eng.kv_cache("k")[0, 1, :T].float().cpu().numpy()
+    assert np.abs(one - chunked).max() <= (3e-2 if fp8 else 2e-3) * np.abs(chunked).max() + 1e-4
+    frac = float((np.abs(k1 - kc) > (2.0 ** -3 if fp8 else 2.0 ** -9) * np.abs(kc) + 2e-3 * np.abs(kc).max()).mean())
+    assert frac <= (2e-3 if fp8 else 0.0), frac  # fp8: a value on a rounding boundary may land on the neighbour code

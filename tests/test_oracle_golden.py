@@ -257,3 +257,51 @@ def test_cpu_port_matches_the_oracle_definition(group, asym):
     got = orc.CpuPortLinear(q, s, z, group)(x, b)
     assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
     assert orc.cpu_port_isa() in ("avx512", "avx2", "scalar")
+
+
+def _tiny_oracle(window=0, kv_heads=2, seed=11):
+    cfg = dict(hidden=128, inter=256, heads=4, kv_heads=kv_heads, head_dim=32, layers=2, vocab=96, eps=1e-5,
+               theta=10000.0, window=window)
+    rng = np.random.default_rng(seed)
+    H, I, NH, KV, D = cfg["hidden"], cfg["inter"], cfg["heads"], cfg["kv_heads"], cfg["head_dim"]
+    layers = []
+    for _ in range(cfg["layers"]):
+        ly = {}
+        for n, (k, nn) in dict(q=(H, NH * D), k=(H, KV * D), v=(H, KV * D), o=(NH * D, H), gate=(H, I), up=(H, I),
+                               down=(I, H)).items():
+            q, s, z = orc.rtn_quantize(rng.standard_normal((k, nn)).astype(np.float32) * 0.08, False, 32, True)
+            ly[n] = orc.repack(q, s, z, None, 32)
+        ly["ln1"] = (1 + 0.1 * rng.standard_normal(H)).astype(np.float32)
+        ly["ln2"] = (1 + 0.1 * rng.standard_normal(H)).astype(np.float32)
+        layers.append(ly)
+    embed = rng.standard_normal((cfg["vocab"], H)).astype(np.float32)
+    lm = (rng.standard_normal((cfg["vocab"], H)) * 0.1).astype(np.float32)
+    norm = (1 + 0.1 * rng.standard_normal(H)).astype(np.float32)
+    return orc.LlamaOracle(cfg, embed, layers, norm, lm), cfg
+
+
+@pytest.mark.parametrize("window", [0, 7])
+def test_many_row_prompt_oracle_equals_the_token_loop(window):
+    """`LlamaOracle.forward_prompt` (the many-row restatement the full-geometry attention parity tests use) is the
+    token-by-token oracle: same logits at every position, one shot and in chunks, and `forward_token` continues on the
+    cache it leaves — causal mask, sliding window and grouped-query heads included."""
+    oracle, cfg = _tiny_oracle(window=window)
+    rng = np.random.default_rng(3)
+    prompt = rng.integers(0, cfg["vocab"], 23).tolist()
+    ref = np.stack([oracle.forward_token(t, i) for i, t in enumerate(prompt)])
+    kref = [k.copy() for k in oracle.k]
+    oracle.reset()
+    got = oracle.forward_prompt(prompt, all_logits=True)
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+    for a, b in zip(oracle.k, kref):
+        assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max()
+    oracle.reset()
+    for s0 in (0, 9, 18):
+        last = oracle.forward_prompt(prompt[s0:s0 + 9], start_pos=s0)
+    assert np.abs(last - ref[-1]).max() <= 2e-5 * np.abs(ref).max()
+    nxt = int(ref[-1].argmax())
+    a = oracle.forward_token(nxt, len(prompt))
+    oracle.reset()
+    for i, t in enumerate(prompt + [nxt]):
+        b = oracle.forward_token(t, i)
+    assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max()
