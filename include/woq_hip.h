@@ -199,6 +199,12 @@ WOQ_API int woq_engine_attn_splits(woq_engine* e);
  * fp8 cache — silently the per-query-head slices otherwise). Default off. Same capture rule as attn_splits. */
 WOQ_API int woq_engine_set_attn_grouped(woq_engine* e, int on);
 WOQ_API int woq_engine_attn_grouped(woq_engine* e);
+/* grouped form only: `chunk` > 0 (a multiple of 32) = position-independent slice geometry — slice s owns the absolute
+ * cached positions [s * chunk, (s + 1) * chunk) (the last slice also whatever lies beyond), so its K / V rows are
+ * requested before the device-side position is read; 0 = slices cut evenly from the current span (the default; always
+ * used with a sliding window). Pick splits >= ceil(positions / chunk). Same capture rule as attn_splits. */
+WOQ_API int woq_engine_set_attn_chunk(woq_engine* e, int chunk);
+WOQ_API int woq_engine_attn_chunk(woq_engine* e);
 /* decode step, XQ path: [RMSNorm + qkv GEMV] and [RoPE + KV append + attention] as ONE launch — the workgroup whose
  * column strip completes a head's q / k / v runs that head's attention (csrc/woq_gemv_attn.hip). Applies to multi-head
  * shapes (heads == kv_heads), head_dim 128, hidden 4096, one context slice, no sliding window; the two launches

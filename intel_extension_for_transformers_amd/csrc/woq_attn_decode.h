@@ -2,6 +2,7 @@
 // launch (woq_ops.hip: attn_decode_kernel) and the fused qkv-GEMV + attention launch (woq_gemv_attn.hip).
 // Reference: stock HF eager attention over the KV cache run by PyTorch CPU ops.
 #pragma once
+#include "woq_attn_merge.h"
 #include "woq_device.h"
 #include "woq_xq.h"
 
@@ -134,6 +135,16 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
     const int tc = min(16 * wid + g + u * GP, plast);
     vpre[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
   }
+  // round 4: the V rows of the SECOND 16-position run too (contexts 64 .. 128 used to pay one exposed round trip for
+  // them behind the q hand-off, on the launch's tail: the 128-step bench value sat 4 % under the 20-step one)
+  kv8 vpre2[VU];
+  if (n_w > 16) {
+#pragma unroll
+    for (int u = 0; u < VU; ++u) {
+      const int tc = min(64 + 16 * wid + g + u * GP, plast);
+      vpre2[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
+    }
+  }
   // ---- RoPE of q (every wave for itself | wave 0 for all); wave 0 also rotates k, rounds k / v and appends them ----
   const float scale = 1.0f / sqrtf((float)HD);
   float s_new = 0.f;
@@ -265,7 +276,11 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
   if (n_w > 0) {
 #pragma unroll
     for (int u = 0; u < VU; ++u) pv(g + u * GP, vpre[u]);
-    for (int j0 = 16; j0 < n_w; j0 += 16) {  // later 16-position runs: all their rows requested, then consumed
+    if (n_w > 16) {
+#pragma unroll
+      for (int u = 0; u < VU; ++u) pv(16 + g + u * GP, vpre2[u]);
+    }
+    for (int j0 = 32; j0 < n_w; j0 += 16) {  // later 16-position runs: all their rows requested, then consumed
       kv8 vv[VU];
 #pragma unroll
       for (int u = 0; u < VU; ++u) vload(j0 + g + u * GP, vv[u]);
@@ -307,12 +322,12 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
     const float e2 = m2 == -INFINITY ? 0.f : __expf(m2 - mx), e3 = m3 == -INFINITY ? 0.f : __expf(m3 - mx);
     const float o = (slab[tid] * e0 + slab[HD + tid] * e1) + (slab[2 * HD + tid] * e2 + slab[3 * HD + tid] * e3);
     const float den = (ml[4] * e0 + ml[5] * e1) + (ml[6] * e2 + ml[7] * e3);
-    if constexpr (SPLIT) {
-      float* part = out + ((size_t)h * n_slices + slice) * (HD + 2);
-      part[tid] = o;
+    if constexpr (SPLIT) {  // publish the slice's partial (woq_attn_merge.h); `out` is the partial buffer here
+      st_agent(attn_part_o(out, h, slice, HD) + tid, o);
       if (tid == 0) {
-        part[HD] = mx;
-        part[HD + 1] = den;
+        float* pml = attn_part_ml(out, heads, h, slice, HD);
+        st_agent(pml, mx);
+        st_agent(pml + 1, den);
       }
     } else {
       env.put(o / den, h * HD + tid);  // tid < HD is a whole number of 16-lane rows

@@ -30,7 +30,8 @@ void launch_embed(const void* embed, int dtype, const int32_t* token, int hidden
                   hipStream_t st);
 int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
                        const float* cs, const float* sn, int heads, int kv_heads, int D, int max_ctx, int window,
-                       float* out, int splits, int grouped, float* part, const XqPtrs& xo, hipStream_t st);
+                       float* out, int splits, int grouped, float* part, const XqPtrs& xo, hipStream_t st,
+                       unsigned int* merge_counters, int chunk_fixed);
 // batch-1 GEMV over an XQ activation vector (woq_gemv_xq.hip)
 bool gemv_xq_supported(const woq_blob_header& h, int epi);
 int launch_gemv_xq(const XqPtrs& xin, const void* blob, const woq_blob_header& h, const float* bias, float* out,
@@ -161,7 +162,10 @@ struct woq_engine {
   int window = 0;               // sliding-window attention (HF Mistral sliding_window), 0 = full causal
   int attn_splits = 1;          // decode attention: context slices per head (long contexts)
   int attn_grouped = 0;         // sliced regime: one workgroup per kv head x slice on the matrix cores (GQA shapes)
-  float* attn_part = nullptr;   // fp32 [heads][attn_splits][head_dim + 2] partials
+  float* attn_part = nullptr;   // fp32 partials of the sliced decode attention (layout: woq_attn_merge.h)
+  unsigned int* attn_cnt = nullptr;  // [heads] arrival counters of the slices' last-workgroup merge, zero between launches
+  bool attn_fold = true;        // the last slice workgroup merges (WOQ_ATTN_FOLD=0: a combine launch does, the A/B twin)
+  int attn_chunk = 0;           // grouped form: positions per slice of the position-independent geometry, 0 = adaptive
   int max_batch = 1;
   size_t pf_rows = 0, pf_ws_bytes = 0;
   float* pf_h = nullptr;        // fp32 residual stream [rows][hidden]
@@ -265,7 +269,7 @@ static int engine_attn_block_xq(woq_engine* e, int l, hipStream_t st) {
     rc = launch_attn_decode(e->qkv, e->kcache + (size_t)l * e->kv_layer_bytes,
                             e->vcache + (size_t)l * e->kv_layer_bytes, c.kv_dtype, e->pos, e->cs, e->sn, c.heads,
                             c.kv_heads, c.head_dim, c.max_ctx, e->window, e->attn, e->attn_splits, e->attn_grouped,
-                            e->attn_part, e->xq_attn, st);
+                            e->attn_part, e->xq_attn, st, e->attn_fold ? e->attn_cnt : nullptr, e->attn_chunk);
   if (rc) return rc;
   if (skip & 4) return 0;
   // hidden += attn . W_o ; the new hidden leaves as the MLP's XQ input (times ln2) with its sums of squares
@@ -317,7 +321,8 @@ static int engine_attn_block(woq_engine* e, int l, hipStream_t st) {
   if (rc) return rc;
   rc = launch_attn_decode(e->qkv, e->kcache + (size_t)l * e->kv_layer_bytes, e->vcache + (size_t)l * e->kv_layer_bytes,
                           c.kv_dtype, e->pos, e->cs, e->sn, c.heads, c.kv_heads, c.head_dim, c.max_ctx, e->window,
-                          e->attn, e->attn_splits, e->attn_grouped, e->attn_part, kNoXq, st);
+                          e->attn, e->attn_splits, e->attn_grouped, e->attn_part, kNoXq, st,
+                          e->attn_fold ? e->attn_cnt : nullptr, e->attn_chunk);
   if (rc) return rc;
   // row-parallel o_proj: rank 0 carries the residual so that the sum over ranks adds it exactly once
   const float* res = (c.tp_size <= 1 || c.tp_rank == 0) ? e->hidden : nullptr;
@@ -560,6 +565,13 @@ int woq_engine_set_attn_grouped(woq_engine* e, int on) {
   WOQ_END
 }
 int woq_engine_attn_grouped(woq_engine* e) { return e ? e->attn_grouped : 0; }
+int woq_engine_set_attn_chunk(woq_engine* e, int chunk) {
+  WOQ_TRY
+  WOQ_CHECK(e != nullptr && chunk >= 0 && chunk % 32 == 0, "QBits: attn_chunk must be a non-negative multiple of 32");
+  e->attn_chunk = chunk;  // takes effect at the next step / capture
+  WOQ_END
+}
+int woq_engine_attn_chunk(woq_engine* e) { return e ? e->attn_chunk : 0; }
 int woq_engine_set_chain(woq_engine* e, int on) {
   WOQ_TRY
   WOQ_CHECK(e != nullptr, "QBits: null engine");
@@ -664,6 +676,12 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
   WOQ_CHECK(e->attn_splits <= 64, "QBits: attn_splits must be <= 64");
   e->window = cfg->reserved[2] > 0 ? cfg->reserved[2] : 0;
   WOQ_HIP(hipMalloc((void**)&e->attn_part, (size_t)cfg->heads * 64 * (cfg->head_dim + 2) * 4));  // room for 64 slices
+  WOQ_HIP(hipMalloc((void**)&e->attn_cnt, (size_t)cfg->heads * 4));
+  WOQ_HIP(hipMemset(e->attn_cnt, 0, (size_t)cfg->heads * 4));
+  {
+    const char* af = getenv("WOQ_ATTN_FOLD");
+    e->attn_fold = af ? af[0] != '0' : true;
+  }
   WOQ_HIP(hipMalloc((void**)&e->tok_log, (size_t)(cfg->max_ctx + 1) * 4));
   WOQ_HIP(hipMemset(e->tok_log, 0, (size_t)(cfg->max_ctx + 1) * 4));
   WOQ_HIP(hipMalloc((void**)&e->am_val, (size_t)((cfg->vocab + 15) / 16) * 4));
@@ -674,7 +692,7 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
   WOQ_HIP(hipMemset(e->step_seq, 0, 8));
   e->fuse_status = (int*)(e->step_seq + 1);
   e->owned = {e->hidden, e->qkv, e->attn, e->act, e->logits, e->token, e->pos, e->kcache, e->vcache, e->pf_last,
-              e->pf_logits, e->attn_part, e->am_val, e->am_idx, e->tok_log, e->step_seq};
+              e->pf_logits, e->attn_part, e->attn_cnt, e->am_val, e->am_idx, e->tok_log, e->step_seq};
   {  // XQ vectors (woq_xq.h) for the three GEMV inputs of a layer
     // WOQ_ENGINE_XQ=0 turns the XQ hand-off off (the fp32-activation kernels). Round 2 picked by shape — at hidden 8192
     // the second recombination per tile cost more than the staging it removed (Llama-2-70B 119-120 vs 125-127 tokens/s);

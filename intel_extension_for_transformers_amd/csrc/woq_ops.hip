@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
                                                           KV* __restrict__ vcache, const int32_t* __restrict__ pos_p,
                                                           const float* __restrict__ cs, const float* __restrict__ sn,
                                                           int heads, int kv_heads, int window, int spw,
-                                                          float* __restrict__ out, XqPtrs xo) {
+                                                          float* __restrict__ out, XqPtrs xo, AttnMerge mg) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   // workgroup ids go round-robin over the 8 XCDs: give every XCD a run of consecutive heads, so that the query heads
   // sharing a kv head (GQA) share an L2 instead of pulling the same cache rows into several
@@ -120,6 +120,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
   const int h = (heads & 7) == 0 ? (bx & 7) * (heads >> 3) + (bx >> 3) : bx;
   attn_decode_body<KV, HD, SPLIT>(sm, h, (int)blockIdx.y, (int)gridDim.y, AttnPlain{qkv}, kcache, vcache, pos_p, cs,
                                   sn, heads, kv_heads, window, spw, out, xo);
+  if constexpr (SPLIT) {  // `out` = the partial buffer; the head's last slice workgroup merges (woq_attn_merge.h)
+    if (mg.counter != nullptr) attn_slices_merge<HD>(out, heads, h, 1, (int)gridDim.y, mg.counter + h, mg, sm);
+  }
 }
 
 // merge the slices of attn_decode_kernel<SPLIT>: out[h][d] = sum_s o_s[d] e^(m_s - m) / sum_s l_s e^(m_s - m).
@@ -131,10 +134,11 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
                                                           float* __restrict__ out, XqPtrs xo) {
   __shared__ float ms[64], wl[64], wsc[64], red[256];
   const int h = blockIdx.x, tid = threadIdx.x;
-  const float* p = part + (size_t)h * ns * (HD + 2);
+  const float* p = part + (size_t)h * ATTN_MAX_SLICES * HD;  // woq_attn_merge.h: o [head][64][HD], then ml [head][64][2]
+  const float* pml = part + (size_t)gridDim.x * ATTN_MAX_SLICES * HD + (size_t)h * ATTN_MAX_SLICES * 2;
   if (tid < ns) {
-    ms[tid] = p[(size_t)tid * (HD + 2) + HD];
-    wl[tid] = p[(size_t)tid * (HD + 2) + HD + 1];
+    ms[tid] = pml[tid * 2];
+    wl[tid] = pml[tid * 2 + 1];
   }
   __syncthreads();
   float m = -INFINITY;
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
   const int d = tid % HD, grp = tid / HD;
   float o = 0.f;
 #pragma unroll 8
-  for (int s = grp; s < ns; s += GROUPS) o = fmaf(p[(size_t)s * (HD + 2) + d], wsc[s], o);
+  for (int s = grp; s < ns; s += GROUPS) o = fmaf(p[(size_t)s * HD + d], wsc[s], o);
   red[tid] = o;
   __syncthreads();
   if (grp == 0) {
@@ -298,14 +302,14 @@ void launch_embed(const void* embed, int dtype, const int32_t* token, int hidden
 
 bool launch_attn_decode_mfma(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
                              const float* cs, const float* sn, int heads, int kv_heads, int D, int window, int splits,
-                             float* part, hipStream_t st);
+                             float* part, int chunk_fixed, int max_ctx, const AttnMerge& mg, hipStream_t st);
 void launch_attn_combine(const float* part, int heads, int D, int splits, float* out, const XqPtrs& xo,
                          hipStream_t st);
 
 template <typename KV, int HD>
 static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int32_t* pos, const float* cs,
                          const float* sn, int heads, int kv_heads, int max_ctx, int window, float* out, int splits,
-                         float* part, const XqPtrs& xo, hipStream_t st) {
+                         float* part, const XqPtrs& xo, unsigned int* merge_counters, hipStream_t st) {
   const int reach = window > 0 ? min(window, max_ctx) : max_ctx;  // positions a query can see
   const int span = splits > 1 ? ((((reach + splits - 1) / splits) + 63) & ~63) + 64 : reach;
   const int spw = attn_dec_spw(span);
@@ -318,9 +322,11 @@ static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int
       hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       once = true;
     }
+    const AttnMerge mg{merge_counters, out, xo};
     hipLaunchKernelGGL(k, dim3(heads, splits), dim3(256), lds, st, qkv, (KV*)kcache, (KV*)vcache, pos, cs, sn, heads,
-                       kv_heads, window, spw, part, XqPtrs{nullptr, nullptr, nullptr});
-    hipLaunchKernelGGL(attn_combine_kernel<HD>, dim3(heads), dim3(256), 0, st, part, splits, out, xo);
+                       kv_heads, window, spw, part, XqPtrs{nullptr, nullptr, nullptr}, mg);
+    if (merge_counters == nullptr)
+      hipLaunchKernelGGL(attn_combine_kernel<HD>, dim3(heads), dim3(256), 0, st, part, splits, out, xo);
     return 0;
   }
   auto k = attn_decode_kernel<KV, HD, false>;
@@ -330,28 +336,32 @@ static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int
     once = true;
   }
   hipLaunchKernelGGL(k, dim3(heads), dim3(256), lds, st, qkv, (KV*)kcache, (KV*)vcache, pos, cs, sn, heads, kv_heads,
-                     window, spw, out, xo);
+                     window, spw, out, xo, AttnMerge{nullptr, nullptr, XqPtrs{nullptr, nullptr, nullptr}});
   return 0;
 }
 
 // splits <= 1: one workgroup per head (short contexts); else `splits` slices per head + a combine launch, partials in
 // `part` (fp32 [heads][splits][D + 2]).
+// merge_counters (nullable): [heads] zero-initialised words — the slices' last workgroup merges (woq_attn_merge.h) and
+// no combine launch follows; chunk_fixed: position-independent slice geometry of the grouped form (0 = adaptive)
 int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
                        const float* cs, const float* sn, int heads, int kv_heads, int D, int max_ctx, int window,
-                       float* out, int splits, int grouped, float* part, const XqPtrs& xo, hipStream_t st) {
+                       float* out, int splits, int grouped, float* part, const XqPtrs& xo, hipStream_t st,
+                       unsigned int* merge_counters, int chunk_fixed) {
   if (D != 64 && D != 128) return woq::fail("QBits: attention head_dim must be 64 or 128");
+  if (splits > ATTN_MAX_SLICES) return woq::fail("QBits: at most 64 context slices");
   // grouped-query form (woq_prefill.hip): only where it applies — head_dim 128, 2 / 4 / 8 query heads per kv head,
   // an fp16 or fp8 cache — anything else keeps the per-query-head slices
   if (grouped && launch_attn_decode_mfma(qkv, kcache, vcache, kv_dtype, pos, cs, sn, heads, kv_heads, D, window, splits,
-                                          part, st)) {
-    launch_attn_combine(part, heads, D, splits, out, xo, st);
+                                          part, chunk_fixed, max_ctx, AttnMerge{merge_counters, out, xo}, st)) {
+    if (merge_counters == nullptr) launch_attn_combine(part, heads, D, splits, out, xo, st);
     return 0;
   }
 #define WOQ_ATTN_DEC(T)                                                                                              \
   return D == 128 ? launch_attn_t<T, 128>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, window, out,   \
-                                          splits, part, xo, st)                                                     \
+                                          splits, part, xo, merge_counters, st)                                     \
                   : launch_attn_t<T, 64>(qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, max_ctx, window, out,    \
-                                         splits, part, xo, st);
+                                         splits, part, xo, merge_counters, st);
   if (kv_dtype == WOQ_F16) { WOQ_ATTN_DEC(_Float16) }
   if (kv_dtype == WOQ_FP8_E4M3) { WOQ_ATTN_DEC(Fp8) }
   WOQ_ATTN_DEC(__bf16)

@@ -22,6 +22,7 @@
 // 450 vs 353 us per layer at 4 x 2048 tokens — two workgroups per CU already overlap each other's staging). fp32 accumulation throughout; Q, K, V, P enter the MFMAs as fp16.
 #include <cstdlib>
 
+#include "woq_attn_merge.h"
 #include "woq_device.h"
 #include "woq_launch.h"
 
@@ -33,6 +34,17 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 // ---- KV element codecs: cache dtype <-> fp16 lanes -------------------------------------------------------------
+// eight e4m3 bytes -> eight fp16, exact (every e4m3 value is an fp16): gfx950's packed converter, one instruction per
+// pair (round 4; the f32 detour cost three per pair, ~100 VALU per 32-position sub-tile of the long-context decode)
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ _Float16 __attribute__((ext_vector_type(8))) fp8x8_to_h8(
+    unsigned int __attribute__((ext_vector_type(2))) raw) {
+  const h2v a = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(raw.x, 1.0f, false);
+  const h2v b = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(raw.x, 1.0f, true);
+  const h2v c = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(raw.y, 1.0f, false);
+  const h2v d = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(raw.y, 1.0f, true);
+  return (_Float16 __attribute__((ext_vector_type(8)))){a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
 // 8 consecutive cache elements -> 8 fp16
 template <int KVD>
 __device__ __forceinline__ h8 kv_load8(const void* base, size_t elem) {
@@ -40,15 +52,7 @@ __device__ __forceinline__ h8 kv_load8(const void* base, size_t elem) {
     return *(const h8*)((const _Float16*)base + elem);
   } else if constexpr (KVD == WOQ_FP8_E4M3) {
     const u32x2 raw = *(const u32x2*)((const uint8_t*)base + elem);
-    h8 r;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t w = j < 2 ? raw.x : raw.y;
-      const auto f = (j & 1) ? __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true) : __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);
-      r[2 * j] = (_Float16)f[0];
-      r[2 * j + 1] = (_Float16)f[1];
-    }
-    return r;
+    return fp8x8_to_h8(raw);
   } else {
     const u32x4 raw = *(const u32x4*)((const uint16_t*)base + elem);
     h8 r;
@@ -387,7 +391,8 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const float* __re
                                                                const int32_t* __restrict__ pos_p,
                                                                const float* __restrict__ cs,
                                                                const float* __restrict__ sn, int heads, int kv_heads,
-                                                               int window, float* __restrict__ part) {
+                                                               int window, float* __restrict__ part, int chunk_fixed,
+                                                               int max_rows, AttnMerge mg) {
   static_assert(HD == 128 && REP <= 16, "one 16-column MFMA tile of query heads, head_dim 128");
   static_assert(16 * (HD + 2) * 4 <= HD * DVRB, "the merge record of a wave reuses its V^T tile");
   constexpr int DC = HD / 32, DT = HD / 16, half = HD / 2;
@@ -400,20 +405,18 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const float* __re
   float* qs = vn + HD;                                // [REP][HD] rotated query heads
   const int i16 = lane & 15, kq = lane >> 4;
   const int kh = blockIdx.x, ns = (int)gridDim.y, sp = (int)blockIdx.y;
-  const int apos = pos_p[0];
-  const int w_lo = window > 0 ? max(0, apos + 1 - window) : 0;
-  const int span = apos - w_lo;
-  const int chunk = (((span + ns - 1) / ns) + 4 * DST - 1) & ~(4 * DST - 1);
-  const int t_lo = w_lo + min(sp * chunk, span);
-  const int npos = min(apos - t_lo, chunk);  // cached positions of this slice
-  const bool incl_new = sp == ns - 1;
+  // Two slice geometries. ADAPTIVE (chunk_fixed == 0, or a sliding window): the cached span is cut into ns even
+  // chunks — every address then depends on the position, which is a device-side word: one dependent round trip before
+  // the first K / V byte can be asked for. FIXED (round 4): slice sp owns absolute positions [sp * chunk_fixed,
+  // (sp + 1) * chunk_fixed) whatever the position is (the last slice also takes whatever lies beyond), so the two
+  // sub-tiles every wave starts with are requested BEFORE the position is read; rows at or beyond it hold zeros or
+  // older finite values (the cache is zero-filled at creation) and are masked like ragged tails. Slices that lie
+  // wholly beyond the position publish an empty partial.
+  const bool fixed = chunk_fixed > 0 && window == 0;
   const size_t cache_row = (size_t)kv_heads * HD;
-  const size_t cache0 = (size_t)t_lo * cache_row + (size_t)kh * HD;
-  const int n_sub = (npos + DST - 1) / DST;
-  const int last = max(npos - 1, 0);
-  const float sc = 1.44269504088896f / sqrtf((float)HD);
-
   const int v_g = lane >> 3, v_c = lane & 7;  // V staging: positions 4 v_g .. + 4, d = 16 v_c .. + 16
+  size_t cache0 = (size_t)(fixed ? sp * chunk_fixed : 0) * cache_row + (size_t)kh * HD;
+  int last = fixed ? max(0, min(chunk_fixed, max_rows - sp * chunk_fixed) - 1) : 0;
   // two register sets: a wave's first two sub-tiles are requested back to back, then set X is refilled for
   // sub-tile n + 8 as soon as sub-tile n has left it (one exposed load latency per wave, not one per sub-tile)
   h8 kfA[2][DC], vrA[4][2], kfB[2][DC], vrB[4][2];
@@ -432,8 +435,36 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const float* __re
       vr[r][1] = kv_load8<KVD>(vcache, row + 8);
     }
   };
-  if (wid < n_sub) fetch(kfA, vrA, wid);
-  if (wid + 4 < n_sub) fetch(kfB, vrB, wid + 4);
+  const bool early = fixed && sp * chunk_fixed < max_rows;
+  if (early) {
+    if (wid * DST <= last) fetch(kfA, vrA, wid);
+    if ((wid + 4) * DST <= last) fetch(kfB, vrB, wid + 4);
+  }
+  const int apos = pos_p[0];
+  const int w_lo = window > 0 ? max(0, apos + 1 - window) : 0;
+  const int span = apos - w_lo;
+  int t_lo, npos;
+  bool incl_new;
+  if (fixed) {
+    t_lo = sp * chunk_fixed;
+    npos = sp == ns - 1 ? max(apos - t_lo, 0) : max(0, min(apos - t_lo, chunk_fixed));
+    incl_new = sp == min(apos / chunk_fixed, ns - 1);
+  } else {
+    const int chunk = (((span + ns - 1) / ns) + 4 * DST - 1) & ~(4 * DST - 1);
+    t_lo = w_lo + min(sp * chunk, span);
+    npos = min(apos - t_lo, chunk);  // cached positions of this slice
+    incl_new = sp == ns - 1;
+    cache0 = (size_t)t_lo * cache_row + (size_t)kh * HD;
+  }
+  const int n_sub = (npos + DST - 1) / DST;
+  const int last_early = last;
+  last = max(npos - 1, 0);
+  const float sc = 1.44269504088896f / sqrtf((float)HD);
+
+  // what the early requests did not cover: everything in the adaptive geometry; in the fixed one the sub-tiles past
+  // the slice's own chunk (short chunks, or the last slice's overflow)
+  if (wid < n_sub && !(early && wid * DST <= last_early)) fetch(kfA, vrA, wid);
+  if (wid + 4 < n_sub && !(early && (wid + 4) * DST <= last_early)) fetch(kfB, vrB, wid + 4);
 
   // prologue through LDS: threads 0..15 build the new k / v of this kv head (rotated, rounded through the cache dtype
   // like the rows a later step reads back; the last slice appends them), everyone rotates the REP query heads
@@ -605,14 +636,17 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const float* __re
         acc = fmaf(rec[h * HD + d], wt, acc);
         den = fmaf(rec[16 * HD + 16 + h], wt, den);
       }
-      float* pp = part + ((size_t)(kh * REP + h) * ns + sp) * (HD + 2);
-      pp[d] = acc;
+      // publish (woq_attn_merge.h: agent-scope write-through stores; the merging workgroup may sit on another XCD)
+      st_agent(attn_part_o(part, kh * REP + h, sp, HD) + d, acc);
       if (d == 0) {
-        pp[HD] = m == -INFINITY ? -INFINITY : m * 0.6931471805599453f;  // exp2 domain -> natural
-        pp[HD + 1] = den;
+        float* ml = attn_part_ml(part, heads, kh * REP + h, sp, HD);
+        st_agent(ml, m == -INFINITY ? -INFINITY : m * 0.6931471805599453f);  // exp2 domain -> natural
+        st_agent(ml + 1, den);
       }
     }
   }
+  // the last slice workgroup of this kv head to get here merges the group's REP heads and emits the attention output
+  if (mg.counter != nullptr) attn_slices_merge<HD>(part, heads, kh * REP, REP, ns, mg.counter + kh, mg, (float*)dsm_raw);
 }
 
 // last row of every sequence -> dst fp32 [n_seq][hidden]
@@ -694,16 +728,19 @@ int launch_attn_prefill(const _Float16* qkv, int n_seq, int T, int start, int he
 
 // long-context decode attention of grouped-query models: true when this kernel took the call (head_dim 128, 2 / 4 / 8
 // query heads per kv head), false -> the caller uses the per-query-head sliced kernel
+// chunk_fixed: 0 = adaptive slices, else positions per slice (multiple of 32) of the position-independent geometry;
+// mg.counter != null: the last slice workgroup of a kv head merges (no combine launch needed)
 bool launch_attn_decode_mfma(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
                              const float* cs, const float* sn, int heads, int kv_heads, int D, int window, int splits,
-                             float* part, hipStream_t st) {
+                             float* part, int chunk_fixed, int max_ctx, const AttnMerge& mg, hipStream_t st) {
   const int rep = kv_heads > 0 ? heads / kv_heads : 0;
-  if (D != 128 || splits <= 1 || !(rep == 2 || rep == 4 || rep == 8)) return false;
+  if (D != 128 || splits <= 1 || splits > ATTN_MAX_SLICES || !(rep == 2 || rep == 4 || rep == 8)) return false;
+  if (chunk_fixed % DST != 0) chunk_fixed = 0;
   const dim3 grid((unsigned)kv_heads, (unsigned)splits);
 #define WOQ_DEC_CASE(KVD, R)                                                                                       \
   if (kv_dtype == KVD && rep == R) {                                                                               \
     hipLaunchKernelGGL((attn_decode_mfma_kernel<KVD, 128, R>), grid, dim3(256), (attn_dec_lds_bytes<128, R>()), st, \
-                       qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, window, part);                           \
+                       qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, window, part, chunk_fixed, max_ctx, mg);  \
     return true;                                                                                                   \
   }
   WOQ_DEC_CASE(WOQ_F16, 2) WOQ_DEC_CASE(WOQ_F16, 4) WOQ_DEC_CASE(WOQ_F16, 8)

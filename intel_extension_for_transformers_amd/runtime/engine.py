@@ -223,6 +223,16 @@ class WoqDecoderEngine:
             L.check(L.lib().woq_engine_set_attn_grouped(self._h, int(bool(on))))
             self.captured = False
 
+    GROUPED_CHUNK = 256  # positions per slice of the grouped form's position-independent geometry (two 32-position sub-tiles per wave, both requested before the position is read)
+
+    def set_attn_chunk(self, chunk):
+        """Grouped form: `chunk` > 0 = slice s owns the absolute positions [s * chunk, (s + 1) * chunk) whatever the
+        current position is (K / V requested before it is read); 0 = slices cut evenly from the current span.
+        Invalidates a captured graph."""
+        if int(chunk) != L.lib().woq_engine_attn_chunk(self._h):
+            L.check(L.lib().woq_engine_set_attn_chunk(self._h, int(chunk)))
+            self.captured = False
+
     def set_chain(self, on):
         """Decode step: each layer as two chained launches where the shape allows (csrc/woq_gemv_chain.hip; default on).
         Invalidates a captured graph."""
@@ -296,8 +306,12 @@ class WoqDecoderEngine:
         grouped-query shapes take 256-position slices of the matrix-core form."""
         grouped = positions >= self.GROUPED_CTX and self._grouped_applies()
         self.set_attn_grouped(grouped)
+        fixed = grouped and not self.cfg.reserved[2]  # a sliding window moves the slices with the position
+        self.set_attn_chunk(self.GROUPED_CHUNK if fixed else 0)
         if positions <= self.LONG_CTX:
             self.set_attn_splits(1)
+        elif fixed:  # enough fixed slices to cover `positions`; the last one takes what lies beyond
+            self.set_attn_splits(max(2, min(64, -(-positions // self.GROUPED_CHUNK))))
         elif grouped:
             self.set_attn_splits(max(2, min(64, positions // 256)))
         else:

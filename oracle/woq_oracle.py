@@ -653,6 +653,11 @@ class LlamaOracle:
         L = len(layers)
         self.k = [np.zeros((0, cfg["kv_heads"], cfg["head_dim"]), np.float32) for _ in range(L)]
         self.v = [np.zeros((0, cfg["kv_heads"], cfg["head_dim"]), np.float32) for _ in range(L)]
+        # kv_hook(layer, first_position, k_rows, v_rows) -> (k_rows, v_rows) to CACHE instead (None: cache what was
+        # computed). Parity tests of a low-precision device cache (fp8) hand the device's own stored rows back here, so
+        # that every layer is checked on the inputs the device really attended over and one layer's storage rounding
+        # does not blur the comparison of the next.
+        self.kv_hook = None
 
     def reset(self):
         for i in range(len(self.k)):
@@ -676,6 +681,8 @@ class LlamaOracle:
                 v = woq_linear(x, ly["v"]).reshape(1, KV, D)
             q = rope(q, [pos], c["theta"])
             k = rope(k, [pos], c["theta"])
+            if self.kv_hook is not None:
+                k, v = self.kv_hook(li, pos, k, v)
             self.k[li] = np.concatenate([self.k[li], k], 0)
             self.v[li] = np.concatenate([self.v[li], v], 0)
             w = c.get("window", 0)  # HF Mistral sliding_window: a query sees the last `window` positions (itself included)
@@ -715,8 +722,11 @@ class LlamaOracle:
                 q, k, v = (linear_rows(x, ly[n]) for n in ("q", "k", "v"))
             q = rope(q.reshape(T, H, D), pos, c["theta"])
             k = rope(k.reshape(T, KV, D), pos, c["theta"])
+            v = np.ascontiguousarray(v).reshape(T, KV, D)
+            if self.kv_hook is not None:
+                k, v = self.kv_hook(li, start_pos, k, v)
             self.k[li] = np.concatenate([self.k[li], k], 0)
-            self.v[li] = np.concatenate([self.v[li], np.ascontiguousarray(v).reshape(T, KV, D)], 0)
+            self.v[li] = np.concatenate([self.v[li], v], 0)
             a = attn_prompt(q, self.k[li], self.v[li], start_pos, c.get("window", 0)).reshape(T, H * D)
             h = h + linear_rows(a, ly["o"])
             x = rmsnorm(h, ly["ln2"], c["eps"])

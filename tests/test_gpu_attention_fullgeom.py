@@ -149,10 +149,16 @@ def L_splits(eng):
 @pytest.mark.parametrize("kv_dtype", [torch.float8_e4m3fn, torch.float16])
 def test_mistral_geometry_chunked_8k_window_vs_oracle(kv_dtype):
     """(ii) Mistral attention geometry — 32 query / 8 kv heads, sliding window 4096, fp8 (and fp16) cache — as the
-    benchmark runs it: 8192 tokens in 4 chunks of 2048 with start_pos > 0, against the fp32-cache oracle and against the
-    same engine's one-shot pass; then decode steps at 8192 cached positions (grouped-query matrix-core slices).
-    fp8 bound: the cache rounds K / V to 3-bit significands (2^-4 relative per element); logits within 6e-2 of the
-    largest (tests/test_gpu_engine.py::test_fp8_kv_cache_prefill_and_decode), cache rows 2^-4 |x| + KV_TOL * max."""
+    benchmark runs it: 8192 tokens in 4 chunks of 2048 with start_pos > 0, against the oracle and against the same
+    engine's one-shot pass; then decode steps at 8192 cached positions (grouped-query matrix-core slices).
+
+    fp16 cache: the oracle keeps its own fp32 rows; every layer-1 row within KV_TOL of the tensor's maximum.
+    fp8 cache: a 3-bit significand per stored element would blur layer 1's rows by several percent if the oracle
+    attended over unrounded rows (measured: 2.5 % of the elements beyond 2e-2 of the maximum), so the oracle is
+    TEACHER-FORCED: through `kv_hook` it caches the rows the device stored (read back from the engine's cache) and the
+    rows it computed itself are what the device's are compared with — per layer, on identical attention inputs:
+    |device - oracle| <= KV_TOL * max + 2^-4 |oracle| (half an e4m3 step: round-to-nearest of a value the fp16-operand
+    GEMM got right to KV_TOL). Logits then agree at the fp16-cache bound."""
     T, C, W = 8192, 2048, 4096
     fp8 = kv_dtype == torch.float8_e4m3fn
     eng, oracle, cfg = build_attention_geometry(kv_heads=8, window=W, kv_dtype=kv_dtype, max_ctx=T + 64)
@@ -162,24 +168,53 @@ def test_mistral_geometry_chunked_8k_window_vs_oracle(kv_dtype):
         lg = eng.prefill(prompt[s0:s0 + C].tolist(), start_pos=s0, greedy=True)
     chunked = lg[0].cpu().numpy().copy()
     kc = eng.kv_cache("k")[0, 1, :T].float().cpu().numpy().copy()
+    own = {}
+    if fp8:
+        dev = {w: eng.kv_cache(w)[0, :, :T].float().cpu().numpy() for w in ("k", "v")}
+
+        def hook(li, start, k, v):
+            s0 = int(np.asarray(start).ravel()[0])
+            own.setdefault(li, []).append((s0, k, v))
+            n = k.shape[0]
+            return dev["k"][li, s0:s0 + n].copy(), dev["v"][li, s0:s0 + n].copy()
+
+        oracle.kv_hook = hook
     for s0 in range(0, T, C):
         ref = oracle.forward_prompt(prompt[s0:s0 + C], start_pos=s0)
-    ltol = 6e-2 if fp8 else PF_TOL
-    w = check_cache_rows(eng, oracle, 0, T, tol=KV_TOL * (4 if fp8 else 1), rel_storage=2.0 ** -4 if fp8 else 2.0 ** -11)
+    if fp8:
+        worst = 0.0
+        for li in range(cfg["layers"]):
+            for j, which in ((1, "k"), (2, "v")):
+                mine = np.concatenate([rec[j] for rec in sorted(own[li], key=lambda r: r[0])], 0)
+                got = dev[which][li]
+                scale = float(np.abs(mine).max())
+                err = np.abs(got - mine)
+                bad = err > KV_TOL * scale + 2.0 ** -4 * np.abs(mine)
+                assert not bad.any(), "%s rows of layer %d: %d elements off, first %s, worst %.3e of max" % (
+                    which, li, int(bad.sum()), tuple(np.argwhere(bad)[0]), float(err.max()) / scale)
+                worst = max(worst, float((err - 2.0 ** -4 * np.abs(mine)).max()) / scale)
+        w = worst
+    else:
+        w = check_cache_rows(eng, oracle, 0, T)
     err = float(np.abs(chunked - ref).max())
-    print("mistral geometry, %s cache: rows worst %.2e of max, logits %.2e of max" % (kv_dtype, w, err / np.abs(ref).max()))
-    assert err <= ltol * np.abs(ref).max() + 1e-3
-    if not fp8:
-        assert int(chunked.argmax()) == int(ref.argmax())
-    # decode at 8192 cached positions, regime as generate() picks it; the oracle continues on its own cache
+    print("mistral geometry, %s cache: rows worst %.2e of max (beyond storage rounding), logits %.2e of max" % (
+        kv_dtype, w, err / np.abs(ref).max()))
+    assert err <= PF_TOL * np.abs(ref).max() + 1e-3
+    assert int(chunked.argmax()) == int(ref.argmax())
+    # decode at 8192 cached positions, regime as generate() picks it; the oracle continues on its cache (fp8: on the
+    # device's rows — the step's own appended row included, read back after the step)
     eng.tune_attn_for(T + 3)
     nxt = int(eng.token.item())
+    assert nxt == int(ref.argmax())
     for j in range(2):
         eng.step(greedy=True)
+        if fp8:
+            dev = {w_: eng.kv_cache(w_)[0, :, :T + j + 1].float().cpu().numpy() for w_ in ("k", "v")}
         refd = oracle.forward_token(nxt, T + j)
         g = eng.logits.cpu().numpy()
-        assert np.abs(g - refd).max() <= ltol * np.abs(refd).max() + 1e-3, (j, np.abs(g - refd).max())
+        assert np.abs(g - refd).max() <= PF_TOL * np.abs(refd).max() + 1e-3, (j, np.abs(g - refd).max())
         nxt = int(eng.token.item())
+        assert nxt == int(refd.argmax())
     assert eng.status() == 0
     # one-shot pass over the same tokens: same cache rows up to the rounding of identical arithmetic
     one = eng.prefill(prompt.tolist(), greedy=True)[0].cpu().numpy()

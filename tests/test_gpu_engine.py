@@ -291,6 +291,65 @@ def test_decode_attention_context_slices_vs_oracle(head_dim, splits, grouped, hi
         assert int(eng.token.item()) == nxt
 
 
+@pytest.mark.parametrize("hidden,chunk,splits", [(512, 32, 5), (512, 64, 3), (1024, 64, 4), (256, 96, 3)])
+def test_grouped_attention_fixed_chunk_slices_vs_oracle(hidden, chunk, splits):
+    """Round 4: the grouped-query sliced decode attention with POSITION-INDEPENDENT slices (slice s owns the absolute
+    positions [s * chunk, (s + 1) * chunk), K / V requested before the device-side position is read) and the merge done
+    by the last slice workgroup to finish (csrc/woq_attn_merge.h) instead of a combine launch. Token by token over 200
+    positions with small chunks: slices wholly beyond the position (empty partials), the position crossing slice
+    boundaries, the new token's row landing in every slice in turn, and the last slice's overflow (splits * chunk <
+    200) — against the fp32 oracle at the decode tolerance; then graph replays (the arrival counters must come back to
+    zero by themselves) with identical greedy tokens."""
+    eng, oracle, cfg = _tiny(128, False, "fp16", seed=5, max_ctx=256, head_dim=128, attn_splits=splits, hidden=hidden,
+                             attn_grouped=True)
+    eng.set_attn_chunk(chunk)
+    rng = np.random.default_rng(8)
+    toks = rng.integers(0, cfg["vocab"], 200).tolist()
+    check = {0, 1, chunk - 1, chunk, chunk + 1, 2 * chunk - 1, 2 * chunk, splits * chunk - 1, splits * chunk,
+             splits * chunk + 1, 150, 199}
+    for i, t in enumerate(toks):
+        eng.token.fill_(t)
+        eng.pos.fill_(i)
+        eng.step(greedy=False)
+        ref = oracle.forward_token(t, i)
+        if i in check:
+            got = eng.logits.cpu().numpy()
+            assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-4, i
+    eng.token.fill_(int(ref.argmax()))
+    eng.pos.fill_(200)
+    eng.capture(greedy=True)
+    nxt = int(ref.argmax())
+    for j in range(6):
+        eng.replay(1)
+        ref = oracle.forward_token(nxt, 200 + j)
+        nxt = int(ref.argmax())
+        assert int(eng.token.item()) == nxt
+    assert eng.status() == 0
+
+
+@pytest.mark.parametrize("grouped,hidden,head_dim", [(False, 256, 64), (False, 256, 128), (True, 512, 128)])
+def test_slice_merge_by_last_workgroup_equals_the_combine_launch(grouped, hidden, head_dim, monkeypatch):
+    """The two ways of merging context-slice partials — the last slice workgroup of a head (default) and the separate
+    combine launch (WOQ_ATTN_FOLD=0, the A/B twin) — run the same sums in the same order: logits equal to 1e-6 of the
+    largest over 150 decode steps, greedy tokens identical."""
+    monkeypatch.setenv("WOQ_ATTN_FOLD", "0")
+    e0, _, cfg = _tiny(128, False, "fp16", seed=6, max_ctx=256, head_dim=head_dim, attn_splits=4, hidden=hidden,
+                       attn_grouped=grouped)
+    monkeypatch.delenv("WOQ_ATTN_FOLD")
+    e1, _, _ = _tiny(128, False, "fp16", seed=6, max_ctx=256, head_dim=head_dim, attn_splits=4, hidden=hidden,
+                     attn_grouped=grouped)
+    rng = np.random.default_rng(9)
+    for i, t in enumerate(rng.integers(0, cfg["vocab"], 150).tolist()):
+        outs = []
+        for e in (e0, e1):
+            e.token.fill_(t)
+            e.pos.fill_(i)
+            e.step(greedy=True)
+            outs.append((e.logits.clone(), int(e.token.item())))
+        assert outs[0][1] == outs[1][1], i
+        assert (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-6 * outs[0][0].abs().max().item() + 1e-7, i
+
+
 def test_tp_seam_world_size_one_rccl():
     """The tensor-parallel plumbing on a real device with a one-rank RCCL group: TPDecoder.prefill (native prompt pass
     + all-reduce callback into torch.distributed + vocab all-gather) and TPDecoder.step (host-driven sub-blocks +

@@ -1,0 +1,71 @@
+"""Same-box A/B of the long-context decode attention forms (round 4) on the BASELINE configs[4] shape (Mistral-7B:
+32 q / 8 kv heads, fp8 KV, 8192 cached positions), `layers` layers: per variant the decode time per token after 0.8 s
+of clock conditioning, and the per-layer difference against the first variant.
+  python tools/longctx_ab.py [layers=16] [ctx=8192] [kv=fp8|fp16]
+variants: fixed-chunk slices + in-launch merge (the default) | adaptive slices + in-launch merge | adaptive slices +
+combine launch (round 3's form; WOQ_ATTN_FOLD=0 is read at engine creation) | fixed + combine launch."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from intel_extension_for_transformers_amd import _lib as L  # noqa: E402
+from intel_extension_for_transformers_amd.runtime.engine import WoqDecoderEngine, synth_llama_weights  # noqa: E402
+
+
+def run(layers, ctx, kv, fold, fixed):
+    os.environ["WOQ_ATTN_FOLD"] = "1" if fold else "0"
+    hidden, inter, heads, kvh, hd, vocab = 4096, 14336, 32, 8, 128, 32000
+    eng = WoqDecoderEngine(hidden, inter, heads, kvh, hd, layers, vocab, max_ctx=ctx + 256,
+                           kv_dtype=torch.float8_e4m3fn if kv == "fp8" else torch.float16)
+    synth_llama_weights(eng, hidden, inter, heads, kvh, hd, layers, vocab, group=128, sym=True, scale_dtype="fp16")
+    g = torch.Generator().manual_seed(1)
+    toks = torch.randint(0, vocab, (ctx,), generator=g).cuda()
+    for s0 in range(0, ctx, 2048):
+        eng.prefill(toks[s0:s0 + 2048], start_pos=s0, greedy=True)
+    eng.tune_attn_for(ctx + 128)
+    if not fixed:
+        eng.set_attn_chunk(0)
+        eng.set_attn_splits(max(2, min(64, (ctx + 128) // 256)))
+    eng.capture(greedy=True)
+    tok0, pos0 = eng.token.clone(), eng.pos.clone()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.8:  # clock conditioning
+        eng.token.copy_(tok0)
+        eng.pos.copy_(pos0)
+        eng.replay(64)
+        torch.cuda.synchronize()
+    eng.token.copy_(tok0)
+    eng.pos.copy_(pos0)
+    eng.replay(8)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.replay(64)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 64
+    out = dict(fold=fold, fixed=fixed, splits=L.lib().woq_engine_attn_splits(eng._h),
+               chunk=L.lib().woq_engine_attn_chunk(eng._h), ms_per_token=dt * 1e3, token=int(eng.token.item()),
+               status=eng.status())
+    del eng
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    layers = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    ctx = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+    kv = sys.argv[3] if len(sys.argv) > 3 else "fp8"
+    base = None
+    for fold, fixed in ((True, True), (True, False), (False, False), (False, True), (True, True)):
+        r = run(layers, ctx, kv, fold, fixed)
+        if base is None:
+            base = r["ms_per_token"]
+        r["us_per_layer_vs_first"] = (r["ms_per_token"] - base) * 1e3 / layers
+        print(json.dumps(r), flush=True)
+
+
+if __name__ == "__main__":
+    main()
