@@ -129,11 +129,14 @@ def condition_clocks(run, eng, fence, dist=None, ms=None):
     """Untimed steady-state conditioning BEFORE the warm-up steps. Measured (profiles/r04a_sclk_ramp.txt): an MI355X that
     has been idle sits at ~160 MHz sclk and needs ~0.6 s of continuous load to reach 2.4 GHz (2.19 GHz after 0.25 s), and
     bench.py's GPU phases before the timed region are bursts between host-only legs — a 20-step timed region (23 ms)
-    would sit entirely on the ramp and read 5-8 % low against the steady state a serving process sees; it is also why a
-    profiled run of the same command read faster than an unprofiled one. So: the same captured
-    step is replayed for `ms` milliseconds in chunks that stay inside max_ctx, then the device-side token / position
-    are put back, so the warm-up + timed steps that follow see exactly the contexts they would have seen. The number of
-    conditioning steps is agreed over the process group (every rank replays the same collectives)."""
+    sits entirely on that ramp. For THIS workload it turned out not to matter (same box, profiles/r04b_conditioning_ab.txt:
+    855.1 vs 856.5 tokens/s at 20 steps with sclk 2394 vs <= 2176 MHz behind the region, 837.6 vs 837.1 at 128): the
+    decode step waits on memory and launch boundaries (mclk / fclk do not ramp), not on shader-clock cycles — which also
+    retires the "profiled runs are faster because of clocks" reading of VERDICT r03 2(e). The conditioning stays so
+    that the line states its clock: the same captured step is replayed for `ms` milliseconds in chunks that stay
+    inside max_ctx, then the device-side token / position are put back, so the warm-up + timed steps that follow see
+    exactly the contexts they would have seen. The number of conditioning steps is agreed over the process group (every
+    rank replays the same collectives)."""
     import torch
 
     ms = CONDITION_MS if ms is None else ms
@@ -167,8 +170,9 @@ def condition_clocks(run, eng, fence, dist=None, ms=None):
     eng.pos.copy_(pos0)
     fence()
     LAST_CONDITIONING.update({"untimed_steps": done, "ms": (time.perf_counter() - t0) * 1e3,
-                              "why": "sclk ramps from idle (~160 MHz) to 2.4 GHz over ~0.6 s of load; the timed region "
-                                     "measures the steady state (profiles/r04a_sclk_ramp.txt)"})
+                              "why": "sclk ramps from idle (~160 MHz) to 2.4 GHz over ~0.6 s of load "
+                                     "(profiles/r04a_sclk_ramp.txt); measured effect on this workload: none "
+                                     "(profiles/r04b_conditioning_ab.txt)"})
 
 
 def timed(run, steps, warmup, fence, condition=None):
@@ -431,7 +435,8 @@ def prefill_attention_check(cfg, n_seq, T, seqs=None):
     runs the SAME n_seq x T prompt pass; layer 1's K and V rows at EVERY position (functions of layer 0's attention
     output at every query row) and the last-position logits of the first and last sequence are compared with
     oracle.LlamaOracle.forward_prompt on the engine's own blobs. Two layers because with one the logits would depend
-    on a single query row. Bounds: rows 5e-3 * max|row tensor| (+ half an fp16 ulp), logits 1e-2 * max|logit| + 1e-3."""
+    on a single query row. Bounds: rows 1e-2 * max|row tensor| (+ half an fp16 ulp) over ~8M elements each (a skipped or misplaced tile shows
+    up at 1e-1), logits 1e-2 * max|logit| + 1e-3."""
     import numpy as np
     import torch
 
@@ -446,20 +451,22 @@ def prefill_attention_check(cfg, n_seq, T, seqs=None):
     for seq in (seqs if seqs is not None else sorted({0, n_seq - 1})):
         oracle.reset()
         ref = oracle.forward_prompt(prompts[seq].tolist())
-        rows = 0.0
+        rows, rms = 0.0, 0.0
         for which, rc in (("k", oracle.k[1]), ("v", oracle.v[1])):
             c = eng.kv_cache(which)[seq, 1, :T].float().cpu().numpy()
             err = np.abs(c - rc)
             scale = float(np.abs(rc).max())
-            if (err > 5e-3 * scale + 2.0 ** -11 * np.abs(rc)).any():
-                p, hd, d = (int(v) for v in np.argwhere(err > 5e-3 * scale + 2.0 ** -11 * np.abs(rc))[0])
+            if (err > 1e-2 * scale + 2.0 ** -11 * np.abs(rc)).any():
+                p, hd, d = (int(v) for v in np.argwhere(err > 1e-2 * scale + 2.0 ** -11 * np.abs(rc))[0])
                 raise RuntimeError("prefill attention parity FAILED: layer-1 %s row of sequence %d, position %d, head %d, "
                                    "d %d: %.3e of the tensor's maximum" % (which, seq, p, hd, d, float(err.max()) / scale))
             rows = max(rows, float(err.max()) / scale)
+            rms = max(rms, float(np.sqrt((err.astype(np.float64) ** 2).mean())) / scale)
         lerr = float(np.abs(got[seq] - ref).max()) / float(np.abs(ref).max())
         if lerr > 1e-2 or int(got[seq].argmax()) != int(ref.argmax()):
             raise RuntimeError("prefill attention parity FAILED: logits of sequence %d off by %.3e of the largest" % (seq, lerr))
-        res["sequence_%d" % seq] = {"layer1_kv_rows_worst_over_max": rows, "logits_max_abs_over_max_logit": lerr}
+        res["sequence_%d" % seq] = {"layer1_kv_rows_worst_over_max": rows, "layer1_kv_rows_rms_over_max": rms,
+                                    "logits_max_abs_over_max_logit": lerr}
     del eng
     free_gpu()
     return {
@@ -469,7 +476,7 @@ def prefill_attention_check(cfg, n_seq, T, seqs=None):
                    % (cfg["hidden"], cfg["heads"], cfg["kv_heads"], cfg["head_dim"], n_seq, T, T, cfg["kv_heads"],
                       sorted(int(k.split("_")[1]) for k in res)),
         "per_sequence": res, "greedy_tokens_equal": True,
-        "tol": "rows 5e-3 * max + fp16 half-ulp; logits 1e-2 * max|logit| (fp16-operand GEMMs, fp16 q/k/v between kernels)",
+        "tol": "rows 1e-2 * max + fp16 half-ulp; logits 1e-2 * max|logit| (fp16-operand GEMMs, fp16 q/k/v between kernels)",
         "seconds": time.perf_counter() - t0,
     }
 

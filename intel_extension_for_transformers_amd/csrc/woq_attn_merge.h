@@ -42,7 +42,7 @@ __device__ __forceinline__ float ld_agent(const float* p) {
 // Called by ALL 256 threads of a slice workgroup after its partials of heads [h0, h0 + nh) (slice `sp` of `ns`) went out
 // through st_agent. `lds`: at least 3 * nh * ns + 256 + 8 floats of workgroup LDS nobody else is using any more.
 // nh <= 8, ns <= 64, HD in {64, 128}.
-template <int HD>
+template <int HD, int HB>  // HB = heads whose partial rows are in flight together (HB * 64 * HD / 256 registers per thread)
 __device__ __forceinline__ void attn_slices_merge(float* part, int heads, int h0, int nh, int ns, unsigned int* counter,
                                                   const AttnMerge& mg, float* lds) {
   const int tid = threadIdx.x;
@@ -61,58 +61,68 @@ __device__ __forceinline__ void attn_slices_merge(float* part, int heads, int h0
   float* ms = lds;                // [nh][ns] slice maxima
   float* wl = ms + nh * ns;       // [nh][ns] slice sums -> weighted sums
   float* wsc = wl + nh * ns;      // [nh][ns] weights e^(m_s - m)
-  float* hl = wsc + nh * ns;      // [nh] 1 / sum
+  float* hl = wsc + nh * ns;      // [nh] sum of the weighted sums
   float* red = hl + 8;            // [256]
   constexpr int GROUPS = 256 / HD;  // thread groups that walk alternate slices
+  constexpr int PER = ATTN_MAX_SLICES / GROUPS;  // partial rows one thread may have to fetch per head
   const int d = tid % HD, grp = tid / HD;
+  // ONE round trip: the maxima / sums and the first batch of partial rows are all requested before anything is
+  // waited for (a first version walked head by head and slice group by slice group: ten dependent trips to memory,
+  // 8.7 us on the launch's tail against 5.2 us for a whole combine launch — profiles/r04b_longctx_ab.txt)
   for (int i = tid; i < nh * ns; i += 256) {
     const int hh = i / ns, s = i - hh * ns;
     const float* p = attn_part_ml(part, heads, h0 + hh, s, HD);
     ms[i] = ld_agent(p);
     wl[i] = ld_agent(p + 1);
   }
-  __syncthreads();
-  for (int i = tid; i < nh * ns; i += 256) {
-    const int hh = i / ns;
-    float m = -INFINITY;
-    for (int s = 0; s < ns; ++s) m = fmaxf(m, ms[hh * ns + s]);
-    const float w = ms[i] == -INFINITY ? 0.f : __expf(ms[i] - m);
-    wsc[i] = w;
-    wl[i] *= w;  // own element only
-  }
-  __syncthreads();
-  if (tid < nh) {
-    float l = 0.f;
-    for (int s = 0; s < ns; ++s) l += wl[tid * ns + s];
-    hl[tid] = 1.0f / l;
-  }
-  for (int hh = 0; hh < nh; ++hh) {
-    float o = 0.f;
-    constexpr int UNR = 8;
-    for (int s0 = grp; s0 < ns; s0 += GROUPS * UNR) {
-      float v[UNR];
+  for (int hb = 0; hb < nh; hb += HB) {
+    float v[HB][PER];
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int s = s0 + u * GROUPS;
-        v[u] = s < ns ? ld_agent(attn_part_o(part, h0 + hh, s, HD) + d) : 0.f;
+    for (int j = 0; j < HB; ++j)
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int s = grp + u * GROUPS;
+        v[j][u] = (hb + j < nh && s < ns) ? ld_agent(attn_part_o(part, h0 + hb + j, s, HD) + d) : 0.f;
       }
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int s = s0 + u * GROUPS;
-        if (s < ns) o = fmaf(v[u], wsc[hh * ns + s], o);
+    if (hb == 0) {  // weights of every head of the group (LDS only; the partial rows above are still in flight)
+      __syncthreads();
+      for (int i = tid; i < nh * ns; i += 256) {
+        const int hh = i / ns;
+        float m = -INFINITY;
+        for (int s = 0; s < ns; ++s) m = fmaxf(m, ms[hh * ns + s]);
+        const float w = ms[i] == -INFINITY ? 0.f : __expf(ms[i] - m);
+        wsc[i] = w;
+        wl[i] *= w;  // own element only
+      }
+      __syncthreads();
+      if (tid < nh) {
+        float l = 0.f;
+        for (int s = 0; s < ns; ++s) l += wl[tid * ns + s];
+        hl[tid] = l;
       }
     }
-    __syncthreads();  // red (and hl on the first round) are settled / free again
-    red[tid] = o;
-    __syncthreads();
-    if (grp == 0) {
-      float t = 0.f;
 #pragma unroll
-      for (int g2 = 0; g2 < GROUPS; ++g2) t += red[g2 * HD + d];
-      const float r = t * hl[hh];
-      const int idx = (h0 + hh) * HD + d;
-      mg.out[idx] = r;
-      if (mg.xo.limbs != nullptr) xq_emit16(r, mg.xo, idx >> 4, d & 15);
+    for (int j = 0; j < HB; ++j) {
+      if (hb + j >= nh) break;  // (uniform)
+      const int hh = hb + j;
+      float o = 0.f;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int s = grp + u * GROUPS;
+        if (s < ns) o = fmaf(v[j][u], wsc[hh * ns + s], o);  // ascending s: the combine launch's order
+      }
+      __syncthreads();  // red is free again (and hl / wsc are settled on the first pass)
+      red[tid] = o;
+      __syncthreads();
+      if (grp == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < GROUPS; ++g2) t += red[g2 * HD + d];
+        const float r = t / hl[hh];
+        const int idx = (h0 + hh) * HD + d;
+        mg.out[idx] = r;
+        if (mg.xo.limbs != nullptr) xq_emit16(r, mg.xo, idx >> 4, d & 15);
+      }
     }
   }
 }

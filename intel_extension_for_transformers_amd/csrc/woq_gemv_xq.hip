@@ -81,6 +81,13 @@ static bool xq_geometry(int tiles_k, int cb, int smode, int& nw, int& tpw) {
   }();
   tpw = (tiles_k > 16 && cb == 1) ? 8 : 4;
   if (forced == 4 || (forced == 8 && !(cb == 2 && smode == 1))) tpw = forced;
+  // WOQ_XQ_TPW_SHORT=4|8: single column tiles with K <= 4096 only (o_proj and the stand-alone qkv of Llama-2-7B) —
+  // one workgroup per CU there, so more, shorter waves are the other way to hide latency (A/B runs)
+  static const int forced_short = [] {
+    const char* s = getenv("WOQ_XQ_TPW_SHORT");
+    return s ? atoi(s) : 0;
+  }();
+  if (cb == 1 && tiles_k <= 32 && (forced_short == 4 || forced_short == 8)) tpw = forced_short;
   nw = (tiles_k + tpw - 1) / tpw;
   return nw >= 1 && nw <= (cb * tpw > 8 ? 8 : 16);  // the kernel's __launch_bounds__
 }

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
   attn_decode_body<KV, HD, SPLIT>(sm, h, (int)blockIdx.y, (int)gridDim.y, AttnPlain{qkv}, kcache, vcache, pos_p, cs,
                                   sn, heads, kv_heads, window, spw, out, xo);
   if constexpr (SPLIT) {  // `out` = the partial buffer; the head's last slice workgroup merges (woq_attn_merge.h)
-    if (mg.counter != nullptr) attn_slices_merge<HD>(out, heads, h, 1, (int)gridDim.y, mg.counter + h, mg, sm);
+    if (mg.counter != nullptr) attn_slices_merge<HD, 1>(out, heads, h, 1, (int)gridDim.y, mg.counter + h, mg, sm);
   }
 }
 

@@ -380,6 +380,44 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const _Float16* __
 // The new token's k / v are applied from LDS by wave 0 of the last slice (rounded to the cache dtype like the rows a
 // later step reads back) and appended there. Output: un-normalised partials (o[HD], max, sum) per (head, slice) in the
 // natural-exp convention attn_combine_kernel merges.
+// One register set of the kernel below: a 32-position sub-tile's K fragments (lane: rows a * 16 + i16, 32 contiguous d)
+// and V rows (lane: rows 4 v_g + r, 16 contiguous d). fp16 caches hold them as loaded; an fp8 cache keeps the RAW bytes —
+// half the registers, 16-byte requests instead of 8-byte ones — and converts a fragment right where it enters an
+// MFMA / the LDS transpose (round 4: 272 -> under 256 registers puts two workgroups on a CU instead of one).
+template <int KVD>
+struct DecRegs {
+  h8 kf[2][4], vr[4][2];
+  __device__ __forceinline__ void load_k(int a, const void* kc, size_t row) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) kf[a][c] = kv_load8<KVD>(kc, row + c * 8);
+  }
+  __device__ __forceinline__ void load_v(int r, const void* vc, size_t row) {
+    vr[r][0] = kv_load8<KVD>(vc, row);
+    vr[r][1] = kv_load8<KVD>(vc, row + 8);
+  }
+  __device__ __forceinline__ h8 k(int a, int c) const { return kf[a][c]; }
+  __device__ __forceinline__ h8 v(int r, int hh) const { return vr[r][hh]; }
+};
+template <>
+struct DecRegs<WOQ_FP8_E4M3> {
+  u32x4 kf[2][2], vr[4];
+  __device__ __forceinline__ void load_k(int a, const void* kc, size_t row) {
+    kf[a][0] = *(const u32x4*)((const uint8_t*)kc + row);
+    kf[a][1] = *(const u32x4*)((const uint8_t*)kc + row + 16);
+  }
+  __device__ __forceinline__ void load_v(int r, const void* vc, size_t row) {
+    vr[r] = *(const u32x4*)((const uint8_t*)vc + row);
+  }
+  __device__ __forceinline__ h8 k(int a, int c) const {
+    const u32x4& w = kf[a][c >> 1];
+    return fp8x8_to_h8((c & 1) ? (u32x2){w.z, w.w} : (u32x2){w.x, w.y});
+  }
+  __device__ __forceinline__ h8 v(int r, int hh) const {
+    const u32x4& w = vr[r];
+    return fp8x8_to_h8(hh ? (u32x2){w.z, w.w} : (u32x2){w.x, w.y});
+  }
+};
+
 constexpr int DST = 32;   // positions per sub-tile
 constexpr int DVRB = 80;  // bytes per V^T row: 32 positions x 2 B + 16 pad
 template <int HD, int REP>
@@ -419,26 +457,20 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const float* __re
   int last = fixed ? max(0, min(chunk_fixed, max_rows - sp * chunk_fixed) - 1) : 0;
   // two register sets: a wave's first two sub-tiles are requested back to back, then set X is refilled for
   // sub-tile n + 8 as soon as sub-tile n has left it (one exposed load latency per wave, not one per sub-tile)
-  h8 kfA[2][DC], vrA[4][2], kfB[2][DC], vrB[4][2];
-  auto fetch = [&](h8 (&kf)[2][DC], h8 (&vr)[4][2], int sub) {
+  DecRegs<KVD> setA, setB;
+  auto fetch = [&](DecRegs<KVD>& rs, int sub) {
     const int t0 = sub * DST;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const size_t row = cache0 + (size_t)min(t0 + a * 16 + i16, last) * cache_row + kq * 32;
+    for (int a = 0; a < 2; ++a)
+      rs.load_k(a, kcache, cache0 + (size_t)min(t0 + a * 16 + i16, last) * cache_row + kq * 32);
 #pragma unroll
-      for (int c = 0; c < DC; ++c) kf[a][c] = kv_load8<KVD>(kcache, row + c * 8);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const size_t row = cache0 + (size_t)min(t0 + v_g * 4 + r, last) * cache_row + v_c * 16;
-      vr[r][0] = kv_load8<KVD>(vcache, row);
-      vr[r][1] = kv_load8<KVD>(vcache, row + 8);
-    }
+    for (int r = 0; r < 4; ++r)
+      rs.load_v(r, vcache, cache0 + (size_t)min(t0 + v_g * 4 + r, last) * cache_row + v_c * 16);
   };
   const bool early = fixed && sp * chunk_fixed < max_rows;
   if (early) {
-    if (wid * DST <= last) fetch(kfA, vrA, wid);
-    if ((wid + 4) * DST <= last) fetch(kfB, vrB, wid + 4);
+    if (wid * DST <= last) fetch(setA, wid);
+    if ((wid + 4) * DST <= last) fetch(setB, wid + 4);
   }
   const int apos = pos_p[0];
   const int w_lo = window > 0 ? max(0, apos + 1 - window) : 0;
@@ -463,8 +495,8 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const float* __re
 
   // what the early requests did not cover: everything in the adaptive geometry; in the fixed one the sub-tiles past
   // the slice's own chunk (short chunks, or the last slice's overflow)
-  if (wid < n_sub && !(early && wid * DST <= last_early)) fetch(kfA, vrA, wid);
-  if (wid + 4 < n_sub && !(early && (wid + 4) * DST <= last_early)) fetch(kfB, vrB, wid + 4);
+  if (wid < n_sub && !(early && wid * DST <= last_early)) fetch(setA, wid);
+  if (wid + 4 < n_sub && !(early && (wid + 4) * DST <= last_early)) fetch(setB, wid + 4);
 
   // prologue through LDS: threads 0..15 build the new k / v of this kv head (rotated, rounded through the cache dtype
   // like the rows a later step reads back; the last slice appends them), everyone rotates the REP query heads
@@ -526,29 +558,32 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const float* __re
   for (int dt = 0; dt < DT; ++dt) o[dt] = (float4_t){0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_part = 0.f;
 
-  auto process = [&](h8 (&kf)[2][DC], h8 (&vr)[4][2], int sub) {
+  auto process = [&](DecRegs<KVD>& rs, int sub) {
     // this sub-tile: V^T into LDS, K fragments into the score MFMAs; then the refill of the register set
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
+    for (int hh = 0; hh < 2; ++hh) {
+      const h8 v0 = rs.v(0, hh), v1 = rs.v(1, hh), v2 = rs.v(2, hh), v3 = rs.v(3, hh);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int d = v_c * 16 + hh * 8 + i;
-        const h4 col = {vr[0][hh][i], vr[1][hh][i], vr[2][hh][i], vr[3][hh][i]};
+        const h4 col = {v0[i], v1[i], v2[i], v3[i]};
         *(h4*)(vw + d * DVRB + ((v_g ^ v_c) << 3)) = col;
       }
+    }
     float4_t s[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       s[a] = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < DC; ++c) {
-        s[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[a][c], ql[c], s[a], 0, 0, 0);
-        s[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[a][c], qh[c], s[a], 0, 0, 0);
+        const h8 kf = rs.k(a, c);
+        s[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, ql[c], s[a], 0, 0, 0);
+        s[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qh[c], s[a], 0, 0, 0);
       }
     }
     const int t0 = sub * DST;
     __builtin_amdgcn_sched_barrier(0);  // the loads below reuse the registers the stores / MFMAs above just released
-    if (sub + 8 < n_sub) fetch(kf, vr, sub + 8);
+    if (sub + 8 < n_sub) fetch(rs, sub + 8);
     float mx = -INFINITY;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -585,8 +620,8 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const float* __re
     __builtin_amdgcn_wave_barrier();
   };
   for (int sub = wid; sub < n_sub; sub += 8) {
-    process(kfA, vrA, sub);
-    if (sub + 4 < n_sub) process(kfB, vrB, sub + 4);
+    process(setA, sub);
+    if (sub + 4 < n_sub) process(setB, sub + 4);
   }
   if (wid == 0 && incl_new) {  // the new position: score from the fragments, value row from LDS
     float d = 0.f;
@@ -646,7 +681,7 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const float* __re
     }
   }
   // the last slice workgroup of this kv head to get here merges the group's REP heads and emits the attention output
-  if (mg.counter != nullptr) attn_slices_merge<HD>(part, heads, kh * REP, REP, ns, mg.counter + kh, mg, (float*)dsm_raw);
+  if (mg.counter != nullptr) attn_slices_merge<HD, (REP < 4 ? REP : 4)>(part, heads, kh * REP, REP, ns, mg.counter + kh, mg, (float*)dsm_raw);
 }
 
 // last row of every sequence -> dst fp32 [n_seq][hidden]

@@ -306,7 +306,10 @@ class WoqDecoderEngine:
         grouped-query shapes take 256-position slices of the matrix-core form."""
         grouped = positions >= self.GROUPED_CTX and self._grouped_applies()
         self.set_attn_grouped(grouped)
-        fixed = grouped and not self.cfg.reserved[2]  # a sliding window moves the slices with the position
+        # position-independent slices: not with a sliding window (the slices move with the position), and only for
+        # the fp8 cache, whose kernel keeps raw bytes in registers and fits two workgroups on a CU — the fp16 form
+        # holds one (272 registers), and ceil(positions / 256) x kv_heads workgroups would then run a second round
+        fixed = grouped and not self.cfg.reserved[2] and self.cfg.kv_dtype == L.FP8_E4M3
         self.set_attn_chunk(self.GROUPED_CHUNK if fixed else 0)
         if positions <= self.LONG_CTX:
             self.set_attn_splits(1)
