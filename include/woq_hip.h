@@ -212,16 +212,6 @@ WOQ_API int woq_engine_attn_chunk(woq_engine* e);
  * woq_engine_fuse_attn: 1 when the next step / capture will use it. */
 WOQ_API int woq_engine_set_fuse_attn(woq_engine* e, int on);
 WOQ_API int woq_engine_fuse_attn(woq_engine* e);
-/* decode step, XQ path: the layer as TWO launches whose workgroups are chained inside the launch — [qkv strips | attention
- * | o_proj strips] and [gate/up pairs | down_proj strips]; later roles request their weights first and wait (bounded)
- * for the blocks of their input that earlier roles publish (csrc/woq_gemv_chain.hip). Applies where the fused qkv +
- * attention launch does, with fp16 / bf16 scales; separate launches otherwise. Default OFF: correct (tests) but measured
- * slower than the separate launches on MI355X (launch 1 about even, launch 2 +6 us per layer: a CU cannot hold enough
- * waiting waves with a deep enough register window next to the running role — profiles/r03y_chained_layer_negative.txt);
- * WOQ_ENGINE_CHAIN=1 (both) / 2 (launch 1) / 3 (launch 2) or woq_engine_set_chain turn it on; it also needs fuse_attn.
- * Same capture rule as attn_splits. woq_engine_chain: 1 when the next step / capture will use it. */
-WOQ_API int woq_engine_set_chain(woq_engine* e, int on);
-WOQ_API int woq_engine_chain(woq_engine* e);
 /* decode step, XQ path: ALL layers of the step as one persistent launch (csrc/woq_persist.hip): one workgroup per CU,
  * a loader wave streaming the token's weights HBM -> LDS ring without stopping at operator boundaries, eleven consumer
  * waves doing the arithmetic, activation vectors handed between workgroups as tagged 8-byte granules (bounded waits,

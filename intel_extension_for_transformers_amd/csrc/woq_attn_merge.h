@@ -66,24 +66,33 @@ __device__ __forceinline__ void attn_slices_merge(float* part, int heads, int h0
   constexpr int GROUPS = 256 / HD;  // thread groups that walk alternate slices
   constexpr int PER = ATTN_MAX_SLICES / GROUPS;  // partial rows one thread may have to fetch per head
   const int d = tid % HD, grp = tid / HD;
-  // ONE round trip: the maxima / sums and the first batch of partial rows are all requested before anything is
-  // waited for (a first version walked head by head and slice group by slice group: ten dependent trips to memory,
-  // 8.7 us on the launch's tail against 5.2 us for a whole combine launch — profiles/r04b_longctx_ab.txt)
-  for (int i = tid; i < nh * ns; i += 256) {
+  // ONE round trip: the maxima / sums and the first batch of partial rows are all requested — branch-free, into
+  // registers — before anything is waited for. (First version: head by head and slice group by slice group, ten
+  // dependent trips to memory, 8.7 us on the launch's tail against 5.2 us for a whole combine launch; second version:
+  // predicated loads behind a load -> LDS-store loop, still ~10 us — profiles/r04b_longctx_ab.txt, r04c_*.) Rows past
+  // ns are fetched from row ns - 1 and weighted 0.
+  float m_r[2], l_r[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = min(tid + 256 * j, nh * ns - 1);
     const int hh = i / ns, s = i - hh * ns;
     const float* p = attn_part_ml(part, heads, h0 + hh, s, HD);
-    ms[i] = ld_agent(p);
-    wl[i] = ld_agent(p + 1);
+    m_r[j] = ld_agent(p);
+    l_r[j] = ld_agent(p + 1);
   }
   for (int hb = 0; hb < nh; hb += HB) {
     float v[HB][PER];
 #pragma unroll
-    for (int j = 0; j < HB; ++j)
+    for (int j = 0; j < HB; ++j) {
+      const float* row0 = attn_part_o(part, h0 + min(hb + j, nh - 1), 0, HD) + d;
 #pragma unroll
-      for (int u = 0; u < PER; ++u) {
-        const int s = grp + u * GROUPS;
-        v[j][u] = (hb + j < nh && s < ns) ? ld_agent(attn_part_o(part, h0 + hb + j, s, HD) + d) : 0.f;
-      }
+      for (int u = 0; u < PER; ++u) v[j][u] = ld_agent(row0 + (size_t)min(grp + u * GROUPS, ns - 1) * HD);
+    }
+    if (hb == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (tid + 256 * j < nh * ns) ms[tid + 256 * j] = m_r[j], wl[tid + 256 * j] = l_r[j];
+    }
     if (hb == 0) {  // weights of every head of the group (LDS only; the partial rows above are still in flight)
       __syncthreads();
       for (int i = tid; i < nh * ns; i += 256) {

@@ -44,21 +44,6 @@ int launch_gemv_xq_attn(const XqPtrs& xin, const void* blob, const woq_blob_head
                         const float* ssq_in, float eps, const unsigned int* seq, int layer, int* status, void* kcache,
                         void* vcache, int kv_dtype, const int32_t* pos, const float* cs, const float* sn, int heads,
                         int kv_heads, int max_ctx, int window, float* attn_out, const XqPtrs& xq_attn, hipStream_t st);
-// the decode layer as two chained launches (woq_gemv_chain.hip)
-bool chain_layer_supported(const woq_blob_header& hq, const woq_blob_header& ho, const woq_blob_header& hg,
-                           const woq_blob_header& hd, int heads, int kv_heads, int head_dim, int kv_dtype, int max_ctx,
-                           int window, int splits);
-bool chain_mlp_supported(const woq_blob_header& hg, const woq_blob_header& hd);
-int launch_chain_attn(const XqPtrs& xq_hidden, const float* ssq_in, float eps, const void* qkv_blob,
-                      const woq_blob_header& hq, const void* o_blob, const woq_blob_header& ho, const unsigned int* seq,
-                      int layer, int* status, unsigned long long* qkv_g, void* kcache, void* vcache, int kv_dtype,
-                      const int32_t* pos, const float* cs, const float* sn, int heads, int kv_heads, int max_ctx,
-                      int window, float* attn_out, const XqPtrs& xq_attn, unsigned int* flag_attn, float* hidden,
-                      const float* ln2, float* ssq_out, hipStream_t st);
-int launch_chain_mlp(const XqPtrs& xq_hidden, const float* ssq_in, float eps, const void* gu_blob,
-                     const woq_blob_header& hg, const void* down_blob, const woq_blob_header& hd,
-                     const unsigned int* seq, int layer, int* status, const XqPtrs& xq_act, unsigned int* flag_act,
-                     float* hidden, const XqPtrs& xq_next, const float* ln_next, float* ssq_out, hipStream_t st);
 int launch_gemv_twin(const void* blob, const woq_blob_header& h, int epi, int mode, unsigned int* sink, hipStream_t st);
 void launch_lm_head(const float* hidden_in, const float* norm_w, float eps, const void* W, int w_dtype, int hidden,
                     int vocab, float* logits, float* pmax, int32_t* pidx, hipStream_t st);
@@ -127,13 +112,7 @@ struct woq_engine {
   unsigned int* step_seq = nullptr;
   int* fuse_status = nullptr;
   bool fuse_attn = true;             // qkv GEMV + attention in one launch where the shape allows (woq_gemv_attn.hip)
-  // the layer as two chained launches (woq_gemv_chain.hip): flags of the two vectors handed over inside a launch
-  bool chain = false;  // measured slower than the separate launches (profiles/r03y): opt-in, kept for the record
-  int chain_parts = 3;  // bit 0: launch 1 chained, bit 1: launch 2 chained (WOQ_ENGINE_CHAIN=2 / 3 pick one: A/B runs)
-  unsigned int* flag_attn = nullptr;  // [heads * head_dim / 16]
-  unsigned int* flag_act = nullptr;   // [inter / 16]
-  bool chain_ok(int l) const;
-  // in-launch hand-off tags are (step counter << 6) | layer (woq_gemv_attn.hip, the chained and persistent launches):
+  // in-launch hand-off tags are (step counter << 6) | layer (woq_gemv_attn.hip, the persistent launch):
   // beyond 64 layers the layer bits would run into the counter and a stale granule could pass for a fresh one, so
   // deeper models keep the separate launches
   bool tags_ok() const { return cfg.layers <= 64; }
@@ -181,15 +160,6 @@ using namespace woq;
 
 const woq::CommDev* woq_engine::tp_push() const {
   return cfg.tp_size > 1 && comm != nullptr && tp_fused_push ? woq_comm_dev_ptr(comm) : nullptr;
-}
-
-bool woq_engine::chain_ok(int l) const {
-  const woq_engine_config& c = cfg;
-  const woq_layer_weights& w = layers[l];
-  return chain && fuse_attn && use_xq() && c.tp_size <= 1 && qkv_g != nullptr && flag_attn != nullptr &&
-         !attn_grouped && tags_ok() &&
-         woq::chain_layer_supported(w.qkv_hdr, w.o_hdr, w.gate_up_hdr, w.down_hdr, c.heads, c.kv_heads, c.head_dim,
-                                    c.kv_dtype, c.max_ctx, window, attn_splits);
 }
 
 woq::Persist* woq_engine::persist_get() {
@@ -291,27 +261,6 @@ static int engine_mlp_block_xq(woq_engine* e, int l, hipStream_t st) {
                                 last ? nullptr : e->layers[l + 1].ln1, last ? nullptr : e->ssq_part, st);
 }
 
-// the layer as two chained launches (woq_gemv_chain.hip)
-static int engine_layer_chained(woq_engine* e, int l, hipStream_t st) {
-  const woq_engine_config& c = e->cfg;
-  const woq_layer_weights& w = e->layers[l];
-  int rc;
-  if (e->chain_parts & 1)
-    rc = launch_chain_attn(e->xq_hidden, e->ssq_part, c.rms_eps, w.qkv_blob, w.qkv_hdr, w.o_blob, w.o_hdr, e->step_seq,
-                           l, e->fuse_status, e->qkv_g, e->kcache + (size_t)l * e->kv_layer_bytes,
-                           e->vcache + (size_t)l * e->kv_layer_bytes, c.kv_dtype, e->pos, e->cs, e->sn, c.heads,
-                           c.kv_heads, c.max_ctx, e->window, e->attn, e->xq_attn, e->flag_attn, e->hidden, w.ln2,
-                           e->ssq_part, st);
-  else
-    rc = engine_attn_block_xq(e, l, st);
-  if (rc) return rc;
-  if (!(e->chain_parts & 2) || !chain_mlp_supported(w.gate_up_hdr, w.down_hdr)) return engine_mlp_block_xq(e, l, st);
-  const bool last = l + 1 == c.layers;  // the last layer's output feeds the head, which reads fp32
-  return launch_chain_mlp(e->xq_hidden, e->ssq_part, c.rms_eps, w.gate_up_blob, w.gate_up_hdr, w.down_blob, w.down_hdr,
-                          e->step_seq, l, e->fuse_status, e->xq_act, e->flag_act, e->hidden, last ? kNoXq : e->xq_hidden,
-                          last ? nullptr : e->layers[l + 1].ln1, last ? nullptr : e->ssq_part, st);
-}
-
 static int engine_attn_block(woq_engine* e, int l, hipStream_t st) {
   if (e->use_xq()) return engine_attn_block_xq(e, l, st);
   const woq_engine_config& c = e->cfg;
@@ -410,12 +359,7 @@ static int engine_step_impl(woq_engine* e, int greedy, hipStream_t st) {
     return engine_head(e, greedy, st);
   }
   for (int l = 0; l < c.layers; ++l) {
-    int rc;
-    if (engine_skip_mask() == 0 && e->chain_ok(l)) {
-      if ((rc = engine_layer_chained(e, l, st)) != 0) return rc;
-      continue;
-    }
-    rc = engine_attn_block(e, l, st);
+    int rc = engine_attn_block(e, l, st);
     if (rc) return rc;
     if ((rc = engine_allreduce_after(e, l, 0, st)) != 0) return rc;
     rc = engine_mlp_block(e, l, st);
@@ -572,13 +516,6 @@ int woq_engine_set_attn_chunk(woq_engine* e, int chunk) {
   WOQ_END
 }
 int woq_engine_attn_chunk(woq_engine* e) { return e ? e->attn_chunk : 0; }
-int woq_engine_set_chain(woq_engine* e, int on) {
-  WOQ_TRY
-  WOQ_CHECK(e != nullptr, "QBits: null engine");
-  e->chain = on != 0;
-  WOQ_END
-}
-int woq_engine_chain(woq_engine* e) { return e && !e->layers.empty() && e->chain_ok(0) ? 1 : 0; }
 int woq_engine_set_persist(woq_engine* e, int on) {
   WOQ_TRY
   WOQ_CHECK(e != nullptr, "QBits: null engine");
@@ -702,9 +639,6 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
     e->xq_enabled = sw ? sw[0] != '0' : true;
     const char* fa = getenv("WOQ_ENGINE_FUSE_ATTN");
     e->fuse_attn = fa ? fa[0] != '0' : true;
-    const char* ch = getenv("WOQ_ENGINE_CHAIN");
-    e->chain = ch ? ch[0] != '0' : false;
-    e->chain_parts = ch && ch[0] == '2' ? 1 : (ch && ch[0] == '3' ? 2 : 3);
     const char* pe = getenv("WOQ_ENGINE_PERSIST");
     e->persist_on = pe ? pe[0] != '0' : false;
     const char* tx = getenv("WOQ_TP_XQ");
@@ -720,11 +654,6 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
       WOQ_HIP(hipMalloc((void**)&e->ssq_part, (size_t)(cfg->hidden / 16) * 4));
       WOQ_HIP(hipMalloc((void**)&e->qkv_g, (size_t)qkv_n * 8));
       WOQ_HIP(hipMemset(e->qkv_g, 0, (size_t)qkv_n * 8));  // tag 0 is never a live tag
-      const size_t nfl = (size_t)(attn_k / 16) + (size_t)(cfg->inter / 16);
-      WOQ_HIP(hipMalloc((void**)&e->flag_attn, nfl * 4));
-      WOQ_HIP(hipMemset(e->flag_attn, 0, nfl * 4));
-      e->flag_act = e->flag_attn + attn_k / 16;
-      e->owned.push_back(e->flag_attn);
       WOQ_HIP(hipMemset(bh, 0, xq_bytes(cfg->hidden)));
       WOQ_HIP(hipMemset(ba, 0, xq_bytes(attn_k)));
       WOQ_HIP(hipMemset(bc, 0, xq_bytes(cfg->inter)));

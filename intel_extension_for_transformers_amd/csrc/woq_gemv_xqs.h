@@ -99,7 +99,7 @@ __device__ __forceinline__ float digit_combine(const i32x4& d) {
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// In-launch chaining (woq_gemv_chain.hip): the input vector may still be in the making by workgroups of the SAME launch
+// In-launch chaining (round 3; its one user left the library: tools/rejected/woq_gemv_chain.hip): the input vector may still be in the making by workgroups of the SAME launch
 // (CHAIN_IN: every wave polls the flags of its K slice's blocks, bounded, and reads the blocks with agent-scope loads),
 // and the output vector may have a consumer there (out.flag != null: published block by block, woq_xq.h XqPub).
 struct XqsChain {

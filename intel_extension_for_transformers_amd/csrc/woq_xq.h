@@ -65,7 +65,7 @@ __device__ __forceinline__ int row16_sum_i32(int v) {
   return v + WOQ_DPP_I32(v, 0x140);
 }
 
-// In-launch hand-off of an XQ vector (round 3, the chained launches of woq_gemv_chain.hip): a consumer workgroup of the
+// In-launch hand-off of an XQ vector (round 3, the chained launches — tools/rejected/woq_gemv_chain.hip — and the persistent launch): a consumer workgroup of the
 // SAME launch may be waiting for block `blk`. The producer then stores the block write-through (agent-scope stores
 // never stay in this XCD's L2 alone), drains them, and only then stores the block's flag word = the (step, vector) tag;
 // the consumer polls the flags of its K slice and reads the blocks with agent-scope loads afterwards

@@ -233,16 +233,6 @@ class WoqDecoderEngine:
             L.check(L.lib().woq_engine_set_attn_chunk(self._h, int(chunk)))
             self.captured = False
 
-    def set_chain(self, on):
-        """Decode step: each layer as two chained launches where the shape allows (csrc/woq_gemv_chain.hip; default on).
-        Invalidates a captured graph."""
-        L.check(L.lib().woq_engine_set_chain(self._h, int(bool(on))))
-        self.captured = False
-
-    def uses_chain(self):
-        """True when the next step / capture runs the chained layer launches."""
-        return bool(L.lib().woq_engine_chain(self._h))
-
     def set_persist(self, on):
         """Decode step: all layers as ONE persistent launch (csrc/woq_persist.hip) where the model fits its scope.
         Invalidates a captured graph."""

@@ -286,7 +286,8 @@ def test_fp8_weight_dtype_config_on_the_hip_path():
 def test_plain_c_client_of_the_abi(tmp_path):
     """include/woq_blob.h + include/woq_hip.h are valid C99 (what a cgo / JNI / FFI binding would include), and a
     plain-C program links against libwoq_hip.so and agrees with the library on the blob geometry of every weight
-    type (examples/c_client.c: host arithmetic only, no GPU call)."""
+    type (examples/c_client.c, host part; its device part — quantise, dequantise, woq_linear through the C ABI alone — runs in
+    tests/test_gpu_api.py::test_plain_c_client_device_leg)."""
     import os
     import shutil
     import subprocess
@@ -299,8 +300,8 @@ def test_plain_c_client_of_the_abi(tmp_path):
     libdir = os.path.dirname(_lib.LIB_PATH)
     exe = str(tmp_path / "c_client")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
-                    os.path.join(root, "examples", "c_client.c"), "-L" + libdir, "-lwoq_hip",
-                    "-Wl,-rpath," + libdir, "-o", exe], check=True)
+                    os.path.join(root, "examples", "c_client.c"), "-L" + libdir, "-lwoq_hip", "-L/opt/rocm/lib",
+                    "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert "host checks ok" in out
     first = out.splitlines()[0].split()

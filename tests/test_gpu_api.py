@@ -686,3 +686,27 @@ def test_desc_act_checkpoint_save_load_round_trip(tmp_path, layout):
     for (na, ma), (nb, mb) in zip(model.named_modules(), again.named_modules()):
         if hasattr(ma, "recover_qparms_kn"):
             assert torch.equal(ma.weight.data, mb.weight.data), na
+
+
+def test_plain_c_client_device_leg(tmp_path):
+    """examples/c_client.c with a GPU: a plain-C99 program that owns its device memory (four HIP runtime entry points
+    declared by hand) and goes quantize_to_packed_weight -> read_header -> dequantize_packed_weight -> woq_linear
+    through the C ABI alone — no Python, no torch — and checks the reference's own criterion (op == activation x
+    dequantised weight) and the RTN step."""
+    import os
+    import shutil
+    import subprocess
+
+    from intel_extension_for_transformers_amd import _lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "c_client")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "c_client.c"), "-L" + libdir, "-lwoq_hip", "-L/opt/rocm/lib",
+                    "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    res = subprocess.run([exe, "gpu"], capture_output=True, text=True)
+    assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)
+    assert "gpu checks ok" in res.stdout

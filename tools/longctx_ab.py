@@ -16,7 +16,8 @@ from intel_extension_for_transformers_amd import _lib as L  # noqa: E402
 from intel_extension_for_transformers_amd.runtime.engine import WoqDecoderEngine, synth_llama_weights  # noqa: E402
 
 
-def run(layers, ctx, kv, fold, fixed):
+def run(layers, ctx, kv, fold, chunk, splits):
+    """chunk: 0 = adaptive slices, else the fixed slice length; splits: 0 = tune_attn_for's choice"""
     os.environ["WOQ_ATTN_FOLD"] = "1" if fold else "0"
     hidden, inter, heads, kvh, hd, vocab = 4096, 14336, 32, 8, 128, 32000
     eng = WoqDecoderEngine(hidden, inter, heads, kvh, hd, layers, vocab, max_ctx=ctx + 256,
@@ -27,13 +28,17 @@ def run(layers, ctx, kv, fold, fixed):
     for s0 in range(0, ctx, 2048):
         eng.prefill(toks[s0:s0 + 2048], start_pos=s0, greedy=True)
     eng.tune_attn_for(ctx + 128)
-    if not fixed:
-        eng.set_attn_chunk(0)
+    eng.set_attn_chunk(chunk)
+    if splits:
+        eng.set_attn_splits(splits)
+    elif chunk:
+        eng.set_attn_splits(max(2, min(64, -(-(ctx + 128) // chunk))))
+    else:
         eng.set_attn_splits(max(2, min(64, (ctx + 128) // 256)))
     eng.capture(greedy=True)
     tok0, pos0 = eng.token.clone(), eng.pos.clone()
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < 0.8:  # clock conditioning
+    while time.perf_counter() - t0 < 0.5:  # clock conditioning
         eng.token.copy_(tok0)
         eng.pos.copy_(pos0)
         eng.replay(64)
@@ -46,9 +51,8 @@ def run(layers, ctx, kv, fold, fixed):
     eng.replay(64)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 64
-    out = dict(fold=fold, fixed=fixed, splits=L.lib().woq_engine_attn_splits(eng._h),
-               chunk=L.lib().woq_engine_attn_chunk(eng._h), ms_per_token=dt * 1e3, token=int(eng.token.item()),
-               status=eng.status())
+    out = dict(fold=fold, splits=L.lib().woq_engine_attn_splits(eng._h), chunk=L.lib().woq_engine_attn_chunk(eng._h),
+               ms_per_token=round(dt * 1e3, 4), token=int(eng.token.item()), status=eng.status())
     del eng
     torch.cuda.empty_cache()
     return out
@@ -58,12 +62,15 @@ def main():
     layers = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     ctx = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
     kv = sys.argv[3] if len(sys.argv) > 3 else "fp8"
+    # variants "fold:chunk:splits" (argv[4:]); default: the forms of DESIGN.md 3.2
+    variants = sys.argv[4:] or ["0:0:0", "1:0:0", "0:256:0", "1:256:0", "0:0:16", "1:0:16", "0:0:24", "0:512:0", "0:0:0"]
     base = None
-    for fold, fixed in ((True, True), (True, False), (False, False), (False, True), (True, True)):
-        r = run(layers, ctx, kv, fold, fixed)
+    for v in variants:
+        fold, chunk, splits = (int(x) for x in v.split(":"))
+        r = run(layers, ctx, kv, bool(fold), chunk, splits)
         if base is None:
             base = r["ms_per_token"]
-        r["us_per_layer_vs_first"] = (r["ms_per_token"] - base) * 1e3 / layers
+        r["us_per_layer_vs_first"] = round((r["ms_per_token"] - base) * 1e3 / layers, 2)
         print(json.dumps(r), flush=True)
 
 

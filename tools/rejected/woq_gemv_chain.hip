@@ -1,3 +1,12 @@
+// MOVED OUT OF THE PRODUCT (round 4): the decode layer as two chained launches — a built,
+// parity-tested and measured NEGATIVE of round 3 (profiles/r03y_chained_layer_negative.txt: launch 1 about even,
+// launch 2 +4.5..6.4 us per layer). It was an opt-in path of csrc/woq_engine.hip up to commit fa9f694 (engine hooks
+// `chain_ok`, `engine_layer_chained`, ABI `woq_engine_set_chain`; its GPU test arm was the "chained" modes of
+// tests/test_gpu_fullsize_oracle.py::test_in_launch_handoffs_equal_separate_launches in that commit: bit-identical
+// repeats, greedy tokens equal to the separate launches, logits within 2e-5). Kept here as the record of the form
+// that was tried; it still compiles against csrc/ headers (`hipcc -I intel_extension_for_transformers_amd/csrc -I
+// include -c tools/rejected/woq_gemv_chain.hip`) but nothing links it. The second negative of the same idea, the
+// persistent one-launch engine (csrc/woq_persist.hip), stays in the library because bench.py re-measures it every run.
 // woq_gemv_chain.hip — the decode layer as TWO launches whose workgroups are chained inside the launch (round 3):
 //     launch 1: [RMSNorm + qkv GEMV strips | one attention workgroup per head | o_proj strips]
 //     launch 2: [RMSNorm + gate/up GEMV pairs (SiLU * mul) | down_proj strips]
