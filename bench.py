@@ -195,8 +195,8 @@ def timed(run, steps, warmup, fence, condition=None):
 def gemv_roofline(eng, traffic=None, ceiling=True):
     """Dominant kernel: the batch-1 int4 GEMV. `achieved` = algorithmic bytes per launch / average launch duration from
     HIP events on the launch stream around passes of the step's OWN four GEMV launches per layer (same kernels,
-    epilogues, XQ outputs and residual chaining as the captured step; back to back, so the boundaries a token pays are
-    inside). `ceiling`: the same launches with the arithmetic taken out, timed the same way in the same run — load-only
+    epilogues, XQ outputs and residual chaining as the step; issued eagerly back to back like the step's bursts, so the
+    boundaries a token pays are inside). `ceiling`: the same launches with the arithmetic taken out, timed the same way in the same run — load-only
     twins (what this launch structure reaches as a pure stream) and empty kernels (what its launches cost)."""
     ms, by, n_launch = eng.time_gemv(reps=8)
     us = ms * 1e3 / (8 * n_launch)
@@ -211,8 +211,9 @@ def gemv_roofline(eng, traffic=None, ceiling=True):
         "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,
         "us_per_launch": us, "algorithmic_bytes_per_launch": per_launch,
         "launches_per_token": n_launch,
-        "timed": "HIP events on the launch stream around 8 replays of a captured pass of %d launches (the step's own "
-                 "kernel variants, chained as in the step; boundaries included)" % n_launch,
+        "timed": "HIP events on the launch stream around 8 passes of %d launches issued eagerly back to back (the step's "
+                 "own kernel variants, chained as in the step; boundaries included) — the way the step itself is "
+                 "issued; round 3 timed replays of a captured pass, whose kernel boundaries cost ~1 us more" % n_launch,
     }
     # the four projections one at a time (the instantiations rocprofv3 lists separately): a pass of ONE projection per
     # layer, back to back — each launch then starts behind a launch of its own kind, not behind its real predecessor
@@ -255,8 +256,7 @@ def launch_structures(eng, cfg, args):
         eng.set_persist(False)
         return {"persistent_launch": None, "note": "outside the persistent launch's scope on this model / device"}
     feed_prompt(eng, cfg["vocab"], args.prompt)
-    eng.capture(greedy=True)
-    el = timed(lambda n: eng.replay(n), args.steps, args.warmup, torch.cuda.synchronize, condition=(eng, None))
+    el = timed(lambda n: eng.run(n), args.steps, args.warmup, torch.cuda.synchronize, condition=(eng, None))
     status = eng.status()
     eng.set_persist(False)
     return {"persistent_launch": {"tokens_per_s": args.steps / el, "ms_per_step": el * 1e3 / args.steps,
@@ -590,8 +590,7 @@ def decode_entry(name, cfg, eng, steps, warmup, group, asym, ctx_note, kv_bytes_
     def fence():
         torch.cuda.synchronize()
 
-    eng.capture(greedy=True)
-    dt = timed(eng.replay, steps, warmup, fence, condition=(eng, None)) / steps
+    dt = timed(eng.run, steps, warmup, fence, condition=(eng, None)) / steps  # eager bursts (runtime/engine.py LAUNCH)
     wbytes = algorithmic_bytes_per_token(cfg, group=group, asym=asym)
     return {
         "config": name, "decode_tokens_per_s": 1.0 / dt, "ms_per_token": dt * 1e3,
@@ -691,13 +690,16 @@ def tp_point(args, cfg, rank, world, dist, steps, warmup, as_extra=False):
             dec.step(greedy=greedy, return_logits=False)
 
     feed_prompt(eng, cfg["vocab"], args.prompt, step=step)
-    use_graph = not args.no_graph and (world == 1 or comm is not None)
+    use_graph = args.graph and (world == 1 or comm is not None)
+    native = world == 1 or comm is not None  # the whole token (exchange included) is one native call
     if use_graph:
         eng.capture(greedy=True)
 
     def run(n):
         if use_graph:
-            eng.replay(n)
+            eng.replay_graph(n)
+        elif native:
+            eng.run(n)  # n tokens issued eagerly by one native call; the device exchange's kernels are part of the step
         else:
             for _ in range(n):
                 step(True)
@@ -708,7 +710,7 @@ def tp_point(args, cfg, rank, world, dist, steps, warmup, as_extra=False):
             dist.barrier()
         torch.cuda.synchronize()
 
-    elapsed = timed(run, steps, warmup, fence, condition=(eng, dist) if use_graph else None)
+    elapsed = timed(run, steps, warmup, fence, condition=(eng, dist) if native else None)
     conditioning = dict(LAST_CONDITIONING)
     agree = True
     if dist is not None:
@@ -762,7 +764,10 @@ def main():
     ap.add_argument("--no-70b", action="store_true", help="skip the 70B single-GPU point of extra_configs")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-structures", action="store_true", help="skip other_launch_structures (the persistent launch)")
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="time hipGraph replays of the captured step instead of eager bursts (round 3's form; ~1 us per "
+                         "kernel boundary slower, profiles/r04g_graph_vs_eager_steps.txt)")
+    ap.add_argument("--no-graph", action="store_true", help="(accepted for compatibility: eager bursts are the default)")
     ap.add_argument("--condition-ms", type=float, default=800.0,
                     help="untimed replays before the warm-up steps so that sclk has left its idle ramp (0 = off)")
     ap.add_argument("--host-allreduce", action="store_true", help="N > 1: force the RCCL host-driven transport")
@@ -848,22 +853,30 @@ def main():
     eng = build_engine(cfg, max_ctx=max_ctx, max_batch=max(1, args.prefill_seqs) if want_prefill else 1,
                        layers=cfg["layers"])
     feed_prompt(eng, cfg["vocab"], args.prompt)
-    use_graph = not args.no_graph
+    use_graph = args.graph and not args.no_graph
     if use_graph:
         eng.capture(greedy=True)
+    run = eng.replay_graph if use_graph else eng.run  # eng.run(n): n steps issued eagerly by one native call
 
-    def run(n):
-        if use_graph:
-            eng.replay(n)
-        else:
-            for _ in range(n):
-                eng.step(greedy=True)
-
-    elapsed = timed(run, args.steps, args.warmup, torch.cuda.synchronize, condition=(eng, None) if use_graph else None)
+    elapsed = timed(run, args.steps, args.warmup, torch.cuda.synchronize, condition=(eng, None))
     timed_region = list(LAST_TIMED_REGION)
     conditioning = dict(LAST_CONDITIONING)
     tok_s = args.steps / elapsed
-    structures = launch_structures(eng, cfg, args) if use_graph and not args.no_structures else None
+    # the other way of issuing the same steps, same engine, same prompt, right after the headline
+    feed_prompt(eng, cfg["vocab"], args.prompt)
+    if not use_graph:
+        eng.capture(greedy=True)
+    other = eng.run if use_graph else eng.replay_graph
+    el2 = timed(other, args.steps, args.warmup, torch.cuda.synchronize, condition=(eng, None))
+    launch_modes = {"eager_bursts_tokens_per_s": args.steps / (el2 if use_graph else elapsed),
+                    "hipgraph_replay_tokens_per_s": args.steps / (elapsed if use_graph else el2),
+                    "headline": "hipgraph_replay" if use_graph else "eager_bursts",
+                    "note": "the same kernels and device-side token chain either way; a replayed hipGraph pays ~1 us more "
+                            "per kernel boundary than consecutive launches on one stream (MI355X, ROCm 7.0 runtime; "
+                            "profiles/r04g_graph_vs_eager_steps.txt). Eager bursts cost ~0.4 ms of host launch calls per "
+                            "token, issued ahead of the device"}
+    feed_prompt(eng, cfg["vocab"], args.prompt)
+    structures = launch_structures(eng, cfg, args) if not args.no_structures else None
     qbytes = algorithmic_bytes_per_token(cfg)
     out = dict(base, value=tok_s, ms_per_step=elapsed * 1e3 / args.steps, scaling="weak",
                data="synthetic (random-init int4 weights of the Llama-2-7B shape, random prompt ids)",
@@ -871,7 +884,7 @@ def main():
                                    "lm_head fp16 unquantised, KV fp16%s"
                                    % (args.prompt, "" if cfg["layers"] == 32 else " [REDUCED to %d layers]" % cfg["layers"]),
                        "global_batch": 1, "parallelism": "single GPU", "hipgraph": use_graph},
-               timed_region_unix=timed_region, clock_conditioning=conditioning,
+               timed_region_unix=timed_region, clock_conditioning=conditioning, launch_modes=launch_modes,
                hbm_gbps_quantized_weight_stream=qbytes * tok_s / 1e9,
                hbm_frac_of_peak_end_to_end=qbytes * tok_s / 1e9 / HBM_PEAK_GBPS,
                hbm_frac_of_measured_copy_ceiling_end_to_end=qbytes * tok_s / 1e9 / HBM_COPY_GBPS,

@@ -243,6 +243,10 @@ WOQ_API int woq_engine_uses_xq(woq_engine* e);
 /* capture one step into a hipGraph and replay it `n` times (greedy chaining). */
 WOQ_API int woq_engine_capture(woq_engine* e, int greedy, void* stream);
 WOQ_API int woq_engine_replay(woq_engine* e, int n, void* stream);
+/* `n` decode steps issued eagerly back to back (no graph, no host synchronisation; with greedy != 0 the token /
+ * position chain on the device like a replayed graph). The faster way to run a burst on MI355X / ROCm 7: ~1 us less
+ * per kernel boundary than hipGraphLaunch of the captured step (profiles/r04g_graph_vs_eager_steps.txt). */
+WOQ_API int woq_engine_steps(woq_engine* e, int n, int greedy, void* stream);
 /* tensor-parallel seam: when set, the engine calls `fn(user, buf_dev, count_f32, stream)` after
  * o_proj and after down_proj (row-parallel partial sums -> sum over ranks). The Python host binds it
  * to RCCL via torch.distributed. NULL = single GPU. */
@@ -299,6 +303,9 @@ WOQ_API int woq_engine_time_gemv_mask(woq_engine* e, int mask, int reps, void* s
  * the engine's own blobs: what this launch structure reaches as a pure stream), mode 1 = empty kernels on the same
  * grids (what the launches cost before they do anything). bench.py reports both as roofline.ceiling. */
 WOQ_API int woq_engine_time_twin(woq_engine* e, int mode, int reps, void* stream, float* total_ms);
+/* how woq_engine_time_gemv / _gemv_mask / _twin issue their timed passes: on != 0 (default) eagerly back to back on
+ * the stream — the way decode bursts run by default since round 4 — else as replays of a captured graph. */
+WOQ_API int woq_engine_set_time_eager(woq_engine* e, int on);
 /* the prompt pass's dominant GEMM in place: the engine's own gate/up call of `layer` over n_rows rows of the residual
  * stream a preceding woq_engine_prefill left (RMSNorm pack pass + MFMA GEMM + SiLU * mul epilogue), the MEDIAN of `reps`
  * calls after a warm-up one: gemm_ms = the GEMM kernel alone (HIP events on the launch stream right around its launch),

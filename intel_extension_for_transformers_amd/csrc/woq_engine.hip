@@ -143,8 +143,12 @@ struct woq_engine {
   int attn_grouped = 0;         // sliced regime: one workgroup per kv head x slice on the matrix cores (GQA shapes)
   float* attn_part = nullptr;   // fp32 partials of the sliced decode attention (layout: woq_attn_merge.h)
   unsigned int* attn_cnt = nullptr;  // [heads] arrival counters of the slices' last-workgroup merge, zero between launches
-  bool attn_fold = true;        // the last slice workgroup merges (WOQ_ATTN_FOLD=0: a combine launch does, the A/B twin)
+  bool attn_fold = false;       // WOQ_ATTN_FOLD=1: the last slice workgroup merges instead of a combine launch — built,
+                                // parity-tested and measured SLOWER (+3..5 us per layer: three dependent device-scope
+                                // round trips on the launch's tail, profiles/r04d_*); opt-in, default off
   int attn_chunk = 0;           // grouped form: positions per slice of the position-independent geometry, 0 = adaptive
+  bool time_eager = true;       // woq_engine_time_gemv / _twin: passes issued eagerly (how bursts run by default) or as a
+                                // replayed graph (round 3's measure; woq_engine_set_time_eager(e, 0))
   int max_batch = 1;
   size_t pf_rows = 0, pf_ws_bytes = 0;
   float* pf_h = nullptr;        // fp32 residual stream [rows][hidden]
@@ -450,10 +454,25 @@ static int engine_prefill_impl(woq_engine* e, const int32_t* tokens, int n_seq, 
 // one pass of `body` captured into a hipGraph and replayed `reps` times between two events on `st` (after one
 // untimed replay): what the launches cost inside the engine's own regime (captured, no host in the loop)
 template <typename F>
-static int time_captured(hipStream_t st, int reps, F body, float* total_ms) {
+static int time_captured(hipStream_t st, int reps, F body, float* total_ms, bool eager = false) {
   int rc = body();  // eager once: lazy kernel attributes outside of capture
   if (rc) return rc;
   WOQ_HIP(hipStreamSynchronize(st));
+  if (eager) {  // the passes issued back to back on the stream, no graph: how the decode step runs by default (round 4)
+    hipEvent_t ev0, ev1;
+    WOQ_HIP(hipEventCreate(&ev0));
+    WOQ_HIP(hipEventCreate(&ev1));
+    if ((rc = body()) != 0) return rc;
+    WOQ_HIP(hipEventRecord(ev0, st));
+    for (int r = 0; r < reps; ++r)
+      if ((rc = body()) != 0) return rc;
+    WOQ_HIP(hipEventRecord(ev1, st));
+    WOQ_HIP(hipStreamSynchronize(st));
+    WOQ_HIP(hipEventElapsedTime(total_ms, ev0, ev1));
+    hipEventDestroy(ev0);
+    hipEventDestroy(ev1);
+    return 0;
+  }
   hipGraph_t g = nullptr;
   hipGraphExec_t ge = nullptr;
   WOQ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -516,6 +535,12 @@ int woq_engine_set_attn_chunk(woq_engine* e, int chunk) {
   WOQ_END
 }
 int woq_engine_attn_chunk(woq_engine* e) { return e ? e->attn_chunk : 0; }
+int woq_engine_set_time_eager(woq_engine* e, int on) {
+  WOQ_TRY
+  WOQ_CHECK(e != nullptr, "QBits: null engine");
+  e->time_eager = on != 0;
+  WOQ_END
+}
 int woq_engine_set_persist(woq_engine* e, int on) {
   WOQ_TRY
   WOQ_CHECK(e != nullptr, "QBits: null engine");
@@ -617,7 +642,7 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
   WOQ_HIP(hipMemset(e->attn_cnt, 0, (size_t)cfg->heads * 4));
   {
     const char* af = getenv("WOQ_ATTN_FOLD");
-    e->attn_fold = af ? af[0] != '0' : true;
+    e->attn_fold = af ? af[0] != '0' : false;
   }
   WOQ_HIP(hipMalloc((void**)&e->tok_log, (size_t)(cfg->max_ctx + 1) * 4));
   WOQ_HIP(hipMemset(e->tok_log, 0, (size_t)(cfg->max_ctx + 1) * 4));
@@ -815,6 +840,21 @@ int woq_engine_capture(woq_engine* e, int greedy, void* stream) {
   WOQ_END
 }
 
+// n decode steps issued eagerly, back to back, no graph: the greedy token / position chain on the device exactly as in
+// a replayed graph, and the host stays ahead of the GPU (~130 launches of 2-4 us host time against ~1 ms of device
+// time per 7B token). Measured FASTER than hipGraphLaunch of the captured step by ~1 us per kernel launch (round 4,
+// profiles/r04g_graph_vs_eager_steps.txt: Llama-2-7B 1.045 vs 1.178 ms per token, Mistral-7B 16 layers at 8k 0.760 vs
+// 0.870) — the graph's kernel nodes pay a heavier boundary than consecutive launches on one stream.
+int woq_engine_steps(woq_engine* e, int n, int greedy, void* stream) {
+  WOQ_TRY
+  WOQ_CHECK(e && e->embed && e->lm_head, "QBits: engine head not set");
+  for (int i = 0; i < n; ++i) {
+    const int rc = engine_step_impl(e, greedy, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  WOQ_END
+}
+
 int woq_engine_replay(woq_engine* e, int n, void* stream) {
   WOQ_TRY
   WOQ_CHECK(e && e->exec, "QBits: engine graph not captured");
@@ -882,7 +922,7 @@ int woq_engine_time_gemv_mask(woq_engine* e, int mask, int reps, void* stream, f
     }
     return 0;
   };
-  const int rc = time_captured(st, reps, pass, total_ms);
+  const int rc = time_captured(st, reps, pass, total_ms, e->time_eager);
   if (rc) return rc;
   *bytes_per_pass = bytes;
   *launches_per_pass = c.layers * __builtin_popcount(mask & 15);
@@ -912,7 +952,7 @@ int woq_engine_time_twin(woq_engine* e, int mode, int reps, void* stream, float*
     }
     return 0;
   };
-  const int rc = time_captured(st, reps, pass, total_ms);
+  const int rc = time_captured(st, reps, pass, total_ms, e->time_eager);
   if (rc) return rc;
   WOQ_END
 }

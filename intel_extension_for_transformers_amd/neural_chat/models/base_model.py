@@ -145,8 +145,7 @@ class BaseModel:
         for s0 in range(0, len(ids), 2048):
             eng.prefill(ids[s0:s0 + 2048], start_pos=s0, greedy=True)
         eng.tune_attn_for(len(ids) + config.max_new_tokens)
-        if not eng.captured:
-            eng.capture(greedy=True)
+        eng.prepare_decode(greedy=True)  # a captured graph only in "graph" launch mode (engine.py LAUNCH)
         out, shown = [], ""
         for i in range(config.max_new_tokens):
             t = int(eng.token.item())

@@ -7,6 +7,7 @@ decode path is an optional post-pass over the same WQH1 blobs. torch is plumbing
 streams); every kernel is in libwoq_hip.so.
 """
 import ctypes
+import os
 
 import torch
 
@@ -113,6 +114,23 @@ class WoqDecoderEngine:
     def step(self, greedy=True):
         L.check(L.lib().woq_engine_step(self._h, int(greedy), L.stream_ptr()))
 
+    # How a burst of decode steps is issued. "eager" (default since round 4): `n` steps back to back through ONE native
+    # call, no graph — measured ~1 us per kernel boundary faster than replaying the captured hipGraph on MI355X / ROCm 7
+    # (Llama-2-7B 1.045 vs 1.178 ms per token, profiles/r04g_graph_vs_eager_steps.txt); the host stays ahead of the
+    # device (~0.4 ms of launch calls per 7B token). "graph": hipGraphLaunch of the captured step (no host work per
+    # token at all — the right choice when the host is busy or slow). WOQ_ENGINE_LAUNCH=graph|eager picks the default.
+    LAUNCH = os.environ.get("WOQ_ENGINE_LAUNCH", "eager")
+
+    @property
+    def launch(self):
+        return getattr(self, "_launch", None) or type(self).LAUNCH
+
+    @launch.setter
+    def launch(self, mode):
+        if mode not in ("eager", "graph"):
+            raise ValueError("launch mode is 'eager' or 'graph'")
+        self._launch = mode
+
     def capture(self, greedy=True):
         """Capture one token step into a hipGraph (on the engine's own stream)."""
         cur = torch.cuda.current_stream(self.device)
@@ -121,14 +139,33 @@ class WoqDecoderEngine:
             L.check(L.lib().woq_engine_capture(self._h, int(greedy), L.stream_ptr()))
         cur.wait_stream(self._stream)
         self.captured = True
+        self._captured_greedy = bool(greedy)
 
-    def replay(self, n=1):
-        """Replay the captured step n times (greedy chaining stays on the device)."""
+    def prepare_decode(self, greedy=True):
+        """Whatever `replay` needs before a burst: a captured graph in "graph" mode, nothing in "eager" mode."""
+        if self.launch == "graph" and not self.captured:
+            self.capture(greedy=greedy)
+        self._burst_greedy = bool(greedy)
+
+    def run(self, n=1, greedy=True):
+        """`n` decode steps issued eagerly by one native call (greedy: token / position chain on the device)."""
+        L.check(L.lib().woq_engine_steps(self._h, int(n), int(greedy), L.stream_ptr()))
+
+    def replay_graph(self, n=1):
+        """Replay the captured hipGraph n times (greedy chaining stays on the device)."""
         cur = torch.cuda.current_stream(self.device)
         self._stream.wait_stream(cur)
         with torch.cuda.stream(self._stream):
             L.check(L.lib().woq_engine_replay(self._h, int(n), L.stream_ptr()))
         cur.wait_stream(self._stream)
+
+    def replay(self, n=1):
+        """A burst of `n` decode steps of the kind last captured / prepared (greedy chaining stays on the device): the
+        captured graph in "graph" mode, `run` in "eager" mode (same kernels, same results — the tests hold graph replays
+        and eager steps to bit-identical tokens)."""
+        if self.launch == "graph":
+            return self.replay_graph(n)
+        self.run(n, greedy=getattr(self, "_burst_greedy", getattr(self, "_captured_greedy", True)))
 
     def token_log(self):
         """int32 view [max_ctx + 1] of the engine's token log: slot p = the greedy token of the step that fed position
@@ -150,6 +187,10 @@ class WoqDecoderEngine:
             out = fn()
         cur.wait_stream(self._stream)
         return out
+
+    def set_time_eager(self, on=True):
+        """time_gemv / time_twin: passes issued eagerly back to back (default: how bursts run) or as a replayed graph."""
+        L.check(L.lib().woq_engine_set_time_eager(self._h, int(bool(on))))
 
     def time_gemv(self, reps=1, mask=15):
         """(total ms, algorithmic bytes per pass, launches per pass) of `reps` replays of a captured pass over every
@@ -299,7 +340,7 @@ class WoqDecoderEngine:
         # position-independent slices: not with a sliding window (the slices move with the position), and only for
         # the fp8 cache, whose kernel keeps raw bytes in registers and fits two workgroups on a CU — the fp16 form
         # holds one (272 registers), and ceil(positions / 256) x kv_heads workgroups would then run a second round
-        fixed = grouped and not self.cfg.reserved[2] and self.cfg.kv_dtype == L.FP8_E4M3
+        fixed = False and grouped and not self.cfg.reserved[2] and self.cfg.kv_dtype == L.FP8_E4M3  # measured slower (r04d): off
         self.set_attn_chunk(self.GROUPED_CHUNK if fixed else 0)
         if positions <= self.LONG_CTX:
             self.set_attn_splits(1)

@@ -213,8 +213,8 @@ class TPDecoder:
             self._since_check += 1
             if self._since_check >= self.CHECK_EVERY:
                 self.check_status()
-            if greedy and not return_logits and e.captured:
-                e.replay(1)
+            if greedy and not return_logits and e.captured and e.launch == "graph":
+                e.replay_graph(1)
                 return None
             e.step(greedy=greedy)  # all-reduces and, when greedy, the token exchange run inside the native step
             if return_logits:

@@ -362,8 +362,8 @@ def _engine_generate(self, inputs=None, generation_config=None, **kwargs):
         for s0 in range(0, n_in, 2048):
             eng.prefill(prompt[s0:s0 + 2048], start_pos=s0, greedy=True)
         eng.tune_attn_for(n_in + max_new)
-        if max_new > 1 and not eng.captured:
-            eng.capture(greedy=True)
+        if max_new > 1:
+            eng.prepare_decode(greedy=True)  # a captured graph only in "graph" launch mode (engine.py LAUNCH)
         # Tokens are read back in bursts: the steps chain on the device and log their tokens (engine.token_log), so the
         # host synchronises once per burst instead of once per token. A stop token is noticed at the end of its burst —
         # the few steps run past it are discarded. With a streamer the burst is one token (latency first).

@@ -132,6 +132,35 @@ def test_engine_graph_replay_matches_eager():
     assert ref == eager
 
 
+def test_eager_bursts_equal_graph_replays():
+    """runtime/engine.py launch modes: a burst of n decode steps issued eagerly through ONE native call
+    (`woq_engine_steps`, the product default since round 4) against n replays of the captured hipGraph and against n
+    separate `step()` calls: identical greedy token chains and bit-identical final logits; `replay()` follows the
+    engine's launch mode."""
+    outs = {}
+    for mode in ("graph", "eager", "steps"):
+        eng, _, _ = _tiny(128, False, "fp16", seed=1)
+        eng.launch = "eager" if mode == "eager" else "graph"
+        for i, t in enumerate([5, 9, 2]):
+            eng.token.fill_(t)
+            eng.pos.fill_(i)
+            eng.step(greedy=(i == 2))
+        first = int(eng.token.item())
+        if mode == "steps":
+            for _ in range(12):
+                eng.step(greedy=True)
+        else:
+            eng.prepare_decode(greedy=True)
+            assert eng.captured == (mode == "graph")
+            eng.replay(5)
+            eng.replay(7)
+        torch.cuda.synchronize()
+        outs[mode] = ([first] + eng.token_log()[3:15].tolist(), eng.logits.clone())
+        assert eng.status() == 0
+    assert outs["graph"][0] == outs["eager"][0] == outs["steps"][0]
+    assert torch.equal(outs["graph"][1], outs["eager"][1]) and torch.equal(outs["graph"][1], outs["steps"][1])
+
+
 # ---- prompt pass (woq_engine_prefill) ---------------------------------------------------------------------------
 # Stated tolerance: the prefill linears contract fp16 operands (11-bit significands; the reference's own
 # reduced-precision cores use bf16, 8 bits) and keep q / k / v / attention / MLP activations in fp16 between kernels,
@@ -292,7 +321,7 @@ def test_decode_attention_context_slices_vs_oracle(head_dim, splits, grouped, hi
 
 
 @pytest.mark.parametrize("hidden,chunk,splits", [(512, 32, 5), (512, 64, 3), (1024, 64, 4), (256, 96, 3)])
-def test_grouped_attention_fixed_chunk_slices_vs_oracle(hidden, chunk, splits):
+def test_grouped_attention_fixed_chunk_slices_vs_oracle(hidden, chunk, splits, monkeypatch):
     """Round 4: the grouped-query sliced decode attention with POSITION-INDEPENDENT slices (slice s owns the absolute
     positions [s * chunk, (s + 1) * chunk), K / V requested before the device-side position is read) and the merge done
     by the last slice workgroup to finish (csrc/woq_attn_merge.h) instead of a combine launch. Token by token over 200
@@ -300,8 +329,10 @@ def test_grouped_attention_fixed_chunk_slices_vs_oracle(hidden, chunk, splits):
     boundaries, the new token's row landing in every slice in turn, and the last slice's overflow (splits * chunk <
     200) — against the fp32 oracle at the decode tolerance; then graph replays (the arrival counters must come back to
     zero by themselves) with identical greedy tokens."""
+    monkeypatch.setenv("WOQ_ATTN_FOLD", "1")  # read at engine creation (the in-launch merge is opt-in: measured slower)
     eng, oracle, cfg = _tiny(128, False, "fp16", seed=5, max_ctx=256, head_dim=128, attn_splits=splits, hidden=hidden,
                              attn_grouped=True)
+    monkeypatch.delenv("WOQ_ATTN_FOLD")
     eng.set_attn_chunk(chunk)
     rng = np.random.default_rng(8)
     toks = rng.integers(0, cfg["vocab"], 200).tolist()
@@ -335,7 +366,7 @@ def test_slice_merge_by_last_workgroup_equals_the_combine_launch(grouped, hidden
     monkeypatch.setenv("WOQ_ATTN_FOLD", "0")
     e0, _, cfg = _tiny(128, False, "fp16", seed=6, max_ctx=256, head_dim=head_dim, attn_splits=4, hidden=hidden,
                        attn_grouped=grouped)
-    monkeypatch.delenv("WOQ_ATTN_FOLD")
+    monkeypatch.setenv("WOQ_ATTN_FOLD", "1")
     e1, _, _ = _tiny(128, False, "fp16", seed=6, max_ctx=256, head_dim=head_dim, attn_splits=4, hidden=hidden,
                      attn_grouped=grouped)
     rng = np.random.default_rng(9)

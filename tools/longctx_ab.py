@@ -19,7 +19,8 @@ from intel_extension_for_transformers_amd.runtime.engine import WoqDecoderEngine
 def run(layers, ctx, kv, fold, chunk, splits):
     """chunk: 0 = adaptive slices, else the fixed slice length; splits: 0 = tune_attn_for's choice"""
     os.environ["WOQ_ATTN_FOLD"] = "1" if fold else "0"
-    hidden, inter, heads, kvh, hd, vocab = 4096, 14336, 32, 8, 128, 32000
+    hidden, heads, hd, vocab = 4096, 32, 128, 32000
+    kvh, inter = int(os.environ.get("LCAB_KVH", "8")), int(os.environ.get("LCAB_INTER", "14336"))  # 32 / 11008: Llama-2-7B
     eng = WoqDecoderEngine(hidden, inter, heads, kvh, hd, layers, vocab, max_ctx=ctx + 256,
                            kv_dtype=torch.float8_e4m3fn if kv == "fp8" else torch.float16)
     synth_llama_weights(eng, hidden, inter, heads, kvh, hd, layers, vocab, group=128, sym=True, scale_dtype="fp16")
@@ -28,8 +29,14 @@ def run(layers, ctx, kv, fold, chunk, splits):
     for s0 in range(0, ctx, 2048):
         eng.prefill(toks[s0:s0 + 2048], start_pos=s0, greedy=True)
     eng.tune_attn_for(ctx + 128)
+    if kvh == heads:  # multi-head: the per-query-head slices (no grouped form)
+        if splits:
+            eng.set_attn_splits(splits)
+        chunk = splits = 0
     eng.set_attn_chunk(chunk)
-    if splits:
+    if kvh == heads:
+        pass
+    elif splits:
         eng.set_attn_splits(splits)
     elif chunk:
         eng.set_attn_splits(max(2, min(64, -(-(ctx + 128) // chunk))))
@@ -51,8 +58,20 @@ def run(layers, ctx, kv, fold, chunk, splits):
     eng.replay(64)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 64
+    reps = []
+    for _ in range(3):  # how stable is the number inside one engine instance?
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.token.copy_(tok0)
+        eng.pos.copy_(pos0)
+        eng.replay(64)
+        torch.cuda.synchronize()
+        reps.append(round((time.perf_counter() - t0) / 64 * 1e3, 4))
+    kptr = L.lib().woq_engine_kv_cache_ptr(eng._h, 0)
     out = dict(fold=fold, splits=L.lib().woq_engine_attn_splits(eng._h), chunk=L.lib().woq_engine_attn_chunk(eng._h),
-               ms_per_token=round(dt * 1e3, 4), token=int(eng.token.item()), status=eng.status())
+               ms_per_token=round(dt * 1e3, 4), again=reps, token=int(eng.token.item()), status=eng.status(),
+               kcache="%x" % kptr, qkv0="%x" % eng.layer_tensors[0]["qkv"].data_ptr(),
+               gu0="%x" % eng.layer_tensors[0]["gate_up"].data_ptr())
     del eng
     torch.cuda.empty_cache()
     return out
