@@ -203,3 +203,39 @@ def test_tp_world_size_two_device_exchange(tmp_path):
     except Exception:
         msg = open(errfile).read() if os.path.exists(errfile) else "(no traceback captured)"
         pytest.fail("a tensor-parallel rank failed:\n" + msg)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_bench_py_multi_rank_line_on_one_gpu(graph):
+    """The driver's N > 1 command — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` — end to end with two ranks on this one GPU
+    (WOQ_BENCH_BACKEND=gloo: RCCL refuses two ranks per device; the device exchange does not need it): process-group
+    set-up, the 70B-shaped shards (2 layers here), the device communicator's self-test, eager bursts (default) and the
+    captured graph with the all-reduce kernels inside, rank agreement on the greedy token, and ONE JSON line from rank 0
+    with the contract's keys. So that the driver's first multi-GPU run cannot fail on plumbing."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, WOQ_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
+           "--warmup", "2", "--layers", "2", "--condition-ms", "20"] + (["--graph"] if graph else [])
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["parallelism"] == "tp2" and d["config"]["hipgraph"] == graph
+    assert "device one-shot all-reduce" in d["config"]["allreduce_transport"], d["config"]["allreduce_transport"]

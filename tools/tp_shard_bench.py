@@ -20,18 +20,29 @@ def main():
     synth_llama_weights(eng, d["hidden"], d["inter"], d["heads"], d["kv_heads"], d["head_dim"], layers, d["vocab"],
                         group=128, sym=True, scale_dtype="fp16")
     eng.prefill(torch.randint(0, d["vocab"], (32,)).tolist())
-    eng.capture(greedy=True)
-    eng.replay(8)
-    torch.cuda.synchronize()
-    n = 64
-    t0 = time.perf_counter()
-    eng.replay(n)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / n
+    tok0, pos0 = eng.token.clone(), eng.pos.clone()
+    res = {}
+    for mode in ("eager", "graph"):  # eager bursts (the default since round 4) and the replayed graph
+        if mode == "graph":
+            eng.capture(greedy=True)
+        run = eng.run if mode == "eager" else eng.replay_graph
+        for _ in range(6):  # conditioning + warm-up
+            eng.token.copy_(tok0)
+            eng.pos.copy_(pos0)
+            run(64)
+            torch.cuda.synchronize()
+        eng.token.copy_(tok0)
+        eng.pos.copy_(pos0)
+        n = 64
+        t0 = time.perf_counter()
+        run(n)
+        torch.cuda.synchronize()
+        res[mode] = (time.perf_counter() - t0) / n
+    dt = res["eager"]
     params = layers * (d["hidden"] * (d["heads"] + 2 * d["kv_heads"]) * d["head_dim"] + d["heads"] * d["head_dim"] * d["hidden"]
                        + 3 * d["hidden"] * d["inter"])
     wbytes = params // 2 + params // 128 * 2
-    print(json.dumps(dict(layers=layers, ms_per_token_compute_only=dt * 1e3, rank_weight_bytes=wbytes,
+    print(json.dumps(dict(layers=layers, ms_per_token_compute_only=dt * 1e3, ms_per_token_graph_replay=res["graph"] * 1e3, rank_weight_bytes=wbytes,
                           rank_gbps=wbytes / dt / 1e9, allreduces_per_token=2 * layers)))
 
 
