@@ -126,20 +126,26 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
 }
 
 // merge the slices of attn_decode_kernel<SPLIT>: out[h][d] = sum_s o_s[d] e^(m_s - m) / sum_s l_s e^(m_s - m).
-// 256 threads per head: the slice maxima / sums go through LDS once, then two thread groups of HD walk alternate
-// slices with their loads unrolled (independent addresses) — a serial per-thread walk over 32 slices of freshly
-// written partials cost 14 us of pure load latency.
+// 256 threads per head; two thread groups of HD walk alternate slices. Round 4: ONE round trip — a thread's partial
+// rows (clamped, branch-free; rows past ns weigh 0) are requested together with the slice maxima / sums, before anything
+// is waited for; the weights are then worked out in LDS while the rows are in flight (round 3 read the maxima, then
+// the rows: two dependent trips in a launch that is nothing but latency, 5.1 us per layer at 32 slices).
 template <int HD>
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part, int ns,
                                                           float* __restrict__ out, XqPtrs xo) {
   __shared__ float ms[64], wl[64], wsc[64], red[256];
+  constexpr int GROUPS = 256 / HD;                // 2 for head_dim 128, 4 for 64
+  constexpr int PER = ATTN_MAX_SLICES / GROUPS;   // partial rows a thread may have to fetch
   const int h = blockIdx.x, tid = threadIdx.x;
+  const int d = tid % HD, grp = tid / HD;
   const float* p = part + (size_t)h * ATTN_MAX_SLICES * HD;  // woq_attn_merge.h: o [head][64][HD], then ml [head][64][2]
   const float* pml = part + (size_t)gridDim.x * ATTN_MAX_SLICES * HD + (size_t)h * ATTN_MAX_SLICES * 2;
-  if (tid < ns) {
-    ms[tid] = pml[tid * 2];
-    wl[tid] = pml[tid * 2 + 1];
-  }
+  const int si = min(tid, ns - 1);
+  const float m_r = pml[si * 2], l_r = pml[si * 2 + 1];
+  float v[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) v[u] = p[(size_t)min(grp + u * GROUPS, ns - 1) * HD + d];
+  if (tid < ns) ms[tid] = m_r, wl[tid] = l_r;
   __syncthreads();
   float m = -INFINITY;
   for (int s = 0; s < ns; ++s) m = fmaxf(m, ms[s]);
@@ -151,11 +157,12 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
   __syncthreads();
   float l = 0.f;
   for (int s = 0; s < ns; ++s) l += wl[s];
-  constexpr int GROUPS = 256 / HD;  // 2 for head_dim 128, 4 for 64
-  const int d = tid % HD, grp = tid / HD;
   float o = 0.f;
-#pragma unroll 8
-  for (int s = grp; s < ns; s += GROUPS) o = fmaf(p[(size_t)s * HD + d], wsc[s], o);
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int s = grp + u * GROUPS;
+    if (s < ns) o = fmaf(v[u], wsc[s], o);  // ascending s
+  }
   red[tid] = o;
   __syncthreads();
   if (grp == 0) {

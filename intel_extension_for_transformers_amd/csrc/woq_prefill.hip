@@ -495,22 +495,46 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const float* __re
 
   // what the early requests did not cover: everything in the adaptive geometry; in the fixed one the sub-tiles past
   // the slice's own chunk (short chunks, or the last slice's overflow)
+  // prologue, request phase (round 4): the new token's q / k / v and its cos / sin rows are asked for BEFORE the K / V
+  // sub-tiles — returns come back in order, so behind 16 KB of cache rows per wave the rotation could not start until
+  // the whole first burst had landed; in front of it the Q fragments are ready when the first K fragment arrives
+  constexpr int QIT = (REP * HD + 255) / 256;
+  static_assert(256 % HD == 0, "a thread keeps its d across the query heads it rotates");
+  float q_a[QIT], q_b[QIT];
+  const float q_co = cs[(size_t)apos * half + (tid & (half - 1))], q_si = sn[(size_t)apos * half + (tid & (half - 1))];
+#pragma unroll
+  for (int it = 0; it < QIT; ++it) {
+    const int idx = min(tid + it * 256, REP * HD - 1);
+    const int d = idx & (HD - 1);
+    const float* q = qkv + (size_t)kh * REP * HD + (idx - d);
+    q_a[it] = q[d], q_b[it] = q[d ^ half];
+  }
+  float k_a[8], k_b[8], k_co[8], k_si[8], v_in[8];
+  if (tid < HD / 8) {
+    const float* k = qkv + (size_t)(heads + kh) * HD;
+    const float* v = qkv + (size_t)(heads + kv_heads + kh) * HD;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int d = tid * 8 + j, i = d & (half - 1);
+      k_co[j] = cs[(size_t)apos * half + i], k_si[j] = sn[(size_t)apos * half + i];
+      k_a[j] = k[d], k_b[j] = k[d ^ half];
+      v_in[j] = v[d];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
   if (wid < n_sub && !(early && wid * DST <= last_early)) fetch(setA, wid);
   if (wid + 4 < n_sub && !(early && (wid + 4) * DST <= last_early)) fetch(setB, wid + 4);
 
   // prologue through LDS: threads 0..15 build the new k / v of this kv head (rotated, rounded through the cache dtype
-  // like the rows a later step reads back; the last slice appends them), everyone rotates the REP query heads
+  // like the rows a later step reads back; the slice that holds the new position appends them), everyone rotates the REP
+  // query heads
   if (tid < HD / 8) {
-    const float* k = qkv + (size_t)(heads + kh) * HD;
-    const float* v = qkv + (size_t)(heads + kv_heads + kh) * HD;
     float kk[8], vv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int d = tid * 8 + j, i = d & (half - 1);
-      const float co = cs[(size_t)apos * half + i], si = sn[(size_t)apos * half + i];
-      const float ka = k[d], kb = k[d ^ half];
-      kk[j] = d < half ? ka * co - kb * si : ka * co + kb * si;
-      vv[j] = v[d];
+      const int d = tid * 8 + j;
+      kk[j] = d < half ? k_a[j] * k_co[j] - k_b[j] * k_si[j] : k_a[j] * k_co[j] + k_b[j] * k_si[j];
+      vv[j] = v_in[j];
     }
     alignas(16) unsigned char tmp[32];
     kv_store8<KVD>(tmp, 0, kk);
@@ -525,12 +549,13 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const float* __re
       kv_store8<KVD>(vcache, e, vv);
     }
   }
-  for (int idx = tid; idx < REP * HD; idx += 256) {
-    const int d = idx & (HD - 1), i = d & (half - 1);
-    const float* q = qkv + (size_t)kh * REP * HD + (idx - d);
-    const float co = cs[(size_t)apos * half + i], si = sn[(size_t)apos * half + i];
-    const float qa = q[d], qb = q[d ^ half];
-    qs[idx] = d < half ? qa * co - qb * si : qa * co + qb * si;
+#pragma unroll
+  for (int it = 0; it < QIT; ++it) {
+    const int idx = tid + it * 256;
+    if (idx < REP * HD) {
+      const int d = idx & (HD - 1);
+      qs[idx] = d < half ? q_a[it] * q_co - q_b[it] * q_si : q_a[it] * q_co + q_b[it] * q_si;
+    }
   }
   __syncthreads();
   // Q^T fragments, fp16 hi + lo: lane (head i16, quarter kq) holds d = 32 kq + 8 c + e
@@ -681,7 +706,7 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const float* __re
     }
   }
   // the last slice workgroup of this kv head to get here merges the group's REP heads and emits the attention output
-  if (mg.counter != nullptr) attn_slices_merge<HD, (REP < 4 ? REP : 4)>(part, heads, kh * REP, REP, ns, mg.counter + kh, mg, (float*)dsm_raw);
+  if (mg.counter != nullptr) attn_slices_merge<HD, (REP < 2 ? REP : 2)>(part, heads, kh * REP, REP, ns, mg.counter + kh, mg, (float*)dsm_raw);
 }
 
 // last row of every sequence -> dst fp32 [n_seq][hidden]

@@ -42,20 +42,23 @@ def run(layers, ctx, kv, fold, chunk, splits):
         eng.set_attn_splits(max(2, min(64, -(-(ctx + 128) // chunk))))
     else:
         eng.set_attn_splits(max(2, min(64, (ctx + 128) // 256)))
-    eng.capture(greedy=True)
+    run = eng.run  # eager bursts (the default launch mode since r04h); LCAB_GRAPH=1: the replayed graph
+    if os.environ.get("LCAB_GRAPH") == "1":
+        eng.capture(greedy=True)
+        run = eng.replay_graph
     tok0, pos0 = eng.token.clone(), eng.pos.clone()
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.5:  # clock conditioning
         eng.token.copy_(tok0)
         eng.pos.copy_(pos0)
-        eng.replay(64)
+        run(64)
         torch.cuda.synchronize()
     eng.token.copy_(tok0)
     eng.pos.copy_(pos0)
-    eng.replay(8)
+    run(8)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    eng.replay(64)
+    run(64)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 64
     reps = []
@@ -64,7 +67,7 @@ def run(layers, ctx, kv, fold, chunk, splits):
         t0 = time.perf_counter()
         eng.token.copy_(tok0)
         eng.pos.copy_(pos0)
-        eng.replay(64)
+        run(64)
         torch.cuda.synchronize()
         reps.append(round((time.perf_counter() - t0) / 64 * 1e3, 4))
     kptr = L.lib().woq_engine_kv_cache_ptr(eng._h, 0)
