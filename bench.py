@@ -5,6 +5,9 @@
 
 A "step" is one batch-1 greedy decode token, weights synthetic (random-init, no checkpoints / network) and resident in
 HBM when the timed region starts; barrier + synchronize on both sides, max over ranks, ONE JSON line from rank 0.
+The K timed steps are issued as ONE eager burst (woq_engine_steps: K x ~131 launches back to back, token / position
+chained on the device); `--graph` times K replays of the captured hipGraph instead — measured ~1 us per kernel boundary
+slower on MI355X / ROCm 7 (profiles/r04g_graph_vs_eager_steps.txt); the N = 1 line reports both (`launch_modes`).
 
 Which workload (`--workload auto`, the default):
   * N = 1 on a one-GPU box  -> BASELINE.json configs[1]: Llama-2-7B int4 sym g128 (the configuration the metric is
@@ -14,11 +17,13 @@ Which workload (`--workload auto`, the default):
     (q, scale, zp)), `roofline`, `cpu_baseline`.
   * N > 1 -> configs[3]: Llama-2-70B int4 sym g128 at tensor-parallel degree N (strong scaling: the SAME model cut N
     ways; column-parallel q/k/v/gate/up, row-parallel o/down, 2 all-reduces per layer + 1 token exchange per token,
-    SURVEY.md §8(e)). The exchange runs on the device over xGMI inside the captured graph (csrc/woq_comm.hip) after a
+    SURVEY.md §8(e)). The exchange runs on the device over xGMI as kernels of the native step (csrc/woq_comm.hip) after a
     start-up self-test; if that fails on this node the run falls back to host-issued RCCL all-reduces and says so.
   * N = 1 on a multi-GPU node (the first point of the driver's 1/2/4/8 sweep) -> the same 70B model on one GPU, so
     that the sweep's N = 1 value is the strong-scaling base; the 7B number rides along in `extra_configs`.
 
+Key order of the line: the contract's scalars, then the bulky side objects (extra_configs, cpu_baseline, ...), then
+launch_modes / prefill / parity / roofline LAST, so that a truncated log tail still holds them.
 Objects in the line: see DESIGN.md §6. roofline.achieved = algorithmic bytes per launch of the dominant kernel
 (woq::gemv_xqs_kernel) / its average duration from HIP events on the launch stream around back-to-back passes of the
 step's own launches; roofline.ceiling = the same launches as load-only twins / empty kernels, same run.
