@@ -43,7 +43,10 @@ struct FusedAttnArgs {
   XqPtrs xq_attn;
 };
 
-constexpr int FUSED_TPW = 8, FUSED_D = 4;
+#ifndef WOQ_XQS_DEPTH
+#define WOQ_XQS_DEPTH 4
+#endif
+constexpr int FUSED_TPW = 8, FUSED_D = WOQ_XQS_DEPTH;
 
 template <int SMODE, bool ASYM, bool S32, typename KV>
 __global__ __launch_bounds__(256) void gemv_xqs_attn_kernel(

@@ -31,9 +31,12 @@ struct XqLaunch {
 };
 
 // window depth by tiles per wave (tools/xq_probe.hip grid, profiles/r03c_xq_probe.txt)
+#ifndef WOQ_XQS_DEPTH  // A/B builds: tools/mkvariant_xq.sh -DWOQ_XQS_DEPTH=6 | 8 (all of a wave's tiles up front)
+#define WOQ_XQS_DEPTH 4
+#endif
 template <int TPW>
 struct XqsDepth {
-  static constexpr int value = TPW >= 4 ? 4 : TPW;
+  static constexpr int value = TPW >= WOQ_XQS_DEPTH ? WOQ_XQS_DEPTH : TPW;
 };
 
 template <int TPW, int CB, int SMODE, bool ASYM, bool S32>

@@ -246,7 +246,7 @@ class WoqDecoderEngine:
         return _device_view(ptr, (n_seq, self.cfg.vocab), self.device)
 
     # ---- decode attention regime -----------------------------------------------------------------------------
-    LONG_CTX = 256  # cached positions beyond which the sliced decode attention wins (measured: 160 -> one workgroup per head 1.43 vs 1.48 ms/token sliced; 400 -> 1.59 vs 1.50)
+    LONG_CTX = 448  # cached positions beyond which the sliced decode attention wins. Round 4 (eager bursts, V rows of two runs prefetched; Llama-2-7B shape, 16 layers, ms per token, one workgroup per head inside the fused launch vs context slices + combine: 256 -> 0.593 vs 0.618, 384 -> 0.615 vs 0.621, 512 -> 0.644 vs 0.635; profiles/r04k_*). Round 1 had measured the crossover near 256 on the two-launch form
 
     def set_attn_splits(self, n):
         """1 = one workgroup per head, n > 1 = n context slices per head + combine. Invalidates a captured graph."""
