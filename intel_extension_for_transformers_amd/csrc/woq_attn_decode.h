@@ -250,6 +250,17 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
   }
   const float m_w = wave_max_dpp(lmax);
   const int n_l = n_w + (has_new ? 1 : 0);  // entries of this wave's list
+  // round 4: the V rows of the third 16-position run are requested HERE — the K registers have just died, and the
+  // exponentials below run under the request instead of in front of it (later runs are double-buffered in the loop)
+  kv8 vnext[VU];
+  if (n_w > 32) {
+#pragma unroll
+    for (int u = 0; u < VU; ++u) {
+      const int j = 32 + g + u * GP;
+      const int tc = min(64 * (j >> 4) + 16 * wid + (j & 15), plast);
+      vnext[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
+    }
+  }
   __builtin_amdgcn_wave_barrier();
   // ---- probabilities and their sum ----
   float lsum = 0.f;
@@ -280,10 +291,14 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
 #pragma unroll
       for (int u = 0; u < VU; ++u) pv(16 + g + u * GP, vpre2[u]);
     }
-    for (int j0 = 32; j0 < n_w; j0 += 16) {  // later 16-position runs: all their rows requested, then consumed
+    for (int j0 = 32; j0 < n_w; j0 += 16) {  // later 16-position runs: run j0 + 16 is requested before run j0 is consumed
       kv8 vv[VU];
 #pragma unroll
-      for (int u = 0; u < VU; ++u) vload(j0 + g + u * GP, vv[u]);
+      for (int u = 0; u < VU; ++u) vv[u] = vnext[u];
+      if (j0 + 16 < n_w) {
+#pragma unroll
+        for (int u = 0; u < VU; ++u) vload(j0 + 16 + g + u * GP, vnext[u]);
+      }
 #pragma unroll
       for (int u = 0; u < VU; ++u) pv(j0 + g + u * GP, vv[u]);
     }

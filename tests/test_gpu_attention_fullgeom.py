@@ -119,10 +119,12 @@ def test_prefill_attention_4x2048_32_heads_vs_oracle():
     assert eng.status() == 0
 
 
-@pytest.mark.parametrize("ctx", [300, 520])
-def test_decode_step_sliced_regime_7b_attention_geometry_vs_oracle(ctx):
-    """(iii) decode steps past LONG_CTX at the 7B attention geometry: `ctx` prompt tokens, then 3 greedy steps in the
-    regime `tune_attn_for` picks (context slices per head + combine), each against the oracle."""
+@pytest.mark.parametrize("ctx,sliced", [(300, False), (520, True)])
+def test_decode_step_sliced_regime_7b_attention_geometry_vs_oracle(ctx, sliced):
+    """(iii) decode steps at a few hundred cached positions at the 7B attention geometry: `ctx` prompt tokens, then 3
+    greedy steps in the regime `tune_attn_for` picks — below LONG_CTX the one-workgroup-per-head attention inside the
+    fused qkv launch (five 16-position passes per wave at 300, three of them beyond the prefetched rows), above it context
+    slices per head + the combine launch — each against the oracle."""
     eng, oracle, cfg = build_attention_geometry(max_ctx=640)
     rng = np.random.default_rng(ctx)
     prompt = rng.integers(0, cfg["vocab"], ctx).tolist()
@@ -130,7 +132,7 @@ def test_decode_step_sliced_regime_7b_attention_geometry_vs_oracle(ctx):
     ref = oracle.forward_prompt(prompt)
     assert np.abs(got - ref).max() <= PF_TOL * np.abs(ref).max() + 1e-3
     eng.tune_attn_for(ctx + 3)
-    assert L_splits(eng) > 1
+    assert (L_splits(eng) > 1) == sliced and eng.uses_fused_attn() == (not sliced)
     nxt = int(ref.argmax())
     for j in range(3):
         assert int(eng.token.item()) == nxt
