@@ -246,7 +246,7 @@ class WoqDecoderEngine:
         return _device_view(ptr, (n_seq, self.cfg.vocab), self.device)
 
     # ---- decode attention regime -----------------------------------------------------------------------------
-    LONG_CTX = 448  # cached positions beyond which the sliced decode attention wins. Round 4 (eager bursts, V rows of two runs prefetched; Llama-2-7B shape, 16 layers, ms per token, one workgroup per head inside the fused launch vs context slices + combine: 256 -> 0.593 vs 0.618, 384 -> 0.615 vs 0.621, 512 -> 0.644 vs 0.635; profiles/r04k_*). Round 1 had measured the crossover near 256 on the two-launch form
+    LONG_CTX = 480  # cached positions beyond which the sliced decode attention wins (r04l, V runs double-buffered: 448 -> 0.617 vs 0.631, 512 -> 0.635 vs 0.634, 640 -> 0.661 vs 0.634). Round 4 (eager bursts, V rows of two runs prefetched; Llama-2-7B shape, 16 layers, ms per token, one workgroup per head inside the fused launch vs context slices + combine: 256 -> 0.593 vs 0.618, 384 -> 0.615 vs 0.621, 512 -> 0.644 vs 0.635; profiles/r04k_*). Round 1 had measured the crossover near 256 on the two-launch form
 
     def set_attn_splits(self, n):
         """1 = one workgroup per head, n > 1 = n context slices per head + combine. Invalidates a captured graph."""
