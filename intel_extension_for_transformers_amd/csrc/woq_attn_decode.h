@@ -110,44 +110,40 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
   // this wave's cached positions: list index j <-> relative position 64 (j / 16) + 16 wid + (j % 16)
   const int n_w = 16 * (pos >> 6) + max(0, min((pos & 63) - 16 * wid, 16));
   const bool has_new = incl_new && wid == 0;
-  // ---- requests that depend on `pos` only, issued before q exists (round 4: four register sets, two regimes) ----
-  // A set holds one 16-position K pass (4 lanes per position, DPL dims each) or one 16-position V run (LPR lanes per
-  // row): the same NK x 16 bytes per lane. Up to 32 positions per wave (contexts <= 128) everything the wave needs is
-  // asked for now: K passes 0, 1 -> sets 0, 1 and V runs 0, 1 -> sets 2, 3. Beyond that ("deep") the four sets first
-  // carry K passes 0..3 (256 positions per workgroup) as a rolling window — pass i + 4 is requested when pass i has been
-  // scored — and then, the K registers being dead, V runs 0..3 at once behind the score phase, again as a rolling
-  // window; the round-3 form kept two K passes and one V run in flight and paid a round trip per further 64 positions
-  // on the fused launch's tail.
+  // ---- requests that depend on `pos` only: K rows of the first score pass, V rows of the first P.V pass ----
   const int sub = lane & 3, r16 = lane >> 2;
   const int g = lane / LPR, l8 = lane % LPR;
   const int plast = max(pos - 1, 0);
-  constexpr int NK = DPL / 8;   // 16-byte pieces of a lane's share of a K row
-  constexpr int VU = 16 / GP;   // P.V passes that cover one 16-position run
-  static_assert(NK == VU, "a K pass and a V run fill the same register set");
-  kv8 r0[NK], r1[NK], r2[NK], r3[NK];
-  auto kload = [&](int i, kv8 (&kv)[NK]) {
-    const int tc = min(64 * i + 16 * wid + r16, plast);
+  kv8 kpre[DPL / 8];
+  {
+    const int tc = min(16 * wid + r16, plast);
     const kv8* kp = (const kv8*)(kcache + ((size_t)tc * kv_heads + kh) * HD + sub * DPL);
 #pragma unroll
-    for (int j = 0; j < NK; ++j) kv[j] = kp[j];
-  };
-  auto vload = [&](int run, kv8 (&vv)[VU]) {  // run = 16-position run of this wave's list
+    for (int j = 0; j < DPL / 8; ++j) kpre[j] = kp[j];
+  }
+  kv8 kb[DPL / 8];  // second score pass (positions 64 + 16 w + r): needs only `pos` as well
+  if (n_w > 16) {
+    const int tc = min(64 + 16 * wid + r16, plast);
+    const kv8* kp = (const kv8*)(kcache + ((size_t)tc * kv_heads + kh) * HD + sub * DPL);
+#pragma unroll
+    for (int j = 0; j < DPL / 8; ++j) kb[j] = kp[j];
+  }
+  constexpr int VU = 16 / GP;  // P.V passes that cover one 16-position run
+  kv8 vpre[VU];
+#pragma unroll
+  for (int u = 0; u < VU; ++u) {
+    const int tc = min(16 * wid + g + u * GP, plast);
+    vpre[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
+  }
+  // round 4: the V rows of the SECOND 16-position run too (contexts 64 .. 128 used to pay one exposed round trip for
+  // them behind the q hand-off, on the launch's tail: the 128-step bench value sat 4 % under the 20-step one)
+  kv8 vpre2[VU];
+  if (n_w > 16) {
 #pragma unroll
     for (int u = 0; u < VU; ++u) {
-      const int tc = min(64 * run + 16 * wid + g + u * GP, plast);
-      vv[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
+      const int tc = min(64 + 16 * wid + g + u * GP, plast);
+      vpre2[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
     }
-  };
-  const int n_it = (n_w + 15) >> 4;  // 16-position passes / runs of this wave
-  const bool deep = n_it > 2;
-  kload(0, r0);
-  if (n_it > 1) kload(1, r1);
-  if (!deep) {
-    vload(0, r2);
-    if (n_it > 1) vload(1, r3);
-  } else {
-    kload(2, r2);
-    if (n_it > 3) kload(3, r3);
   }
   // ---- RoPE of q (every wave for itself | wave 0 for all); wave 0 also rotates k, rounds k / v and appends them ----
   const float scale = 1.0f / sqrtf((float)HD);
@@ -215,11 +211,11 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
 #pragma unroll
   for (int i = 0; i < DPL; ++i) qreg[i] = qw[sub * DPL + i];
   float lmax = -INFINITY;
-  auto score = [&](int i, const kv8 (&kv)[NK]) {
+  auto score = [&](int i, const kv8 (&kv)[DPL / 8]) {
     const int t = 64 * i + 16 * wid + r16;
     float d = 0.f;
 #pragma unroll
-    for (int j = 0; j < NK; ++j)
+    for (int j = 0; j < DPL / 8; ++j)
 #pragma unroll
       for (int e = 0; e < 8; ++e) d = fmaf(qreg[j * 8 + e], (float)kv[j][e], d);
     d += WOQ_DPP_F32(d, 0xB1);  // quad_perm xor 1
@@ -229,26 +225,22 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
       lmax = fmaxf(lmax, d);
     }
   };
+  auto kload = [&](int i, kv8 (&kv)[DPL / 8]) {
+    const int tc = min(64 * i + 16 * wid + r16, plast);
+    const kv8* kp = (const kv8*)(kcache + ((size_t)tc * kv_heads + kh) * HD + sub * DPL);
+#pragma unroll
+    for (int j = 0; j < DPL / 8; ++j) kv[j] = kp[j];
+  };
+  const int n_it = (n_w + 15) >> 4;  // 16-position passes of this wave
   if (n_it > 0) {
-    if (!deep) {
-      score(0, r0);
-      if (n_it > 1) score(1, r1);
-    } else {  // rolling window of four passes: set i & 3 is refilled with pass i + 4 as soon as pass i is scored
-      for (int i = 0; i < n_it; i += 4) {
-        score(i, r0);
-        if (i + 4 < n_it) kload(i + 4, r0);
-        if (i + 1 < n_it) {
-          score(i + 1, r1);
-          if (i + 5 < n_it) kload(i + 5, r1);
-        }
-        if (i + 2 < n_it) {
-          score(i + 2, r2);
-          if (i + 6 < n_it) kload(i + 6, r2);
-        }
-        if (i + 3 < n_it) {
-          score(i + 3, r3);
-          if (i + 7 < n_it) kload(i + 7, r3);
-        }
+    score(0, kpre);
+    // rows of pass i + 1 are in flight while pass i is scored
+    for (int i = 1; i < n_it; i += 2) {
+      if (i + 1 < n_it) kload(i + 1, kpre);
+      score(i, kb);
+      if (i + 1 < n_it) {
+        if (i + 2 < n_it) kload(i + 2, kb);
+        score(i + 1, kpre);
       }
     }
   }
@@ -258,11 +250,16 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
   }
   const float m_w = wave_max_dpp(lmax);
   const int n_l = n_w + (has_new ? 1 : 0);  // entries of this wave's list
-  if (deep) {  // the K registers are dead: V runs 0..3 all at once, under the exponentials below
-    vload(0, r0);
-    vload(1, r1);
-    vload(2, r2);
-    if (n_it > 3) vload(3, r3);
+  // round 4: the V rows of the third 16-position run are requested HERE — the K registers have just died, and the
+  // exponentials below run under the request instead of in front of it (later runs are double-buffered in the loop)
+  kv8 vnext[VU];
+  if (n_w > 32) {
+#pragma unroll
+    for (int u = 0; u < VU; ++u) {
+      const int j = 32 + g + u * GP;
+      const int tc = min(64 * (j >> 4) + 16 * wid + (j & 15), plast);
+      vnext[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
+    }
   }
   __builtin_amdgcn_wave_barrier();
   // ---- probabilities and their sum ----
@@ -278,36 +275,32 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  auto pv = [&](int run, const kv8 (&vv)[VU]) {
-#pragma unroll
-    for (int u = 0; u < VU; ++u) {
-      const int j = 16 * run + g + u * GP;
-      const float p = j < n_w ? scw[j] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, (float)vv[u][i], acc[i]);
-    }
+  auto vload = [&](int j, kv8& vv) {
+    const int tc = min(64 * (j >> 4) + 16 * wid + (j & 15), plast);
+    vv = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
   };
-  if (n_it > 0) {
-    if (!deep) {
-      pv(0, r2);
-      if (n_it > 1) pv(1, r3);
-    } else {
-      for (int i = 0; i < n_it; i += 4) {
-        pv(i, r0);
-        if (i + 4 < n_it) vload(i + 4, r0);
-        if (i + 1 < n_it) {
-          pv(i + 1, r1);
-          if (i + 5 < n_it) vload(i + 5, r1);
-        }
-        if (i + 2 < n_it) {
-          pv(i + 2, r2);
-          if (i + 6 < n_it) vload(i + 6, r2);
-        }
-        if (i + 3 < n_it) {
-          pv(i + 3, r3);
-          if (i + 7 < n_it) vload(i + 7, r3);
-        }
+  auto pv = [&](int j, const kv8& vv) {
+    const float p = j < n_w ? scw[j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, (float)vv[i], acc[i]);
+  };
+  if (n_w > 0) {
+#pragma unroll
+    for (int u = 0; u < VU; ++u) pv(g + u * GP, vpre[u]);
+    if (n_w > 16) {
+#pragma unroll
+      for (int u = 0; u < VU; ++u) pv(16 + g + u * GP, vpre2[u]);
+    }
+    for (int j0 = 32; j0 < n_w; j0 += 16) {  // later 16-position runs: run j0 + 16 is requested before run j0 is consumed
+      kv8 vv[VU];
+#pragma unroll
+      for (int u = 0; u < VU; ++u) vv[u] = vnext[u];
+      if (j0 + 16 < n_w) {
+#pragma unroll
+        for (int u = 0; u < VU; ++u) vload(j0 + 16 + g + u * GP, vnext[u]);
       }
+#pragma unroll
+      for (int u = 0; u < VU; ++u) pv(j0 + g + u * GP, vv[u]);
     }
   }
   if (has_new && g == 0) {  // the new position
