@@ -108,10 +108,13 @@ class BaseModel:
         t_start = time.time()
         first = [None]
         n_out = [0]
-        greedy = (not config.do_sample) and config.num_beams == 1 and config.repetition_penalty in (None, 1.0)
+        # one sequence, one beam: the fused engine — greedy chains on the device; sampling (the reference's default:
+        # do_sample, temperature, top_k, top_p) and the repetition penalty pick the next token with the device sampler
+        engine_ok = config.num_beams == 1 and (config.num_return_sequences or 1) == 1 and not config.bad_words_ids \
+            and not config.force_words_ids
 
         def pieces():
-            if greedy and self.engine is not None and n_in + config.max_new_tokens <= self.engine.cfg.max_ctx:
+            if engine_ok and self.engine is not None and n_in + config.max_new_tokens <= self.engine.cfg.max_ctx:
                 yield from self._engine_stream(ids[0].tolist(), config, n_out)
             else:
                 yield from self._hf_stream(ids, config, n_out)
@@ -142,6 +145,9 @@ class BaseModel:
     def _engine_stream(self, ids, config, n_out):
         eng, tok = self.engine, self.tokenizer
         eos = tok.eos_token_id
+        if config.do_sample or (config.repetition_penalty or 1.0) != 1.0:
+            yield from self._engine_stream_sampled(ids, config, n_out)
+            return
         for s0 in range(0, len(ids), 2048):
             eng.prefill(ids[s0:s0 + 2048], start_pos=s0, greedy=True)
         eng.tune_attn_for(len(ids) + config.max_new_tokens)
@@ -159,6 +165,27 @@ class BaseModel:
                 shown = text
             if i + 1 < config.max_new_tokens:
                 eng.replay(1)
+
+    def _engine_stream_sampled(self, ids, config, n_out):
+        """The reference's default request (sampling + repetition penalty) on the fused engine: tokens are chosen on the
+        device (runtime.engine.DeviceSampler) and handed to the text stream one at a time."""
+        from ...runtime.engine import DeviceSampler, iter_sampled
+
+        eng, tok = self.engine, self.tokenizer
+        eos = tok.eos_token_id
+        sampler = DeviceSampler(do_sample=config.do_sample, temperature=config.temperature, top_k=config.top_k,
+                                top_p=config.top_p, repetition_penalty=config.repetition_penalty)
+        out, shown = [], ""
+        for new in iter_sampled(eng, ids, config.max_new_tokens, sampler, eos=() if eos is None else (eos,), burst=1):
+            for t in new:
+                if eos is not None and t == eos:
+                    continue
+                out.append(t)
+                n_out[0] += 1
+            text = tok.decode(out, skip_special_tokens=True)
+            if not text.endswith("\ufffd"):  # hold back incomplete multi-byte pieces, like TextIteratorStreamer
+                yield text[len(shown):]
+                shown = text
 
     def _hf_stream(self, ids, config, n_out):
         import torch

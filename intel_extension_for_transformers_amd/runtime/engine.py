@@ -414,6 +414,99 @@ class WoqDecoderEngine:
         return out
 
 
+class DeviceSampler:
+    """Next-token choice on the device from the engine's fp32 logits, with Hugging Face's semantics for the options the
+    reference's NeuralChat passes by default (`neural_chat/config.py:400-409`: do_sample=True, temperature 0.1, top_k 40,
+    top_p 0.75, repetition_penalty 1.1): RepetitionPenaltyLogitsProcessor over prompt + generated ids, then — when
+    sampling — TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper (min_tokens_to_keep 1) and
+    `torch.multinomial` on the softmax; argmax otherwise. Plain torch ops in HF's order (checked against the HF classes in
+    tests/test_api_cpu.py); no host synchronisation — the caller reads tokens back in bursts."""
+
+    def __init__(self, do_sample=False, temperature=1.0, top_k=0, top_p=1.0, repetition_penalty=1.0, generator=None):
+        self.do_sample = bool(do_sample)
+        self.temperature = float(temperature if temperature is not None else 1.0)
+        self.top_k = int(top_k or 0)
+        self.top_p = float(top_p if top_p is not None else 1.0)
+        self.penalty = float(repetition_penalty if repetition_penalty is not None else 1.0)
+        self.generator = generator
+        if self.do_sample and self.temperature <= 0:
+            raise ValueError("`temperature` has to be a strictly positive float when sampling")
+
+    def processed(self, logits, history):
+        """logits fp32 [vocab]; history int64 [n] (prompt + generated so far) -> the scores sampling draws from."""
+        scores = logits.clone()
+        if self.penalty != 1.0 and history.numel():
+            picked = scores[history]
+            scores[history] = torch.where(picked < 0, picked * self.penalty, picked / self.penalty)
+        if not self.do_sample:
+            return scores
+        if self.temperature != 1.0:
+            scores = scores / self.temperature
+        if self.top_k > 0:
+            k = min(self.top_k, scores.numel())
+            kth = torch.topk(scores, k).values[-1]
+            scores = scores.masked_fill(scores < kth, float("-inf"))
+        if self.top_p < 1.0:
+            sorted_scores, order = torch.sort(scores, descending=False)
+            cum = sorted_scores.softmax(-1).cumsum(-1)
+            drop = cum <= (1.0 - self.top_p)
+            drop[-1] = False  # min_tokens_to_keep = 1
+            scores = scores.masked_fill(torch.zeros_like(drop).scatter(0, order, drop), float("-inf"))
+        return scores
+
+    def __call__(self, logits, history):
+        scores = self.processed(logits, history)
+        if not self.do_sample:
+            return scores.argmax().reshape(1)
+        return torch.multinomial(scores.softmax(-1), 1, generator=self.generator)
+
+
+def iter_sampled(engine, prompt_ids, max_new_tokens, sampler, eos=(), burst=16, chunk=2048):
+    """Prompt pass + decode steps with the next token chosen by `sampler` on the device (sampling and / or repetition
+    penalty: the requests `generate`'s greedy chain does not cover). Every step is the engine's native step (logits
+    only) followed by a dozen small torch kernels; nothing synchronises until `burst` tokens are read back (1 for a
+    text stream). Yields each burst's new tokens; stops after the first id in `eos` (kept in the output, like HF)."""
+    ids = [int(t) for t in prompt_ids]
+    n = len(ids)
+    if n + max_new_tokens > engine.cfg.max_ctx:
+        raise RuntimeError("QBits: prompt (%d) + max_new_tokens (%d) exceeds the engine's max_ctx (%d)"
+                           % (n, max_new_tokens, engine.cfg.max_ctx))
+    dev = engine.device
+    hist = torch.empty(n + max_new_tokens, dtype=torch.int64, device=dev)
+    hist[:n] = torch.tensor(ids, dtype=torch.int64, device=dev)
+    for s0 in range(0, n, chunk):
+        engine.prefill(ids[s0:s0 + chunk], start_pos=s0, greedy=False)
+    engine.tune_attn_for(n + max_new_tokens)
+    eos = set(int(e) for e in eos)
+    done, made = False, 0
+    while not done and made < max_new_tokens:
+        k = min(burst, max_new_tokens - made)
+        for _ in range(k):
+            if made > 0:
+                engine.step(greedy=False)  # logits of the token just chosen, at position n + made - 1
+            tok = sampler(engine.logits, hist[:n + made])
+            hist[n + made] = tok[0]
+            engine.token.copy_(tok.to(torch.int32))
+            engine.pos.fill_(n + made)
+            made += 1
+        new = hist[n + made - k:n + made].tolist()  # the burst's one host synchronisation
+        for j, t in enumerate(new):
+            if t in eos:
+                new, done = new[:j + 1], True
+                break
+        yield new
+
+
+def generate_sampled(engine, prompt_ids, max_new_tokens, sampler, eos=(), on_tokens=None, burst=16, chunk=2048):
+    """`iter_sampled` to the end; `on_tokens(list)` receives each burst. Returns the new tokens."""
+    out = []
+    for new in iter_sampled(engine, prompt_ids, max_new_tokens, sampler, eos=eos, burst=burst, chunk=chunk):
+        out += new
+        if on_tokens is not None:
+            on_tokens(new)
+    return out
+
+
 def _device_view(ptr, shape, device, typestr="<f4"):
     """torch view of engine-owned device memory (no copy) through the CUDA array interface."""
 

@@ -313,9 +313,19 @@ def _engine_generate(self, inputs=None, generation_config=None, **kwargs):
     ids = inputs if inputs is not None else kwargs.get("input_ids")
     gc = generation_config if generation_config is not None else self.generation_config
     opt = lambda k, d=None: kwargs[k] if k in kwargs else getattr(gc, k, d)  # noqa: E731
+    # sampling (temperature / top-k / top-p) and the repetition penalty — the reference's NeuralChat defaults
+    # (neural_chat/config.py:400-409) — ride the engine too, the next token chosen on the device (runtime.engine.
+    # DeviceSampler: HF's processors / warpers in HF's order); any other logits processing keeps HF's loop
+    sampled = bool(opt("do_sample", False)) or (opt("repetition_penalty", 1.0) or 1.0) != 1.0
+    plain_sampling = ((opt("typical_p", 1.0) or 1.0) == 1.0 and not opt("epsilon_cutoff", 0.0) and not opt("eta_cutoff", 0.0)
+                      and opt("min_p") is None and opt("penalty_alpha") is None
+                      and (opt("encoder_repetition_penalty", 1.0) or 1.0) == 1.0 and not opt("renormalize_logits", False)
+                      and all(opt(k) is None for k in ("exponential_decay_length_penalty", "suppress_tokens",
+                                                       "begin_suppress_tokens", "forced_bos_token_id", "forced_eos_token_id",
+                                                       "sequence_bias", "guidance_scale")))
     simple = (torch.is_tensor(ids) and ids.dim() == 2 and ids.shape[0] == 1 and ids.shape[1] >= 1
-              and not opt("do_sample", False) and (opt("num_beams", 1) or 1) == 1
-              and (opt("repetition_penalty", 1.0) or 1.0) == 1.0 and (opt("num_return_sequences", 1) or 1) == 1
+              and (not sampled or plain_sampling) and (opt("num_beams", 1) or 1) == 1
+              and (opt("num_return_sequences", 1) or 1) == 1
               and not opt("no_repeat_ngram_size", 0) and not opt("bad_words_ids") and not opt("force_words_ids")
               and not opt("min_new_tokens", 0) and not opt("min_length", 0)
               and not any(kwargs.get(k) is not None for k in ("logits_processor", "stopping_criteria",
@@ -355,8 +365,31 @@ def _engine_generate(self, inputs=None, generation_config=None, **kwargs):
         streamer.put(ids.cpu())
     import time
 
+    def run_sampled():
+        """prompt pass + steps whose next token the device sampler picks; returns (tokens, per-token latency)."""
+        from ...runtime.engine import DeviceSampler, generate_sampled
+
+        sampler = DeviceSampler(do_sample=opt("do_sample", False), temperature=opt("temperature", 1.0),
+                                top_k=opt("top_k", 0), top_p=opt("top_p", 1.0),
+                                repetition_penalty=opt("repetition_penalty", 1.0))
+        latency, mark = [], [time.time()]
+
+        def on_tokens(new):
+            now = time.time()
+            latency.extend([(now - mark[0]) / len(new)] * len(new))
+            mark[0] = now
+            if streamer is not None:
+                for t in new:
+                    streamer.put(torch.tensor([t]))
+
+        out = generate_sampled(eng, prompt, max_new, sampler, eos=eos, on_tokens=on_tokens,
+                               burst=1 if streamer is not None else 16)
+        return out, latency
+
     def run_once():
         """prompt pass + chained decode steps; returns (tokens, per-token latency)."""
+        if sampled:
+            return run_sampled()
         latency = []
         tic = time.time()
         for s0 in range(0, n_in, 2048):

@@ -330,3 +330,50 @@ def test_matmul_kbit_seam_host_logic(monkeypatch):
     with pytest.raises(NotImplementedError):
         F.matmul_kbit(torch.zeros(1, 4), torch.zeros(4, dtype=torch.int8), None, torch.zeros(1, 4), "fp32", "int4_clip",
                       "fp32", "sym", do_dequant=True)
+
+
+def test_device_sampler_matches_hf_logits_processors():
+    """runtime.engine.DeviceSampler (the next-token choice of engine-backed sampling requests) against Hugging Face's own
+    RepetitionPenaltyLogitsProcessor / TemperatureLogitsWarper / TopKLogitsWarper / TopPLogitsWarper in HF's order, on
+    the reference's NeuralChat defaults (neural_chat/config.py:400-409) and a few other settings: identical processed
+    scores (same -inf pattern, same finite values), and identical draws under the same RNG state. Pure torch: runs on
+    the CPU."""
+    import torch
+    from transformers import (LogitsProcessorList, RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper,
+                              TopKLogitsWarper, TopPLogitsWarper)
+
+    from intel_extension_for_transformers_amd.runtime.engine import DeviceSampler
+
+    g = torch.Generator().manual_seed(0)
+    vocab = 500
+    for kw in (dict(do_sample=True, temperature=0.1, top_k=40, top_p=0.75, repetition_penalty=1.1),
+               dict(do_sample=True, temperature=0.8, top_k=0, top_p=0.9, repetition_penalty=1.0),
+               dict(do_sample=True, temperature=1.0, top_k=5, top_p=1.0, repetition_penalty=1.3),
+               dict(do_sample=False, temperature=1.0, top_k=50, top_p=1.0, repetition_penalty=1.2)):
+        procs = LogitsProcessorList()
+        if kw["repetition_penalty"] != 1.0:
+            procs.append(RepetitionPenaltyLogitsProcessor(kw["repetition_penalty"]))
+        if kw["do_sample"]:
+            if kw["temperature"] != 1.0:
+                procs.append(TemperatureLogitsWarper(kw["temperature"]))
+            if kw["top_k"]:
+                procs.append(TopKLogitsWarper(kw["top_k"]))
+            if kw["top_p"] < 1.0:
+                procs.append(TopPLogitsWarper(kw["top_p"]))
+        sampler = DeviceSampler(**kw)
+        for _ in range(5):
+            logits = torch.randn(vocab, generator=g) * 3
+            hist = torch.randint(0, vocab, (37,), generator=g)
+            want = procs(hist[None], logits[None].clone())[0]
+            got = sampler.processed(logits, hist)
+            assert torch.equal(torch.isinf(got), torch.isinf(want))
+            fin = ~torch.isinf(want)
+            assert torch.allclose(got[fin], want[fin], rtol=1e-6, atol=1e-6)
+            if kw["do_sample"]:
+                torch.manual_seed(7)
+                a = torch.multinomial(want.softmax(-1), 1)
+                torch.manual_seed(7)
+                b = sampler(logits, hist)
+                assert int(a) == int(b)
+            else:
+                assert int(sampler(logits, hist)) == int(want.argmax())

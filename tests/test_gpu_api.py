@@ -259,8 +259,9 @@ def _tiny_tokenizer(path, vocab_size):
 def test_neural_chat_build_chatbot_predict_and_stream(tmp_path):
     """SURVEY §8(f)3 / north_star: PipelineConfig(optimization_config=RtnConfig) -> build_chatbot -> predict /
     predict_stream. Greedy requests ride the fused engine (prompt pass + graph-replayed decode); the streamed pieces
-    concatenate to predict()'s text and match the HF module path's greedy continuation; sampling requests take the
-    model.generate + TextIteratorStreamer route; return_stats appends the reference's stats table."""
+    concatenate to predict()'s text and match the HF module path's greedy continuation; sampling requests (the reference's
+    default) ride the engine with the device sampler, beam requests take the model.generate + TextIteratorStreamer route;
+    return_stats appends the reference's stats table."""
     from intel_extension_for_transformers_amd.neural_chat import GenerationConfig, PipelineConfig, build_chatbot
     from intel_extension_for_transformers_amd.transformers import RtnConfig
 
@@ -287,11 +288,29 @@ def test_neural_chat_build_chatbot_predict_and_stream(tmp_path):
     finally:
         bot.engine = bot_engine
         bot.model._woq_engine_off = False
-    # sampling -> HF generate + streamer thread; stats block in the v2 table format
-    scfg = GenerationConfig(max_new_tokens=5, do_sample=True, temperature=0.7, return_stats=True)
-    out = list(bot.predict_stream(q, config=scfg)[0])
+    # sampling (the reference's DEFAULT GenerationConfig: do_sample, temperature 0.1, top_k 40, top_p 0.75, repetition
+    # penalty 1.1) rides the engine too since round 4 (device sampler); stats block in the v2 table format
+    scfg = GenerationConfig(max_new_tokens=5, return_stats=True)
+    assert scfg.do_sample and scfg.repetition_penalty == 1.1
+
+    def no_hf(*a, **k):
+        raise AssertionError("a default NeuralChat request must not fall back to HF's loop")
+
+    hf_stream, bot._hf_stream = bot._hf_stream, no_hf
+    try:
+        out = list(bot.predict_stream(q, config=scfg)[0])
+    finally:
+        bot._hf_stream = hf_stream
     joined = "".join(out)
     assert "| Key" in joined and "msecond_per_token" in joined and "input_token_len" in joined
+    assert len(joined.split("| Key")[0].split()) == 5
+    # temperature 0.1 over a random-init model is all but greedy: with top_k = 1 it IS the penalised greedy chain
+    g1 = bot.predict(q, config=GenerationConfig(max_new_tokens=6, top_k=1))
+    g2 = bot.predict(q, config=GenerationConfig(max_new_tokens=6, do_sample=False))
+    assert g1 == g2
+    # beams keep HF's generate + streamer thread
+    bcfg = GenerationConfig(max_new_tokens=4, do_sample=False, num_beams=2, repetition_penalty=1.0)
+    assert len(bot.predict(q, config=bcfg).split()) == 4
 
 
 def test_from_pretrained_bits8_int8_weights(tmp_path):
@@ -686,6 +705,57 @@ def test_desc_act_checkpoint_save_load_round_trip(tmp_path, layout):
     for (na, ma), (nb, mb) in zip(model.named_modules(), again.named_modules()):
         if hasattr(ma, "recover_qparms_kn"):
             assert torch.equal(ma.weight.data, mb.weight.data), na
+
+
+def test_generate_sampling_and_repetition_penalty_ride_the_engine():
+    """The reference's NeuralChat default request samples (do_sample=True, temperature 0.1, top_k 40, top_p 0.75,
+    repetition_penalty 1.1 — neural_chat/config.py:400-409); such requests now run on the fused engine with the next
+    token chosen on the device (runtime.engine.DeviceSampler) instead of HF's loop over the per-linear modules.
+    Deterministic cases against HF's own generate over the quantised modules: repetition penalty without sampling
+    (token for token), sampling with top_k = 1 (== greedy with the penalty); sampling proper: reproducible under a seed,
+    every token inside the top-k set HF's processors leave at that step, eos honoured, streamer fed."""
+    from intel_extension_for_transformers_amd.transformers import AutoModelForCausalLM, RtnConfig
+
+    fp = _tiny_llama()
+    fp.generation_config.eos_token_id = None
+    q = AutoModelForCausalLM.from_pretrained(copy.deepcopy(fp), quantization_config=RtnConfig(
+        bits=4, group_size=32, compute_dtype="fp32", scale_dtype="fp32"), device_map="cuda")
+    ids = torch.tensor([[5, 9, 33, 2, 71, 9, 9]], device="cuda")
+    hf = q._woq_hf_generate(ids, max_new_tokens=12, do_sample=False, repetition_penalty=1.3, pad_token_id=0)
+    eng_out = q.generate(ids, max_new_tokens=12, do_sample=False, repetition_penalty=1.3)
+    assert hasattr(q, "woq_engine") and torch.equal(eng_out, hf)
+    top1 = q.generate(ids, max_new_tokens=12, do_sample=True, top_k=1, temperature=0.7, repetition_penalty=1.3)
+    assert torch.equal(top1, hf)
+    torch.manual_seed(11)
+    a = q.generate(ids, max_new_tokens=24, do_sample=True, temperature=0.9, top_k=8, top_p=0.95, repetition_penalty=1.1)
+    torch.manual_seed(11)
+    b = q.generate(ids, max_new_tokens=24, do_sample=True, temperature=0.9, top_k=8, top_p=0.95, repetition_penalty=1.1)
+    assert torch.equal(a, b) and a.shape == (1, ids.shape[1] + 24)
+    # every sampled token is one of the 8 best of HF's penalised scores for its prefix (module-path logits)
+    from transformers import RepetitionPenaltyLogitsProcessor
+
+    for i in range(ids.shape[1], a.shape[1]):
+        lg = q(a[:, :i]).logits[0, -1].float()
+        sc = RepetitionPenaltyLogitsProcessor(1.1)(a[:, :i], lg[None].clone())[0]
+        assert int(a[0, i]) in torch.topk(sc, 10).indices.tolist(), i  # 8 + slack for near-ties between the two paths
+    first = int(hf[0, ids.shape[1]])
+    short = q.generate(ids, max_new_tokens=12, do_sample=False, repetition_penalty=1.3, eos_token_id=first)
+    assert short.shape[1] == ids.shape[1] + 1
+
+    class Collect:
+        def __init__(self):
+            self.items, self.ended = [], False
+
+        def put(self, v):
+            self.items.append(v.reshape(-1).tolist())
+
+        def end(self):
+            self.ended = True
+
+    st = Collect()
+    q.generate(ids, max_new_tokens=5, do_sample=False, repetition_penalty=1.3, streamer=st)
+    assert st.ended and st.items[0] == ids[0].tolist() and sum(st.items[1:], []) == hf[0, 7:12].tolist()
+    assert q.woq_engine.status() == 0
 
 
 def test_plain_c_client_device_leg(tmp_path):
