@@ -395,9 +395,9 @@ class WoqDecoderEngine:
         L.check(L.lib().woq_engine_set_allreduce(self._h, ctypes.cast(None, L.ALLREDUCE_FN), None))
         self._allreduce_cb = None
 
-    def generate(self, prompt_ids, max_new_tokens, chunk=2048):
-        """Greedy decode: the prompt goes through the prefill pass in chunks of `chunk` tokens, then steps are
-        chained on the device."""
+    def generate(self, prompt_ids, max_new_tokens, chunk=2048, burst=16):
+        """Greedy decode: the prompt goes through the prefill pass in chunks of `chunk` tokens, then bursts of `burst`
+        steps chained on the device (one host read of the token log per burst)."""
         out = []
         ids = [int(t) for t in prompt_ids]
         if len(ids) + max_new_tokens > self.cfg.max_ctx:  # the kernels index the KV cache by position, unchecked
@@ -406,11 +406,16 @@ class WoqDecoderEngine:
         for s0 in range(0, len(ids), chunk):
             self.prefill(ids[s0:s0 + chunk], start_pos=s0, greedy=True)
         self.tune_attn_for(len(ids) + max_new_tokens)
-        for _ in range(max_new_tokens):
-            out.append(int(self.token.item()))
-            if len(out) == max_new_tokens:
-                break
-            self.step(greedy=True)
+        if max_new_tokens < 1:
+            return out
+        out.append(int(self.token.item()))  # the prompt pass's token
+        self.prepare_decode(greedy=True)
+        log = self.token_log()
+        while len(out) < max_new_tokens:
+            k = min(int(burst), max_new_tokens - len(out))
+            p0 = len(ids) + len(out) - 1  # position the next step feeds
+            self.replay(k)
+            out += log[p0:p0 + k].tolist()
         return out
 
 
