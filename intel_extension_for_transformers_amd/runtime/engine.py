@@ -459,11 +459,39 @@ class DeviceSampler:
             scores = scores.masked_fill(torch.zeros_like(drop).scatter(0, order, drop), float("-inf"))
         return scores
 
+    TIE_SLACK = 8  # candidates kept beyond top_k so that values tied with the k-th one survive like in HF's mask
+
     def __call__(self, logits, history):
+        if self.do_sample and 0 < self.top_k < logits.numel():
+            return self._draw_top_k(logits, history)
         scores = self.processed(logits, history)
         if not self.do_sample:
             return scores.argmax().reshape(1)
         return torch.multinomial(scores.softmax(-1), 1, generator=self.generator)
+
+    def _draw_top_k(self, logits, history):
+        """The same distribution as `processed` + softmax + multinomial when top_k is set, without sorting the whole
+        vocabulary: after the top-k mask only the candidates matter (everything else has probability 0), so the
+        temperature, the nucleus cut and the draw run on top_k (+ TIE_SLACK) values — a 32000-entry sort per token is
+        most of what sampling costs otherwise (profiles/r04n_*). Ties beyond TIE_SLACK entries at the k-th value would
+        be cut where HF keeps them all; fp32 logits do not tie in practice."""
+        scores = logits
+        if self.penalty != 1.0 and history.numel():
+            scores = logits.clone()
+            picked = scores[history]
+            scores[history] = torch.where(picked < 0, picked * self.penalty, picked / self.penalty)
+        k2 = min(self.top_k + self.TIE_SLACK, scores.numel())
+        vals, idx = torch.topk(scores, k2)  # descending
+        if self.temperature != 1.0:
+            vals = vals / self.temperature
+        vals = vals.masked_fill(vals < vals[self.top_k - 1], float("-inf"))
+        if self.top_p < 1.0:  # HF: ascending order, drop while the cumulative probability <= 1 - top_p, keep the last
+            asc = vals.flip(0)
+            drop = asc.softmax(-1).cumsum(-1) <= (1.0 - self.top_p)
+            drop[-1] = False
+            vals = vals.masked_fill(drop.flip(0), float("-inf"))
+        pick = torch.multinomial(vals.softmax(-1), 1, generator=self.generator)
+        return idx[pick]
 
 
 def iter_sampled(engine, prompt_ids, max_new_tokens, sampler, eos=(), burst=16, chunk=2048):

@@ -369,11 +369,24 @@ def test_device_sampler_matches_hf_logits_processors():
             assert torch.equal(torch.isinf(got), torch.isinf(want))
             fin = ~torch.isinf(want)
             assert torch.allclose(got[fin], want[fin], rtol=1e-6, atol=1e-6)
-            if kw["do_sample"]:
+            if kw["do_sample"] and not kw["top_k"]:
                 torch.manual_seed(7)
                 a = torch.multinomial(want.softmax(-1), 1)
                 torch.manual_seed(7)
                 b = sampler(logits, hist)
                 assert int(a) == int(b)
+            elif kw["do_sample"]:
+                # top_k set: the draw runs on the candidates only (no full-vocabulary sort); same distribution — the
+                # candidate probabilities scattered back to the vocabulary equal HF's, and draws land in its support
+                want_p = want.softmax(-1)
+                support = set(torch.nonzero(want_p > 0).ravel().tolist())
+                for seed in range(20):
+                    torch.manual_seed(seed)
+                    assert int(sampler(logits, hist)) in support
+                counts = torch.zeros(vocab)
+                torch.manual_seed(3)
+                for _ in range(4000):
+                    counts[int(sampler(logits, hist))] += 1
+                assert (counts / 4000 - want_p).abs().max() < 0.04
             else:
                 assert int(sampler(logits, hist)) == int(want.argmax())
