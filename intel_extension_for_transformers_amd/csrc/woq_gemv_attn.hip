@@ -79,8 +79,11 @@ bool gemv_xq_attn_supported(const woq_blob_header& h, int heads, int kv_heads, i
     const int tpg = h.group / WOQ_TILE_K;
     if (tpg < 1 || (tpg & (tpg - 1)) != 0) return false;
   }
-  if (heads != kv_heads || head_dim != 128 || splits > 1 || window != 0) return false;
-  if (h.N != 3 * heads * head_dim) return false;
+  // round 4: grouped-query shapes (Mistral-7B: 32 query / 8 kv heads) and a sliding window are taken as well — the
+  // attention body always handled both (kh = h / rep, re-based cache pointers); round 3 simply had not tested them here
+  if (kv_heads < 1 || heads % kv_heads != 0 || head_dim != 128 || splits > 1) return false;
+  if (h.N != (heads + 2 * kv_heads) * head_dim) return false;
+  (void)window;
   if (kv_dtype != WOQ_F16 && kv_dtype != WOQ_BF16 && kv_dtype != WOQ_FP8_E4M3) return false;
   // every workgroup of the launch gets max(attention LDS, GEMV LDS): the 768 strip workgroups (three per CU, four on
   // the CUs that also hold an attention workgroup) inherit the attention's score buffer, which grows with max_ctx.
@@ -133,7 +136,7 @@ static int launch_fused_kv(const FusedLaunch& a, int smode, bool asym, bool s32,
   return woq::fail("QBits: bad fused qkv + attention configuration");
 }
 
-// qkv_g ({tag, fp32} granules [3 * heads * 128]) = xin . W_qkv_deq * rsqrt(mean(x^2) + eps); per head, as its granules
+// qkv_g ({tag, fp32} granules [(heads + 2 kv_heads) * 128]) = xin . W_qkv_deq * rsqrt(mean(x^2) + eps); per head, as its granules
 // arrive: RoPE, KV append at *pos, attention over the cache -> attn_out (+ its XQ form).
 int launch_gemv_xq_attn(const XqPtrs& xin, const void* blob, const woq_blob_header& h, unsigned long long* qkv_g,
                         const float* ssq_in, float eps, const unsigned int* seq, int layer, int* status, void* kcache,

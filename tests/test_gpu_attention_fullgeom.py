@@ -226,3 +226,40 @@ def test_mistral_geometry_chunked_8k_window_vs_oracle(kv_dtype):
     assert np.abs(one - chunked).max() <= (3e-2 if fp8 else 2e-3) * np.abs(chunked).max() + 1e-4
     frac = float((np.abs(k1 - kc) > (2.0 ** -3 if fp8 else 2.0 ** -9) * np.abs(kc) + 2e-3 * np.abs(kc).max()).mean())
     assert frac <= (2e-3 if fp8 else 0.0), frac  # fp8: a value on a rounding boundary may land on the neighbour code
+
+
+@pytest.mark.parametrize("kv_dtype,window", [(torch.float16, 4096), (torch.float16, 64), (torch.float8_e4m3fn, 4096)])
+def test_fused_launch_takes_grouped_query_and_window_shapes(kv_dtype, window):
+    """Round 4: the fused qkv + attention launch (csrc/woq_gemv_attn.hip) also serves grouped-query shapes and a sliding
+    window (Mistral-7B: 32 query / 8 kv heads, hidden 4096) — round 3 admitted multi-head, window-less models only.
+    After a 150-token prompt: greedy steps through the fused launch, bit-identical (logits and tokens) to the same engine
+    on separate launches, eager and as graph replays; with the fp16 cache also against the oracle (window 64 < context:
+    the window's lower edge moves with every step)."""
+    eng, oracle, cfg = build_attention_geometry(kv_heads=8, window=window, kv_dtype=kv_dtype, max_ctx=512)
+    rng = np.random.default_rng(61)
+    prompt = rng.integers(0, cfg["vocab"], 150).tolist()
+    out = {}
+    for mode in ("separate", "fused"):
+        eng.set_fuse_attn(mode == "fused")
+        assert eng.uses_fused_attn() == (mode == "fused")
+        eng.prefill(prompt, greedy=True)
+        logs = []
+        for _ in range(5):
+            eng.step(greedy=True)
+            logs.append(eng.logits.clone())
+        eng.capture(greedy=True)
+        eng.replay_graph(12)
+        torch.cuda.synchronize()
+        logs.append(eng.logits.clone())
+        out[mode] = (torch.stack(logs), eng.token_log()[150:168].clone())
+    assert eng.status() == 0
+    assert torch.equal(out["fused"][0], out["separate"][0]) and torch.equal(out["fused"][1], out["separate"][1])
+    if kv_dtype == torch.float16:
+        ref = oracle.forward_prompt(prompt)
+        nxt = int(ref.argmax())
+        for j in range(5):
+            ref = oracle.forward_token(nxt, 150 + j)
+            g = out["fused"][0][j].cpu().numpy()
+            assert np.abs(g - ref).max() <= PF_TOL * np.abs(ref).max() + 1e-3, j
+            nxt = int(ref.argmax())
+            assert int(out["fused"][1][j + 1]) == nxt
