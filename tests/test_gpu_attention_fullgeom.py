@@ -262,4 +262,4 @@ def test_fused_launch_takes_grouped_query_and_window_shapes(kv_dtype, window):
             g = out["fused"][0][j].cpu().numpy()
             assert np.abs(g - ref).max() <= PF_TOL * np.abs(ref).max() + 1e-3, j
             nxt = int(ref.argmax())
-            assert int(out["fused"][1][j + 1]) == nxt
+            assert int(out["fused"][1][j]) == nxt  # log[150 + j] = the token the step feeding position 150 + j produced
