@@ -5,9 +5,10 @@
 
 A "step" is one batch-1 greedy decode token, weights synthetic (random-init, no checkpoints / network) and resident in
 HBM when the timed region starts; barrier + synchronize on both sides, max over ranks, ONE JSON line from rank 0.
-The K timed steps are issued as ONE eager burst (woq_engine_steps: K x ~131 launches back to back, token / position
-chained on the device); `--graph` times K replays of the captured hipGraph instead — measured ~1 us per kernel boundary
-slower on MI355X / ROCm 7 (profiles/r04g_graph_vs_eager_steps.txt); the N = 1 line reports both (`launch_modes`).
+The K timed steps are K replays of the captured hipGraph on the current stream (token / position chained on the device,
+no host work per token); `--eager` times ONE eager burst instead (woq_engine_steps: K x ~131 launches back to back) — the
+same device time since round 4 found and removed what made graph replays ~1 us per kernel boundary slower (cross-stream
+event waits in front of the replay, profiles/r04ab_stream_mode_probe.txt); the N = 1 line reports both (`launch_modes`).
 
 Which workload (`--workload auto`, the default):
   * N = 1 on a one-GPU box  -> BASELINE.json configs[1]: Llama-2-7B int4 sym g128 (the configuration the metric is
@@ -276,7 +277,8 @@ def launch_structures(eng, cfg, args):
         eng.set_persist(False)
         return {"persistent_launch": None, "note": "outside the persistent launch's scope on this model / device"}
     feed_prompt(eng, cfg["vocab"], args.prompt)
-    el = timed(lambda n: eng.run(n), args.steps, args.warmup, torch.cuda.synchronize, condition=(eng, None))
+    eng.capture(greedy=True)
+    el = timed(eng.replay_graph, args.steps, args.warmup, torch.cuda.synchronize, condition=(eng, None))
     status = eng.status()
     eng.set_persist(False)
     return {"persistent_launch": {"tokens_per_s": args.steps / el, "ms_per_step": el * 1e3 / args.steps,
@@ -610,15 +612,16 @@ def decode_entry(name, cfg, eng, steps, warmup, group, asym, ctx_note, kv_bytes_
     def fence():
         torch.cuda.synchronize()
 
-    # eager bursts (runtime/engine.py LAUNCH). Three timed regions from the same cache state, the median reported: an
-    # eagerly issued burst feels box hiccups the replayed graph does not (one 64-step region in r04zz read 586 tokens/s
-    # between two visits' 786-800 for the same row); the headline keeps the contract's single region
+    # graph replays on the current stream (runtime/engine.py LAUNCH). Three timed regions from the same cache state, the
+    # median reported: one 64-step region of an eagerly issued burst read 586 tokens/s in r04zz between two visits'
+    # 786-800 for the same row (a ~28 ms stall); the headline keeps the contract's single region
+    eng.capture(greedy=True)
     tok0, pos0 = eng.token.clone(), eng.pos.clone()
     regions = []
     for r in range(3):
         eng.token.copy_(tok0)
         eng.pos.copy_(pos0)
-        regions.append(timed(eng.run, steps, warmup, fence, condition=(eng, None) if r == 0 else None) / steps)
+        regions.append(timed(eng.replay_graph, steps, warmup, fence, condition=(eng, None) if r == 0 else None) / steps)
         if r == 0:
             cond = dict(LAST_CONDITIONING)
     dt = sorted(regions)[1]
@@ -722,7 +725,7 @@ def tp_point(args, cfg, rank, world, dist, steps, warmup, as_extra=False):
             dec.step(greedy=greedy, return_logits=False)
 
     feed_prompt(eng, cfg["vocab"], args.prompt, step=step)
-    use_graph = args.graph and (world == 1 or comm is not None)
+    use_graph = not args.no_graph and (world == 1 or comm is not None)
     native = world == 1 or comm is not None  # the whole token (exchange included) is one native call
     if use_graph:
         eng.capture(greedy=True)
@@ -796,10 +799,10 @@ def main():
     ap.add_argument("--no-70b", action="store_true", help="skip the 70B single-GPU point of extra_configs")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-structures", action="store_true", help="skip other_launch_structures (the persistent launch)")
-    ap.add_argument("--graph", action="store_true",
-                    help="time hipGraph replays of the captured step instead of eager bursts (round 3's form; ~1 us per "
-                         "kernel boundary slower, profiles/r04g_graph_vs_eager_steps.txt)")
-    ap.add_argument("--no-graph", action="store_true", help="(accepted for compatibility: eager bursts are the default)")
+    ap.add_argument("--graph", action="store_true", help="(the default: replays of the captured hipGraph on the current stream)")
+    ap.add_argument("--no-graph", "--eager", dest="no_graph", action="store_true",
+                    help="time eager bursts (one native call issuing every launch) instead of graph replays; same device "
+                         "time (profiles/r04ab_stream_mode_probe.txt), but the host has to keep ahead of the device")
     ap.add_argument("--condition-ms", type=float, default=800.0,
                     help="untimed replays before the warm-up steps so that sclk has left its idle ramp (0 = off)")
     ap.add_argument("--host-allreduce", action="store_true", help="N > 1: force the RCCL host-driven transport")
@@ -885,7 +888,7 @@ def main():
     eng = build_engine(cfg, max_ctx=max_ctx, max_batch=max(1, args.prefill_seqs) if want_prefill else 1,
                        layers=cfg["layers"])
     feed_prompt(eng, cfg["vocab"], args.prompt)
-    use_graph = args.graph and not args.no_graph
+    use_graph = not args.no_graph
     if use_graph:
         eng.capture(greedy=True)
     run = eng.replay_graph if use_graph else eng.run  # eng.run(n): n steps issued eagerly by one native call
@@ -900,13 +903,19 @@ def main():
         eng.capture(greedy=True)
     other = eng.run if use_graph else eng.replay_graph
     el2 = timed(other, args.steps, args.warmup, torch.cuda.synchronize, condition=(eng, None))
+    feed_prompt(eng, cfg["vocab"], args.prompt)
+    eng.capture(greedy=True)
+    el3 = timed(eng.replay_graph_round3, args.steps, args.warmup, torch.cuda.synchronize, condition=(eng, None))
     launch_modes = {"eager_bursts_tokens_per_s": args.steps / (el2 if use_graph else elapsed),
                     "hipgraph_replay_tokens_per_s": args.steps / (elapsed if use_graph else el2),
+                    "hipgraph_replay_behind_cross_stream_waits_tokens_per_s": args.steps / el3,
                     "headline": "hipgraph_replay" if use_graph else "eager_bursts",
-                    "note": "the same kernels and device-side token chain either way; a replayed hipGraph pays ~1 us more "
-                            "per kernel boundary than consecutive launches on one stream (MI355X, ROCm 7.0 runtime; "
-                            "profiles/r04g_graph_vs_eager_steps.txt). Eager bursts cost ~0.4 ms of host launch calls per "
-                            "token, issued ahead of the device"}
+                    "note": "the same kernels and device-side token chain either way, and the same device time since the "
+                            "graph is launched on the caller's stream: through round 3 it was replayed on the engine's "
+                            "capture stream behind cross-stream event waits, which cost every kernel boundary ~1 us "
+                            "(1.17 vs 1.04 ms per token; profiles/r04g_graph_vs_eager_steps.txt found the gap, "
+                            "profiles/r04ab_stream_mode_probe.txt its cause). Eager bursts cost ~0.34 ms of host launch "
+                            "calls per token, issued ahead of the device; graph replays none"}
     feed_prompt(eng, cfg["vocab"], args.prompt)
     structures = launch_structures(eng, cfg, args) if not args.no_structures else None
     qbytes = algorithmic_bytes_per_token(cfg)

@@ -244,8 +244,9 @@ WOQ_API int woq_engine_uses_xq(woq_engine* e);
 WOQ_API int woq_engine_capture(woq_engine* e, int greedy, void* stream);
 WOQ_API int woq_engine_replay(woq_engine* e, int n, void* stream);
 /* `n` decode steps issued eagerly back to back (no graph, no host synchronisation; with greedy != 0 the token /
- * position chain on the device like a replayed graph). The faster way to run a burst on MI355X / ROCm 7: ~1 us less
- * per kernel boundary than hipGraphLaunch of the captured step (profiles/r04g_graph_vs_eager_steps.txt). */
+ * position chain on the device like a replayed graph). Same device time as woq_engine_replay on the same stream; costs
+ * the host ~2.6 us per launch. (Round 4 note: graph replays looked ~1 us per kernel boundary slower until their launch
+ * was moved off a stream that sat behind cross-stream event waits — profiles/r04ab_stream_mode_probe.txt.) */
 WOQ_API int woq_engine_steps(woq_engine* e, int n, int greedy, void* stream);
 /* tensor-parallel seam: when set, the engine calls `fn(user, buf_dev, count_f32, stream)` after
  * o_proj and after down_proj (row-parallel partial sums -> sum over ranks). The Python host binds it

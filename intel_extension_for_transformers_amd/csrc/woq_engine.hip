@@ -841,10 +841,10 @@ int woq_engine_capture(woq_engine* e, int greedy, void* stream) {
 }
 
 // n decode steps issued eagerly, back to back, no graph: the greedy token / position chain on the device exactly as in
-// a replayed graph, and the host stays ahead of the GPU (~130 launches of 2-4 us host time against ~1 ms of device
-// time per 7B token). Measured FASTER than hipGraphLaunch of the captured step by ~1 us per kernel launch (round 4,
-// profiles/r04g_graph_vs_eager_steps.txt: Llama-2-7B 1.045 vs 1.178 ms per token, Mistral-7B 16 layers at 8k 0.760 vs
-// 0.870) — the graph's kernel nodes pay a heavier boundary than consecutive launches on one stream.
+// a replayed graph, and the host stays ahead of the GPU (~131 launches of ~2.6 us host time against ~1 ms of device
+// time per 7B token). Same device time as hipGraphLaunch of the captured step on the same stream (1.04 ms per
+// Llama-2-7B token either way, profiles/r04ab_stream_mode_probe.txt); what made graph replays 12 % slower through
+// round 3 was the stream they were launched on (behind cross-stream event waits), not the graph.
 int woq_engine_steps(woq_engine* e, int n, int greedy, void* stream) {
   WOQ_TRY
   WOQ_CHECK(e && e->embed && e->lm_head, "QBits: engine head not set");

@@ -114,12 +114,15 @@ class WoqDecoderEngine:
     def step(self, greedy=True):
         L.check(L.lib().woq_engine_step(self._h, int(greedy), L.stream_ptr()))
 
-    # How a burst of decode steps is issued. "eager" (default since round 4): `n` steps back to back through ONE native
-    # call, no graph — measured ~1 us per kernel boundary faster than replaying the captured hipGraph on MI355X / ROCm 7
-    # (Llama-2-7B 1.045 vs 1.178 ms per token, profiles/r04g_graph_vs_eager_steps.txt); the host stays ahead of the
-    # device (~0.4 ms of launch calls per 7B token). "graph": hipGraphLaunch of the captured step (no host work per
-    # token at all — the right choice when the host is busy or slow). WOQ_ENGINE_LAUNCH=graph|eager picks the default.
-    LAUNCH = os.environ.get("WOQ_ENGINE_LAUNCH", "eager")
+    # How a burst of decode steps is issued: "graph" = hipGraphLaunch of the captured step on the CALLER'S stream (no
+    # host work per token: immune to host jitter), "eager" = `n` steps issued back to back by one native call
+    # (`woq_engine_steps`; ~0.34 ms of launch calls per 7B token, ahead of the device). Same kernels, same device time:
+    # 1.04 ms per Llama-2-7B token either way (profiles/r04ab_stream_mode_probe.txt). What made the replayed graph 12 %
+    # slower through round 3 (1.17 ms) was not the graph but the way it was launched: on the engine's capture stream,
+    # bracketed by `wait_stream` in both directions — after a cross-stream event wait every kernel boundary of the
+    # following launches on that stream costs ~1 us more. Round 4 first switched to eager bursts (profiles/r04g_*), then
+    # found the cause; the graph is launched on the current stream now. WOQ_ENGINE_LAUNCH=graph|eager picks the default.
+    LAUNCH = os.environ.get("WOQ_ENGINE_LAUNCH", "graph")
 
     @property
     def launch(self):
@@ -152,12 +155,16 @@ class WoqDecoderEngine:
         L.check(L.lib().woq_engine_steps(self._h, int(n), int(greedy), L.stream_ptr()))
 
     def replay_graph(self, n=1):
-        """Replay the captured hipGraph n times (greedy chaining stays on the device)."""
-        cur = torch.cuda.current_stream(self.device)
-        self._stream.wait_stream(cur)
-        with torch.cuda.stream(self._stream):
-            L.check(L.lib().woq_engine_replay(self._h, int(n), L.stream_ptr()))
-        cur.wait_stream(self._stream)
+        """Replay the captured hipGraph n times on the CURRENT stream (greedy chaining stays on the device). Only the
+        capture needs a stream of its own; replaying on that stream behind `wait_stream` calls was what made graph
+        replays ~1 us per kernel boundary slower than eager launches (profiles/r04ab_stream_mode_probe.txt)."""
+        L.check(L.lib().woq_engine_replay(self._h, int(n), L.stream_ptr()))
+
+    def replay_graph_round3(self, n=1):
+        """MEASUREMENT ONLY: the graph replayed the way rounds 1-3 did it — on the engine's capture stream, bracketed by
+        `wait_stream` in both directions. bench.py times it next to the other two so that the cause of round 3's 12 %
+        stays on record in every line."""
+        self._on_own_stream(lambda: L.check(L.lib().woq_engine_replay(self._h, int(n), L.stream_ptr())))
 
     def replay(self, n=1):
         """A burst of `n` decode steps of the kind last captured / prepared (greedy chaining stays on the device): the
@@ -189,14 +196,22 @@ class WoqDecoderEngine:
         return out
 
     def set_time_eager(self, on=True):
-        """time_gemv / time_twin: passes issued eagerly back to back (default: how bursts run) or as a replayed graph."""
+        """time_gemv / time_twin: passes issued eagerly back to back on the current stream (default) or as a replayed
+        graph on the engine's own stream (round 3's measure; that stream sits behind a `wait_stream`, which costs every
+        kernel boundary ~1 us — see LAUNCH)."""
         L.check(L.lib().woq_engine_set_time_eager(self._h, int(bool(on))))
+        self._time_eager = bool(on)
+
+    def _timed_call(self, fn):
+        """Timing helpers: eagerly issued passes need no stream of their own and must not sit behind a cross-stream wait;
+        captured ones cannot run on the legacy default stream."""
+        return fn() if getattr(self, "_time_eager", True) else self._on_own_stream(fn)
 
     def time_gemv(self, reps=1, mask=15):
         """(total ms, algorithmic bytes per pass, launches per pass) of `reps` replays of a captured pass over every
         layer's GEMV launches in the decode step's own forms; mask picks projections (bit 0 qkv, 1 o, 2 gate/up, 3 down)."""
         ms, by, n = ctypes.c_float(), ctypes.c_double(), ctypes.c_int()
-        self._on_own_stream(lambda: L.check(L.lib().woq_engine_time_gemv_mask(
+        self._timed_call(lambda: L.check(L.lib().woq_engine_time_gemv_mask(
             self._h, int(mask), reps, L.stream_ptr(), ctypes.byref(ms), ctypes.byref(by), ctypes.byref(n))))
         return ms.value, by.value, n.value
 
@@ -205,7 +220,7 @@ class WoqDecoderEngine:
         out: mode 0 = load-only twins over the engine's own blobs, mode 1 = empty kernels on the same grids (bench.py
         roofline.ceiling)."""
         ms = ctypes.c_float()
-        self._on_own_stream(lambda: L.check(L.lib().woq_engine_time_twin(
+        self._timed_call(lambda: L.check(L.lib().woq_engine_time_twin(
             self._h, int(mode), int(reps), L.stream_ptr(), ctypes.byref(ms))))
         return ms.value
 

@@ -37,10 +37,10 @@ def golden_dir():
     return GOLDEN
 
 # The GPU tests call `engine.capture()` + `engine.replay(n)` to hold hipGraph replays of the decode step to the same
-# tokens as eager steps (tag counters, arrival counters and device-side positions must survive a replayed graph).
-# Since round 4 the PRODUCT default issues bursts eagerly (runtime/engine.py LAUNCH: ~1 us per kernel boundary faster
-# than hipGraphLaunch); the tests keep `replay` on the graph so that path stays covered, and
-# tests/test_gpu_engine.py::test_eager_bursts_equal_graph_replays covers the eager burst against it.
+# tokens as eager steps (tag counters, arrival counters and device-side positions must survive a replayed graph). The
+# product default is the graph too (runtime/engine.py LAUNCH); pinned here so that a WOQ_ENGINE_LAUNCH=eager left in the
+# environment cannot take the graph path out of the suite. tests/test_gpu_engine.py::test_eager_bursts_equal_graph_replays
+# covers the eager burst against it.
 import os  # noqa: E402
 
 os.environ.setdefault("WOQ_ENGINE_LAUNCH", "graph")

@@ -227,7 +227,7 @@ def test_bench_py_multi_rank_line_on_one_gpu(graph):
     env = dict(os.environ, WOQ_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
-           "--warmup", "2", "--layers", "2", "--condition-ms", "20"] + (["--graph"] if graph else [])
+           "--warmup", "2", "--layers", "2", "--condition-ms", "20"] + ([] if graph else ["--eager"])
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]

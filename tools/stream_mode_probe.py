@@ -50,7 +50,19 @@ def main():
         torch.cuda.synchronize()
         return round((time.perf_counter() - t0) / n * 1e3, 4)
 
-    for name, fn in (("eager / null stream", eager(None)), ("eager / created stream", eager(created)),
+    def via_engine(n):
+        eng.replay_graph(n)
+
+    def on_capture_stream_with_waits(n):  # what engine.replay_graph does, spelled out
+        cur = torch.cuda.current_stream()
+        eng._stream.wait_stream(cur)
+        L.check(lib.woq_engine_replay(h, n, ctypes.c_void_p(eng._stream.cuda_stream)))
+        cur.wait_stream(eng._stream)
+
+    for name, fn in (("graph / the capture stream, direct C call", graph(eng._stream)),
+                     ("graph / capture stream + wait_stream both ways", on_capture_stream_with_waits),
+                     ("graph / engine.replay_graph", via_engine),
+                     ("eager / null stream", eager(None)), ("eager / created stream", eager(created)),
                      ("eager / high-priority stream", eager(prio)), ("graph / null stream", graph(None)),
                      ("graph / created stream", graph(created)), ("graph / high-priority stream", graph(prio)),
                      ("eager / null stream (again)", eager(None))):
