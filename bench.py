@@ -234,7 +234,7 @@ def gemv_roofline(eng, traffic=None, ceiling=True):
         "launches_per_token": n_launch,
         "timed": "HIP events on the launch stream around 8 passes of %d launches issued eagerly back to back (the step's "
                  "own kernel variants, chained as in the step; boundaries included) — the way the step itself is "
-                 "issued; round 3 timed replays of a captured pass, whose kernel boundaries cost ~1 us more" % n_launch,
+                 "issued; round 3 timed replays of a captured pass on a stream behind a cross-stream event wait, where kernel boundaries cost ~1 us more" % n_launch,
     }
     # the four projections one at a time (the instantiations rocprofv3 lists separately): a pass of ONE projection per
     # layer, back to back — each launch then starts behind a launch of its own kind, not behind its real predecessor
