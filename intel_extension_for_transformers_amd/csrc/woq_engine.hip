@@ -708,9 +708,13 @@ int woq_engine_set_layer(woq_engine* e, int layer, const woq_layer_weights* w) {
   WOQ_TRY
   WOQ_CHECK(e && w && layer >= 0 && layer < e->cfg.layers, "QBits: bad layer index");
   const woq_engine_config& c = e->cfg;
-  WOQ_CHECK(w->qkv_hdr.weight_type == WOQ_W_INT4_CLIP && w->o_hdr.weight_type == WOQ_W_INT4_CLIP &&
-                w->gate_up_hdr.weight_type == WOQ_W_INT4_CLIP && w->down_hdr.weight_type == WOQ_W_INT4_CLIP,
-            "QBits: the fused engine takes int4_clip layers");
+  // int4, or (round 4) a 4-bit table type: the same kernels with a digit-plane unpack (woq_gemv_common.h LutArgs); the
+  // fused qkv + attention launch and the persistent launch stay int4-only (their support checks say no)
+  auto takes = [](const woq_blob_header& h) {
+    return h.weight_type == WOQ_W_INT4_CLIP || (is_table_type(h.weight_type) && h.off_zp == 0);
+  };
+  WOQ_CHECK(takes(w->qkv_hdr) && takes(w->o_hdr) && takes(w->gate_up_hdr) && takes(w->down_hdr),
+            "QBits: the fused engine takes int4_clip / nf4 / fp4 layers");
   WOQ_CHECK(w->qkv_hdr.magic == WOQ_BLOB_MAGIC && w->o_hdr.magic == WOQ_BLOB_MAGIC &&
                 w->gate_up_hdr.magic == WOQ_BLOB_MAGIC && w->down_hdr.magic == WOQ_BLOB_MAGIC,
             "QBits: layer weights must be WQH1 blobs");

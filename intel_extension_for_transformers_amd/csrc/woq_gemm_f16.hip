@@ -1019,8 +1019,9 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   size_t part_bytes = kper ? (size_t)nz * M * ldp * sizeof(float) : 0;
   if (part_bytes > SPLITK_WS) kper = 0, nz = 1, part_bytes = 0;  // (cannot happen: see SPLITK_WS)
   const size_t total = base_bytes + frag_bytes + part_bytes;  // [tiles | row scales | column scales][fragments][partials]
-  if (frag && (ws != nullptr || epi != 0 || h.off_zp != 0))
-    return woq::fail("QBits: table weight types go through woq_linear (no fused epilogue, no zero points)");
+  if (frag && h.off_zp != 0) return woq::fail("QBits: float weight types are symmetric (no zero points)");
+  // the fragment image (4-8x the blob) lives in per-call scratch: a caller's workspace is sized for the int4 path
+  if (frag) ws = nullptr;
   unsigned char* w = (unsigned char*)ws;
   const bool mine = w == nullptr;  // no workspace passed in (the engine passes its own): take scratch
   bool own = false;

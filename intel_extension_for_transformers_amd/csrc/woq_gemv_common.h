@@ -50,6 +50,53 @@ __device__ __forceinline__ float limb_combine(const i32x4& d) {
   return fmaf((float)i2, 65536.f, fmaf((float)i1, 256.f, (float)i0));
 }
 
+// ---- 4-bit table weight types (nf4 / fp4) on the int8 MFMA (round 4) ----
+// w = table[code] * scale is not linear in the code, but the table has 16 entries: table[c] * S (S = 2^22 for nf4,
+// 2 for fp4_e2m1, 192 for the bitsandbytes fp4 table — exact for both fp4 tables, |error| <= 2^-23 of the table's
+// largest magnitude for nf4) is an integer written in NDIG balanced base-256 digits, and each digit plane of a weight
+// tile is a byte-table lookup of its nibbles: v_perm_b32 picks from 8 table bytes, so a 16-entry lookup of four codes is
+// two perms (codes 0..7, codes 8..15) and a select by bit 3 of each code. One MFMA per digit plane against the same A
+// operand, the results recombined as f0 + 2^8 f1 + 2^16 f2 — weights stay 4 bits in HBM, the inner product stays exact
+// in int32, and the kernels are the int4 ones with a different B-operand unpack (13 VALU per four weights for three
+// digits against 0.4 for int4: such a launch is issue-bound at ~1.5x the int4 time, against 4x for the fp32 VALU kernel
+// these types ran on through round 3).
+struct LutArgs {
+  uint32_t d[3][4];  // digit plane j: bytes 0..15 = digit j of table[0..15] * S
+  float wmul;        // 16 / S: the int4 kernels carry 16 q and fold 2^-4 into the activation factor
+};
+
+// digits of the four codes held one per byte in idx (values 0..15)
+template <int NDIG>
+__device__ __forceinline__ void lut_quad(const LutArgs& L, uint32_t idx, uint32_t (&out)[NDIG]) {
+  const uint32_t sel = idx & 0x07070707u;
+  const uint32_t m8 = idx & 0x08080808u;
+  const uint32_t mask = (m8 << 5) - (m8 >> 3);  // 0xff in every byte whose code is >= 8
+#pragma unroll
+  for (int j = 0; j < NDIG; ++j) {
+    const uint32_t lo = __builtin_amdgcn_perm(L.d[j][1], L.d[j][0], sel);  // {hi:lo} = table bytes 7..0
+    const uint32_t hi = __builtin_amdgcn_perm(L.d[j][3], L.d[j][2], sel);  // table bytes 15..8
+    out[j] = (hi & mask) | (lo & ~mask);
+  }
+}
+// B operands (one per digit plane) of the 64-k half whose nibbles sit in w0, w1 — same k order as the int4 unpack:
+// low nibbles of w0, high nibbles of w0, low nibbles of w1, high nibbles of w1
+template <int NDIG>
+__device__ __forceinline__ void lut_b(const LutArgs& L, uint32_t w0, uint32_t w1, i32x4 (&b)[NDIG]) {
+  uint32_t q0[NDIG], q1[NDIG], q2[NDIG], q3[NDIG];
+  lut_quad<NDIG>(L, w0 & 0x0f0f0f0fu, q0);
+  lut_quad<NDIG>(L, (w0 >> 4) & 0x0f0f0f0fu, q1);
+  lut_quad<NDIG>(L, w1 & 0x0f0f0f0fu, q2);
+  lut_quad<NDIG>(L, (w1 >> 4) & 0x0f0f0f0fu, q3);
+#pragma unroll
+  for (int j = 0; j < NDIG; ++j) b[j] = i32x4{(int)q0[j], (int)q1[j], (int)q2[j], (int)q3[j]};
+}
+__device__ __forceinline__ void int4_b(uint32_t w0, uint32_t w1, i32x4& b) {
+  b = i32x4{(int)((w0 << 4) & 0xf0f0f0f0u), (int)(w0 & 0xf0f0f0f0u), (int)((w1 << 4) & 0xf0f0f0f0u),
+            (int)(w1 & 0xf0f0f0f0u)};
+}
+// host: the digit planes of a table weight type; returns NDIG the kernels are instantiated for (1 | 3), 0 = not a table
+int lut_args_for(uint32_t weight_type, LutArgs& L);
+
 // geometry pick of the tile GEMVs (woq_gemv_i8.hip): nw waves x tpw tiles cover tiles_k; false = not covered
 bool gemv_tile_geometry(int tiles_k, int cb, int smode, int& nw, int& tpw);
 // K ranges one launch cannot hold run as chained launches; number of chunks, 0 = not covered

@@ -42,6 +42,9 @@
 //    (RMSNorm factor, bias, residual, SiLU*mul) and store.
 // Kernel arguments are plain scalars (not a struct) so the first 14 dwords are preloaded into SGPRs at dispatch
 // (-mllvm -amdgpu-kernarg-preload-count, see the Makefile): no s_load round trip before the first address.
+#include <math.h>
+#include <string.h>
+
 #include <algorithm>
 
 #include "woq_gemv_common.h"
@@ -101,15 +104,31 @@ __host__ __device__ inline size_t tile_lds_bytes(int M, int nw, int TPW, int CB)
 
 
 // flags: bit 0 scales are bf16 (else fp16; ignored for fp32 scales), bit 1 SiLU(gate)*up epilogue (CB == 2)
-template <int TPW, int CB, int SMODE, bool ASYM, bool S32, bool M1>
+// NDIG: 0 = int4 weights; 1 | 3 = a 4-bit table type (nf4 / fp4) as that many digit planes (woq_gemv_common.h LutArgs)
+template <int TPW, int CB, int SMODE, bool ASYM, bool S32, bool M1, int NDIG>
 // register budget by workgroup size: 1024 threads -> 128 VGPRs (group-128 paths), 768 -> 168 (per-32 scales keep
 // 3 more registers per tile and twice the A fragments), 512 -> 256
 __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) void gemv_tile_kernel(
     const u32x4* __restrict__ q, const void* __restrict__ scales, const void* __restrict__ x,
     const float* __restrict__ norm_w, int tiles_k, int K, int base_tiles, int rem_tiles, int n_groups, int tpg_shift,
     const uint8_t* __restrict__ zp, void* __restrict__ out, const float* __restrict__ bias, const float* residual,
-    float eps, int N, int Mrows, int lda, int ldo, int ld_res, int out_dtype, int flags, int kt_off) {
+    float eps, int N, int Mrows, int lda, int ldo, int ld_res, int out_dtype, int flags, int kt_off, LutArgs lut) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  static_assert(!(ASYM && NDIG > 0), "table weight types are symmetric");
+  constexpr int NB = NDIG > 0 ? NDIG : 1;  // B operands per 64-k half
+  // one 64-k half against the A operand `av`: sum_k (activation) x (16 q | table digits), recombined in fp32
+  auto half_dot = [&](const i32x4& av, uint32_t w0, uint32_t w1) -> float {
+    i32x4 b[NB];
+    if constexpr (NDIG > 0)
+      lut_b<NDIG>(lut, w0, w1, b);
+    else
+      int4_b(w0, w1, b[0]);
+    float f = limb_combine(__builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[NB - 1], i32x4{0, 0, 0, 0}, 0, 0, 0));
+#pragma unroll
+    for (int j = NB - 2; j >= 0; --j)
+      f = fmaf(f, 256.f, limb_combine(__builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[j], i32x4{0, 0, 0, 0}, 0, 0, 0)));
+    return f;
+  };
   constexpr int RB = tile_row_bytes(TPW);
   constexpr int XJ = TPW / 2;  // float4 loads per lane per row covering TPW*128 activations
   constexpr int ESZ = S32 ? 4 : 2;
@@ -353,6 +372,12 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
   } else
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
+    if constexpr (NDIG > 0 && !M1) {
+      // the digit planes of a tile do not depend on the row set: left alone, the compiler computes all of them once in
+      // front of the row-set loop (up to 192 registers) and spills. Opaque per iteration: they are rebuilt per row set.
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) asm volatile("" : "+v"(w[cb][t]));
+    }
     if constexpr (SMODE == 0) {
       const i32x4 a0 = *(const i32x4*)(a_base + t * a_step_t);
       const i32x4 a1 = *(const i32x4*)(a_base + t * a_step_t + a_step_h);
@@ -366,6 +391,25 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
       for (int cb = 0; cb < CB; ++cb) {
         if (!WOQ_REST_EARLY && t * CB + cb + PF < CB * TPW) issue_w(t * CB + cb + PF);
         const u32x4 wv = w[cb][t];
+        if constexpr (NDIG > 0) {  // table weights: one MFMA pair per digit plane, recombined most significant first
+          i32x4 b0[NB], b1[NB];
+          lut_b<NDIG>(lut, wv.x, wv.y, b0);
+          lut_b<NDIG>(lut, wv.z, wv.w, b1);
+          float f = 0.f;
+#pragma unroll
+          for (int j = NB - 1; j >= 0; --j) {
+            i32x4 d = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0[j], izero, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1[j], d, 0, 0, 0);
+            f = fmaf(f, 256.f, limb_combine(d));
+          }
+          float scv;
+          if constexpr (S32)
+            scv = rsc[cb][t];
+          else
+            scv = tscale16(rsc[cb][t], bf);
+          tot[cb] = fmaf(scv, f, tot[cb]);
+          continue;
+        }
         const i32x4 b0 = {(int)((wv.x << 4) & 0xf0f0f0f0u), (int)(wv.x & 0xf0f0f0f0u),
                           (int)((wv.y << 4) & 0xf0f0f0f0u), (int)(wv.y & 0xf0f0f0f0u)};
         const i32x4 b1 = {(int)((wv.z << 4) & 0xf0f0f0f0u), (int)(wv.z & 0xf0f0f0f0u),
@@ -395,9 +439,7 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
           if (h == 0 && !WOQ_REST_EARLY && t * CB + cb + PF < CB * TPW) issue_w(t * CB + cb + PF);
           const u32x4 wv = w[cb][t];
           const uint32_t w0 = h == 0 ? wv.x : wv.z, w1 = h == 0 ? wv.y : wv.w;
-          const i32x4 b = {(int)((w0 << 4) & 0xf0f0f0f0u), (int)(w0 & 0xf0f0f0f0u), (int)((w1 << 4) & 0xf0f0f0f0u),
-                           (int)(w1 & 0xf0f0f0f0u)};
-          float f = limb_combine(__builtin_amdgcn_mfma_i32_16x16x64_i8(av, b, izero, 0, 0, 0));
+          float f = half_dot(av, w0, w1);
           // this lane quarter's group: s = 2h + (kq & 1) (quarters 2, 3 hold zeros: their A rows are dead)
           if constexpr (ASYM) {
             const uint32_t zb = (rzp[cb][t] >> (16 * h)) & 0xffffu;
@@ -437,12 +479,19 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const uint32_t w0 = h == 0 ? wv.x : wv.z, w1 = h == 0 ? wv.y : wv.w;
-          const i32x4 b = {(int)((w0 << 4) & 0xf0f0f0f0u), (int)(w0 & 0xf0f0f0f0u), (int)((w1 << 4) & 0xf0f0f0f0u),
-                           (int)(w1 & 0xf0f0f0f0u)};
+          i32x4 b[NB];
+          if constexpr (NDIG > 0)
+            lut_b<NDIG>(lut, w0, w1, b);
+          else
+            int4_b(w0, w1, b[0]);
 #pragma unroll
           for (int g2 = 0; g2 < 2; ++g2) {
             const int s = 2 * h + g2;  // 32-k block of the tile
-            float f = limb_combine(__builtin_amdgcn_mfma_i32_16x16x64_i8(g2 == 0 ? al[h] : ah[h], b, izero, 0, 0, 0));
+            const i32x4& ag = g2 == 0 ? al[h] : ah[h];
+            float f = limb_combine(__builtin_amdgcn_mfma_i32_16x16x64_i8(ag, b[NB - 1], izero, 0, 0, 0));
+#pragma unroll
+            for (int j = NB - 2; j >= 0; --j)
+              f = fmaf(f, 256.f, limb_combine(__builtin_amdgcn_mfma_i32_16x16x64_i8(ag, b[j], izero, 0, 0, 0)));
             if constexpr (ASYM) f = fmaf(-16.f * (float)((int)((rzp[cb][t] >> (8 * s)) & 0xff) - 8), sx[s], f);
             float scv;
             if constexpr (S32) {
@@ -466,7 +515,8 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
     // slab layout [row set][wave][cb][activation row of the set = lane >> 4][16 columns]
-    if (!M1 || lane < 16) slab[(((size_t)rs * nw + wid) * CB + cb) * 64 + lane] = tot[cb] * unsc;
+    if (!M1 || lane < 16)
+      slab[(((size_t)rs * nw + wid) * CB + cb) * 64 + lane] = tot[cb] * (NDIG > 0 ? unsc * lut.wmul : unsc);
   }
   WOQ_STAMP(6);
   if (WOQ_SKIP(8)) {
@@ -531,13 +581,15 @@ struct TileLaunch {
   float eps;
   int nw, grid;
   int kt_begin, kt_count;  // K tiles [kt_begin, kt_begin + kt_count) of the blob covered by this launch
+  LutArgs lut;             // table weight types (ndig > 0)
+  int ndig;
 };
 
-template <int TPW, int CB, int SMODE, bool ASYM, bool S32, bool M1>
+template <int TPW, int CB, int SMODE, bool ASYM, bool S32, bool M1, int NDIG>
 static int launch_tile_t(const TileLaunch& a, hipStream_t st) {
   const size_t lds = tile_lds_bytes(a.M, a.nw, TPW, CB);
   if (lds > 160 * 1024) return woq::fail("QBits: activation rows do not fit LDS");
-  auto kern = gemv_tile_kernel<TPW, CB, SMODE, ASYM, S32, M1>;
+  auto kern = gemv_tile_kernel<TPW, CB, SMODE, ASYM, S32, M1, NDIG>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -547,25 +599,59 @@ static int launch_tile_t(const TileLaunch& a, hipStream_t st) {
   const int base = a.kt_count / a.nw, rem = a.kt_count % a.nw;
   hipLaunchKernelGGL(kern, dim3(a.grid), dim3(a.nw * 64), lds, st, (const u32x4*)a.q, a.scales, a.x, a.norm_w,
                      a.tiles_k, a.K, base, rem, a.n_groups, a.tpg_shift, (const uint8_t*)a.zp, a.out, a.bias,
-                     a.residual, a.eps, a.N, a.M, a.lda, a.ldo, a.ld_res, a.out_dtype, a.flags, a.kt_begin);
+                     a.residual, a.eps, a.N, a.M, a.lda, a.ldo, a.ld_res, a.out_dtype, a.flags, a.kt_begin, a.lut);
   return 0;
 }
 
 template <int TPW, int CB>
 static int launch_tile_sm(const TileLaunch& a, int smode, bool asym, bool s32, hipStream_t st) {
-#define WOQ_TILE_CASE(SM, AS, S3)                                                                                 \
-  if (smode == SM && asym == AS && s32 == S3)                                                                     \
-    return a.M == 1 ? launch_tile_t<TPW, CB, SM, AS, S3, true>(a, st) : launch_tile_t<TPW, CB, SM, AS, S3, false>(a, st);
-  WOQ_TILE_CASE(0, false, false)
-  WOQ_TILE_CASE(0, false, true)
-  WOQ_TILE_CASE(0, true, false)
-  WOQ_TILE_CASE(0, true, true)
-  WOQ_TILE_CASE(1, false, false)
-  WOQ_TILE_CASE(1, false, true)
-  WOQ_TILE_CASE(1, true, false)
-  WOQ_TILE_CASE(1, true, true)
+#define WOQ_TILE_CASE(SM, AS, S3, ND)                                                   \
+  if (smode == SM && asym == AS && s32 == S3 && a.ndig == ND)                           \
+    return a.M == 1 ? launch_tile_t<TPW, CB, SM, AS, S3, true, ND>(a, st)               \
+                    : launch_tile_t<TPW, CB, SM, AS, S3, false, ND>(a, st);
+  WOQ_TILE_CASE(0, false, false, 0)
+  WOQ_TILE_CASE(0, false, true, 0)
+  WOQ_TILE_CASE(0, true, false, 0)
+  WOQ_TILE_CASE(0, true, true, 0)
+  WOQ_TILE_CASE(1, false, false, 0)
+  WOQ_TILE_CASE(1, false, true, 0)
+  WOQ_TILE_CASE(1, true, false, 0)
+  WOQ_TILE_CASE(1, true, true, 0)
+  // 4-bit table types: symmetric only; one digit plane (fp4_e2m1) or three (nf4, the bitsandbytes fp4 table)
+  WOQ_TILE_CASE(0, false, false, 1)
+  WOQ_TILE_CASE(0, false, true, 1)
+  WOQ_TILE_CASE(1, false, false, 1)
+  WOQ_TILE_CASE(1, false, true, 1)
+  WOQ_TILE_CASE(0, false, false, 3)
+  WOQ_TILE_CASE(0, false, true, 3)
+  WOQ_TILE_CASE(1, false, false, 3)
+  WOQ_TILE_CASE(1, false, true, 3)
 #undef WOQ_TILE_CASE
   return woq::fail("QBits: bad tile GEMV configuration");
+}
+
+// Digit planes of a table weight type (woq_gemv_common.h): v = round(table[c] * S) = d0 + 2^8 d1 + 2^16 d2, balanced
+// (d0, d1 in [-128, 127]). S: nf4 2^22 (three digits, |d2| <= 64), fp4_e2m1 2 (integers up to 12: one digit), the
+// bitsandbytes fp4 table 192 (integers up to 192: two digits, run as three).
+int lut_args_for(uint32_t weight_type, LutArgs& L) {
+  memset(&L, 0, sizeof(L));
+  L.wmul = 1.f;
+  if (!is_table_type(weight_type)) return 0;
+  static const float nf4[16] = WOQ_LUT_NF4;
+  static const float e2m1[16] = WOQ_LUT_FP4_E2M1;
+  static const float bnb[16] = WOQ_LUT_FP4_BNB;
+  const float* tab = weight_type == WOQ_W_NF4 ? nf4 : (weight_type == WOQ_W_FP4_E2M1 ? e2m1 : bnb);
+  const double S = weight_type == WOQ_W_NF4 ? 4194304.0 : (weight_type == WOQ_W_FP4_E2M1 ? 2.0 : 192.0);
+  for (int c = 0; c < 16; ++c) {
+    long v = lrint((double)tab[c] * S);
+    for (int j = 0; j < 3; ++j) {
+      const int dj = (int)(int8_t)(uint8_t)(v & 0xff);  // low byte, sign-extended
+      L.d[j][c >> 2] |= (uint32_t)(uint8_t)dj << (8 * (c & 3));
+      v = (v - dj) >> 8;
+    }
+  }
+  L.wmul = (float)(16.0 / S);
+  return weight_type == WOQ_W_FP4_E2M1 ? 1 : 3;
 }
 
 // K ranges one launch cannot hold are split into equal chunks run as chained launches (chunk i + 1 adds onto chunk
@@ -597,7 +683,9 @@ bool gemv_tile_geometry(int tiles_k, int cb, int smode, int& nw, int& tpw) {
 // woq_gemv.hip.
 int gemv_tile_max_rows(const void* act, int act_dtype, int lda, const woq_blob_header& h, const float* norm_w,
                        int epi, int out_dtype) {
-  if (h.weight_type != WOQ_W_INT4_CLIP || h.off_shuffle != 0 || (h.K & 3) != 0 || (lda & 3) != 0 ||
+  static const bool table_generic = getenv("WOQ_TABLE_GENERIC") != nullptr;  // A/B switch: round 3's fp32 VALU kernel
+  const bool table = is_table_type(h.weight_type) && h.off_zp == 0 && !table_generic;
+  if ((h.weight_type != WOQ_W_INT4_CLIP && !table) || h.off_shuffle != 0 || (h.K & 3) != 0 || (lda & 3) != 0 ||
       (((uintptr_t)act) & (act_dtype == WOQ_F32 ? 15 : 7)) != 0 || (((uintptr_t)norm_w) & 15) != 0)
     return 0;
   const int tiles_k = h.Kpad / WOQ_TILE_K;
@@ -653,6 +741,7 @@ int launch_gemv_tile(const void* act, int act_dtype, int lda, int M, const void*
   a.residual = residual;
   a.flags = (h.scale_type == WOQ_BF16 ? 1 : 0) | (epi == 1 ? 2 : 0) |
             (act_dtype == WOQ_F16 ? 4 : (act_dtype == WOQ_BF16 ? 8 : 0));
+  a.ndig = lut_args_for(h.weight_type, a.lut);
 #ifdef WOQ_PROBE
   a.flags |= ::g_probe_flags;
 #endif

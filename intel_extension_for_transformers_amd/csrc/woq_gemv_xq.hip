@@ -28,6 +28,8 @@ struct XqLaunch {
   float* ssq_out;
   const CommDev* tp;  // tensor parallel: push the outputs (partial sums) into the peers' inboxes from the epilogue
   int nw, grid, kt_begin, kt_count;
+  LutArgs lut;  // 4-bit table weight types (ndig > 0)
+  int ndig;
 };
 
 // window depth by tiles per wave (tools/xq_probe.hip grid, profiles/r03c_xq_probe.txt)
@@ -39,12 +41,12 @@ struct XqsDepth {
   static constexpr int value = TPW >= WOQ_XQS_DEPTH ? WOQ_XQS_DEPTH : TPW;
 };
 
-template <int TPW, int CB, int SMODE, bool ASYM, bool S32>
+template <int TPW, int CB, int SMODE, bool ASYM, bool S32, int NDIG>
 static int launch_xq_t(const XqLaunch& a, hipStream_t st) {
   typedef XqsLds<TPW, CB, SMODE, ASYM, S32> L;
   const size_t lds = L::total(a.nw);
   if (lds > 160 * 1024) return woq::fail("QBits: XQ GEMV geometry does not fit LDS");
-  auto kern = gemv_xqs_kernel<TPW, CB, XqsDepth<TPW>::value, SMODE, ASYM, S32>;
+  auto kern = gemv_xqs_kernel<TPW, CB, XqsDepth<TPW>::value, SMODE, ASYM, S32, NDIG>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -54,22 +56,32 @@ static int launch_xq_t(const XqLaunch& a, hipStream_t st) {
   const int base = a.kt_count / a.nw, rem = a.kt_count % a.nw;
   hipLaunchKernelGGL(kern, dim3(a.grid), dim3(a.nw * 64), lds, st, (const u32x4*)a.q, a.scales, a.xin.limbs, a.xin.u,
                      a.tiles_k, a.kt_begin, base, rem, a.n_groups, a.tpg_shift, (const uint8_t*)a.zp, a.xin.sx, a.out,
-                     a.bias, a.residual, a.eps, a.N, a.K, a.flags, a.ssq_in, a.n_ssq, a.xo, a.next_norm_w, a.ssq_out, a.tp);
+                     a.bias, a.residual, a.eps, a.N, a.K, a.flags, a.ssq_in, a.n_ssq, a.xo, a.next_norm_w, a.ssq_out, a.tp,
+                     a.lut);
   return 0;
 }
 
 template <int TPW, int CB>
 static int launch_xq_sm(const XqLaunch& a, int smode, bool asym, bool s32, hipStream_t st) {
-#define WOQ_XQ_CASE(SM, AS, S3) \
-  if (smode == SM && asym == AS && s32 == S3) return launch_xq_t<TPW, CB, SM, AS, S3>(a, st);
-  WOQ_XQ_CASE(0, false, false)
-  WOQ_XQ_CASE(0, false, true)
-  WOQ_XQ_CASE(0, true, false)
-  WOQ_XQ_CASE(0, true, true)
-  WOQ_XQ_CASE(1, false, false)
-  WOQ_XQ_CASE(1, false, true)
-  WOQ_XQ_CASE(1, true, false)
-  WOQ_XQ_CASE(1, true, true)
+#define WOQ_XQ_CASE(SM, AS, S3, ND) \
+  if (smode == SM && asym == AS && s32 == S3 && a.ndig == ND) return launch_xq_t<TPW, CB, SM, AS, S3, ND>(a, st);
+  WOQ_XQ_CASE(0, false, false, 0)
+  WOQ_XQ_CASE(0, false, true, 0)
+  WOQ_XQ_CASE(0, true, false, 0)
+  WOQ_XQ_CASE(0, true, true, 0)
+  WOQ_XQ_CASE(1, false, false, 0)
+  WOQ_XQ_CASE(1, false, true, 0)
+  WOQ_XQ_CASE(1, true, false, 0)
+  WOQ_XQ_CASE(1, true, true, 0)
+  // 4-bit table types (nf4 / fp4): symmetric; one digit plane (fp4_e2m1) or three
+  WOQ_XQ_CASE(0, false, false, 1)
+  WOQ_XQ_CASE(0, false, true, 1)
+  WOQ_XQ_CASE(1, false, false, 1)
+  WOQ_XQ_CASE(1, false, true, 1)
+  WOQ_XQ_CASE(0, false, false, 3)
+  WOQ_XQ_CASE(0, false, true, 3)
+  WOQ_XQ_CASE(1, false, false, 3)
+  WOQ_XQ_CASE(1, false, true, 3)
 #undef WOQ_XQ_CASE
   return woq::fail("QBits: bad XQ GEMV configuration");
 }
@@ -77,7 +89,7 @@ static int launch_xq_sm(const XqLaunch& a, int smode, bool asym, bool s32, hipSt
 // Geometry: nw waves x tpw tiles cover a K range of tiles_k tiles. Measured per projection of the Llama-2-7B layer
 // (tools/xq_probe.hip, profiles/r03c_xq_probe.txt): 8 tiles per wave for single column tiles with long K, 4 for the
 // fused gate/up pairs (twice the bytes per tile step) and short K. WOQ_XQ_TPW=4|8 forces one (timing experiments).
-static bool xq_geometry(int tiles_k, int cb, int smode, int& nw, int& tpw) {
+static bool xq_geometry(int tiles_k, int cb, int smode, int& nw, int& tpw, int ndig = 0) {
   static const int forced = [] {
     const char* s = getenv("WOQ_XQ_TPW");
     return s ? atoi(s) : 0;
@@ -91,29 +103,34 @@ static bool xq_geometry(int tiles_k, int cb, int smode, int& nw, int& tpw) {
     return s ? atoi(s) : 0;
   }();
   if (cb == 1 && tiles_k <= 32 && (forced_short == 4 || forced_short == 8)) tpw = forced_short;
+  const bool wide = cb == 2 && ndig == 3;  // table weights, three digit planes, column-tile pairs: 512-thread launches
+  if (wide && tiles_k > 32 && smode == 0) tpw = 8;
   nw = (tiles_k + tpw - 1) / tpw;
-  return nw >= 1 && nw <= (cb * tpw > 8 ? 8 : 16);  // the kernel's __launch_bounds__
+  return nw >= 1 && nw <= ((cb * tpw > 8 || wide) ? 8 : 16);  // the kernel's __launch_bounds__
 }
 // K ranges one launch cannot hold run as chained launches; number of chunks, 0 = not covered
-static int xq_k_chunks(int tiles_k, int cb, int smode, bool chainable) {
+static int xq_k_chunks(int tiles_k, int cb, int smode, bool chainable, int ndig = 0) {
   int nw, tpw;
-  if (xq_geometry(tiles_k, cb, smode, nw, tpw)) return 1;
+  if (xq_geometry(tiles_k, cb, smode, nw, tpw, ndig)) return 1;
   if (!chainable) return 0;
   for (int s = 2; s <= 8; ++s)
-    if (xq_geometry((tiles_k + s - 1) / s, cb, smode, nw, tpw)) return s;
+    if (xq_geometry((tiles_k + s - 1) / s, cb, smode, nw, tpw, ndig)) return s;
   return 0;
 }
 
 // does the XQ kernel take this blob as a batch-1 projection? epi 1 = fused gate/up (SiLU * mul)
 bool gemv_xq_supported(const woq_blob_header& h, int epi) {
-  if (h.weight_type != WOQ_W_INT4_CLIP || h.off_shuffle != 0 || (h.K % WOQ_TILE_K) != 0 || h.K != h.Kpad) return false;
+  const bool table = is_table_type(h.weight_type) && h.off_zp == 0;
+  if ((h.weight_type != WOQ_W_INT4_CLIP && !table) || h.off_shuffle != 0 || (h.K % WOQ_TILE_K) != 0 || h.K != h.Kpad)
+    return false;
   const int tiles_k = h.Kpad / WOQ_TILE_K, cb = epi == 1 ? 2 : 1;
   if (epi == 1 && ((h.Npad / WOQ_TILE_N) & 1)) return false;
   if (h.scale_mode == 0 && h.n_groups > 1) {
     const int tpg = h.group / WOQ_TILE_K;
     if (tpg < 1 || (tpg & (tpg - 1)) != 0) return false;
   }
-  return xq_k_chunks(tiles_k, cb, (int)h.scale_mode, epi == 0) > 0;
+  LutArgs lut;
+  return xq_k_chunks(tiles_k, cb, (int)h.scale_mode, epi == 0, lut_args_for(h.weight_type, lut)) > 0;
 }
 
 // out[N] (fp32, may be null when only the XQ output is wanted) = xin . W_deq (* rsqrt(mean(x^2) + eps) when ssq_in)
@@ -142,6 +159,7 @@ int launch_gemv_xq(const XqPtrs& xin, const void* blob, const woq_blob_header& h
     }
   }
   a.flags = (h.scale_type == WOQ_BF16 ? 1 : 0) | (epi == 1 ? 2 : 0);
+  a.ndig = lut_args_for(h.weight_type, a.lut);
   a.eps = eps;
   a.n_ssq = h.K / 16;
   if (ssq_in != nullptr && a.n_ssq > 1024) return woq::fail("QBits: RMSNorm partials beyond K = 16384");
@@ -150,7 +168,7 @@ int launch_gemv_xq(const XqPtrs& xin, const void* blob, const woq_blob_header& h
   const int tiles_n = h.Npad / WOQ_TILE_N, cb = epi == 1 ? 2 : 1;
   const int smode = (int)h.scale_mode;
   const bool asym = a.zp != nullptr, s32 = h.scale_type == WOQ_F32;
-  const int chunks = xq_k_chunks(a.tiles_k, cb, smode, epi == 0);
+  const int chunks = xq_k_chunks(a.tiles_k, cb, smode, epi == 0, a.ndig);
   if (chunks > 1 && (ssq_in != nullptr || out == nullptr))
     return woq::fail("QBits: a K range split over chained launches takes no norm and needs an fp32 output");
   a.grid = tiles_n / cb;
@@ -161,7 +179,8 @@ int launch_gemv_xq(const XqPtrs& xin, const void* blob, const woq_blob_header& h
     if (a.kt_count <= 0) break;
     const bool last = c == chunks - 1 || a.kt_begin + a.kt_count >= a.tiles_k;
     int tpw;
-    if (!xq_geometry(a.kt_count, cb, smode, a.nw, tpw)) return woq::fail("QBits: shape not covered by the XQ GEMV");
+    if (!xq_geometry(a.kt_count, cb, smode, a.nw, tpw, a.ndig))
+      return woq::fail("QBits: shape not covered by the XQ GEMV");
     a.out = out;
     a.bias = c == 0 ? bias : nullptr;
     a.residual = c == 0 ? residual : out;  // chunk c > 0 adds onto the previous chunk's output
@@ -209,7 +228,9 @@ __global__ void gemv_empty_twin_kernel(unsigned int* __restrict__ sink) {
 // mode 0: load-only twin of the batch-1 GEMV of this blob; mode 1: an empty kernel on the same grid and block
 int launch_gemv_twin(const void* blob, const woq_blob_header& h, int epi, int mode, unsigned int* sink, hipStream_t st) {
   const int tiles_k = h.Kpad / WOQ_TILE_K, tiles_n = h.Npad / WOQ_TILE_N, cb = epi == 1 ? 2 : 1;
-  const int chunks = xq_k_chunks(tiles_k, cb, (int)h.scale_mode, epi == 0);
+  LutArgs lut;
+  const int ndig = lut_args_for(h.weight_type, lut);
+  const int chunks = xq_k_chunks(tiles_k, cb, (int)h.scale_mode, epi == 0, ndig);
   if (chunks == 0) return woq::fail("QBits: shape not covered by the XQ GEMV");
   const int per = (tiles_k + chunks - 1) / chunks;
   const u32x4* q = (const u32x4*)((const uint8_t*)blob + h.off_q);
@@ -217,7 +238,8 @@ int launch_gemv_twin(const void* blob, const woq_blob_header& h, int epi, int mo
     const int kt_begin = c * per, kt_count = std::min(per, tiles_k - kt_begin);
     if (kt_count <= 0) break;
     int nw, tpw;
-    if (!xq_geometry(kt_count, cb, (int)h.scale_mode, nw, tpw)) return woq::fail("QBits: shape not covered by the XQ GEMV");
+    if (!xq_geometry(kt_count, cb, (int)h.scale_mode, nw, tpw, ndig))
+      return woq::fail("QBits: shape not covered by the XQ GEMV");
     const int base = kt_count / nw, rem = kt_count % nw;
     const dim3 grid(tiles_n / cb), block(nw * 64);
     if (mode == 1) {

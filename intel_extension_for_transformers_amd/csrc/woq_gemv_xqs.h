@@ -112,7 +112,8 @@ struct XqsChain {
 
 // FUSED (woq_gemv_attn.hip): the outputs are consumed by another workgroup of the SAME launch: `out` is then an array
 // of 8-byte {tag, fp32} granules, each written by ONE write-through agent-scope store (the data is its own flag).
-template <int TPW, int CB, int D, int SMODE, bool ASYM, bool S32, bool FUSED, bool CHAIN_IN = false>
+// NDIG: 0 = int4 weights; 1 | 3 = a 4-bit table type (nf4 / fp4) as that many digit planes (woq_gemv_common.h LutArgs)
+template <int TPW, int CB, int D, int SMODE, bool ASYM, bool S32, bool FUSED, bool CHAIN_IN = false, int NDIG = 0>
 __device__ __forceinline__ void gemv_xqs_body(
     unsigned char* smem_raw, const u32x4* __restrict__ q, const void* __restrict__ scales,
     const uint8_t* __restrict__ xlimbs, const float* __restrict__ xu, int tiles_k, int kt_off, int base_tiles,
@@ -120,7 +121,8 @@ __device__ __forceinline__ void gemv_xqs_body(
     float* __restrict__ out, const float* __restrict__ bias, const float* residual, float eps, int N, int K, int flags,
     const float* __restrict__ ssq_in, int n_ssq, const XqPtrs& xo, const float* __restrict__ next_norm_w,
     float* __restrict__ ssq_out, unsigned int fused_tag = 0u, const CommDev* __restrict__ tp = nullptr,
-    const XqsChain& chain = XqsChain{nullptr, 0u, XqPub{nullptr, 0u}, nullptr, -1}) {
+    const XqsChain& chain = XqsChain{nullptr, 0u, XqPub{nullptr, 0u}, nullptr, -1}, const LutArgs& lut = LutArgs{}) {
+  static_assert(!(ASYM && NDIG > 0), "table weight types are symmetric");
   typedef XqsLds<TPW, CB, SMODE, ASYM, S32> L;
   constexpr int ESZ = L::ESZ;
   constexpr int DD = D < TPW ? D : TPW;  // tiles requested before the first one is consumed
@@ -315,13 +317,27 @@ __device__ __forceinline__ void gemv_xqs_body(
       }
       const unsigned char* scp = wbase + L::O_SC + cb * L::SCB;
       const unsigned char* zpp = wbase + L::O_ZP + cb * L::ZPB;
-      const i32x4 b0 = {(int)((wv.x << 4) & 0xf0f0f0f0u), (int)(wv.x & 0xf0f0f0f0u), (int)((wv.y << 4) & 0xf0f0f0f0u),
-                        (int)(wv.y & 0xf0f0f0f0u)};
-      const i32x4 b1 = {(int)((wv.z << 4) & 0xf0f0f0f0u), (int)(wv.z & 0xf0f0f0f0u), (int)((wv.w << 4) & 0xf0f0f0f0u),
-                        (int)(wv.w & 0xf0f0f0f0u)};
-      const i32x4 d0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, izero, 0, 0, 0);
-      const i32x4 d1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, izero, 0, 0, 0);
-      float f0 = digit_combine(d0), f1 = digit_combine(d1);
+      float f0, f1;
+      if constexpr (NDIG > 0) {  // table weights: one MFMA per digit plane and half, most significant plane first
+        i32x4 b0[NDIG], b1[NDIG];
+        lut_b<NDIG>(lut, wv.x, wv.y, b0);
+        lut_b<NDIG>(lut, wv.z, wv.w, b1);
+        f0 = digit_combine(__builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0[NDIG - 1], izero, 0, 0, 0));
+        f1 = digit_combine(__builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1[NDIG - 1], izero, 0, 0, 0));
+#pragma unroll
+        for (int j = NDIG - 2; j >= 0; --j) {
+          f0 = fmaf(f0, 256.f, digit_combine(__builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0[j], izero, 0, 0, 0)));
+          f1 = fmaf(f1, 256.f, digit_combine(__builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1[j], izero, 0, 0, 0)));
+        }
+      } else {
+        const i32x4 b0 = {(int)((wv.x << 4) & 0xf0f0f0f0u), (int)(wv.x & 0xf0f0f0f0u),
+                          (int)((wv.y << 4) & 0xf0f0f0f0u), (int)(wv.y & 0xf0f0f0f0u)};
+        const i32x4 b1 = {(int)((wv.z << 4) & 0xf0f0f0f0u), (int)(wv.z & 0xf0f0f0f0u),
+                          (int)((wv.w << 4) & 0xf0f0f0f0u), (int)(wv.w & 0xf0f0f0f0u)};
+        const i32x4 d0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, izero, 0, 0, 0);
+        const i32x4 d1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, izero, 0, 0, 0);
+        f0 = digit_combine(d0), f1 = digit_combine(d1);
+      }
       if constexpr (SMODE == 0) {
         if constexpr (ASYM) {  // the weights carry 16 * q: the zero point enters as 16 * zp
           const float z16 = -16.f * (float)((int)zpp[gi * 16 + i16] - 8);
@@ -350,6 +366,9 @@ __device__ __forceinline__ void gemv_xqs_body(
         }
         tot[cb] = fmaf(sc0 * u0, f0, fmaf(sc1 * u1, f1, tot[cb]));
       }
+      // three digit planes of two halves are 24 registers per column tile: keep one tile's planes from being built
+      // under the previous one's MFMAs (the 128-register budget of the 1024-thread launches spills otherwise)
+      if constexpr (NDIG == 3) __builtin_amdgcn_sched_barrier(0);
     }
     if (t == 0) WOQ_XQS_STAMP(3);
     // memory requests stay in their iteration (that IS the window); ALU, MFMA and LDS work may move across
@@ -363,7 +382,7 @@ __device__ __forceinline__ void gemv_xqs_body(
   // the four lane quarters hold the four blocks' shares of each column
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
-    float v = tot[cb];
+    float v = NDIG > 0 ? tot[cb] * lut.wmul : tot[cb];
     v += xqs_swap32(v);  // lanes 0..31: this lane + lane ^ 32
     v += xqs_swap16(v);  // lanes 0..15: + lane ^ 16
     if (lane < 16) slab[((size_t)wid * CB + cb) * 16 + lane] = v;
@@ -430,18 +449,20 @@ __device__ __forceinline__ void gemv_xqs_body(
 // flags: bit 0 scales are bf16 (else fp16; ignored for fp32 scales), bit 1 SiLU(gate)*up epilogue (CB == 2)
 // The first 14 argument dwords are preloaded into SGPRs (-amdgpu-kernarg-preload-count=14): everything the weight
 // requests need sits there.
-template <int TPW, int CB, int D, int SMODE, bool ASYM, bool S32>
-__global__ __launch_bounds__(CB * TPW > 8 ? 512 : 1024) void gemv_xqs_kernel(
+// (three digit planes x two column tiles need more than the 128 registers of a 1024-thread workgroup: 512 there)
+template <int TPW, int CB, int D, int SMODE, bool ASYM, bool S32, int NDIG>
+__global__ __launch_bounds__((CB * TPW > 8 || (CB == 2 && NDIG == 3)) ? 512 : 1024) void gemv_xqs_kernel(
     const u32x4* __restrict__ q, const void* __restrict__ scales, const uint8_t* __restrict__ xlimbs,
     const float* __restrict__ xu, int tiles_k, int kt_off, int base_tiles, int rem_tiles, int n_groups, int tpg_shift,
     const uint8_t* __restrict__ zp, const float* __restrict__ xsx, float* __restrict__ out,
     const float* __restrict__ bias, const float* residual, float eps, int N, int K, int flags,
     const float* __restrict__ ssq_in, int n_ssq, XqPtrs xo, const float* __restrict__ next_norm_w,
-    float* __restrict__ ssq_out, const CommDev* __restrict__ tp) {
+    float* __restrict__ ssq_out, const CommDev* __restrict__ tp, LutArgs lut) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  gemv_xqs_body<TPW, CB, D, SMODE, ASYM, S32, false>(smem_raw, q, scales, xlimbs, xu, tiles_k, kt_off, base_tiles,
-                                                      rem_tiles, n_groups, tpg_shift, zp, xsx, out, bias, residual, eps,
-                                                      N, K, flags, ssq_in, n_ssq, xo, next_norm_w, ssq_out, 0u, tp);
+  gemv_xqs_body<TPW, CB, D, SMODE, ASYM, S32, false, false, NDIG>(
+      smem_raw, q, scales, xlimbs, xu, tiles_k, kt_off, base_tiles, rem_tiles, n_groups, tpg_shift, zp, xsx, out, bias,
+      residual, eps, N, K, flags, ssq_in, n_ssq, xo, next_norm_w, ssq_out, 0u, tp,
+      XqsChain{nullptr, 0u, XqPub{nullptr, 0u}, nullptr, -1}, lut);
 }
 
 }  // namespace woq

@@ -568,14 +568,19 @@ def _device_view(ptr, shape, device, typestr="<f4"):
 
 def synth_llama_weights(engine, hidden, inter, heads, kv_heads, head_dim, layers, vocab, group=128, sym=True,
                         scale_dtype="fp16", seed=1234, model_dtype=torch.float16, embed_vocab=None,
-                        shared_seed=None):
+                        shared_seed=None, weight_dtype="int4_clip"):
     """Synthetic random-init quantised Llama-shaped weights built directly on the device (no checkpoint, no
     network): int4 values uniform in [-8,7], scales ~ 0.02-ish/7 so dequantised weights look like N(0, 0.02^2),
     norms 1 + N(0, 0.02^2), embeddings N(0, 0.02^2). Returns the list of blobs (kept alive by the engine).
     Tensor-parallel shards: pass the PER-RANK heads / kv_heads / inter / vocab (what the engine was built with) and
     `embed_vocab` = the full vocabulary (the embedding table is replicated, lm_head is the rank's rows), and
     `shared_seed` = one seed for all ranks: the replicated tensors (norm weights, embedding) are drawn from it so
-    that every rank holds the same copy, while `seed` (per rank) draws the shards."""
+    that every rank holds the same copy, while `seed` (per rank) draws the shards.
+    `weight_dtype` "nf4" / "fp4_e2m1" / "fp4_e2m1_bnb": uniform table codes 0..15 instead of int4 values (symmetric),
+    scales sized so that the dequantised weights keep the same spread."""
+    table = weight_dtype in TABLE_WEIGHT_DTYPES
+    if table and not sym:
+        raise RuntimeError("QBits: float weight types are symmetric")
     dev = engine.device
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
@@ -585,15 +590,15 @@ def synth_llama_weights(engine, hidden, inter, heads, kv_heads, head_dim, layers
         gs.manual_seed(shared_seed)
 
     def rand_q(k, n):
-        q = torch.randint(-8, 8, (k, n), generator=g, device=dev, dtype=torch.int8)
+        q = torch.randint(0 if table else -8, 16 if table else 8, (k, n), generator=g, device=dev, dtype=torch.int8)
         kg = (k + (k if group == -1 else group) - 1) // (k if group == -1 else group)
-        s = (0.5 + torch.rand(kg, n, generator=g, device=dev)) * (0.02 / 4.0)
+        s = (0.5 + torch.rand(kg, n, generator=g, device=dev)) * (0.02 / (TABLE_WEIGHT_DTYPES[weight_dtype] if table else 4.0))
         z = None if sym else torch.randint(-8, 8, (kg, n), generator=g, device=dev, dtype=torch.int8)
         return q, s, z
 
     def pack(q, s, z):
         return qbits.repack_quantized_weight(q, s, z if z is not None else torch.empty(0, dtype=torch.int8),
-                                             torch.empty(0, dtype=torch.int32), "int4_clip", scale_dtype, "fp32",
+                                             torch.empty(0, dtype=torch.int32), weight_dtype, scale_dtype, "fp32",
                                              z is not None, group)
 
     qkv_n = (heads + 2 * kv_heads) * head_dim
@@ -619,8 +624,42 @@ def synth_llama_weights(engine, hidden, inter, heads, kv_heads, head_dim, layers
 
 
 # ---- fused decode engine from a quantised HF model (the `ipex.optimize_transformers` analogue) ---------------------
+# 4-bit table weight types the engine takes (round 4) -> the rms of their table over uniform codes (synthetic weights)
+TABLE_WEIGHT_DTYPES = {"nf4": 0.5, "fp4_e2m1": 2.9, "fp4_e2m1_bnb": 0.47}
+_TABLES = {
+    "nf4": [-1.0, -0.6961928009986877, -0.5250730514526367, -0.39491748809814453, -0.28444138169288635,
+            -0.18477343022823334, -0.09105003625154495, 0.0, 0.07958029955625534, 0.16093020141124725,
+            0.24611230194568634, 0.33791524171829224, 0.44070982933044434, 0.5626170039176941, 0.7229568362236023, 1.0],
+    "fp4_e2m1": [0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0, -0.0, -0.5, -1.0, -1.5, -2.0, -3.0, -4.0, -6.0],
+    "fp4_e2m1_bnb": [0.0, 0.0625 / 12, 8.0 / 12, 1.0, 4.0 / 12, 0.5, 2.0 / 12, 0.25,
+                     -0.0, -0.0625 / 12, -8.0 / 12, -1.0, -4.0 / 12, -0.5, -2.0 / 12, -0.25],
+}
+
+
+def _code_parts(mod):
+    """QuantizedLinearQBits of a 4-bit table type -> (codes int8 [K,N] in 0..15, scales fp32 [G,N], None): the blob has
+    no integer export (modules.py recover_qparms raises), so the codes are read back as the nearest table entry of
+    dequantised / scale — exact, the entries are >= 5e-3 apart and the quotient is off by an fp32 rounding."""
+    w = mod.weight.data
+    info = lambda t: qbits.acquire_packed_weight_info(w, t)  # noqa: E731
+    k, n = int(info(2)[0]), int(info(3)[0])
+    if int(info(4)[0]):
+        raise RuntimeError("QBits: the fused decode engine does not take act-order (g_idx) layers")
+    scales = info(9)
+    deq = torch.empty(k, n, dtype=torch.float32, device=w.device)
+    qbits.dequantize_packed_weight(w, deq, False, mod.compute_dtype, mod.weight_dtype, mod.scale_dtype)
+    s = scales[torch.arange(k, device=w.device) // int(info(1)[0])]
+    x = deq / torch.where(s == 0, torch.ones_like(s), s)
+    tab = torch.tensor(_TABLES[mod.weight_dtype], dtype=torch.float32, device=w.device)
+    vals, order = torch.sort(tab, stable=True)
+    pos = torch.bucketize(x, (vals[1:] + vals[:-1]) * 0.5)
+    return order[pos].to(torch.int8), scales, None
+
+
 def _signed_parts(mod):
     """QuantizedLinearQBits -> (q int8 [K,N] in [-8,7], scales fp32 [G,N], zp int8 [G,N] signed or None)."""
+    if getattr(mod, "weight_dtype", "int4_clip") in TABLE_WEIGHT_DTYPES:
+        return _code_parts(mod)
     int_w, scales, zeros, g_idx = mod.recover_qparms_kn()
     if g_idx is not None:
         raise RuntimeError("QBits: the fused decode engine does not take act-order (g_idx) layers")
@@ -645,9 +684,10 @@ def optimize_transformers(model, max_ctx=2048, kv_dtype=torch.float16):
         raise RuntimeError("QBits: the fused decode engine implements the SiLU-gated MLP only (%r)" % cfg.hidden_act)
     layers = model.model.layers
     first = layers[0].self_attn.q_proj
-    if getattr(first, "bits", 4) != 4 or getattr(first, "weight_dtype", "int4_clip") != "int4_clip":
-        raise RuntimeError("QBits: the fused decode engine takes int4_clip layers (int8 / nf4 / fp4 models run on the "
-                           "module path)")
+    wdt = getattr(first, "weight_dtype", "int4_clip")
+    if getattr(first, "bits", 4) != 4 or (wdt != "int4_clip" and wdt not in TABLE_WEIGHT_DTYPES):
+        raise RuntimeError("QBits: the fused decode engine takes int4_clip / nf4 / fp4 layers (int8 / fp8 models run "
+                           "on the module path)")
     hidden, inter = cfg.hidden_size, cfg.intermediate_size
     heads = cfg.num_attention_heads
     kv_heads = getattr(cfg, "num_key_value_heads", heads) or heads
@@ -666,7 +706,7 @@ def optimize_transformers(model, max_ctx=2048, kv_dtype=torch.float16):
     def pack(q, s, z):
         return qbits.repack_quantized_weight(q.contiguous(), s.contiguous(),
                                              z.contiguous() if z is not None else torch.empty(0, dtype=torch.int8),
-                                             torch.empty(0, dtype=torch.int32), "int4_clip", sdt, "fp32", asym, group)
+                                             torch.empty(0, dtype=torch.int32), wdt, sdt, "fp32", asym, group)
 
     def cat(parts):
         return (torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 1),

@@ -575,8 +575,9 @@ def test_from_pretrained_hf_awq_checkpoint(tmp_path):
                                               ("fp8_e5m2", 8, "fp8_e8m0")])
 def test_from_pretrained_table_weight_dtype(tmp_path, wname, bits, sname):
     """RtnConfig(weight_dtype="nf4" | "fp4_e2m1" | "fp8_e4m3" | "fp8_e5m2") (reference docs/weightonlyquant.md dtype
-    table; fp8 weights take fp32 or power-of-two fp8_e8m0 scales): quantised on the device, module path (no fused
-    engine), logits against the fp32 twin carrying the dequantised weights."""
+    table; fp8 weights take fp32 or power-of-two fp8_e8m0 scales): quantised on the device, logits of the module path
+    against the fp32 twin carrying the dequantised weights; greedy generate — the fused engine for the 4-bit table types
+    (round 4: codes read back from the modules' blobs, runtime/engine.py _code_parts), the module path for fp8."""
     from intel_extension_for_transformers_amd import qbits
     from intel_extension_for_transformers_amd.transformers import AutoModelForCausalLM, RtnConfig
     from intel_extension_for_transformers_amd.transformers.llm.quantization.nn.modules import QuantizedLinearQBits
@@ -604,7 +605,20 @@ def test_from_pretrained_table_weight_dtype(tmp_path, wname, bits, sname):
     assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-5
     out = qmodel.generate(ids, max_new_tokens=4, do_sample=False, pad_token_id=0)
     assert torch.equal(out, twin.generate(ids, max_new_tokens=4, do_sample=False, pad_token_id=0))
-    assert not hasattr(qmodel, "woq_engine")
+    assert hasattr(qmodel, "woq_engine") == (bits == 4)
+    if bits == 4:  # the engine's fused qkv / gate-up blobs hold exactly the modules' weights
+        eng = qmodel.woq_engine
+        at = qmodel.model.layers[0].self_attn
+        H = at.q_proj.in_features
+        parts = []
+        for m in (at.q_proj, at.k_proj, at.v_proj):
+            d = torch.empty(H, m.out_features, dtype=torch.float32, device="cuda")
+            qbits.dequantize_packed_weight(m.weight.data, d, False, "fp32", wname, sname)
+            parts.append(d)
+        want = torch.cat(parts, 1)
+        got = torch.empty_like(want)
+        qbits.dequantize_packed_weight(eng.layer_tensors[0]["qkv"], got, False, "fp32", wname, sname)
+        assert torch.equal(got, want)
     with pytest.raises(ValueError, match="asym"):
         RtnConfig(bits=bits, weight_dtype=wname, sym=False).post_init_hip()
 

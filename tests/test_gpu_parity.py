@@ -638,6 +638,46 @@ def test_table_weight_types_quantize_dequant_linear(qbits, wname, K, N, group):
         qbits.quantize_to_packed_weight(torch.from_numpy(w).cuda(), True, group, "fp32", wname, "fp32", True)
 
 
+@pytest.mark.parametrize("wname", sorted(TABLE_TYPES))
+@pytest.mark.parametrize("K,N,group,sname", [(4096, 256, 128, "fp32"), (1024, 96, 32, "bf16"), (2048, 64, 64, "fp16"),
+                                             (11008, 48, 128, "fp16"), (384, 272, -1, "fp32"), (160, 24, 64, "fp32")])
+def test_table_weight_types_decode_kernel(qbits, wname, K, N, group, sname):
+    """Round 4: nf4 / fp4 at decode row counts run the int4 MFMA kernel with a digit-plane unpack of the codes
+    (csrc/woq_gemv_common.h LutArgs: table * S as one or three balanced int8 digits per code, one MFMA per plane) instead
+    of the fp32 VALU kernel. 1..8 rows (one and two MFMA row sets), fp32 and 16-bit activation rows, every scale type,
+    per-128 / per-32 / per-64 / per-channel groups, ragged N and K, K beyond one wave slice: within fp32 summation error
+    of dequantise -> matmul -> + bias (nf4's table is held to 2^-23 of its largest entry; both fp4 tables exactly). The
+    fp32 VALU kernel these types ran on before (still the path of misaligned rows and g_idx blobs; reached here through
+    activation rows one element off 16-byte alignment) is held to the same bound."""
+    wt = TABLE_TYPES[wname]
+    rng = np.random.default_rng(43)
+    w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    q, s = orc.rtn_quantize_table(w, True, group, wt)
+    st = {"fp32": orc.F32, "fp16": orc.F16, "bf16": orc.BF16}[sname]
+    ref_blob = orc.repack_table(q, s, wt, group, scale_type=st)
+    e8, e32 = torch.empty(0, dtype=torch.int8), torch.empty(0, dtype=torch.int32)
+    blob = qbits.repack_quantized_weight(torch.from_numpy(q).cuda(), torch.from_numpy(s).cuda(), e8, e32, wname, sname,
+                                         "fp32", False, group)
+    assert np.array_equal(blob.cpu().numpy().view(np.uint8), ref_blob)
+    want = orc.dequantize_blob(ref_blob)
+    bias = rng.random(N, dtype=np.float32)
+    for M, adt in ((1, torch.float32), (2, torch.float32), (4, torch.float32), (5, torch.float32), (8, torch.float32),
+                   (1, torch.float16), (3, torch.bfloat16)):
+        x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(adt)
+        xf = x.float().numpy()
+        ref = orc.woq_linear(xf, ref_blob, bias)
+        out = torch.full((M, N), float("nan"), device="cuda")
+        qbits.woq_linear(x.cuda(), blob, torch.from_numpy(bias).cuda(), out, "fp32", wname, sname, False)
+        mag = np.abs(xf) @ np.abs(want)
+        assert (np.abs(out.cpu().numpy() - ref) <= 2e-6 * mag + 1e-5).all(), (M, adt)
+        # the same call with the activation rows one element off 16-byte alignment: the generic fp32 kernel
+        xp = torch.zeros(M, K + 8, dtype=adt, device="cuda")[:, 1:K + 1]
+        xp.copy_(x)
+        out2 = torch.full((M, N), float("nan"), device="cuda")
+        qbits.woq_linear(xp, blob, torch.from_numpy(bias).cuda(), out2, "fp32", wname, sname, False)
+        assert (np.abs(out2.cpu().numpy() - ref) <= 2e-6 * mag + 1e-5).all(), (M, adt, "generic")
+
+
 # ---- fp8 weight types: fp8_e4m3, fp8_e5m2 (+ fp8_e8m0 scales) — reference strings, qbits_ut/test_weightonly.py:20-27 -----
 FP8_TYPES = {"fp8_e4m3": orc.W_FP8_E4M3, "fp8_e5m2": orc.W_FP8_E5M2}
 
