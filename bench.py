@@ -71,7 +71,7 @@ def linear_params(cfg):
 
 
 def build_engine(cfg, group=128, sym=True, max_ctx=512, max_batch=1, kv_dtype=None, tp_rank=0, tp=1, seed=1234,
-                 layers=None):
+                 layers=None, weight_dtype="int4_clip", compute_dtype="fp32"):
     import torch
 
     from intel_extension_for_transformers_amd.runtime.engine import WoqDecoderEngine, synth_llama_weights
@@ -81,7 +81,8 @@ def build_engine(cfg, group=128, sym=True, max_ctx=512, max_batch=1, kv_dtype=No
     eng = WoqDecoderEngine(cfg["hidden"], inter, heads, kv, cfg["head_dim"], n_layers, vocab, max_ctx=max_ctx,
                            max_batch=max_batch, kv_dtype=kv_dtype or torch.float16, tp_rank=tp_rank, tp_size=tp)
     synth_llama_weights(eng, cfg["hidden"], inter, heads, kv, cfg["head_dim"], n_layers, vocab, group=group, sym=sym,
-                        scale_dtype="fp16", seed=seed + tp_rank, embed_vocab=cfg["vocab"], shared_seed=seed)
+                        scale_dtype="fp16", seed=seed + tp_rank, embed_vocab=cfg["vocab"], shared_seed=seed,
+                        weight_dtype=weight_dtype, compute_dtype=compute_dtype)
     return eng
 
 
@@ -668,6 +669,16 @@ def extra_configs(args):
                                 eng, 64, 8, 128, False, "%d cached positions, fp16 KV" % ctx, kv_bytes_per_token=kvb))
     del eng
     free_gpu()
+    # SURVEY §8(f)-4, the float 4-bit weight types at the same shape (round 4: digit-plane unpack of the table codes on
+    # the int8 MFMA, csrc/woq_gemv_common.h LutArgs; through round 3 these models ran the fp32 VALU kernel outside the
+    # engine, 35-87 us per projection): nf4 as three planes (compute fp32) and two (compute bf16), fp4_e2m1 as one
+    for wname, cname in (("nf4", "fp32"), ("nf4", "bf16"), ("fp4_e2m1", "fp32")):
+        eng = build_engine(LLAMA2_7B, group=128, sym=True, max_ctx=512, weight_dtype=wname, compute_dtype=cname)
+        feed_prompt(eng, LLAMA2_7B["vocab"], 32)
+        out.append(decode_entry("SURVEY 8(f)-4: Llama-2-7B %s sym g128 (compute %s), batch-1 decode" % (wname, cname),
+                                LLAMA2_7B, eng, 64, 8, 128, False, "prompt 32"))
+        del eng
+        free_gpu()
     # configs[4]: Mistral-7B shape, int4 sym g128, fp8 (e4m3) KV cache, 8k context: chunked prompt pass then decode
     cfg, ctx = MISTRAL_7B, 8192
     eng = build_engine(cfg, group=128, sym=True, max_ctx=ctx + 256, kv_dtype=torch.float8_e4m3fn)

@@ -53,7 +53,8 @@ __device__ __forceinline__ float limb_combine(const i32x4& d) {
 // ---- 4-bit table weight types (nf4 / fp4) on the int8 MFMA (round 4) ----
 // w = table[code] * scale is not linear in the code, but the table has 16 entries: table[c] * S (S = 2^22 for nf4,
 // 2 for fp4_e2m1, 192 for the bitsandbytes fp4 table — exact for both fp4 tables, |error| <= 2^-23 of the table's
-// largest magnitude for nf4) is an integer written in NDIG balanced base-256 digits, and each digit plane of a weight
+// largest magnitude for nf4 at S = 2^22; 127 * 256 and two digits for the reduced-precision compute modes) is an integer
+// written in NDIG balanced base-256 digits, and each digit plane of a weight
 // tile is a byte-table lookup of its nibbles: v_perm_b32 picks from 8 table bytes, so a 16-entry lookup of four codes is
 // two perms (codes 0..7, codes 8..15) and a select by bit 3 of each code. One MFMA per digit plane against the same A
 // operand, the results recombined as f0 + 2^8 f1 + 2^16 f2 — weights stay 4 bits in HBM, the inner product stays exact
@@ -94,8 +95,10 @@ __device__ __forceinline__ void int4_b(uint32_t w0, uint32_t w1, i32x4& b) {
   b = i32x4{(int)((w0 << 4) & 0xf0f0f0f0u), (int)(w0 & 0xf0f0f0f0u), (int)((w1 << 4) & 0xf0f0f0f0u),
             (int)(w1 & 0xf0f0f0f0u)};
 }
-// host: the digit planes of a table weight type; returns NDIG the kernels are instantiated for (1 | 3), 0 = not a table
-int lut_args_for(uint32_t weight_type, LutArgs& L);
+// host: the digit planes of a table weight type; returns NDIG (1 | 2 | 3), 0 = not a table. compute_type (woq_blob.h):
+// nf4 takes three planes for fp32 compute and two (table held to 2^-16 of its largest entry — finer than the bf16 / fp16
+// operands those modes ask for) otherwise
+int lut_args_for(uint32_t weight_type, uint32_t compute_type, LutArgs& L);
 
 // geometry pick of the tile GEMVs (woq_gemv_i8.hip): nw waves x tpw tiles cover tiles_k; false = not covered
 bool gemv_tile_geometry(int tiles_k, int cb, int smode, int& nw, int& tpw);

@@ -104,7 +104,7 @@ __host__ __device__ inline size_t tile_lds_bytes(int M, int nw, int TPW, int CB)
 
 
 // flags: bit 0 scales are bf16 (else fp16; ignored for fp32 scales), bit 1 SiLU(gate)*up epilogue (CB == 2)
-// NDIG: 0 = int4 weights; 1 | 3 = a 4-bit table type (nf4 / fp4) as that many digit planes (woq_gemv_common.h LutArgs)
+// NDIG: 0 = int4 weights; 1 | 2 | 3 = a 4-bit table type (nf4 / fp4) as that many digit planes (woq_gemv_common.h LutArgs)
 template <int TPW, int CB, int SMODE, bool ASYM, bool S32, bool M1, int NDIG>
 // register budget by workgroup size: 1024 threads -> 128 VGPRs (group-128 paths), 768 -> 168 (per-32 scales keep
 // 3 more registers per tile and twice the A fragments), 512 -> 256
@@ -617,11 +617,16 @@ static int launch_tile_sm(const TileLaunch& a, int smode, bool asym, bool s32, h
   WOQ_TILE_CASE(1, false, true, 0)
   WOQ_TILE_CASE(1, true, false, 0)
   WOQ_TILE_CASE(1, true, true, 0)
-  // 4-bit table types: symmetric only; one digit plane (fp4_e2m1) or three (nf4, the bitsandbytes fp4 table)
+  // 4-bit table types: symmetric only; one digit plane (fp4_e2m1), two (bitsandbytes fp4; nf4 at reduced-precision
+  // compute) or three (nf4 at compute fp32)
   WOQ_TILE_CASE(0, false, false, 1)
   WOQ_TILE_CASE(0, false, true, 1)
   WOQ_TILE_CASE(1, false, false, 1)
   WOQ_TILE_CASE(1, false, true, 1)
+  WOQ_TILE_CASE(0, false, false, 2)
+  WOQ_TILE_CASE(0, false, true, 2)
+  WOQ_TILE_CASE(1, false, false, 2)
+  WOQ_TILE_CASE(1, false, true, 2)
   WOQ_TILE_CASE(0, false, false, 3)
   WOQ_TILE_CASE(0, false, true, 3)
   WOQ_TILE_CASE(1, false, false, 3)
@@ -631,9 +636,10 @@ static int launch_tile_sm(const TileLaunch& a, int smode, bool asym, bool s32, h
 }
 
 // Digit planes of a table weight type (woq_gemv_common.h): v = round(table[c] * S) = d0 + 2^8 d1 + 2^16 d2, balanced
-// (d0, d1 in [-128, 127]). S: nf4 2^22 (three digits, |d2| <= 64), fp4_e2m1 2 (integers up to 12: one digit), the
-// bitsandbytes fp4 table 192 (integers up to 192: two digits, run as three).
-int lut_args_for(uint32_t weight_type, LutArgs& L) {
+// (d0, d1 in [-128, 127]). S: fp4_e2m1 2 (integers up to 12: one digit); the bitsandbytes fp4 table 192 (integers up
+// to 192: two digits, exact); nf4 2^22 (three digits, |d2| <= 64) for compute fp32, 127 * 256 (two digits, |d1| <= 127)
+// for the reduced-precision compute modes.
+int lut_args_for(uint32_t weight_type, uint32_t compute_type, LutArgs& L) {
   memset(&L, 0, sizeof(L));
   L.wmul = 1.f;
   if (!is_table_type(weight_type)) return 0;
@@ -641,7 +647,8 @@ int lut_args_for(uint32_t weight_type, LutArgs& L) {
   static const float e2m1[16] = WOQ_LUT_FP4_E2M1;
   static const float bnb[16] = WOQ_LUT_FP4_BNB;
   const float* tab = weight_type == WOQ_W_NF4 ? nf4 : (weight_type == WOQ_W_FP4_E2M1 ? e2m1 : bnb);
-  const double S = weight_type == WOQ_W_NF4 ? 4194304.0 : (weight_type == WOQ_W_FP4_E2M1 ? 2.0 : 192.0);
+  const int ndig = weight_type == WOQ_W_FP4_E2M1 ? 1 : (weight_type == WOQ_W_NF4 && compute_type == WOQ_C_FP32 ? 3 : 2);
+  const double S = weight_type == WOQ_W_FP4_E2M1 ? 2.0 : (weight_type == WOQ_W_FP4_E2M1_BNB ? 192.0 : (ndig == 3 ? 4194304.0 : 32512.0));
   for (int c = 0; c < 16; ++c) {
     long v = lrint((double)tab[c] * S);
     for (int j = 0; j < 3; ++j) {
@@ -651,7 +658,7 @@ int lut_args_for(uint32_t weight_type, LutArgs& L) {
     }
   }
   L.wmul = (float)(16.0 / S);
-  return weight_type == WOQ_W_FP4_E2M1 ? 1 : 3;
+  return ndig;
 }
 
 // K ranges one launch cannot hold are split into equal chunks run as chained launches (chunk i + 1 adds onto chunk
@@ -741,7 +748,7 @@ int launch_gemv_tile(const void* act, int act_dtype, int lda, int M, const void*
   a.residual = residual;
   a.flags = (h.scale_type == WOQ_BF16 ? 1 : 0) | (epi == 1 ? 2 : 0) |
             (act_dtype == WOQ_F16 ? 4 : (act_dtype == WOQ_BF16 ? 8 : 0));
-  a.ndig = lut_args_for(h.weight_type, a.lut);
+  a.ndig = lut_args_for(h.weight_type, h.compute_type, a.lut);
 #ifdef WOQ_PROBE
   a.flags |= ::g_probe_flags;
 #endif

@@ -73,11 +73,16 @@ static int launch_xq_sm(const XqLaunch& a, int smode, bool asym, bool s32, hipSt
   WOQ_XQ_CASE(1, false, true, 0)
   WOQ_XQ_CASE(1, true, false, 0)
   WOQ_XQ_CASE(1, true, true, 0)
-  // 4-bit table types (nf4 / fp4): symmetric; one digit plane (fp4_e2m1) or three
+  // 4-bit table types (nf4 / fp4): symmetric; one digit plane (fp4_e2m1), two (bitsandbytes fp4, nf4 at reduced-
+  // precision compute) or three (nf4 at compute fp32)
   WOQ_XQ_CASE(0, false, false, 1)
   WOQ_XQ_CASE(0, false, true, 1)
   WOQ_XQ_CASE(1, false, false, 1)
   WOQ_XQ_CASE(1, false, true, 1)
+  WOQ_XQ_CASE(0, false, false, 2)
+  WOQ_XQ_CASE(0, false, true, 2)
+  WOQ_XQ_CASE(1, false, false, 2)
+  WOQ_XQ_CASE(1, false, true, 2)
   WOQ_XQ_CASE(0, false, false, 3)
   WOQ_XQ_CASE(0, false, true, 3)
   WOQ_XQ_CASE(1, false, false, 3)
@@ -130,7 +135,7 @@ bool gemv_xq_supported(const woq_blob_header& h, int epi) {
     if (tpg < 1 || (tpg & (tpg - 1)) != 0) return false;
   }
   LutArgs lut;
-  return xq_k_chunks(tiles_k, cb, (int)h.scale_mode, epi == 0, lut_args_for(h.weight_type, lut)) > 0;
+  return xq_k_chunks(tiles_k, cb, (int)h.scale_mode, epi == 0, lut_args_for(h.weight_type, h.compute_type, lut)) > 0;
 }
 
 // out[N] (fp32, may be null when only the XQ output is wanted) = xin . W_deq (* rsqrt(mean(x^2) + eps) when ssq_in)
@@ -159,7 +164,7 @@ int launch_gemv_xq(const XqPtrs& xin, const void* blob, const woq_blob_header& h
     }
   }
   a.flags = (h.scale_type == WOQ_BF16 ? 1 : 0) | (epi == 1 ? 2 : 0);
-  a.ndig = lut_args_for(h.weight_type, a.lut);
+  a.ndig = lut_args_for(h.weight_type, h.compute_type, a.lut);
   a.eps = eps;
   a.n_ssq = h.K / 16;
   if (ssq_in != nullptr && a.n_ssq > 1024) return woq::fail("QBits: RMSNorm partials beyond K = 16384");
@@ -229,7 +234,7 @@ __global__ void gemv_empty_twin_kernel(unsigned int* __restrict__ sink) {
 int launch_gemv_twin(const void* blob, const woq_blob_header& h, int epi, int mode, unsigned int* sink, hipStream_t st) {
   const int tiles_k = h.Kpad / WOQ_TILE_K, tiles_n = h.Npad / WOQ_TILE_N, cb = epi == 1 ? 2 : 1;
   LutArgs lut;
-  const int ndig = lut_args_for(h.weight_type, lut);
+  const int ndig = lut_args_for(h.weight_type, h.compute_type, lut);
   const int chunks = xq_k_chunks(tiles_k, cb, (int)h.scale_mode, epi == 0, ndig);
   if (chunks == 0) return woq::fail("QBits: shape not covered by the XQ GEMV");
   const int per = (tiles_k + chunks - 1) / chunks;

@@ -112,7 +112,7 @@ struct XqsChain {
 
 // FUSED (woq_gemv_attn.hip): the outputs are consumed by another workgroup of the SAME launch: `out` is then an array
 // of 8-byte {tag, fp32} granules, each written by ONE write-through agent-scope store (the data is its own flag).
-// NDIG: 0 = int4 weights; 1 | 3 = a 4-bit table type (nf4 / fp4) as that many digit planes (woq_gemv_common.h LutArgs)
+// NDIG: 0 = int4 weights; 1 | 2 | 3 = a 4-bit table type (nf4 / fp4) as that many digit planes (woq_gemv_common.h LutArgs)
 template <int TPW, int CB, int D, int SMODE, bool ASYM, bool S32, bool FUSED, bool CHAIN_IN = false, int NDIG = 0>
 __device__ __forceinline__ void gemv_xqs_body(
     unsigned char* smem_raw, const u32x4* __restrict__ q, const void* __restrict__ scales,

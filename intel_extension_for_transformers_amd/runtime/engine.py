@@ -568,7 +568,7 @@ def _device_view(ptr, shape, device, typestr="<f4"):
 
 def synth_llama_weights(engine, hidden, inter, heads, kv_heads, head_dim, layers, vocab, group=128, sym=True,
                         scale_dtype="fp16", seed=1234, model_dtype=torch.float16, embed_vocab=None,
-                        shared_seed=None, weight_dtype="int4_clip"):
+                        shared_seed=None, weight_dtype="int4_clip", compute_dtype="fp32"):
     """Synthetic random-init quantised Llama-shaped weights built directly on the device (no checkpoint, no
     network): int4 values uniform in [-8,7], scales ~ 0.02-ish/7 so dequantised weights look like N(0, 0.02^2),
     norms 1 + N(0, 0.02^2), embeddings N(0, 0.02^2). Returns the list of blobs (kept alive by the engine).
@@ -577,7 +577,8 @@ def synth_llama_weights(engine, hidden, inter, heads, kv_heads, head_dim, layers
     `shared_seed` = one seed for all ranks: the replicated tensors (norm weights, embedding) are drawn from it so
     that every rank holds the same copy, while `seed` (per rank) draws the shards.
     `weight_dtype` "nf4" / "fp4_e2m1" / "fp4_e2m1_bnb": uniform table codes 0..15 instead of int4 values (symmetric),
-    scales sized so that the dequantised weights keep the same spread."""
+    scales sized so that the dequantised weights keep the same spread; `compute_dtype` is recorded in the blobs (nf4
+    decodes with three digit planes at "fp32", two at "bf16" / "fp16" / "int8": csrc/woq_gemv_common.h)."""
     table = weight_dtype in TABLE_WEIGHT_DTYPES
     if table and not sym:
         raise RuntimeError("QBits: float weight types are symmetric")
@@ -598,7 +599,7 @@ def synth_llama_weights(engine, hidden, inter, heads, kv_heads, head_dim, layers
 
     def pack(q, s, z):
         return qbits.repack_quantized_weight(q, s, z if z is not None else torch.empty(0, dtype=torch.int8),
-                                             torch.empty(0, dtype=torch.int32), weight_dtype, scale_dtype, "fp32",
+                                             torch.empty(0, dtype=torch.int32), weight_dtype, scale_dtype, compute_dtype,
                                              z is not None, group)
 
     qkv_n = (heads + 2 * kv_heads) * head_dim
@@ -702,11 +703,13 @@ def optimize_transformers(model, max_ctx=2048, kv_dtype=torch.float16):
                            sliding_window=int(window))
     asym = first.scheme == "asym"
     group, sdt = first.blocksize, first.scale_dtype
+    # the blobs' compute type picks nf4's digit-plane count (three at fp32, two otherwise); int4 kernels do not read it
+    cdt = getattr(first, "compute_dtype", "fp32") if wdt in TABLE_WEIGHT_DTYPES else "fp32"
 
     def pack(q, s, z):
         return qbits.repack_quantized_weight(q.contiguous(), s.contiguous(),
                                              z.contiguous() if z is not None else torch.empty(0, dtype=torch.int8),
-                                             torch.empty(0, dtype=torch.int32), wdt, sdt, "fp32", asym, group)
+                                             torch.empty(0, dtype=torch.int32), wdt, sdt, cdt, asym, group)
 
     def cat(parts):
         return (torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 1),

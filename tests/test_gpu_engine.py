@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _tiny(group, asym, scale_dtype, seed=0, max_ctx=64, max_batch=1, head_dim=64, kv_dtype=torch.float16,
-          attn_splits=0, window=0, hidden=256, attn_grouped=False, weight_dtype="int4_clip"):
+          attn_splits=0, window=0, hidden=256, attn_grouped=False, weight_dtype="int4_clip", compute_dtype="fp32"):
     from intel_extension_for_transformers_amd import qbits
     from intel_extension_for_transformers_amd.runtime import WoqDecoderEngine, fuse_gate_up
 
@@ -39,7 +39,7 @@ def _tiny(group, asym, scale_dtype, seed=0, max_ctx=64, max_batch=1, head_dim=64
     def gpu_pack(q, s, z):
         return qbits.repack_quantized_weight(torch.from_numpy(q).cuda(), torch.from_numpy(s).cuda(),
                                              e8 if z is None else torch.from_numpy(z).cuda(), e32, weight_dtype,
-                                             scale_dtype, "fp32", z is not None, group)
+                                             scale_dtype, compute_dtype, z is not None, group)
 
     def cpu_pack(q, s, z):
         if wt is not None:
@@ -554,16 +554,19 @@ def test_short_prompt_split_k_prompt_pass_equals_decode_steps(asym, group):
     assert int(got.argmax()) == int(ref.argmax())
 
 
-@pytest.mark.parametrize("weight_dtype,group,scale_dtype", [("nf4", 128, "fp16"), ("nf4", 32, "fp32"),
-                                                            ("fp4_e2m1", 128, "bf16"), ("fp4_e2m1_bnb", -1, "fp32")])
-def test_engine_table_weight_types_vs_oracle(weight_dtype, group, scale_dtype):
+@pytest.mark.parametrize("weight_dtype,group,scale_dtype,compute_dtype",
+                         [("nf4", 128, "fp16", "fp32"), ("nf4", 32, "fp32", "fp32"), ("nf4", 128, "fp16", "bf16"),
+                          ("fp4_e2m1", 128, "bf16", "fp32"), ("fp4_e2m1_bnb", -1, "fp32", "fp32")])
+def test_engine_table_weight_types_vs_oracle(weight_dtype, group, scale_dtype, compute_dtype):
     """nf4 / fp4 layers in the fused engine (round 4; reference strings bestla_weightonly_dispatcher.hpp:62-70): the
     decode step's XQ GEMVs with the digit-plane unpack (csrc/woq_gemv_common.h LutArgs) — eager steps, graph replays
     and the fp32-activation kernels — and the prompt pass on the MFMA GEMM over a pre-dequantised fragment image (fused
-    RMSNorm and SiLU*mul epilogues), all against the oracle decoder on the same codes and scales."""
+    RMSNorm and SiLU*mul epilogues), all against the oracle decoder on the same codes and scales. nf4 blobs packed for
+    compute bf16 decode with two digit planes (table held to 2^-16 of its largest entry) instead of three."""
     import os
 
-    eng, oracle, cfg = _tiny(group, False, scale_dtype, seed=7, weight_dtype=weight_dtype)
+    eng, oracle, cfg = _tiny(group, False, scale_dtype, seed=7, weight_dtype=weight_dtype,
+                             compute_dtype=compute_dtype)
     assert not eng.uses_fused_attn()  # the fused qkv + attention launch stays int4-only
     prompt = [3, 17, 200, 5, 99, 42, 7]
     for i, t in enumerate(prompt):
@@ -593,7 +596,8 @@ def test_engine_table_weight_types_vs_oracle(weight_dtype, group, scale_dtype):
     # the fp32-activation kernels (WOQ_ENGINE_XQ=0: woq_gemv_i8.hip with the same unpack)
     os.environ["WOQ_ENGINE_XQ"] = "0"
     try:
-        eng0, oracle0, _ = _tiny(group, False, scale_dtype, seed=7, weight_dtype=weight_dtype)
+        eng0, oracle0, _ = _tiny(group, False, scale_dtype, seed=7, weight_dtype=weight_dtype,
+                                 compute_dtype=compute_dtype)
     finally:
         del os.environ["WOQ_ENGINE_XQ"]
     for i, t in enumerate(prompt[:4]):

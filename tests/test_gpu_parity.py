@@ -656,26 +656,32 @@ def test_table_weight_types_decode_kernel(qbits, wname, K, N, group, sname):
     st = {"fp32": orc.F32, "fp16": orc.F16, "bf16": orc.BF16}[sname]
     ref_blob = orc.repack_table(q, s, wt, group, scale_type=st)
     e8, e32 = torch.empty(0, dtype=torch.int8), torch.empty(0, dtype=torch.int32)
-    blob = qbits.repack_quantized_weight(torch.from_numpy(q).cuda(), torch.from_numpy(s).cuda(), e8, e32, wname, sname,
-                                         "fp32", False, group)
-    assert np.array_equal(blob.cpu().numpy().view(np.uint8), ref_blob)
     want = orc.dequantize_blob(ref_blob)
     bias = rng.random(N, dtype=np.float32)
-    for M, adt in ((1, torch.float32), (2, torch.float32), (4, torch.float32), (5, torch.float32), (8, torch.float32),
-                   (1, torch.float16), (3, torch.bfloat16)):
-        x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(adt)
-        xf = x.float().numpy()
-        ref = orc.woq_linear(xf, ref_blob, bias)
-        out = torch.full((M, N), float("nan"), device="cuda")
-        qbits.woq_linear(x.cuda(), blob, torch.from_numpy(bias).cuda(), out, "fp32", wname, sname, False)
-        mag = np.abs(xf) @ np.abs(want)
-        assert (np.abs(out.cpu().numpy() - ref) <= 2e-6 * mag + 1e-5).all(), (M, adt)
-        # the same call with the activation rows one element off 16-byte alignment: the generic fp32 kernel
-        xp = torch.zeros(M, K + 8, dtype=adt, device="cuda")[:, 1:K + 1]
-        xp.copy_(x)
-        out2 = torch.full((M, N), float("nan"), device="cuda")
-        qbits.woq_linear(xp, blob, torch.from_numpy(bias).cuda(), out2, "fp32", wname, sname, False)
-        assert (np.abs(out2.cpu().numpy() - ref) <= 2e-6 * mag + 1e-5).all(), (M, adt, "generic")
+    # compute bf16: nf4 decodes with two digit planes — the table held to 2^-16 of its largest entry, 2e-4 of its
+    # smallest (the reference's bf16 compute rounds every dequantised weight to 8 mantissa bits: 4e-3)
+    for cname, rel in (("fp32", 2e-6), ("bf16", 2.5e-4 if wname == "nf4" else 2e-6)):
+        blob = qbits.repack_quantized_weight(torch.from_numpy(q).cuda(), torch.from_numpy(s).cuda(), e8, e32, wname,
+                                             sname, cname, False, group)
+        if cname == "fp32":
+            assert np.array_equal(blob.cpu().numpy().view(np.uint8), ref_blob)
+        for M, adt in ((1, torch.float32), (2, torch.float32), (4, torch.float32), (5, torch.float32),
+                       (8, torch.float32), (1, torch.float16), (3, torch.bfloat16)):
+            x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(adt)
+            xf = x.float().numpy()
+            ref = orc.woq_linear(xf, ref_blob, bias)
+            out = torch.full((M, N), float("nan"), device="cuda")
+            qbits.woq_linear(x.cuda(), blob, torch.from_numpy(bias).cuda(), out, cname, wname, sname, False)
+            mag = np.abs(xf) @ np.abs(want)
+            assert (np.abs(out.cpu().numpy() - ref) <= rel * mag + 1e-5).all(), (cname, M, adt)
+            if cname != "fp32":
+                continue
+            # the same call with the activation rows one element off 16-byte alignment: the generic fp32 kernel
+            xp = torch.zeros(M, K + 8, dtype=adt, device="cuda")[:, 1:K + 1]
+            xp.copy_(x)
+            out2 = torch.full((M, N), float("nan"), device="cuda")
+            qbits.woq_linear(xp, blob, torch.from_numpy(bias).cuda(), out2, "fp32", wname, sname, False)
+            assert (np.abs(out2.cpu().numpy() - ref) <= 2e-6 * mag + 1e-5).all(), (M, adt, "generic")
 
 
 # ---- fp8 weight types: fp8_e4m3, fp8_e5m2 (+ fp8_e8m0 scales) — reference strings, qbits_ut/test_weightonly.py:20-27 -----

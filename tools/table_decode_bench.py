@@ -20,13 +20,18 @@ from intel_extension_for_transformers_amd.runtime.engine import synth_llama_weig
 SHAPES = {"qkv": (4096, 12288), "o": (4096, 4096), "gate_up": (4096, 22016), "down": (11008, 4096)}
 
 
-def time_linear(wname, K, N, M, reps=200):
+def split(spec):  # "nf4:bf16" -> ("nf4", "bf16"): weight type and the compute type recorded in the blobs
+    return (spec.split(":") + ["fp32"])[:2]
+
+
+def time_linear(spec, K, N, M, reps=200):
+    wname, cname = split(spec)
     g = torch.Generator(device="cuda").manual_seed(1)
     table = wname != "int4_clip"
     q = torch.randint(0 if table else -8, 16 if table else 8, (K, N), generator=g, device="cuda", dtype=torch.int8)
     s = (0.5 + torch.rand(K // 128, N, generator=g, device="cuda")) * 0.005
     blob = qbits.repack_quantized_weight(q, s, torch.empty(0, dtype=torch.int8), torch.empty(0, dtype=torch.int32),
-                                         wname, "fp16", "fp32", False, 128)
+                                         wname, "fp16", cname, False, 128)
     x = torch.randn(M, K, device="cuda")
     out = torch.empty(M, N, device="cuda")
     e = torch.empty(0)
@@ -42,9 +47,11 @@ def time_linear(wname, K, N, M, reps=200):
     return t0.elapsed_time(t1) * 1e3 / reps
 
 
-def engine_rate(wname, layers, steps=64):
+def engine_rate(spec, layers, steps=64):
+    wname, cname = split(spec)
     eng = WoqDecoderEngine(4096, 11008, 32, 32, 128, layers, 32000, max_ctx=512)
-    synth_llama_weights(eng, 4096, 11008, 32, 32, 128, layers, 32000, group=128, sym=True, weight_dtype=wname)
+    synth_llama_weights(eng, 4096, 11008, 32, 32, 128, layers, 32000, group=128, sym=True, weight_dtype=wname,
+                        compute_dtype=cname)
     eng.reset(token=1, pos=0)
     eng.run(48, greedy=True)
     eng.capture(greedy=True)
@@ -66,7 +73,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--engine", action="store_true")
     ap.add_argument("--layers", type=int, default=32)
-    ap.add_argument("--types", default="int4_clip,nf4,fp4_e2m1")
+    ap.add_argument("--types", default="int4_clip,nf4,nf4:bf16,fp4_e2m1,fp4_e2m1_bnb")
     args = ap.parse_args()
     mode = "generic fp32 VALU kernel" if os.environ.get("WOQ_TABLE_GENERIC") else "digit-plane MFMA kernel"
     for wname in args.types.split(","):

@@ -99,7 +99,7 @@ struct Shape {
 template <int TPW, int CB, int D>
 static void launch_xqs(const woq::XqLaunch& a, hipStream_t st) {
   typedef woq::XqsLds<TPW, CB, 0, false, false> L;
-  auto kern = woq::gemv_xqs_kernel<TPW, CB, D, 0, false, false>;
+  auto kern = woq::gemv_xqs_kernel<TPW, CB, D, 0, false, false, 0>;
   static bool attr_set = false;
   if (!attr_set) {
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -109,7 +109,7 @@ static void launch_xqs(const woq::XqLaunch& a, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(a.grid), dim3(a.nw * 64), L::total(a.nw), st, (const u32x4*)a.q, a.scales, a.xin.limbs,
                      a.xin.u, a.tiles_k, a.kt_begin, base, rem, a.n_groups, a.tpg_shift, (const uint8_t*)a.zp, a.xin.sx,
                      a.out, a.bias, a.residual, a.eps, a.N, a.K, a.flags, a.ssq_in, a.n_ssq, a.xo, a.next_norm_w,
-                     a.ssq_out, (const woq::CommDev*)nullptr);
+                     a.ssq_out, (const woq::CommDev*)nullptr, woq::LutArgs{});
 }
 
 template <int TPW, int CB>
