@@ -70,8 +70,14 @@ struct LutArgs {
 template <int NDIG>
 __device__ __forceinline__ void lut_quad(const LutArgs& L, uint32_t idx, uint32_t (&out)[NDIG]) {
   const uint32_t sel = idx & 0x07070707u;
+#ifdef WOQ_LUT_PERM_MASK
+  // A/B build (tools/mkvariant_xq.sh lutperm -DWOQ_LUT_PERM_MASK): the mask from v_perm_b32's constant selectors —
+  // 0x05 picks byte 1 of the (zero) high source, 0x0d and above yield 0xff — two instructions instead of three
+  const uint32_t mask = __builtin_amdgcn_perm(0u, 0u, (idx & 0x08080808u) | 0x05050505u);
+#else
   const uint32_t m8 = idx & 0x08080808u;
   const uint32_t mask = (m8 << 5) - (m8 >> 3);  // 0xff in every byte whose code is >= 8
+#endif
 #pragma unroll
   for (int j = 0; j < NDIG; ++j) {
     const uint32_t lo = __builtin_amdgcn_perm(L.d[j][1], L.d[j][0], sel);  // {hi:lo} = table bytes 7..0
