@@ -58,7 +58,7 @@ __device__ __forceinline__ float limb_combine(const i32x4& d) {
 // tile is a byte-table lookup of its nibbles: v_perm_b32 picks from 8 table bytes, so a 16-entry lookup of four codes is
 // two perms (codes 0..7, codes 8..15) and a select by bit 3 of each code. One MFMA per digit plane against the same A
 // operand, the results recombined as f0 + 2^8 f1 + 2^16 f2 — weights stay 4 bits in HBM, the inner product stays exact
-// in int32, and the kernels are the int4 ones with a different B-operand unpack (13 VALU per four weights for three
+// in int32, and the kernels are the int4 ones with a different B-operand unpack (12 VALU per four weights for three
 // digits against 0.4 for int4: such a launch is issue-bound at ~1.5x the int4 time, against 4x for the fp32 VALU kernel
 // these types ran on through round 3).
 struct LutArgs {
@@ -70,13 +70,14 @@ struct LutArgs {
 template <int NDIG>
 __device__ __forceinline__ void lut_quad(const LutArgs& L, uint32_t idx, uint32_t (&out)[NDIG]) {
   const uint32_t sel = idx & 0x07070707u;
-#ifdef WOQ_LUT_PERM_MASK
-  // A/B build (tools/mkvariant_xq.sh lutperm -DWOQ_LUT_PERM_MASK): the mask from v_perm_b32's constant selectors —
-  // 0x05 picks byte 1 of the (zero) high source, 0x0d and above yield 0xff — two instructions instead of three
+#ifndef WOQ_LUT_ARITH_MASK
+  // 0xff in every byte whose code is >= 8, from v_perm_b32's constant selectors: 0x05 picks byte 1 of the (zero) high
+  // source, 0x0d yields 0xff (ISA: selector 12 = 0x00, above = 0xff). Two instructions; the arithmetic form below takes
+  // three: +1.7 % / +2.1 % tokens/s for three / two planes at the 7B shape (profiles/r04ae_last_tree_summary.txt)
   const uint32_t mask = __builtin_amdgcn_perm(0u, 0u, (idx & 0x08080808u) | 0x05050505u);
 #else
   const uint32_t m8 = idx & 0x08080808u;
-  const uint32_t mask = (m8 << 5) - (m8 >> 3);  // 0xff in every byte whose code is >= 8
+  const uint32_t mask = (m8 << 5) - (m8 >> 3);
 #endif
 #pragma unroll
   for (int j = 0; j < NDIG; ++j) {
