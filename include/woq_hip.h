@@ -46,6 +46,13 @@ WOQ_API int woq_abi_version(void);
 /* number of visible HIP devices (0 when there is no GPU); never fails. */
 WOQ_API int woq_device_count(void);
 
+/* How the decode GEMVs read a 4-bit table weight type (nf4 / fp4_e2m1 / fp4_e2m1_bnb; no counterpart in the reference,
+ * whose BesTLA kernels look the value up per weight): table[c] * S as `return value` balanced base-256 int8 digits —
+ * planes[j][c >> 2] byte (c & 3) = digit j of code c — one v_mfma_i32_16x16x64_i8 per digit plane, and *wmul = 16 / S,
+ * the factor that undoes S (and the 16 of the int4 kernels' 16 q operand). compute_type (enum woq_compute_type): nf4
+ * takes three planes at fp32, two otherwise. Host-only (no device needed); 0 = not a table type. */
+WOQ_API int woq_table_digit_planes(int weight_type, int compute_type, uint32_t planes[3][4], float* wmul);
+
 /* ---- packed-weight management (load time) ---------------------------------------------------- */
 
 /* replaces qbits.get_packed_weight_size (qbits.cpp:79-88). 0 = unsupported geometry. */

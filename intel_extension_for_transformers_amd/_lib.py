@@ -74,7 +74,7 @@ EXPORTS = [
     "woq_engine_set_attn_grouped", "woq_engine_attn_grouped", "woq_engine_set_attn_chunk", "woq_engine_attn_chunk", "woq_engine_set_persist", "woq_engine_persist", "woq_engine_persist_stamps", "woq_engine_set_tp_options", "woq_engine_time_twin", "woq_engine_set_time_eager", "woq_engine_time_prefill_gemm", "woq_engine_set_fuse_attn", "woq_engine_fuse_attn", "woq_engine_status", "woq_engine_clear_status",
     "woq_comm_create", "woq_comm_handle", "woq_comm_connect", "woq_comm_allreduce_f32", "woq_comm_status",
     "woq_comm_set_timeout_ms", "woq_comm_destroy", "woq_engine_set_comm", "woq_set_workspace", "woq_engine_uses_xq",
-    "woq_engine_token_log_ptr",
+    "woq_engine_token_log_ptr", "woq_table_digit_planes",
 ]
 
 _lib = None
@@ -94,6 +94,8 @@ def lib():
     L.woq_last_error.restype = ctypes.c_char_p
     L.woq_packed_weight_size.restype = cs
     L.woq_packed_weight_size.argtypes = [ci] * 7
+    L.woq_table_digit_planes.restype = ci
+    L.woq_table_digit_planes.argtypes = [ci, ci, vp, vp]
     L.woq_repack_quantized_weight.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, cs, vp]
     L.woq_quantize_to_packed_weight.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, cs, vp]
     L.woq_dequantize_packed_weight.argtypes = [vp, ctypes.POINTER(BlobHeader), vp, ci, vp]

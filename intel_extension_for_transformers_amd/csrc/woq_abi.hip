@@ -7,7 +7,10 @@
 // compute_dtype fp32, single fp16 product for the reduced-precision compute modes).
 #include <mutex>
 
+#include <string.h>
+
 #include "woq_device.h"
+#include "woq_gemv_common.h"
 #include "woq_launch.h"
 
 namespace woq {
@@ -125,6 +128,14 @@ static int linear_int4(const void* act, int act_dtype, int lda, const void* blob
                            nullptr, h.compute_type == WOQ_C_FP32 ? 1 : 0, st);
   return launch_gemv_from_header(act, act_dtype, lda, blob, h, bias, out, out_dtype, ldo, M, nullptr, 0.f, residual,
                                  ld_res, 0, 1, st);
+}
+
+int woq_table_digit_planes(int weight_type, int compute_type, uint32_t planes[3][4], float* wmul) {
+  woq::LutArgs L;
+  const int nd = woq::lut_args_for((uint32_t)weight_type, (uint32_t)compute_type, L);
+  if (planes != nullptr) memcpy(planes, L.d, sizeof(L.d));
+  if (wmul != nullptr) *wmul = L.wmul;
+  return nd;
 }
 
 int woq_set_workspace(void* workspace_dev, size_t bytes) {

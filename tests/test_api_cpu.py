@@ -266,6 +266,58 @@ def test_library_exports_every_symbol_the_headers_declare():
     assert ctypes.sizeof(_lib.BlobHeader) == 256 and ctypes.sizeof(_lib.EngineConfig) == 4 * 16
 
 
+def test_table_digit_planes_reproduce_the_tables():
+    """nf4 / fp4 at decode row counts (round 4): the kernels read table[c] * S as balanced base-256 int8 digit planes
+    looked up with v_perm_b32 (csrc/woq_gemv_common.h). The planes the library hands its kernels, rebuilt here on the
+    host (no device): digits in range, sum_j d_j 256^j / S == the oracle's table — exactly for both fp4 tables, to
+    2^-23 of the largest entry for nf4 at compute fp32 (three planes) and 2^-16 for the two-plane form — and the byte
+    lookup itself (two 8-entry permutes + a select by bit 3 of the code) emulated on every code."""
+    import ctypes
+    import os
+
+    from intel_extension_for_transformers_amd import _lib
+    from oracle import woq_oracle as orc
+
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libwoq_hip.so not built (python __graft_entry__.py)")
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.woq_table_digit_planes.restype = ctypes.c_int
+    lib.woq_table_digit_planes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+
+    def perm(hi, lo, sel):  # v_perm_b32: byte i of the result = byte sel_i of {hi:lo}; 0x0c = 0x00, >= 0x0d = 0xff
+        src = [(lo >> (8 * i)) & 0xff for i in range(4)] + [(hi >> (8 * i)) & 0xff for i in range(4)]
+        out = 0
+        for i in range(4):
+            b = (sel >> (8 * i)) & 0xff
+            out |= (src[b] if b < 8 else (0 if b == 12 else 0xff)) << (8 * i)
+        return out
+
+    cases = [(orc.W_NF4, 0, 3, 2.0 ** -23), (orc.W_NF4, 1, 2, 2.0 ** -16), (orc.W_NF4, 3, 2, 2.0 ** -16),
+             (orc.W_FP4_E2M1, 0, 1, 0.0), (orc.W_FP4_E2M1_BNB, 0, 2, 1e-7), (orc.W_FP4_E2M1_BNB, 1, 2, 1e-7)]
+    for wt, ct, ndig, tol in cases:
+        planes = (ctypes.c_uint32 * 12)()
+        wmul = ctypes.c_float()
+        assert lib.woq_table_digit_planes(wt, ct, planes, ctypes.byref(wmul)) == ndig
+        d = [[int(planes[j * 4 + i]) for i in range(4)] for j in range(3)]
+        S = 16.0 / wmul.value
+        lut = orc.LUTS[wt]
+        for base in range(0, 16, 4):
+            codes = [base, base + 1, base + 2, base + 3]
+            idx = sum(c << (8 * i) for i, c in enumerate(codes))
+            sel = idx & 0x07070707
+            mask = perm(0, 0, (idx & 0x08080808) | 0x05050505)
+            for i, c in enumerate(codes):
+                v = 0
+                for j in range(3):
+                    word = (perm(d[j][3], d[j][2], sel) & mask) | (perm(d[j][1], d[j][0], sel) & ~mask & 0xffffffff)
+                    b = (word >> (8 * i)) & 0xff
+                    dj = b - 256 if b >= 128 else b
+                    assert j < ndig or dj == 0
+                    v += dj * 256 ** j
+                assert abs(v / S - float(lut[c])) <= tol * float(np.abs(lut).max()) + 1e-12, (wt, ct, c)
+    assert lib.woq_table_digit_planes(0, 0, None, None) == 0  # int4_clip is not a table type
+
+
 def test_fp8_weight_dtype_config_on_the_hip_path():
     """fp8 weights at the config level (reference config.py:298-299,313,335-340): "fp8" means fp8_e4m3, bits = 8,
     symmetric only, fp32 or fp8_e8m0 ("fp8") scales; fp8_e8m0 scales are refused for integer weights."""
