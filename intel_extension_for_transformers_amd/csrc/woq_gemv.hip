@@ -253,12 +253,28 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
   return 0;
 }
 
-// fp8 weights: rows in chunks of GEN_MAXM through the generic kernel reading both nibble planes (functional, untuned).
+bool gemv_fp8_mfma_supported(const void* act, int act_dtype, int lda, const woq_blob_header& hi);
+int launch_gemv_fp8_mfma(const void* act, int act_dtype, int lda, int M, const void* hi_blob, const woq_blob_header& hi,
+                         const void* lo_q, uint32_t fp8_type, const float* bias, void* out, int out_dtype, int ldo,
+                         hipStream_t st);
+
+// fp8 weights at decode row counts: the fp8-MFMA kernel (woq_gemv_fp8.hip: code bytes straight into the matrix cores,
+// activations as base-16 digits; round 4) where it takes the call, rows in chunks of 8; otherwise (per-32 / per-64
+// scales, g_idx, misaligned rows, K beyond 12288) the lookup kernel reading both nibble planes, rows in chunks of GEN_MAXM.
 // `hi` = the HI plane's header (scales, shuffle), `lo_q` = the LO plane's qdata.
 int launch_gemv_fp8(const void* act, int act_dtype, int lda, const void* hi_blob, const woq_blob_header& hi,
                     const void* lo_q, uint32_t fp8_type, const float* bias, void* out, int out_dtype, int ldo, int M,
                     hipStream_t st) {
   const size_t esz_a = act_dtype == WOQ_F32 ? 4 : 2, esz_o = out_dtype == WOQ_F32 ? 4 : 2;
+  if (gemv_fp8_mfma_supported(act, act_dtype, lda, hi)) {
+    for (int m0 = 0; m0 < M; m0 += 8) {
+      const int rc = launch_gemv_fp8_mfma((const char*)act + (size_t)m0 * lda * esz_a, act_dtype, lda,
+                                          M - m0 < 8 ? M - m0 : 8, hi_blob, hi, lo_q, fp8_type, bias,
+                                          (char*)out + (size_t)m0 * ldo * esz_o, out_dtype, ldo, st);
+      if (rc) return rc;
+    }
+    return 0;
+  }
   int rows = GEN_MAXM;
   while (rows > 1 && gen_lds_bytes(rows, hi.Kpad) > 150 * 1024) --rows;
   for (int m0 = 0; m0 < M; m0 += rows) {

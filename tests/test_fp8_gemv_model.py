@@ -1,0 +1,106 @@
+"""Host model of the fp8-weight decode kernel (csrc/woq_gemv_fp8.hip) against the oracle — runs without a GPU.
+
+The kernel feeds OCP fp8 code bytes straight into v_mfma_f32_16x16x32_fp8_{fp8,bf8} and brings the fp32 activation in as
+six balanced base-16 digits (each an exact e4m3 value). What can be checked on the host is everything but the matrix
+instruction itself: the code bytes a lane assembles from the blob's two nibble planes and the k index each byte stands
+for (against the oracle's own reading of the blob), the digit decomposition of the fixed-point activation, and the
+recombination sum_j 16^j S_j with per-tile scales — together against `oracle.woq_linear` (reference definition:
+autograd/functions.py:41-63) at the bound the GPU test uses. The operand layout assumed for the instruction (lane
+l: A[l & 15][8 (l >> 4) + byte], B[8 (l >> 4) + byte][l & 15], D rows 4 (l >> 4) .. + 3 of column l & 15) is the one
+the int8 MFMA of the int4 kernels uses with 16 bytes per lane; the GPU suite checks the real thing.
+"""
+import numpy as np
+import pytest
+
+from oracle import woq_oracle as orc
+
+
+def device_codes(blob):
+    """codes [Kpad, Npad] as the kernel's lanes assemble them: b0..b3 of every (tile, lane, half) -> (k, n)."""
+    bhi, blo = orc._int8_parts(blob)
+    hh = orc.header(bhi)
+    tiles_k, tiles_n = hh["Kpad"] // 128, hh["Npad"] // 16
+    nwords = tiles_n * tiles_k * 256
+    wh = bhi[hh["off_q"]:hh["off_q"] + nwords * 4].view(np.uint32).reshape(tiles_n, tiles_k, 64, 4)
+    lh = orc.header(blo)
+    wl = blo[lh["off_q"]:lh["off_q"] + nwords * 4].view(np.uint32).reshape(tiles_n, tiles_k, 64, 4)
+    codes = np.zeros((hh["Kpad"], hh["Npad"]), np.uint8)
+    lane = np.arange(64)
+    i16, kq = lane & 15, lane >> 4
+    m4 = np.uint32(0x0f0f0f0f)
+    for h in range(2):
+        h0, h1 = wh[..., 2 * h], wh[..., 2 * h + 1]
+        l0, l1 = wl[..., 2 * h], wl[..., 2 * h + 1]
+        b = [((h0 & m4) << np.uint32(4)) | ((l0 & m4) ^ np.uint32(0x08080808)),
+             (h0 & np.uint32(0xf0f0f0f0)) | (((l0 >> np.uint32(4)) & m4) ^ np.uint32(0x08080808)),
+             ((h1 & m4) << np.uint32(4)) | ((l1 & m4) ^ np.uint32(0x08080808)),
+             (h1 & np.uint32(0xf0f0f0f0)) | (((l1 >> np.uint32(4)) & m4) ^ np.uint32(0x08080808))]
+        for s in range(2):          # the two MFMAs of a half: B = {b[2 s], b[2 s + 1]} = 8 bytes
+            for byte in range(8):
+                word = b[2 * s + byte // 4]
+                val = ((word >> np.uint32(8 * (byte % 4))) & np.uint32(0xff)).astype(np.uint8)  # [tn, kt, lane]
+                for tn in range(tiles_n):
+                    for kt in range(tiles_k):
+                        k = kt * 128 + h * 64 + kq * 16 + s * 8 + byte
+                        codes[k, tn * 16 + i16] = val[tn, kt]
+    return codes, hh
+
+
+def e4m3_exact(d):
+    """every digit value in [-8, 8] is an OCP e4m3 value"""
+    return bool(np.isin(np.abs(d), orc.FP8_TABLES[orc.W_FP8_E4M3][:0x80][np.isfinite(orc.FP8_TABLES[orc.W_FP8_E4M3][:0x80])]).all())
+
+
+@pytest.mark.parametrize("wt", [orc.W_FP8_E4M3, orc.W_FP8_E5M2])
+@pytest.mark.parametrize("K,N,group,tpw", [(512, 48, 128, 4), (384, 16, -1, 4), (1024, 32, 256, 8)])
+def test_fp8_decode_kernel_model_vs_oracle(wt, K, N, group, tpw):
+    rng = np.random.default_rng(5)
+    w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    q, s = orc.rtn_quantize_fp8(w, True, group, wt)
+    blob = orc.repack_fp8(q, s, wt, None, group)
+    codes, hh = device_codes(blob)
+    assert np.array_equal(codes[:K, :N], orc.fp8_codes_of(blob))
+    vals = orc.FP8_TABLES[wt][codes[:K, :N]].astype(np.float32)  # what the matrix core reads, [K, N]
+    g = K if group == -1 else group
+    scales = s.astype(np.float32)  # [G, N]
+    tiles_k = hh["Kpad"] // 128
+    nw = (tiles_k + tpw - 1) // tpw
+    base, rem = tiles_k // nw, tiles_k % nw
+    x = rng.standard_normal(K).astype(np.float32)
+    x[::7] *= 1e-3  # values far below the slice maximum
+    out = np.zeros(N, np.float32)
+    for wid in range(nw):  # a wave's K slice: its own exponent
+        kt0 = wid * base + min(wid, rem)
+        cnt = base + (1 if wid < rem else 0)
+        lo, hi = kt0 * 128, min((kt0 + cnt) * 128, K)
+        if lo >= hi:
+            continue
+        xs = x[lo:hi]
+        amax = np.abs(xs).max()
+        e = int(np.frexp(amax)[1]) if amax > 0 else 0
+        sfix = np.float32(2.0 ** (21 - e))
+        Q = (xs * sfix + np.float32(12582912.0)).astype(np.float32).view(np.uint32)  # one fp32 rounding, as the fma
+        v = (Q & np.uint32(0x7fffff)).astype(np.int64) - (1 << 22)
+        assert np.abs(v).max() <= 1 << 21
+        digits, rest = [], v.copy()
+        for _ in range(6):
+            d = ((rest & 15) ^ 8) - 8  # low nibble, sign-extended
+            rest = (rest - d) >> 4
+            digits.append(d)
+        assert not rest.any() and all(np.abs(d).max() <= 8 for d in digits) and all(e4m3_exact(d) for d in digits)
+        assert np.array_equal(sum(d * 16 ** j for j, d in enumerate(digits)), v)
+        tot = np.zeros(N, np.float32)
+        for t in range(cnt):
+            a, b = (kt0 + t) * 128, min((kt0 + t + 1) * 128, K)
+            if a >= b:
+                continue
+            acc = [(digits[j][a - lo:b - lo].astype(np.float32)[:, None] * vals[a:b]).sum(0, dtype=np.float32)
+                   for j in range(6)]
+            comb = np.zeros(N, np.float32)
+            for j in range(6):
+                comb += acc[j] * np.float32(16.0 ** j)
+            tot += scales[min(a // g, scales.shape[0] - 1)] * comb
+        out += tot * np.float32(2.0 ** (e - 21))
+    ref = orc.woq_linear(x[None, :], blob, None)[0]
+    mag = np.abs(x) @ np.abs(orc.dequantize_blob(blob))
+    assert (np.abs(out - ref) <= 2e-6 * mag + 1e-5).all()

@@ -735,6 +735,47 @@ def test_fp8_weight_types_quantize_dequant_linear(qbits, wname, sname, K, N, gro
         qbits.quantize_to_packed_weight(torch.from_numpy(w).cuda(), True, group, "fp32", "int4_clip", "fp8_e8m0", False)
 
 
+@pytest.mark.parametrize("wname,sname", [("fp8_e4m3", "fp32"), ("fp8_e4m3", "fp8_e8m0"), ("fp8_e5m2", "fp32"),
+                                         ("fp8_e5m2", "fp8_e8m0")])
+@pytest.mark.parametrize("K,N,group", [(4096, 128, 128), (11008, 48, 128), (1024, 272, 256), (384, 64, -1)])
+def test_fp8_weight_types_decode_kernel(qbits, wname, sname, K, N, group):
+    """Round 4: fp8 weights at decode row counts on the fp8 matrix cores (csrc/woq_gemv_fp8.hip): the code bytes are the
+    B operand of v_mfma_f32_16x16x32_fp8_{fp8,bf8} as they are, the fp32 activation goes in as six balanced base-16
+    digits (exact e4m3 values), fp32 accumulation and recombination. 1..8 rows (one and two rows per MFMA row set, the
+    one-row form for long K), fp32 / fp16 / bf16 rows, fp32 and power-of-two scales, per-128 / per-256 / per-channel
+    groups, ragged N, K up to 11008 (four and eight tiles per wave) — within fp32 summation error of dequantise -> matmul
+    -> + bias. Weights: RTN codes, and a matrix that holds EVERY finite code (subnormals and both zeros included)."""
+    wt, e8 = FP8_TYPES[wname], sname == "fp8_e8m0"
+    rng = np.random.default_rng(63)
+    w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    q, s = orc.rtn_quantize_fp8(w, True, group, wt, e8)
+    finite = np.flatnonzero(np.isfinite(orc.FP8_TABLES[wt])).astype(np.uint8)
+    q_all = finite[rng.integers(0, finite.size, size=(K, N))]
+    e8t, e32 = torch.empty(0, dtype=torch.int8), torch.empty(0, dtype=torch.int32)
+    bias = rng.random(N, dtype=np.float32)
+    for codes, sc in ((q, s), (q_all, (s * 1e-3).astype(np.float32) if not e8 else s)):
+        ref_blob = orc.repack_fp8(codes, sc, wt, None, group, e8m0=e8)
+        blob = qbits.repack_quantized_weight(torch.from_numpy(codes.view(np.int8)).cuda(), torch.from_numpy(sc).cuda(),
+                                             e8t, e32, wname, sname, "fp32", False, group)
+        assert np.array_equal(blob.cpu().numpy().view(np.uint8), ref_blob)
+        want = orc.dequantize_blob(ref_blob)
+        for M, adt in ((1, torch.float32), (2, torch.float32), (3, torch.float32), (8, torch.float32),
+                       (1, torch.float16), (5, torch.bfloat16)):
+            x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(adt)
+            xf = x.float().numpy()
+            ref = orc.woq_linear(xf, ref_blob, bias)
+            out = torch.full((M, N), float("nan"), device="cuda")
+            qbits.woq_linear(x.cuda(), blob, torch.from_numpy(bias).cuda(), out, "fp32", wname, sname, False)
+            mag = np.abs(xf) @ np.abs(want)
+            assert (np.abs(out.cpu().numpy() - ref) <= 2e-6 * mag + 1e-5).all(), (M, adt)
+            # rows one element off 16-byte alignment: the lookup kernel, same bound
+            xp = torch.zeros(M, K + 8, dtype=adt, device="cuda")[:, 1:K + 1]
+            xp.copy_(x)
+            out2 = torch.full((M, N), float("nan"), device="cuda")
+            qbits.woq_linear(xp, blob, torch.from_numpy(bias).cuda(), out2, "fp32", wname, sname, False)
+            assert (np.abs(out2.cpu().numpy() - ref) <= 2e-6 * mag + 1e-5).all(), (M, adt, "lookup kernel")
+
+
 @pytest.mark.parametrize("wname", sorted(FP8_TYPES))
 def test_fp8_repack_passes_codes_through_with_act_shuffle(qbits, wname):
     """User-supplied code bytes (every finite code), scales and a GPTQ g_idx pass through the composite blob exactly

@@ -28,15 +28,18 @@ def time_linear(spec, K, N, M, reps=200):
     wname, cname = split(spec)
     g = torch.Generator(device="cuda").manual_seed(1)
     table = wname != "int4_clip"
-    q = torch.randint(0 if table else -8, 16 if table else 8, (K, N), generator=g, device="cuda", dtype=torch.int8)
+    if wname.startswith("fp8"):  # code bytes: positive finite codes of either grid
+        q = torch.randint(0, 0x78, (K, N), generator=g, device="cuda", dtype=torch.int8)
+    else:
+        q = torch.randint(0 if table else -8, 16 if table else 8, (K, N), generator=g, device="cuda", dtype=torch.int8)
     s = (0.5 + torch.rand(K // 128, N, generator=g, device="cuda")) * 0.005
     blob = qbits.repack_quantized_weight(q, s, torch.empty(0, dtype=torch.int8), torch.empty(0, dtype=torch.int32),
-                                         wname, "fp16", cname, False, 128)
+                                         wname, "fp32" if wname.startswith("fp8") else "fp16", cname, False, 128)
     x = torch.randn(M, K, device="cuda")
     out = torch.empty(M, N, device="cuda")
     e = torch.empty(0)
     for _ in range(20):
-        qbits.woq_linear(x, blob, e, out, "fp32", wname, "fp16", False)
+        qbits.woq_linear(x, blob, e, out, "fp32", wname, "fp16", False)  # (the type strings are read from the blob)
     torch.cuda.synchronize()
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0.record()
@@ -76,6 +79,8 @@ if __name__ == "__main__":
     ap.add_argument("--types", default="int4_clip,nf4,nf4:bf16,fp4_e2m1,fp4_e2m1_bnb")
     args = ap.parse_args()
     mode = "generic fp32 VALU kernel" if os.environ.get("WOQ_TABLE_GENERIC") else "digit-plane MFMA kernel"
+    if os.environ.get("WOQ_FP8_GENERIC"):
+        mode += "; fp8: lookup kernel"
     for wname in args.types.split(","):
         row = {"weight_dtype": wname, "table_types_on": mode}
         for name, (K, N) in SHAPES.items():
