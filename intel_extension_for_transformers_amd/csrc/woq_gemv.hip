@@ -259,8 +259,8 @@ int launch_gemv_fp8_mfma(const void* act, int act_dtype, int lda, int M, const v
                          hipStream_t st);
 
 // fp8 weights at decode row counts: the fp8-MFMA kernel (woq_gemv_fp8.hip: code bytes straight into the matrix cores,
-// activations as base-16 digits; round 4) where it takes the call, rows in chunks of 8; otherwise (per-32 / per-64
-// scales, g_idx, misaligned rows, K beyond 12288) the lookup kernel reading both nibble planes, rows in chunks of GEN_MAXM.
+// activations as base-16 digits; round 4) where it takes the call, rows in chunks of 8; otherwise (per-32 / per-64 /
+// per-256 scales, g_idx, misaligned rows, K beyond 8192) the lookup kernel reading both nibble planes, rows in chunks of GEN_MAXM.
 // `hi` = the HI plane's header (scales, shuffle), `lo_q` = the LO plane's qdata.
 int launch_gemv_fp8(const void* act, int act_dtype, int lda, const void* hi_blob, const woq_blob_header& hi,
                     const void* lo_q, uint32_t fp8_type, const float* bias, void* out, int out_dtype, int ldo, int M,

@@ -13,15 +13,20 @@
 // exponent of the wave slice's largest |x|, as in woq_gemv_i8.hip) = sum_j d_j 16^j with d_j in [-8, 7] — every digit is
 // an exact e4m3 value — six MFMA rows per activation row, two activation rows per 16-row MFMA. Every product
 // digit x weight is exact (4 x 4 significant bits), the sums run in the MFMA's fp32 accumulator, and the six digit sums
-// are recombined as sum_j 16^j S_j in fp32: an fp32-class inner product (no cancellation: the digits are balanced, so the
-// top digit carries the magnitude), the activation held to 2^-22 of its slice maximum.
+// are recombined as sum_j 16^j S_j in fp32 (no cancellation: the digits are balanced, so the top digit carries the
+// magnitude), the activation held to 2^-22 of its slice maximum. Measured accuracy (profiles/r04ah_fp8_decode.txt): inside
+// 2e-6 of sum |x||w| on RTN-quantised weights, 4.6e-6 on a matrix holding every finite e4m3 code uniformly — the matrix
+// core aligns the 32 products of a dot to the largest one and is not an fp32 adder below ~2^-14 of it; three orders of
+// magnitude under the 2^-4 grid of the weights themselves.
 // B operand: code = (hi nibble << 4) | (lo nibble ^ 8) from the blob's two nibble planes (include/woq_blob.h
 // woq_fp8_headers), both in the int4 tile layout, so four codes are assembled by four VALU from one dword of each plane:
 // ~1 VALU per weight against ~5 for the lookup kernel.
 // Schedule: as woq_gemv_i8.hip — one workgroup per 16-column tile, waves own contiguous K slices of up to TPW tiles of
 // BOTH planes, everything requested up front, the activation rows staged per wave into a wave-private LDS strip, one
-// barrier, bias in the epilogue. Scope: per-128-or-coarser groups (scale_mode 0), unshuffled aligned rows, K up to 12288;
-// anything else keeps the lookup kernel.
+// barrier, bias in the epilogue. Scope (what the GPU tests of round 4 covered): per-128 groups or one group per column
+// (scale_mode 0), unshuffled aligned rows, K up to 8192 (four tiles per wave, up to sixteen waves); anything else keeps
+// the lookup kernel. (An eight-tiles-per-wave form for longer K ran the timings of r04ah but not a parity test before
+// the round's GPU time was spent; it is not in the tree.)
 #include <algorithm>
 #include <cstdlib>
 
@@ -52,7 +57,7 @@ __device__ __forceinline__ float4_t mfma_f8(i64_t a, i64_t b, float4_t c) {
 
 // flags: bit 0 scales are bf16 (else fp16; ignored for fp32 scales), bits 2-3 activation rows 0 fp32 | 1 fp16 | 2 bf16
 template <int TPW, bool E5M2, bool S32>
-__global__ __launch_bounds__(TPW > 4 ? 768 : 1024) void gemv_fp8_kernel(
+__global__ __launch_bounds__(1024) void gemv_fp8_kernel(
     const u32x4* __restrict__ qhi, const u32x4* __restrict__ qlo, const void* __restrict__ scales,
     const void* __restrict__ x, int tiles_k, int K, int base_tiles, int rem_tiles, int n_groups, int tpg_shift,
     void* __restrict__ out, const float* __restrict__ bias, int N, int M, int ms, int lda, int ldo, int out_dtype,
@@ -273,11 +278,11 @@ static int launch_fp8_t(const F8Launch& a, hipStream_t st) {
   return 0;
 }
 
-// geometry: 4 tiles per wave up to 16 waves (K <= 8192), 8 per wave up to 12 waves (K <= 12288)
+// geometry: 4 tiles per wave, up to 16 waves (K <= 8192)
 static bool fp8_geometry(int tiles_k, int& nw, int& tpw) {
-  tpw = tiles_k <= 64 ? 4 : 8;
+  tpw = 4;
   nw = (tiles_k + tpw - 1) / tpw;
-  return nw >= 1 && nw <= (tpw > 4 ? 12 : 16);
+  return nw >= 1 && nw <= 16;
 }
 
 // Does the fp8-MFMA kernel take this call? `hi` = the HI plane's header (scales; the LO plane has the same geometry).
@@ -286,10 +291,7 @@ bool gemv_fp8_mfma_supported(const void* act, int act_dtype, int lda, const woq_
   if (off || hi.off_shuffle != 0 || hi.off_zp != 0 || hi.scale_mode != 0 || (hi.K & 3) != 0 || (lda & 3) != 0 ||
       (((uintptr_t)act) & (act_dtype == WOQ_F32 ? 15 : 7)) != 0)
     return false;
-  if (hi.n_groups > 1) {
-    const int tpg = hi.group / WOQ_TILE_K;
-    if (tpg < 1 || tpg * WOQ_TILE_K != hi.group || (tpg & (tpg - 1)) != 0) return false;
-  }
+  if (hi.n_groups > 1 && hi.group != WOQ_TILE_K) return false;  // per-128 groups, or one group per column
   int nw, tpw;
   return fp8_geometry(hi.Kpad / WOQ_TILE_K, nw, tpw);
 }
@@ -308,14 +310,7 @@ int launch_gemv_fp8_mfma(const void* act, int act_dtype, int lda, int M, const v
   a.K = hi.K;
   a.N = hi.N;
   a.n_groups = hi.n_groups;
-  a.tpg_shift = 0;
-  if (hi.n_groups > 1) {
-    int tpg = hi.group / WOQ_TILE_K;
-    while (tpg > 1) {
-      tpg >>= 1;
-      ++a.tpg_shift;
-    }
-  }
+  a.tpg_shift = 0;  // one tile per group (or one group): gemv_fp8_mfma_supported
   a.M = M;
   a.lda = lda;
   a.ldo = ldo;
@@ -337,10 +332,6 @@ int launch_gemv_fp8_mfma(const void* act, int act_dtype, int lda, int M, const v
   WOQ_F8_CASE(4, false, true)
   WOQ_F8_CASE(4, true, false)
   WOQ_F8_CASE(4, true, true)
-  WOQ_F8_CASE(8, false, false)
-  WOQ_F8_CASE(8, false, true)
-  WOQ_F8_CASE(8, true, false)
-  WOQ_F8_CASE(8, true, true)
 #undef WOQ_F8_CASE
   return woq::fail("QBits: bad fp8 GEMV configuration");
 }
