@@ -1,4 +1,6 @@
-"""Host model of the fp8-weight decode kernel (csrc/woq_gemv_fp8.hip) against the oracle — runs without a GPU.
+"""Host models of the decode-row kernels of the float weight types against the oracle — run without a GPU.
+
+First the fp8-weight kernel (csrc/woq_gemv_fp8.hip), then the digit-plane unpack of the nf4 / fp4 kernels (last test).
 
 The kernel feeds OCP fp8 code bytes straight into v_mfma_f32_16x16x32_fp8_{fp8,bf8} and brings the fp32 activation in as
 six balanced base-16 digits (each an exact e4m3 value). What can be checked on the host is everything but the matrix
@@ -104,3 +106,56 @@ def test_fp8_decode_kernel_model_vs_oracle(wt, K, N, group, tpw):
     ref = orc.woq_linear(x[None, :], blob, None)[0]
     mag = np.abs(x) @ np.abs(orc.dequantize_blob(blob))
     assert (np.abs(out - ref) <= 2e-6 * mag + 1e-5).all()
+
+
+@pytest.mark.parametrize("wt,ct,tol", [(orc.W_NF4, 0, 2.0 ** -23), (orc.W_NF4, 1, 2.0 ** -16), (orc.W_FP4_E2M1, 0, 0.0),
+                                        (orc.W_FP4_E2M1_BNB, 0, 1e-7)])
+def test_table_digit_plane_unpack_model_vs_oracle(wt, ct, tol):
+    """Host model of the nf4 / fp4 unpack of the decode GEMVs (csrc/woq_gemv_common.h lut_b): from the blob's weight
+    dwords as a lane holds them, through the library's own digit planes (woq_table_digit_planes) and the byte lookup
+    (two 8-entry permutes + select), to the value every (k, n) contributes — against the oracle's reading of the same
+    blob (codes and table). Checks the k order of the B operand (low nibbles of w0, high nibbles of w0, low of w1, high of
+    w1 = j 0..15 of the lane's run) and the planes together; the matrix instruction itself is the GPU suite's."""
+    import ctypes
+    import os
+
+    from intel_extension_for_transformers_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libwoq_hip.so not built (python __graft_entry__.py)")
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.woq_table_digit_planes.restype = ctypes.c_int
+    lib.woq_table_digit_planes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    planes = (ctypes.c_uint32 * 12)()
+    wmul = ctypes.c_float()
+    ndig = lib.woq_table_digit_planes(wt, ct, planes, ctypes.byref(wmul))
+    table_bytes = [np.array([(int(planes[j * 4 + c // 4]) >> (8 * (c % 4))) & 0xff for c in range(16)], np.uint8)
+                   .view(np.int8).astype(np.int64) for j in range(3)]  # digit j of code c
+    assert all(not table_bytes[j].any() for j in range(ndig, 3))
+    K, N, group = 384, 48, 128
+    rng = np.random.default_rng(9)
+    codes = rng.integers(0, 16, (K, N)).astype(np.int8)
+    scales = (rng.random((K // group, N), dtype=np.float32) + 0.5) * 0.01
+    blob = orc.repack_table(codes, scales, wt, group)
+    h = orc.header(blob)
+    tiles_k, tiles_n = h["Kpad"] // 128, h["Npad"] // 16
+    words = blob[h["off_q"]:h["off_q"] + tiles_n * tiles_k * 1024].view(np.uint32).reshape(tiles_n, tiles_k, 64, 4)
+    lane = np.arange(64)
+    i16, kq = lane & 15, lane >> 4
+    S = 16.0 / wmul.value
+    got = np.zeros((h["Kpad"], h["Npad"]))
+    m4 = np.uint32(0x0f0f0f0f)
+    for hh in range(2):
+        w0, w1 = words[..., 2 * hh], words[..., 2 * hh + 1]
+        quads = [w0 & m4, (w0 >> np.uint32(4)) & m4, w1 & m4, (w1 >> np.uint32(4)) & m4]  # idx of lut_quad, in B order
+        for qi, idx in enumerate(quads):
+            for byte in range(4):
+                code = ((idx >> np.uint32(8 * byte)) & np.uint32(0xff)).astype(np.int64)  # [tn, kt, lane]
+                # the lookup: codes 0..7 from the low table half, 8..15 from the high one, selected by bit 3
+                val = sum(table_bytes[j][code] * 256 ** j for j in range(3)) / S
+                j16 = qi * 4 + byte
+                for tn in range(tiles_n):
+                    for kt in range(tiles_k):
+                        got[kt * 128 + hh * 64 + kq * 16 + j16, tn * 16 + i16] = val[tn, kt]
+    want = orc.LUTS[wt][orc._codes_of(blob)].astype(np.float64)
+    assert np.abs(got[:K, :N] - want).max() <= tol * float(np.abs(orc.LUTS[wt]).max()) + 1e-12
