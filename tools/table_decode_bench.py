@@ -1,9 +1,11 @@
 """Decode-row timings of the 4-bit table weight types (nf4 / fp4) against int4 on the Llama-2-7B projections, and the
 batch-1 decode rate of a Llama-2-7B-shaped engine with nf4 / fp4 layers (round 4: digit-plane unpack on the int8 MFMA,
 csrc/woq_gemv_common.h LutArgs). WOQ_TABLE_GENERIC=1 in the environment selects the fp32 VALU kernel these types ran
-on through round 3 (separate process: the switch is read once).
+on through round 3 (separate process: the switch is read once). `--types fp8_e4m3,fp8_e5m2` times the 8-bit float
+weights (csrc/woq_gemv_fp8.hip; WOQ_FP8_GENERIC=1: the lookup kernel); a type may carry the compute type its blobs are
+packed for, "nf4:bf16" (two digit planes instead of three).
 
-    python tools/table_decode_bench.py [--engine] [--layers 32]
+    python tools/table_decode_bench.py [--engine] [--layers 32] [--types int4_clip,nf4,nf4:bf16,fp4_e2m1,fp8_e4m3]
 """
 import argparse
 import json
