@@ -707,7 +707,7 @@ def tp_point(args, cfg, rank, world, dist, steps, warmup, as_extra=False):
     from intel_extension_for_transformers_amd.runtime.tp import TPDecoder
 
     n_layers = args.layers if args.layers and not as_extra else cfg["layers"]
-    ranks_verified = None
+    ranks_verified = 1  # no process group at N = 1: this process is the one rank
     if dist is not None:  # how many ranks actually answer a collective (not just the group's nominal size)
         on = "cuda" if dist.get_backend() == "nccl" else "cpu"
         ones = torch.ones(1, dtype=torch.float32, device=on)
@@ -795,6 +795,17 @@ def tp_point(args, cfg, rank, world, dist, steps, warmup, as_extra=False):
     return point
 
 
+def spawn_command(gpus, env, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): the command that runs the
+    same arguments as N ranks of one node under torch.distributed.run — what the driver's own N > 1 command line is
+    (one rank per GPU over RCCL, rendezvous on 127.0.0.1). None when there is nothing to spawn."""
+    if gpus <= 1 or "WORLD_SIZE" in env:
+        return None
+    port = env.get("MASTER_PORT") or str(29500 + os.getpid() % 2000)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -820,12 +831,19 @@ def main():
     args = ap.parse_args()
     global CONDITION_MS
     CONDITION_MS = args.condition_ms
+    respawn = spawn_command(args.gpus, os.environ, sys.argv[1:])
+    if respawn is not None:  # plain `python bench.py --gpus N`, N > 1: become torch.distributed.run's N ranks
+        sys.stdout.flush()
+        os.execvpe(respawn[0], respawn, dict(os.environ, MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1")))
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); the line's n_gpus would "
+                         "not be what was asked for" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     # WOQ_BENCH_BACKEND=gloo (development): the N > 1 code path with several ranks on ONE GPU — RCCL refuses that, the

@@ -213,8 +213,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_bench_py_multi_rank_line_on_one_gpu(graph):
+@pytest.mark.parametrize("graph,plain", [(False, False), (True, False), (True, True)])
+def test_bench_py_multi_rank_line_on_one_gpu(graph, plain):
     """The driver's N > 1 command — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
     127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` — end to end with two ranks on this one GPU
     (WOQ_BENCH_BACKEND=gloo: RCCL refuses two ranks per device; the device exchange does not need it): process-group
@@ -228,6 +228,12 @@ def test_bench_py_multi_rank_line_on_one_gpu(graph):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
            "--warmup", "2", "--layers", "2", "--condition-ms", "20"] + ([] if graph else ["--eager"])
+    if plain:  # `python bench.py --gpus 2` with no launcher around it: bench.py becomes the two ranks itself
+        env = dict(env, MASTER_PORT=str(_free_port()))
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+               "--layers", "2", "--condition-ms", "20"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -238,4 +244,5 @@ def test_bench_py_multi_rank_line_on_one_gpu(graph):
         assert k in d, k
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["parallelism"] == "tp2" and d["config"]["hipgraph"] == graph
+    assert d["config"]["process_group_ranks"] == 2 and d["config"]["rccl_ranks_verified"] == 2
     assert "device one-shot all-reduce" in d["config"]["allreduce_transport"], d["config"]["allreduce_transport"]

@@ -167,3 +167,25 @@ def test_greedy_token_pair_exchange_matches_argmax_of_gathered_logits(tmp_path):
     mp.spawn(_greedy_rank, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     picks = np.load(tmp_path / "picks.npy")
     assert len(picks) == 20 and np.array_equal(picks[:, 0], picks[:, 1])
+
+
+def test_bench_py_gpus_flag_spawns_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher around it must become N ranks: the command it
+    re-executes is the driver's own N > 1 command line; with a launcher (WORLD_SIZE set) or N = 1 it spawns nothing, and
+    a launcher that started a different number of ranks than --gpus is refused before any GPU work."""
+    import subprocess
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    cmd = bench.spawn_command(8, {}, ["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-7].endswith("bench.py") and cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert bench.spawn_command(8, {"MASTER_PORT": "29611"}, [])[cmd.index("--master-port") + 1] == "29611"
+    assert bench.spawn_command(1, {}, []) is None
+    assert bench.spawn_command(8, {"WORLD_SIZE": "8"}, []) is None
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode != 0 and "--gpus 4" in res.stderr and "2 rank" in res.stderr, res.stderr[-500:]
