@@ -311,6 +311,21 @@ WOQ_API int woq_engine_time_gemv_mask(woq_engine* e, int mask, int reps, void* s
  * the engine's own blobs: what this launch structure reaches as a pure stream), mode 1 = empty kernels on the same
  * grids (what the launches cost before they do anything). bench.py reports both as roofline.ceiling. */
 WOQ_API int woq_engine_time_twin(woq_engine* e, int mode, int reps, void* stream, float* total_ms);
+/* Token-long weight prefetcher beside the decode step (csrc/woq_prefetch.hip; round 5): one low-occupancy kernel, a
+ * dependency-free branch forked once per token behind the embedding kernel, walks the layers' blobs in consumption
+ * order with default-policy loads so that the step's launches stream out of the Infinity Cache while HBM works through
+ * their boundaries. grid workgroups x waves (1..4) x depth (4 | 8 | 16 | 32) KiB in flight; it runs at most `lead`
+ * layers (+ projections 0..lead_kind of the next) ahead of the layer whose qkv the fused launch has published; wrap:
+ * touch layer 0 again at the end, for the next token; head_mb: MiB of the lm_head behind the last layer. Applies to
+ * one-GPU engines on the fused qkv + attention launch; woq_engine_prefetch() = 1 when the next step will use it.
+ * No reference counterpart (launch structure around qbits.cpp:113-140's M = 1 calls). */
+WOQ_API int woq_engine_set_prefetch(woq_engine* e, int on, int grid, int waves, int depth, int lead, int lead_kind,
+                                    int wrap, int head_mb);
+WOQ_API int woq_engine_prefetch(woq_engine* e);
+/* measurement: projection `proj` (0 qkv, 1 o, 2 gate/up, 3 down) over every layer, cold vs read by another kernel
+ * `lead` launches earlier: us[0] cold per launch, us[1] readers alone, us[2] readers + launches (hot = us[2] - us[1]);
+ * twin != 0: the load-only twin instead of the GEMV */
+WOQ_API int woq_engine_mall_probe(woq_engine* e, int proj, int twin, int lead, int reps, void* stream, float* us);
 /* how woq_engine_time_gemv / _gemv_mask / _twin issue their timed passes: on != 0 (default) eagerly back to back on
  * the stream — the way decode bursts run by default since round 4 — else as replays of a captured graph. */
 WOQ_API int woq_engine_set_time_eager(woq_engine* e, int on);

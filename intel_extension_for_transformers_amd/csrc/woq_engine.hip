@@ -64,6 +64,13 @@ int launch_attn_prefill(const _Float16* qkv, int n_seq, int T, int start, int he
                         const void* kcache, const void* vcache, int kv_dtype, size_t seq_stride_elems, _Float16* out,
                         int window, hipStream_t st);
 void set_gemm_time_events(hipEvent_t before, hipEvent_t after);
+// token-long weight prefetcher beside the decode step (woq_prefetch.hip)
+int launch_prefetch(const void* items_dev, int n_items, const unsigned long long* qkv_g, const unsigned int* seq,
+                    int lead, int lead_kind, int first_vlayer, int grid, int waves, int depth, unsigned int* sink,
+                    hipStream_t st);
+int prefetch_build_items(const std::vector<const void*>& ptrs, const std::vector<size_t>& bytes,
+                         const std::vector<int>& vlayer, const std::vector<int>& kind, void** items_dev, int* n);
+void launch_stream_read(const void* p, size_t bytes, unsigned int* sink, hipStream_t st);
 void launch_gather_last(const float* h, int n_seq, int T, int hidden, float* dst, hipStream_t st);
 }  // namespace woq
 // device-side tensor-parallel exchange (woq_comm.hip)
@@ -149,6 +156,16 @@ struct woq_engine {
   int attn_chunk = 0;           // grouped form: positions per slice of the position-independent geometry, 0 = adaptive
   bool time_eager = true;       // woq_engine_time_gemv / _twin: passes issued eagerly (how bursts run by default) or as a
                                 // replayed graph (round 3's measure; woq_engine_set_time_eager(e, 0))
+  // token-long weight prefetcher (woq_prefetch.hip): a dependency-free branch of the step, forked behind the embedding
+  // kernel and joined in front of the head's argmax; off by default (woq_engine_set_prefetch / WOQ_ENGINE_PREFETCH)
+  bool wpf_on = false;
+  int wpf_waves = 4, wpf_depth = 16, wpf_lead = 2, wpf_lead_kind = -1, wpf_wrap = 1, wpf_head_mb = 0, wpf_grid = 256;
+  void* wpf_items = nullptr;
+  int wpf_n = 0;
+  hipStream_t wpf_stream = nullptr;
+  hipEvent_t wpf_fork = nullptr, wpf_join = nullptr;
+  int wpf_prepare();
+  bool wpf_applies() const { return wpf_on && use_xq() && cfg.tp_size <= 1 && qkv_g != nullptr && tags_ok(); }
   int max_batch = 1;
   size_t pf_rows = 0, pf_ws_bytes = 0;
   float* pf_h = nullptr;        // fp32 residual stream [rows][hidden]
@@ -353,6 +370,38 @@ static void engine_embed(woq_engine* e, hipStream_t st) {
                st);
 }
 
+// the prefetcher's work list: every layer's blobs in consumption order, the first MiB of the head, then (wrap) layer 0
+// again for the NEXT token — the weights are the same every token, so the tail of this token's prefetcher warms the
+// head of the next one and the next prefetcher starts at layer 1 (first_vlayer)
+int woq_engine::wpf_prepare() {
+  if (wpf_items != nullptr) return 0;
+  std::vector<const void*> ptrs;
+  std::vector<size_t> bytes;
+  std::vector<int> vl, kind;
+  auto add_layer = [&](int l, int v) {
+    const woq_layer_weights& w = layers[l];
+    const void* b[4] = {w.qkv_blob, w.o_blob, w.gate_up_blob, w.down_blob};
+    const woq_blob_header* h[4] = {&w.qkv_hdr, &w.o_hdr, &w.gate_up_hdr, &w.down_hdr};
+    for (int j = 0; j < 4; ++j) {
+      ptrs.push_back(b[j]), bytes.push_back((size_t)h[j]->total_bytes), vl.push_back(v), kind.push_back(j);
+    }
+  };
+  for (int l = 0; l < cfg.layers; ++l) add_layer(l, l);
+  if (wpf_head_mb > 0 && lm_head != nullptr) {
+    const size_t all = (size_t)cfg.vocab * cfg.hidden * 2;
+    ptrs.push_back(lm_head), bytes.push_back(std::min(all, (size_t)wpf_head_mb << 20)), vl.push_back(cfg.layers);
+    kind.push_back(4);
+  }
+  if (wpf_wrap) add_layer(0, cfg.layers + 1);
+  int rc = prefetch_build_items(ptrs, bytes, vl, kind, &wpf_items, &wpf_n);
+  if (rc) return rc;
+  owned.push_back(wpf_items);
+  if (!wpf_stream) WOQ_HIP(hipStreamCreateWithFlags(&wpf_stream, hipStreamNonBlocking));
+  if (!wpf_fork) WOQ_HIP(hipEventCreateWithFlags(&wpf_fork, hipEventDisableTiming));
+  if (!wpf_join) WOQ_HIP(hipEventCreateWithFlags(&wpf_join, hipEventDisableTiming));
+  return 0;
+}
+
 static int engine_step_impl(woq_engine* e, int greedy, hipStream_t st) {
   const woq_engine_config& c = e->cfg;
   engine_embed(e, st);
@@ -362,6 +411,18 @@ static int engine_step_impl(woq_engine* e, int greedy, hipStream_t st) {
     if (rc) return rc;
     return engine_head(e, greedy, st);
   }
+  const bool wpf = e->wpf_applies();
+  if (wpf) {  // fork: the prefetcher depends on the embedding kernel only (it reads the step counter that kernel advanced)
+    int rc = e->wpf_prepare();
+    if (rc) return rc;
+    WOQ_HIP(hipEventRecord(e->wpf_fork, st));
+    WOQ_HIP(hipStreamWaitEvent(e->wpf_stream, e->wpf_fork, 0));
+    if ((rc = launch_prefetch(e->wpf_items, e->wpf_n, e->qkv_g, e->step_seq, e->wpf_lead, e->wpf_lead_kind,
+                              e->wpf_wrap ? 1 : 0, e->wpf_grid, e->wpf_waves, e->wpf_depth, (unsigned int*)e->am_idx,
+                              e->wpf_stream)) != 0)
+      return rc;
+    WOQ_HIP(hipEventRecord(e->wpf_join, e->wpf_stream));
+  }
   for (int l = 0; l < c.layers; ++l) {
     int rc = engine_attn_block(e, l, st);
     if (rc) return rc;
@@ -370,7 +431,9 @@ static int engine_step_impl(woq_engine* e, int greedy, hipStream_t st) {
     if (rc) return rc;
     if ((rc = engine_allreduce_after(e, l, 1, st)) != 0) return rc;
   }
-  return engine_head(e, greedy, st);
+  const int rc = engine_head(e, greedy, st);
+  if (wpf) WOQ_HIP(hipStreamWaitEvent(st, e->wpf_join, 0));  // join: the step ends when both branches have
+  return rc;
 }
 
 // ---- prompt pass -------------------------------------------------------------------------------------------------
@@ -451,49 +514,68 @@ static int engine_prefill_impl(woq_engine* e, const int32_t* tokens, int n_seq, 
   return 0;
 }
 
-// one pass of `body` captured into a hipGraph and replayed `reps` times between two events on `st` (after one
-// untimed replay): what the launches cost inside the engine's own regime (captured, no host in the loop)
+// `reps` passes of `body(stream)` between two events on `st` (after one untimed pass): what the launches cost inside the
+// engine's own regime. eager: the passes issued back to back on `st` — how decode bursts run with WOQ_ENGINE_LAUNCH=eager;
+// otherwise ONE pass captured on a private stream and its graph launched on `st` itself, the way the decode step's graph
+// is replayed since round 4 (a graph launched on a stream that sits behind a cross-stream event wait pays ~1 us per
+// kernel boundary, profiles/r04ab_stream_mode_probe.txt — so the capture stream is never the launch stream here).
 template <typename F>
 static int time_captured(hipStream_t st, int reps, F body, float* total_ms, bool eager = false) {
-  int rc = body();  // eager once: lazy kernel attributes outside of capture
+  int rc = body(st);  // eager once: lazy kernel attributes outside of capture
   if (rc) return rc;
   WOQ_HIP(hipStreamSynchronize(st));
-  if (eager) {  // the passes issued back to back on the stream, no graph: how the decode step runs by default (round 4)
-    hipEvent_t ev0, ev1;
-    WOQ_HIP(hipEventCreate(&ev0));
-    WOQ_HIP(hipEventCreate(&ev1));
-    if ((rc = body()) != 0) return rc;
-    WOQ_HIP(hipEventRecord(ev0, st));
-    for (int r = 0; r < reps; ++r)
-      if ((rc = body()) != 0) return rc;
-    WOQ_HIP(hipEventRecord(ev1, st));
-    WOQ_HIP(hipStreamSynchronize(st));
-    WOQ_HIP(hipEventElapsedTime(total_ms, ev0, ev1));
-    hipEventDestroy(ev0);
-    hipEventDestroy(ev1);
-    return 0;
-  }
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipGraph_t g = nullptr;
   hipGraphExec_t ge = nullptr;
-  WOQ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-  rc = body();
-  hipError_t ce = hipStreamEndCapture(st, &g);
-  if (rc) return rc;
-  WOQ_HIP(ce);
-  WOQ_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-  hipEvent_t ev0, ev1;
-  WOQ_HIP(hipEventCreate(&ev0));
-  WOQ_HIP(hipEventCreate(&ev1));
-  WOQ_HIP(hipGraphLaunch(ge, st));
-  WOQ_HIP(hipEventRecord(ev0, st));
-  for (int r = 0; r < reps; ++r) WOQ_HIP(hipGraphLaunch(ge, st));
-  WOQ_HIP(hipEventRecord(ev1, st));
-  WOQ_HIP(hipStreamSynchronize(st));
-  WOQ_HIP(hipEventElapsedTime(total_ms, ev0, ev1));
-  hipEventDestroy(ev0);
-  hipEventDestroy(ev1);
-  hipGraphExecDestroy(ge);
-  hipGraphDestroy(g);
+  hipStream_t cs = nullptr;
+  auto cleanup = [&]() {
+    if (ev0) hipEventDestroy(ev0);
+    if (ev1) hipEventDestroy(ev1);
+    if (ge) hipGraphExecDestroy(ge);
+    if (g) hipGraphDestroy(g);
+    if (cs) hipStreamDestroy(cs);
+  };
+#define WOQ_TC(expr)                                                                               \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) {                                                                        \
+      cleanup();                                                                                   \
+      return woq::fail(std::string("QBits: HIP error '") + hipGetErrorString(_e) + "' at " #expr); \
+    }                                                                                              \
+  } while (0)
+  WOQ_TC(hipEventCreate(&ev0));
+  WOQ_TC(hipEventCreate(&ev1));
+  if (eager) {
+    if ((rc = body(st)) != 0) {
+      cleanup();
+      return rc;
+    }
+    WOQ_TC(hipEventRecord(ev0, st));
+    for (int r = 0; r < reps; ++r)
+      if ((rc = body(st)) != 0) {
+        cleanup();
+        return rc;
+      }
+  } else {
+    WOQ_TC(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    WOQ_TC(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+    rc = body(cs);
+    hipError_t ce = hipStreamEndCapture(cs, &g);
+    if (rc) {
+      cleanup();
+      return rc;
+    }
+    WOQ_TC(ce);
+    WOQ_TC(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    WOQ_TC(hipGraphLaunch(ge, st));
+    WOQ_TC(hipEventRecord(ev0, st));
+    for (int r = 0; r < reps; ++r) WOQ_TC(hipGraphLaunch(ge, st));
+  }
+  WOQ_TC(hipEventRecord(ev1, st));
+  WOQ_TC(hipStreamSynchronize(st));
+  WOQ_TC(hipEventElapsedTime(total_ms, ev0, ev1));
+#undef WOQ_TC
+  cleanup();
   return 0;
 }
 
@@ -666,6 +748,8 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
     e->fuse_attn = fa ? fa[0] != '0' : true;
     const char* pe = getenv("WOQ_ENGINE_PERSIST");
     e->persist_on = pe ? pe[0] != '0' : false;
+    const char* wp = getenv("WOQ_ENGINE_PREFETCH");
+    e->wpf_on = wp ? wp[0] != '0' : false;
     const char* tx = getenv("WOQ_TP_XQ");
     e->tp_xq = tx ? tx[0] != '0' : true;
     const char* tf = getenv("WOQ_TP_FUSED_PUSH");
@@ -698,6 +782,9 @@ void woq_engine_destroy(woq_engine* e) {
   if (e->exec) hipGraphExecDestroy(e->exec);
   if (e->graph) hipGraphDestroy(e->graph);
   woq::persist_destroy(e->persist);
+  if (e->wpf_stream) hipStreamDestroy(e->wpf_stream);
+  if (e->wpf_fork) hipEventDestroy(e->wpf_fork);
+  if (e->wpf_join) hipEventDestroy(e->wpf_join);
   for (void* p : e->owned) hipFree(p);
   for (void* p : {(void*)e->pf_h, (void*)e->pf_qkv, (void*)e->pf_attn, (void*)e->pf_act, e->pf_ws})
     if (p) hipFree(p);
@@ -725,6 +812,7 @@ int woq_engine_set_layer(woq_engine* e, int layer, const woq_layer_weights* w) {
             "QBits: gate_up blob shape mismatch (inter must be a multiple of 16)");
   WOQ_CHECK(w->down_hdr.K == c.inter && w->down_hdr.N == c.hidden, "QBits: down_proj blob shape mismatch");
   e->layers[layer] = *w;
+  e->wpf_items = nullptr;  // the prefetcher's work list holds the old layer's pointers (the buffer stays in `owned`)
   if (e->persist_tried) {  // the plan holds the old layer's pointers
     woq::persist_destroy(e->persist);
     e->persist = nullptr;
@@ -886,7 +974,7 @@ int woq_engine_time_gemv_mask(woq_engine* e, int mask, int reps, void* stream, f
                (h.off_zp ? (double)h.n_groups * h.N * 0.5 : 0.0);
     }
   }
-  auto pass = [&]() -> int {
+  auto pass = [&](hipStream_t st) -> int {
     for (int l = 0; l < c.layers; ++l) {
       const woq_layer_weights& w = e->layers[l];
       int rc;
@@ -937,6 +1025,81 @@ int woq_engine_time_gemv(woq_engine* e, int reps, void* stream, float* total_ms,
   return woq_engine_time_gemv_mask(e, 15, reps, stream, total_ms, bytes_per_pass, launches_per_pass);
 }
 
+// Token-long weight prefetcher beside the step (woq_prefetch.hip). waves x depth KiB in flight per workgroup, `grid`
+// workgroups; lead / lead_kind: how far ahead of the layer whose qkv has been published it may run (layers, and
+// projections of the last of them: -1 none ... 3 all); wrap: prefetch layer 0 again at the end, for the next token;
+// head_mb: MiB of the lm_head to touch after the last layer. Takes effect at the next step / capture.
+int woq_engine_set_prefetch(woq_engine* e, int on, int grid, int waves, int depth, int lead, int lead_kind, int wrap,
+                            int head_mb) {
+  WOQ_TRY
+  WOQ_CHECK(e != nullptr, "QBits: null engine");
+  WOQ_CHECK(grid >= 1 && grid <= 4096 && waves >= 1 && waves <= 4 && (depth == 4 || depth == 8 || depth == 16 || depth == 32),
+            "QBits: prefetch geometry out of range");
+  WOQ_CHECK(lead >= 1 && lead <= 8 && lead_kind >= -1 && lead_kind <= 3 && head_mb >= 0, "QBits: prefetch lead out of range");
+  e->wpf_on = on != 0;
+  e->wpf_grid = grid, e->wpf_waves = waves, e->wpf_depth = depth, e->wpf_lead = lead, e->wpf_lead_kind = lead_kind;
+  if ((e->wpf_wrap != (wrap != 0)) || e->wpf_head_mb != head_mb) e->wpf_items = nullptr;
+  e->wpf_wrap = wrap != 0, e->wpf_head_mb = head_mb;
+  WOQ_END
+}
+int woq_engine_prefetch(woq_engine* e) { return e && e->wpf_applies() ? 1 : 0; }
+
+// Measurement: one projection's decode launch over every layer, (i) as it runs in the step —
+// every blob cold, the model is 13x the Infinity Cache — and (ii) with each blob READ BY ANOTHER KERNEL `lead` launches
+// earlier (a full-chip default-policy streaming read, what a prefetcher leaves behind): us[0] = cold pass per launch,
+// us[1] = readers alone per launch, us[2] = readers + launches per launch; hot = us[2] - us[1]. proj 0 qkv (stand-alone
+// launch), 1 o, 2 gate/up, 3 down; twin = the load-only twin instead of the GEMV.
+int woq_engine_mall_probe(woq_engine* e, int proj, int twin, int lead, int reps, void* stream, float* us) {
+  WOQ_TRY
+  WOQ_CHECK(e && us && proj >= 0 && proj < 4 && lead >= 0 && reps >= 1 && e->use_xq(), "QBits: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const woq_engine_config& c = e->cfg;
+  unsigned int* sink = (unsigned int*)e->am_idx;
+  auto blob_of = [&](int l, const woq_blob_header** h) -> const void* {
+    const woq_layer_weights& w = e->layers[l];
+    switch (proj) {
+      case 0: *h = &w.qkv_hdr; return w.qkv_blob;
+      case 1: *h = &w.o_hdr; return w.o_blob;
+      case 2: *h = &w.gate_up_hdr; return w.gate_up_blob;
+      default: *h = &w.down_hdr; return w.down_blob;
+    }
+  };
+  auto gemv = [&](int l, hipStream_t st) -> int {
+    const woq_blob_header* h;
+    const void* b = blob_of(l, &h);
+    if (twin) return launch_gemv_twin(b, *h, proj == 2 ? 1 : 0, 0, sink, st);
+    const woq_layer_weights& w = e->layers[l];
+    switch (proj) {
+      case 0: return engine_gemv_xq(e, e->xq_hidden, b, *h, e->qkv, e->ssq_part, nullptr, 0, kNoXq, nullptr, nullptr, st);
+      case 1: return engine_gemv_xq(e, e->xq_attn, b, *h, e->hidden, nullptr, e->hidden, 0, e->xq_hidden, w.ln2, e->ssq_part, st);
+      case 2: return engine_gemv_xq(e, e->xq_hidden, b, *h, nullptr, e->ssq_part, nullptr, 1, e->xq_act, nullptr, nullptr, st);
+      default: return engine_gemv_xq(e, e->xq_act, b, *h, e->hidden, nullptr, e->hidden, 0, kNoXq, nullptr, nullptr, st);
+    }
+  };
+  auto reader = [&](int l, hipStream_t st) {
+    const woq_blob_header* h;
+    const void* b = blob_of((l + lead) % c.layers, &h);
+    launch_stream_read(b, (size_t)h->total_bytes, sink, st);
+  };
+  for (int mode = 0; mode < 3; ++mode) {
+    auto pass = [&](hipStream_t st) -> int {
+      for (int l = 0; l < c.layers; ++l) {
+        if (mode >= 1) reader(l, st);
+        if (mode != 1) {
+          const int rc = gemv(l, st);
+          if (rc) return rc;
+        }
+      }
+      return 0;
+    };
+    float ms = 0.f;
+    const int rc = time_captured(st, reps, pass, &ms, true);
+    if (rc) return rc;
+    us[mode] = ms * 1e3f / (float)(reps * c.layers);
+  }
+  WOQ_END
+}
+
 // roofline.ceiling of bench.py: the decode step's four GEMV launches per layer with the arithmetic taken out — mode 0:
 // load-only twins (same grids, waves, K slices, non-temporal requests over the engine's own blobs), mode 1: empty
 // kernels on the same grids — timed like woq_engine_time_gemv (one event pair around each pass, back to back).
@@ -945,7 +1108,7 @@ int woq_engine_time_twin(woq_engine* e, int mode, int reps, void* stream, float*
   WOQ_CHECK(e && total_ms && (mode == 0 || mode == 1), "QBits: bad argument");
   hipStream_t st = (hipStream_t)stream;
   unsigned int* sink = (unsigned int*)e->am_idx;  // any device word; never written (the twins' store is unreachable)
-  auto pass = [&]() -> int {
+  auto pass = [&](hipStream_t st) -> int {
     for (int l = 0; l < e->cfg.layers; ++l) {
       const woq_layer_weights& w = e->layers[l];
       int rc;
@@ -956,7 +1119,9 @@ int woq_engine_time_twin(woq_engine* e, int mode, int reps, void* stream, float*
     }
     return 0;
   };
-  const int rc = time_captured(st, reps, pass, total_ms, e->time_eager);
+  // empty kernels are shorter than the host's launch call (~2.6 us): issued eagerly the pass would be host-bound and
+  // read the host's rate, not the device's — always a replayed graph for mode 1
+  const int rc = time_captured(st, reps, pass, total_ms, mode == 1 ? false : e->time_eager);
   if (rc) return rc;
   WOQ_END
 }

@@ -40,7 +40,10 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
 }
-constexpr int AUX_NT = 2;  // non-temporal: streamed-once weights
+#ifndef WOQ_AUX_NT  // A/B builds: tools/mkvariant_xq.sh <name> -DWOQ_AUX_NT=0 (default cache policy on the weight stream)
+#define WOQ_AUX_NT 2
+#endif
+constexpr int AUX_NT = WOQ_AUX_NT;  // non-temporal: streamed-once weights
 
 // three limb sums (D rows 4m..4m+2) + sum of 16*q (row 4m+3) of one lane -> the exact integer
 // sum_k 16 q_k (Q_k - 2^22) rounded once to fp32, Q = 23-bit offset-binary activation:

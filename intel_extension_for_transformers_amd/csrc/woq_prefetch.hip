@@ -1,0 +1,127 @@
+// woq_prefetch.hip — a token-long weight prefetcher that runs BESIDE the decode step (round 5).
+//
+// Why. The batch-1 decode step is a chain of 128 dependent GEMV launches; each pays ~2.7 us of boundary + first bytes +
+// tail during which HBM idles (0.35 ms of a 1.03 ms token). The bytes have to cross HBM once either
+// way; what can move is WHEN: one low-occupancy kernel, a dependency-free branch of the step's hipGraph forked once per
+// token, walks the layers' blobs in consumption order with plain (default-policy) 16-byte loads and throws the data
+// away — what it leaves behind is the lines in the 256-MiB Infinity Cache (memory side, shared by all XCDs), so the
+// step's own launches start and stream out of the cache while the prefetcher pulls the next layer across HBM through
+// their boundaries. It never sits in front of a boundary (round 2's rider did, profiles/r02pf_*) and forks once per
+// token, not once per GEMV (round 1's side stream did, profiles/r01i_*).
+//
+// Pacing. The prefetcher must stay ahead of the consumer but inside the cache: it reads the {tag, value} granule the
+// fused qkv + attention launch publishes per layer (tag = step << 6 | layer, woq_gemv_attn.hip) — the layer whose qkv
+// has completed — and (i) skips what the consumer has already passed, (ii) sleeps while it is `lead` layers ahead.
+// No kernel of the step changes. Reference path replaced: none (the reference has no device path); this is launch
+// structure around qbits.cpp:113-140's M = 1 calls.
+#include <vector>
+
+#include "woq_gemv_common.h"
+#include "woq_launch.h"
+
+namespace woq {
+
+struct PfItem {
+  const void* ptr;
+  uint32_t kib;   // whole KiB to touch
+  int32_t vlayer; // layer the bytes are consumed in (lm_head: layers; next token's layer 0: layers + 1)
+  int32_t kind;   // 0 qkv, 1 o, 2 gate/up, 3 down, 4 head
+};
+
+// DEPTH 1-KiB requests in flight per wave; WAVES waves per workgroup; one workgroup per CU intended (grid = CU count)
+template <int DEPTH>
+__global__ __launch_bounds__(256) void prefetch_kernel(const PfItem* __restrict__ items, int n_items,
+                                                       const unsigned long long* __restrict__ qkv_g,
+                                                       const unsigned int* __restrict__ seq, int lead, int lead_kind,
+                                                       int first_vlayer, unsigned int* __restrict__ sink) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)blockIdx.x * ((int)blockDim.x >> 6) + ((int)threadIdx.x >> 6);
+  const int n_waves = (int)gridDim.x * ((int)blockDim.x >> 6);
+  const unsigned int step = seq[0] & 0x03ffffffu;
+  u32x4 acc = {0, 0, 0, 0};
+  int cur = -1;  // the last layer whose qkv has been published in THIS step
+  const unsigned long long t_start = wall_clock64();
+  for (int i = 0; i < n_items; ++i) {
+    const PfItem it = items[i];
+    if (it.vlayer < first_vlayer) continue;  // left in the cache by the previous token's prefetcher (wrap-around items)
+    bool skip = false;
+    for (;;) {
+      const unsigned long long g = __hip_atomic_load(qkv_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int tag = (unsigned int)(g >> 32);
+      if ((tag >> 6) == step) cur = max(cur, (int)(tag & 63u));
+      // behind the consumer: nothing to gain from these bytes any more
+      if (it.vlayer < cur || (it.vlayer == cur && it.kind == 0)) {
+        skip = true;
+        break;
+      }
+      if (it.vlayer < cur + lead || (it.vlayer == cur + lead && it.kind <= lead_kind)) break;
+      if (wall_clock64() - t_start > 5000000ull) {  // 50 ms at 100 MHz: the step is not running — leave
+        skip = true;
+        i = n_items;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(32);
+    }
+    if (skip) continue;
+    const rsrc_t r = make_rsrc(it.ptr, (int)(it.kib << 10));
+    for (unsigned int p0 = (unsigned int)wave; p0 < it.kib; p0 += (unsigned int)n_waves * DEPTH) {
+      u32x4 w[DEPTH];
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d)  // out-of-range pieces read nothing (descriptor bounds)
+        w[d] = __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, (int)((p0 + (unsigned int)(d * n_waves)) << 10), 0);
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) acc |= w[d];
+    }
+  }
+  if ((acc.x & acc.y & acc.z & acc.w) == 0x9e3779b9u && lane == 65) sink[0] = 1;  // keeps the loads alive; unreachable
+}
+
+int launch_prefetch(const void* items_dev, int n_items, const unsigned long long* qkv_g, const unsigned int* seq,
+                    int lead, int lead_kind, int first_vlayer, int grid, int waves, int depth, unsigned int* sink,
+                    hipStream_t st) {
+  const PfItem* it = (const PfItem*)items_dev;
+  const dim3 g(grid), b(waves * 64);
+  switch (depth) {
+    case 4: hipLaunchKernelGGL(prefetch_kernel<4>, g, b, 0, st, it, n_items, qkv_g, seq, lead, lead_kind, first_vlayer, sink);
+      break;
+    case 8: hipLaunchKernelGGL(prefetch_kernel<8>, g, b, 0, st, it, n_items, qkv_g, seq, lead, lead_kind, first_vlayer, sink);
+      break;
+    case 16: hipLaunchKernelGGL(prefetch_kernel<16>, g, b, 0, st, it, n_items, qkv_g, seq, lead, lead_kind, first_vlayer, sink);
+      break;
+    case 32: hipLaunchKernelGGL(prefetch_kernel<32>, g, b, 0, st, it, n_items, qkv_g, seq, lead, lead_kind, first_vlayer, sink);
+      break;
+    default: return woq::fail("QBits: prefetch depth must be 4, 8, 16 or 32");
+  }
+  return 0;
+}
+
+// host-side item list -> device buffer (freed by the caller)
+int prefetch_build_items(const std::vector<const void*>& ptrs, const std::vector<size_t>& bytes,
+                         const std::vector<int>& vlayer, const std::vector<int>& kind, void** items_dev, int* n) {
+  std::vector<PfItem> v(ptrs.size());
+  for (size_t i = 0; i < ptrs.size(); ++i)
+    v[i] = PfItem{ptrs[i], (uint32_t)std::min<size_t>(bytes[i] >> 10, 0x3fffffu), vlayer[i], kind[i]};
+  WOQ_HIP(hipMalloc(items_dev, v.size() * sizeof(PfItem)));
+  WOQ_HIP(hipMemcpy(*items_dev, v.data(), v.size() * sizeof(PfItem), hipMemcpyHostToDevice));
+  *n = (int)v.size();
+  return 0;
+}
+
+// ---- measurement: a full-chip default-policy read of `bytes` (what "read by another kernel first" means in
+// tools/visits/r05a_mall.py) ----
+__global__ __launch_bounds__(256) void stream_read_kernel(const u32x4* __restrict__ p, size_t n16, unsigned int* sink) {
+  u32x4 acc = {0, 0, 0, 0};
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const u32x4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+    acc |= (a | b) | (c | d);
+  }
+  for (; i < n16; i += stride) acc |= p[i];
+  if ((acc.x & acc.y & acc.z & acc.w) == 0x9e3779b9u && threadIdx.x == 999) sink[0] = 1;
+}
+void launch_stream_read(const void* p, size_t bytes, unsigned int* sink, hipStream_t st) {
+  hipLaunchKernelGGL(stream_read_kernel, dim3(2048), dim3(256), 0, st, (const u32x4*)p, bytes / 16, sink);
+}
+
+}  // namespace woq

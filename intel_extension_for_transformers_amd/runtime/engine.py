@@ -289,6 +289,22 @@ class WoqDecoderEngine:
             L.check(L.lib().woq_engine_set_attn_chunk(self._h, int(chunk)))
             self.captured = False
 
+    def set_prefetch(self, on=True, grid=256, waves=4, depth=16, lead=2, lead_kind=-1, wrap=True, head_mb=0):
+        """Token-long weight prefetcher beside the decode step (csrc/woq_prefetch.hip); re-capture afterwards."""
+        L.check(L.lib().woq_engine_set_prefetch(self._h, int(bool(on)), int(grid), int(waves), int(depth), int(lead),
+                                                int(lead_kind), int(bool(wrap)), int(head_mb)))
+        self.captured = False
+
+    def uses_prefetch(self):
+        return bool(L.lib().woq_engine_prefetch(self._h))
+
+    def mall_probe(self, proj, twin=False, lead=1, reps=10):
+        """(cold us, hot us) per launch of projection `proj` (0 qkv, 1 o, 2 gate/up, 3 down): every blob cold, as in the
+        step, vs read by another kernel `lead` launches earlier (tools/visits/r05a_mall.py)."""
+        us = (ctypes.c_float * 3)()
+        L.check(L.lib().woq_engine_mall_probe(self._h, int(proj), int(bool(twin)), int(lead), int(reps), L.stream_ptr(), us))
+        return us[0], us[2] - us[1], us[1]
+
     def set_persist(self, on):
         """Decode step: all layers as ONE persistent launch (csrc/woq_persist.hip) where the model fits its scope.
         Invalidates a captured graph."""

@@ -239,6 +239,31 @@ def test_awq_gemm_pack_unpack_matches_writer_definition():
     assert torch.equal(w, q) and torch.equal(zz, z)
 
 
+def test_awq_gemm_known_answer_words():
+    """External pin of the AutoAWQ "GEMM" nibble order: a hand-written 8 x 8 tensor and the int32
+    words an AutoAWQ writer produces for it, written out as LITERALS — nibble i of a word holds column
+    (0, 2, 4, 6, 1, 3, 5, 7)[i] (AutoAWQ `WQLinear_GEMM.from_linear`: `order_map = [0, 2, 4, 6, 1, 3, 5, 7]`,
+    `qweight[:, col] |= intweight[:, col * 8 + order_map[i]] << (i * 4)`). Nothing below is produced by this repo's
+    `pack_awq_gemm`; the GPTQ-style order (nibble i = column i) would read row 0 as 0xECA86420 and fail."""
+    from intel_extension_for_transformers_amd.transformers.llm.quantization.utils import unpack_awq_gemm
+
+    # w[k][n] = (2 n + 3 k) mod 16, k, n = 0..7
+    w = torch.tensor([[(2 * n + 3 * k) % 16 for n in range(8)] for k in range(8)], dtype=torch.int8)
+    # row 0 = [0,2,4,6,8,10,12,14]: nibbles 0..7 = columns 0,2,4,6,1,3,5,7 = 0,4,8,c,2,6,a,e -> 0xEA62C840
+    # row 1 = [3,5,7,9,11,13,15,1]: 3,7,b,f,5,9,d,1 -> 0x1D95FB73;  row 2 = [6,8,10,12,14,0,2,4]: 6,a,e,2,8,c,0,4 -> 0x40C82EA6
+    words = [0xEA62C840, 0x1D95FB73, 0x40C82EA6, 0x73FB51D9, 0xA62E840C, 0xD951B73F, 0x0C84EA62, 0x3FB71D95]
+    for k in range(8):  # the literals against the definition, spelled out (guards the table above against typos)
+        cols = [0, 2, 4, 6, 1, 3, 5, 7]
+        assert words[k] == sum(((2 * cols[i] + 3 * k) % 16) << (4 * i) for i in range(8)), k
+    qweight = torch.tensor([[x - (1 << 32) if x >= (1 << 31) else x] for x in words], dtype=torch.int32)  # [K = 8, N/8 = 1]
+    # zero points of one group, same packing: z[n] = 15 - n -> nibbles f,d,b,9,e,c,a,8 -> 0x8ACE9BDF
+    qzeros = torch.tensor([[0x8ACE9BDF - (1 << 32)]], dtype=torch.int32)
+    scales = torch.ones(1, 8)
+    got_w, _, got_z = unpack_awq_gemm(qweight, scales, qzeros)
+    assert torch.equal(got_w, w)
+    assert got_z.tolist() == [[15 - n for n in range(8)]]
+
+
 def test_library_exports_every_symbol_the_headers_declare():
     """The C-ABI library loads without a GPU and exports every `WOQ_API` function of include/woq_hip.h (no compute
     call is made); the ctypes binding's EXPORTS list is exactly that set, and the header structs have the sizes
