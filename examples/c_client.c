@@ -12,7 +12,7 @@
 
 int main(int argc, char** argv) {
   const int K = 4096, N = 11008, group = 128;
-  if (woq_abi_version() != 1) return 1;
+  if (woq_abi_version() != WOQ_ABI_VERSION) return 1;  /* built against another revision of include/woq_hip.h */
   /* host arithmetic shared with the library: header geometry of an int4 sym g128 fp16-scale blob */
   woq_blob_header h;
   if (woq_header_init(&h, K, N, group, WOQ_W_INT4_CLIP, WOQ_F16, WOQ_C_FP32, 0, 0) != 0) return 2;

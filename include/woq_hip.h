@@ -42,6 +42,10 @@ extern "C" {
 #define WOQ_API __attribute__((visibility("default")))
 
 WOQ_API const char* woq_last_error(void);
+/* ABI revision of this header: 1 = rounds 1-3; 2 = round 4 (woq_engine_set_chain / woq_engine_chain removed;
+ * woq_engine_steps, _set_attn_chunk, _clear_status, _set_time_eager, woq_table_digit_planes added); 3 = round 5
+ * (woq_engine_set_prefetch / _prefetch / _mall_probe added). A client checks it against WOQ_ABI_VERSION at load time. */
+#define WOQ_ABI_VERSION 3
 WOQ_API int woq_abi_version(void);
 /* number of visible HIP devices (0 when there is no GPU); never fails. */
 WOQ_API int woq_device_count(void);

@@ -96,7 +96,7 @@ using namespace woq;
 extern "C" {
 
 const char* woq_last_error(void) { return last_error_ref().c_str(); }
-int woq_abi_version(void) { return 1; }
+int woq_abi_version(void) { return WOQ_ABI_VERSION; }
 int woq_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -50,13 +50,17 @@ __device__ __forceinline__ void attn_slices_merge(float* part, int heads, int h0
   __syncthreads();
   unsigned int* flag = (unsigned int*)lds;
   if (tid == 0) {
-    const unsigned int old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // acquire + release at agent scope: the arrival orders this workgroup's (already drained, write-through) partials
+    // before it, and the last arriver's loads below after it — no reliance on in-order hardware or on the compiler
+    // keeping ld_agent behind the barrier
+    const unsigned int old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     flag[0] = old == (unsigned int)(ns - 1) ? 1u : 0u;
     if (old == (unsigned int)(ns - 1))  // complete: nobody else touches it before the next launch
       __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   if (flag[0] == 0u) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every thread of the last arriver reads other workgroups' partials
   __syncthreads();  // flag word is about to be reused
   float* ms = lds;                // [nh][ns] slice maxima
   float* wl = ms + nh * ns;       // [nh][ns] slice sums -> weighted sums

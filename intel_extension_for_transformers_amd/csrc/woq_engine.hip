@@ -674,6 +674,9 @@ int woq_engine_clear_status(woq_engine* e, void* stream) {
   WOQ_TRY
   WOQ_CHECK(e, "QBits: null engine");
   if (e->fuse_status) WOQ_HIP(hipMemsetAsync(e->fuse_status, 0, 4, (hipStream_t)stream));
+  // the slices' arrival counters return to zero by themselves when a merge completes; an aborted launch would leave
+  // them mid-count and no later merge would ever fire (WOQ_ATTN_FOLD=1 only)
+  if (e->attn_cnt) WOQ_HIP(hipMemsetAsync(e->attn_cnt, 0, (size_t)e->cfg.heads * 4, (hipStream_t)stream));
   WOQ_END
 }
 int woq_engine_fuse_attn(woq_engine* e) {
@@ -910,6 +913,7 @@ int woq_engine_capture(woq_engine* e, int greedy, void* stream) {
   WOQ_CHECK(!e->allreduce || (e->comm && e->cfg.tp_size > 1),
             "QBits: graph capture with a host all-reduce callback is not supported (bind a device communicator)");
   hipStream_t st = (hipStream_t)stream;
+  if (e->attn_cnt) WOQ_HIP(hipMemsetAsync(e->attn_cnt, 0, (size_t)e->cfg.heads * 4, st));
   // one eager, non-advancing step first: sets the lazy kernel attributes outside of capture.
   // (re-writing the KV slot at the current position is idempotent)
   int rc = engine_step_impl(e, 0, st);

@@ -233,7 +233,7 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
   static const bool force_generic = getenv("WOQ_GEMV_GENERIC") != nullptr;  // A/B switch for tests
   const size_t esz_a = act_dtype == WOQ_F32 ? 4 : 2, esz_o = out_dtype == WOQ_F32 ? 4 : 2;
   int rows = force_generic ? 0 : gemv_tile_max_rows(act, act_dtype, lda, h, norm_w, epi, out_dtype);
-  const bool tile = rows > 0;
+  const bool tile = rows > 0 && !(h.off_shuffle != 0 && M > 1);  // act-order blobs: the tile kernel's gather form is batch-1
   if (!tile) {
     rows = GEN_MAXM;
     while (rows > 1 && gen_lds_bytes(rows, h.Kpad) > 150 * 1024) --rows;

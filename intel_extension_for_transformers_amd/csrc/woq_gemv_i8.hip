@@ -105,16 +105,23 @@ __host__ __device__ inline size_t tile_lds_bytes(int M, int nw, int TPW, int CB)
 
 // flags: bit 0 scales are bf16 (else fp16; ignored for fp32 scales), bit 1 SiLU(gate)*up epilogue (CB == 2)
 // NDIG: 0 = int4 weights; 1 | 2 | 3 = a 4-bit table type (nf4 / fp4) as that many digit planes (woq_gemv_common.h LutArgs)
-template <int TPW, int CB, int SMODE, bool ASYM, bool S32, bool M1, int NDIG>
+// SHUF (round 5, batch 1, int4): GPTQ act-order blobs — weight row k meets activation x[shuffle[k]] (the converted
+// g_idx the blob carries; reference semantics: `index_select(x, 1, g_idx)` in autograd/functions.py:41-63 and BesTLA's
+// ShuffleActivation prologue, bestla_weightonly_dispatcher.cpp:138-142,163-166). The wave's slice of the index vector is
+// requested first; the activation (and RMSNorm weight) elements are gathered by index — dependent 4-byte requests that
+// queue behind the weight tiles — and staged exactly like a contiguous slice. Everything else is the kernel above.
+template <int TPW, int CB, int SMODE, bool ASYM, bool S32, bool M1, int NDIG, bool SHUF = false>
 // register budget by workgroup size: 1024 threads -> 128 VGPRs (group-128 paths), 768 -> 168 (per-32 scales keep
 // 3 more registers per tile and twice the A fragments), 512 -> 256
 __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) void gemv_tile_kernel(
     const u32x4* __restrict__ q, const void* __restrict__ scales, const void* __restrict__ x,
     const float* __restrict__ norm_w, int tiles_k, int K, int base_tiles, int rem_tiles, int n_groups, int tpg_shift,
     const uint8_t* __restrict__ zp, void* __restrict__ out, const float* __restrict__ bias, const float* residual,
-    float eps, int N, int Mrows, int lda, int ldo, int ld_res, int out_dtype, int flags, int kt_off, LutArgs lut) {
+    float eps, int N, int Mrows, int lda, int ldo, int ld_res, int out_dtype, int flags, int kt_off, LutArgs lut,
+    const int32_t* __restrict__ shuffle) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   static_assert(!(ASYM && NDIG > 0), "table weight types are symmetric");
+  static_assert(!SHUF || (M1 && NDIG == 0), "the act-order gather is built for batch-1 int4 launches");
   constexpr int NB = NDIG > 0 ? NDIG : 1;  // B operands per 64-k half
   // one 64-k half against the A operand `av`: sum_k (activation) x (16 q | table digits), recombined in fp32
   auto half_dot = [&](const i32x4& av, uint32_t w0, uint32_t w1) -> float {
@@ -199,10 +206,17 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
   };
   const rsrc_t rg = make_rsrc(norm ? (const void*)(norm_w + kbase) : x, norm ? xlen * 4 : 0);
   float4_t xv0[XJ], gv[XJ];
-  load_row(0, xv0);
+  u32x4 idv[SHUF ? XJ : 1];  // act-order: indices of this lane's activations, elements kbase + 4 lane + 256 j + 0..3
+  if constexpr (SHUF) {
+    const rsrc_t ri = make_rsrc(shuffle + kbase, xlen * 4);
 #pragma unroll
-  for (int j = 0; j < XJ; ++j)
-    gv[j] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, v16 + j * 1024, 0, 0));
+    for (int j = 0; j < XJ; ++j) idv[j] = __builtin_amdgcn_raw_buffer_load_b128(ri, v16 + j * 1024, 0, 0);
+  } else {
+    load_row(0, xv0);
+#pragma unroll
+    for (int j = 0; j < XJ; ++j)
+      gv[j] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, v16 + j * 1024, 0, 0));
+  }
   WOQ_STAMP(1);
 
   // ---- 1. scales / zero points, then the first PF weight tiles ----
@@ -255,6 +269,33 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
   for (int i = 0; i < PF && i < CB * TPW; ++i) issue_w(i);
   WOQ_STAMP(3);
 
+  if constexpr (SHUF) {
+    // gather: x[shuffle[k]] (and norm_w[shuffle[k]]) for this lane's 4 XJ elements; elements past the slice read
+    // through an out-of-range offset and return 0 (no clamp, no branch)
+    const int esz = xdt == 0 ? 4 : 2;
+    const rsrc_t rxa = make_rsrc(x, WOQ_SKIP(7) ? 0 : K * esz);
+    const rsrc_t rga = make_rsrc(norm ? (const void*)norm_w : x, norm ? K * 4 : 0);
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      float f[4], g4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool live = lane * 4 + j * 256 + i < xlen;
+        const uint32_t id = idv[j][i];
+        const int off = live ? (int)id : 0x3fffffff;  // x 4 (or 2) lands beyond every descriptor's range
+        if (xdt == 0) {
+          f[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxa, off * 4, 0, 0));
+        } else {
+          const uint16_t hb = __builtin_amdgcn_raw_buffer_load_b16(rxa, off * 2, 0, 0);
+          const float fb = bf16_bits_to_f32(hb), fh = f16_bits_to_f32(hb);
+          f[i] = xdt == 2 ? fb : fh;
+        }
+        g4[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rga, off * 4, 0, 0));
+      }
+      xv0[j] = (float4_t){f[0], f[1], f[2], f[3]};
+      gv[j] = (float4_t){g4[0], g4[1], g4[2], g4[3]};
+    }
+  }
   // ---- 2. stage this wave's K slice of the activation rows as three int8 limb rows in its LDS strip ----
   ((uint32_t*)zero_blk)[lane] = 0u;
   ((uint32_t*)ones_blk)[lane] = 0x01010101u;
@@ -583,13 +624,14 @@ struct TileLaunch {
   int kt_begin, kt_count;  // K tiles [kt_begin, kt_begin + kt_count) of the blob covered by this launch
   LutArgs lut;             // table weight types (ndig > 0)
   int ndig;
+  const int32_t* shuffle;  // GPTQ act-order: activation index of every weight row (batch 1, int4), or null
 };
 
-template <int TPW, int CB, int SMODE, bool ASYM, bool S32, bool M1, int NDIG>
+template <int TPW, int CB, int SMODE, bool ASYM, bool S32, bool M1, int NDIG, bool SHUF = false>
 static int launch_tile_t(const TileLaunch& a, hipStream_t st) {
   const size_t lds = tile_lds_bytes(a.M, a.nw, TPW, CB);
   if (lds > 160 * 1024) return woq::fail("QBits: activation rows do not fit LDS");
-  auto kern = gemv_tile_kernel<TPW, CB, SMODE, ASYM, S32, M1, NDIG>;
+  auto kern = gemv_tile_kernel<TPW, CB, SMODE, ASYM, S32, M1, NDIG, SHUF>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -599,12 +641,28 @@ static int launch_tile_t(const TileLaunch& a, hipStream_t st) {
   const int base = a.kt_count / a.nw, rem = a.kt_count % a.nw;
   hipLaunchKernelGGL(kern, dim3(a.grid), dim3(a.nw * 64), lds, st, (const u32x4*)a.q, a.scales, a.x, a.norm_w,
                      a.tiles_k, a.K, base, rem, a.n_groups, a.tpg_shift, (const uint8_t*)a.zp, a.out, a.bias,
-                     a.residual, a.eps, a.N, a.M, a.lda, a.ldo, a.ld_res, a.out_dtype, a.flags, a.kt_begin, a.lut);
+                     a.residual, a.eps, a.N, a.M, a.lda, a.ldo, a.ld_res, a.out_dtype, a.flags, a.kt_begin, a.lut,
+                     a.shuffle);
   return 0;
 }
 
 template <int TPW, int CB>
 static int launch_tile_sm(const TileLaunch& a, int smode, bool asym, bool s32, hipStream_t st) {
+  if (a.shuffle != nullptr) {  // act-order blobs: batch 1, int4 (gemv_tile_max_rows admits nothing else)
+    if (a.M != 1 || a.ndig != 0) return woq::fail("QBits: the act-order tile GEMV takes one int4 row");
+#define WOQ_TILE_SHUF(SM, AS, S3) \
+  if (smode == SM && asym == AS && s32 == S3) return launch_tile_t<TPW, CB, SM, AS, S3, true, 0, true>(a, st);
+    WOQ_TILE_SHUF(0, false, false)
+    WOQ_TILE_SHUF(0, false, true)
+    WOQ_TILE_SHUF(0, true, false)
+    WOQ_TILE_SHUF(0, true, true)
+    WOQ_TILE_SHUF(1, false, false)
+    WOQ_TILE_SHUF(1, false, true)
+    WOQ_TILE_SHUF(1, true, false)
+    WOQ_TILE_SHUF(1, true, true)
+#undef WOQ_TILE_SHUF
+    return woq::fail("QBits: bad tile GEMV configuration");
+  }
 #define WOQ_TILE_CASE(SM, AS, S3, ND)                                                   \
   if (smode == SM && asym == AS && s32 == S3 && a.ndig == ND)                           \
     return a.M == 1 ? launch_tile_t<TPW, CB, SM, AS, S3, true, ND>(a, st)               \
@@ -692,7 +750,10 @@ int gemv_tile_max_rows(const void* act, int act_dtype, int lda, const woq_blob_h
                        int epi, int out_dtype) {
   static const bool table_generic = getenv("WOQ_TABLE_GENERIC") != nullptr;  // A/B switch: round 3's fp32 VALU kernel
   const bool table = is_table_type(h.weight_type) && h.off_zp == 0 && !table_generic;
-  if ((h.weight_type != WOQ_W_INT4_CLIP && !table) || h.off_shuffle != 0 || (h.K & 3) != 0 || (lda & 3) != 0 ||
+  // act-order (g_idx) blobs: one int4 row per launch through the gather form (round 5); more rows keep the generic kernel
+  static const bool shuf_generic = getenv("WOQ_SHUFFLE_GENERIC") != nullptr;  // A/B switch: the fp32 VALU kernel
+  if (h.off_shuffle != 0 && (h.weight_type != WOQ_W_INT4_CLIP || shuf_generic)) return 0;
+  if ((h.weight_type != WOQ_W_INT4_CLIP && !table) || (h.K & 3) != 0 || (lda & 3) != 0 ||
       (((uintptr_t)act) & (act_dtype == WOQ_F32 ? 15 : 7)) != 0 || (((uintptr_t)norm_w) & 15) != 0)
     return 0;
   const int tiles_k = h.Kpad / WOQ_TILE_K;
@@ -709,7 +770,7 @@ int gemv_tile_max_rows(const void* act, int act_dtype, int lda, const woq_blob_h
     const int v = s ? atoi(s) : TMAXM;
     return v >= 1 && v <= TMAXM ? v : TMAXM;
   }();
-  int m = cap;
+  int m = h.off_shuffle != 0 ? 1 : cap;
   while (m > 0 && tile_lds_bytes(m, nw, tpw, cb) > 150 * 1024) --m;
   return m;
 }
@@ -749,6 +810,7 @@ int launch_gemv_tile(const void* act, int act_dtype, int lda, int M, const void*
   a.flags = (h.scale_type == WOQ_BF16 ? 1 : 0) | (epi == 1 ? 2 : 0) |
             (act_dtype == WOQ_F16 ? 4 : (act_dtype == WOQ_BF16 ? 8 : 0));
   a.ndig = lut_args_for(h.weight_type, h.compute_type, a.lut);
+  a.shuffle = h.off_shuffle ? (const int32_t*)(b + h.off_shuffle) : nullptr;
 #ifdef WOQ_PROBE
   a.flags |= ::g_probe_flags;
 #endif

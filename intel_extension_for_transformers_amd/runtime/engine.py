@@ -371,7 +371,10 @@ class WoqDecoderEngine:
         # position-independent slices: not with a sliding window (the slices move with the position), and only for
         # the fp8 cache, whose kernel keeps raw bytes in registers and fits two workgroups on a CU — the fp16 form
         # holds one (272 registers), and ceil(positions / 256) x kv_heads workgroups would then run a second round
-        fixed = False and grouped and not self.cfg.reserved[2] and self.cfg.kv_dtype == L.FP8_E4M3  # measured slower (r04d): off
+        # measured slower (+2.5 us per layer, profiles/r04d_*): opt-in through WOQ_ATTN_FIXED_CHUNK=1 (parity:
+        # test_grouped_attention_fixed_chunk_slices_vs_oracle drives the same geometry through set_attn_chunk)
+        fixed = (os.environ.get("WOQ_ATTN_FIXED_CHUNK", "0") not in ("", "0") and grouped and not self.cfg.reserved[2]
+                 and self.cfg.kv_dtype == L.FP8_E4M3)
         self.set_attn_chunk(self.GROUPED_CHUNK if fixed else 0)
         if positions <= self.LONG_CTX:
             self.set_attn_splits(1)
@@ -674,13 +677,25 @@ def _code_parts(mod):
 
 
 def _signed_parts(mod):
-    """QuantizedLinearQBits -> (q int8 [K,N] in [-8,7], scales fp32 [G,N], zp int8 [G,N] signed or None)."""
+    """QuantizedLinearQBits -> (q int8 [K,N] in [-8,7], scales fp32 [G,N], zp int8 [G,N] signed or None, g_idx int32 [K]
+    or None). Act-order (GPTQ desc_act) modules hand their rows back in the regrouped order the blob holds, with the raw
+    g_idx that `repack_quantized_weight` turns into the activation shuffle (reference nn/modules.py:205-224)."""
     if getattr(mod, "weight_dtype", "int4_clip") in TABLE_WEIGHT_DTYPES:
-        return _code_parts(mod)
+        return _code_parts(mod) + (None,)
     int_w, scales, zeros, g_idx = mod.recover_qparms_kn()
-    if g_idx is not None:
-        raise RuntimeError("QBits: the fused decode engine does not take act-order (g_idx) layers")
-    return (int_w - 8).to(torch.int8), scales, None if zeros is None else (zeros - 8).to(torch.int8)
+    return (int_w - 8).to(torch.int8), scales, None if zeros is None else (zeros - 8).to(torch.int8), g_idx
+
+
+def _same_order(parts, what):
+    """Projections fused along N share ONE activation shuffle: q / k / v (and gate / up) of a GPTQ act-order checkpoint
+    see the same inputs, hence the same Hessian diagonal, hence the same permutation — checked, not assumed."""
+    idx = [p[3] for p in parts]
+    if all(i is None for i in idx):
+        return None
+    if any(i is None for i in idx) or any(not torch.equal(idx[0], i) for i in idx[1:]):
+        raise RuntimeError("QBits: %s carry different act-order permutations; the fused decode engine needs one per fused "
+                           "projection (the model keeps the module path)" % what)
+    return idx[0]
 
 
 def optimize_transformers(model, max_ctx=2048, kv_dtype=torch.float16):
@@ -717,28 +732,48 @@ def optimize_transformers(model, max_ctx=2048, kv_dtype=torch.float16):
     eng = WoqDecoderEngine(hidden, inter, heads, kv_heads, head_dim, len(layers), cfg.vocab_size, max_ctx=max_ctx,
                            rms_eps=cfg.rms_norm_eps, rope_theta=float(theta), kv_dtype=kv_dtype, device=dev,
                            sliding_window=int(window))
-    asym = first.scheme == "asym"
+    # every projection of every layer is repacked under ONE (weight type, compute type, group, scale type, scheme): a
+    # model whose modules differ would be repacked under layer 0's q_proj's and decode silently wrong —
+    # refuse it here; such models keep the module path
+    def _sig(m):
+        return (getattr(m, "weight_dtype", "int4_clip"), getattr(m, "bits", 4), m.blocksize, m.scale_dtype, m.scheme,
+                getattr(m, "compute_dtype", "fp32"))
+
+    for l, layer in enumerate(layers):
+        at, mlp = layer.self_attn, layer.mlp
+        for name, m in (("q_proj", at.q_proj), ("k_proj", at.k_proj), ("v_proj", at.v_proj), ("o_proj", at.o_proj),
+                        ("gate_proj", mlp.gate_proj), ("up_proj", mlp.up_proj), ("down_proj", mlp.down_proj)):
+            if not hasattr(m, "blocksize") or _sig(m) != _sig(first):
+                raise RuntimeError("QBits: the fused decode engine needs one quantisation recipe for every projection; "
+                                   "layers.%d.%s is %r, layers.0.q_proj is %r" %
+                                   (l, name, _sig(m) if hasattr(m, "blocksize") else type(m).__name__, _sig(first)))
+    if wdt in TABLE_WEIGHT_DTYPES and first.scheme == "asym":
+        raise RuntimeError("QBits: the 4-bit table weight types are symmetric only (reference utils/config.py:360-370)")
+    asym = first.scheme == "asym" and wdt not in TABLE_WEIGHT_DTYPES
     group, sdt = first.blocksize, first.scale_dtype
     # the blobs' compute type picks nf4's digit-plane count (three at fp32, two otherwise); int4 kernels do not read it
     cdt = getattr(first, "compute_dtype", "fp32") if wdt in TABLE_WEIGHT_DTYPES else "fp32"
 
-    def pack(q, s, z):
+    def pack(q, s, z, g_idx=None):
         return qbits.repack_quantized_weight(q.contiguous(), s.contiguous(),
                                              z.contiguous() if z is not None else torch.empty(0, dtype=torch.int8),
-                                             torch.empty(0, dtype=torch.int32), wdt, sdt, cdt, asym, group)
+                                             g_idx.to(torch.int32).contiguous() if g_idx is not None
+                                             else torch.empty(0, dtype=torch.int32), wdt, sdt, cdt, asym, group)
 
-    def cat(parts):
+    def cat(parts, what):
         return (torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 1),
-                torch.cat([p[2] for p in parts], 1) if asym else None)
+                torch.cat([p[2] for p in parts], 1) if asym else None, _same_order(parts, what))
 
     for l, layer in enumerate(layers):
         at, mlp = layer.self_attn, layer.mlp
         for m in (at.q_proj, at.k_proj, at.v_proj, at.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj):
             if m.bias is not None:
                 raise RuntimeError("QBits: the fused decode engine does not take biased projections")
-        qkv = pack(*cat([_signed_parts(at.q_proj), _signed_parts(at.k_proj), _signed_parts(at.v_proj)]))
+        qkv = pack(*cat([_signed_parts(at.q_proj), _signed_parts(at.k_proj), _signed_parts(at.v_proj)],
+                        "layers.%d q_proj / k_proj / v_proj" % l))
         g, u = _signed_parts(mlp.gate_proj), _signed_parts(mlp.up_proj)
-        gu = pack(fuse_gate_up(g[0], u[0]), fuse_gate_up(g[1], u[1]), fuse_gate_up(g[2], u[2]) if asym else None)
+        gu = pack(fuse_gate_up(g[0], u[0]), fuse_gate_up(g[1], u[1]), fuse_gate_up(g[2], u[2]) if asym else None,
+                  _same_order([g, u], "layers.%d gate_proj / up_proj" % l))
         eng.set_layer(l, qkv, at.o_proj.weight.data, gu, mlp.down_proj.weight.data, layer.input_layernorm.weight,
                       layer.post_attention_layernorm.weight)
     head_dtype = kv_dtype if kv_dtype in (torch.float16, torch.bfloat16) else torch.float16  # fp8 is cache-only

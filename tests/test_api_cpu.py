@@ -285,7 +285,7 @@ def test_library_exports_every_symbol_the_headers_declare():
     for name in sorted(declared):
         assert hasattr(lib, name), name
     lib.woq_abi_version.restype = ctypes.c_int
-    assert lib.woq_abi_version() == 1
+    assert lib.woq_abi_version() == 3  # WOQ_ABI_VERSION of include/woq_hip.h
     lib.woq_last_error.restype = ctypes.c_char_p
     assert isinstance(lib.woq_last_error(), bytes)
     assert ctypes.sizeof(_lib.BlobHeader) == 256 and ctypes.sizeof(_lib.EngineConfig) == 4 * 16

@@ -436,7 +436,7 @@ def test_generate_reads_the_engine_status_and_retries_or_raises():
     assert torch.equal(q.generate(ids, max_new_tokens=12, do_sample=False), clean)
 
 
-def _write_hf_gptq_checkpoint(fp, d, group, sym, desc_act, shards=2, seed=0):
+def _write_hf_gptq_checkpoint(fp, d, group, sym, desc_act, shards=2, seed=0, shared_perm=True):
     """A Hugging Face GPTQ checkpoint directory (AutoGPTQ tensor names / packing) synthesised from a tiny fp model with
     the oracle's RTN per (act-ordered) group: qweight int32 [K/8, N] in ORIGINAL row order, g_idx [K], qzeros storing
     zp - 1, fp16 scales. Returns {linear name: dequantised weight [N, K]} for the fp32 twin."""
@@ -448,13 +448,21 @@ def _write_hf_gptq_checkpoint(fp, d, group, sym, desc_act, shards=2, seed=0):
     from intel_extension_for_transformers_amd.transformers.llm.quantization.utils import pack_weight
 
     rng = np.random.default_rng(seed)
-    tensors, deq = {}, {}
+    tensors, deq, perms = {}, {}, {}
     for name, mod in fp.named_modules():
         if not isinstance(mod, torch.nn.Linear) or name == "lm_head":
             continue
         w = mod.weight.detach().float().numpy().T.copy()  # [K, N]
         K, N = w.shape
-        perm = rng.permutation(K) if desc_act else np.arange(K)
+        # a real GPTQ run orders the rows by the Hessian diagonal of the layer's INPUT, so projections that share their
+        # input (q / k / v; gate / up) come out with the same permutation: `shared_perm` writes that; without it every
+        # linear gets its own (a checkpoint the fused engine must refuse and the module path must still serve)
+        leaf = name.rsplit(".", 1)[-1]
+        key = {"k_proj": "q_proj", "v_proj": "q_proj", "up_proj": "gate_proj"}.get(leaf, leaf) if shared_perm else leaf
+        pkey = name.rsplit(".", 1)[0] + "." + key
+        if pkey not in perms:
+            perms[pkey] = rng.permutation(K) if desc_act else np.arange(K)
+        perm = perms[pkey]
         q_p, s, z = orc.rtn_quantize(w[perm], False, group, not sym)  # groups are contiguous in the permuted order
         s = s.astype(np.float16).astype(np.float32)
         q = np.empty_like(q_p)
@@ -489,17 +497,20 @@ def _write_hf_gptq_checkpoint(fp, d, group, sym, desc_act, shards=2, seed=0):
     return deq
 
 
-@pytest.mark.parametrize("sym,desc_act", [(True, False), (False, True)])
-def test_from_pretrained_hf_gptq_checkpoint(tmp_path, sym, desc_act):
+@pytest.mark.parametrize("sym,desc_act,shared_perm", [(True, False, True), (False, True, True), (False, True, False)])
+def test_from_pretrained_hf_gptq_checkpoint(tmp_path, sym, desc_act, shared_perm):
     """a Hugging Face GPTQ checkpoint directory (sharded safetensors, AutoGPTQ names,
     zp - 1 zeros, act-order g_idx) loads straight to the GPU layout; logits match the fp32 twin carrying the
-    checkpoint's own dequantised weights; the engine-backed generate works on it when there is no act-order."""
+    checkpoint's own dequantised weights; generate runs on the fused engine — act-order checkpoints included (round 5:
+    the decode GEMV gathers its activations by the stored shuffle), as long as q / k / v and gate / up share their
+    permutation the way a GPTQ run leaves them; a checkpoint with a different permutation per linear is refused by the
+    engine and served by the module path, same tokens."""
     from intel_extension_for_transformers_amd.transformers import AutoModelForCausalLM
 
     fp = _tiny_llama()
     fp.generation_config.eos_token_id = None
     d = tmp_path / "tiny-llama-gptq"
-    deq = _write_hf_gptq_checkpoint(fp, str(d), 128, sym, desc_act)
+    deq = _write_hf_gptq_checkpoint(fp, str(d), 128, sym, desc_act, shared_perm=shared_perm)
     model = AutoModelForCausalLM.from_pretrained(str(d))
     assert model.quantization_config.quant_method in ("gptq", getattr(model.quantization_config.quant_method, "value", None))
     twin = copy.deepcopy(fp).cuda()
@@ -515,7 +526,9 @@ def test_from_pretrained_hf_gptq_checkpoint(tmp_path, sym, desc_act):
     out = model.generate(ids, max_new_tokens=6, do_sample=False, pad_token_id=0)
     ref = twin.generate(ids, max_new_tokens=6, do_sample=False, pad_token_id=0)
     assert torch.equal(out, ref)
-    assert hasattr(model, "woq_engine") == (not desc_act)  # act-order layers stay on the module path
+    assert hasattr(model, "woq_engine") == (not desc_act or shared_perm)
+    if desc_act and shared_perm:  # the engine really decoded those tokens, on the fp32-activation kernels with the gather
+        assert not model.woq_engine.uses_xq() and model.woq_engine.status() == 0
 
 
 def test_from_pretrained_hf_awq_checkpoint(tmp_path):

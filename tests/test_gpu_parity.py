@@ -134,6 +134,29 @@ def test_woq_linear_decode_vs_oracle(qbits, K, N, group, asym, shuf, M):
     assert np.allclose(got, ref, rtol=0.03, atol=tol)
 
 
+@pytest.mark.parametrize("K,N,group,asym", [(4096, 4096, 128, False), (11008, 4096, 128, True), (4096, 256, 32, True),
+                                            (4096, 512, 32, False), (640, 96, 64, True), (1536, 48, -1, False)])
+@pytest.mark.parametrize("scale_type,src_dt", [("fp32", "fp32"), ("fp16", "fp32"), ("bf16", "fp16"), ("fp16", "bf16")])
+def test_act_order_decode_gather_vs_oracle(qbits, monkeypatch, K, N, group, asym, scale_type, src_dt):
+    """GPTQ act-order blobs at batch 1 (round 5): the i8-MFMA tile GEMV gathers its activations by the stored shuffle
+    (`index_select(x, 1, g_idx)` of the parity definition, autograd/functions.py:41-63; BesTLA's shuffle prologue,
+    bestla_weightonly_dispatcher.cpp:138-142) instead of handing such layers to the generic fp32 kernel. 7B projection
+    shapes, per-128 / per-32 / per-64 / per-channel groups, a K with a tail slice, 16-bit rows, every scale type — vs the
+    oracle at the decode tolerance, and equal (to that tolerance) to the generic kernel's answer for the same call."""
+    q, s, z, idx = _mk(K, N, group, asym, True, seed=21)
+    blob = _gpu_blob(qbits, q, s, z, idx, group, scale_type)
+    xt = (torch.rand(1, K) - 0.3).to(DT[src_dt])
+    ref = orc.woq_linear(xt.float().numpy(), orc.repack(q, s, z, _cvt(idx, K, group), group, scale_type=ST[scale_type]))
+    out = torch.zeros(1, N, dtype=torch.float32, device="cuda")
+    qbits.woq_linear(xt.cuda(), blob, torch.empty(0), out, "fp32", "int4_clip", scale_type, asym)
+    got = out.cpu().numpy()
+    tol = 1e-4 * np.abs(ref).max() + 1e-6
+    assert np.abs(got - ref).max() <= tol
+    out4 = torch.zeros(4, N, dtype=torch.float32, device="cuda")  # several rows: the generic kernel, same definition
+    qbits.woq_linear(xt.repeat(4, 1).cuda(), blob, torch.empty(0), out4, "fp32", "int4_clip", scale_type, asym)
+    assert np.abs(out4.cpu().numpy() - ref).max() <= tol
+
+
 @pytest.mark.parametrize("src_dt,dst_dt", [("bf16", "bf16"), ("fp16", "fp16"), ("bf16", "fp32"), ("fp32", "bf16")])
 @pytest.mark.parametrize("M", [1, 4])
 def test_woq_linear_decode_dtypes(qbits, src_dt, dst_dt, M):
