@@ -71,7 +71,7 @@ def linear_params(cfg):
 
 
 def build_engine(cfg, group=128, sym=True, max_ctx=512, max_batch=1, kv_dtype=None, tp_rank=0, tp=1, seed=1234,
-                 layers=None, weight_dtype="int4_clip", compute_dtype="fp32"):
+                 layers=None, weight_dtype="int4_clip", compute_dtype="fp32", act_order=False):
     import torch
 
     from intel_extension_for_transformers_amd.runtime.engine import WoqDecoderEngine, synth_llama_weights
@@ -82,7 +82,7 @@ def build_engine(cfg, group=128, sym=True, max_ctx=512, max_batch=1, kv_dtype=No
                            max_batch=max_batch, kv_dtype=kv_dtype or torch.float16, tp_rank=tp_rank, tp_size=tp)
     synth_llama_weights(eng, cfg["hidden"], inter, heads, kv, cfg["head_dim"], n_layers, vocab, group=group, sym=sym,
                         scale_dtype="fp16", seed=seed + tp_rank, embed_vocab=cfg["vocab"], shared_seed=seed,
-                        weight_dtype=weight_dtype, compute_dtype=compute_dtype)
+                        weight_dtype=weight_dtype, compute_dtype=compute_dtype, act_order=act_order)
     return eng
 
 
@@ -703,6 +703,17 @@ def extra_configs(args):
         kvb = 2 * cfg["layers"] * cfg["kv_heads"] * cfg["head_dim"] * ctx * 2
         out.append(decode_entry("configs[1] Llama-2-7B int4 sym g128, batch-1 decode at %d cached positions" % ctx, cfg,
                                 eng, 64, 8, 128, False, "%d cached positions, fp16 KV" % ctx, kv_bytes_per_token=kvb))
+    del eng
+    free_gpu()
+    # a GPTQ act-order (desc_act) model of the same shape on the engine (round 5: the tile GEMV gathers its
+    # activations by the blob's shuffle; such layers ran the fp32 VALU kernel on the module path before)
+    eng = build_engine(LLAMA2_7B, group=128, sym=True, max_ctx=512, act_order=True)
+    feed_prompt(eng, LLAMA2_7B["vocab"], 32)
+    e = decode_entry("SURVEY 8(f)-2: Llama-2-7B int4 sym g128 GPTQ act-order (g_idx on every projection), batch-1 decode",
+                     LLAMA2_7B, eng, 64, 8, 128, False, "prompt 32")
+    e["kernels"] = "fp32-activation tile GEMV with the act-order gather (xq=%s, fused attention=%s)" % (
+        eng.uses_xq(), eng.uses_fused_attn())
+    out.append(e)
     del eng
     free_gpu()
     # SURVEY §8(f)-4, the float 4-bit weight types at the same shape (round 4: digit-plane unpack of the table codes on

@@ -392,7 +392,7 @@ int woq_engine::wpf_prepare() {
     ptrs.push_back(lm_head), bytes.push_back(std::min(all, (size_t)wpf_head_mb << 20)), vl.push_back(cfg.layers);
     kind.push_back(4);
   }
-  if (wpf_wrap) add_layer(0, cfg.layers + 1);
+  if (wpf_wrap) add_layer(0, cfg.layers);  // paced like the head: allowed once the last layer's qkv is out
   int rc = prefetch_build_items(ptrs, bytes, vl, kind, &wpf_items, &wpf_n);
   if (rc) return rc;
   owned.push_back(wpf_items);

@@ -24,10 +24,9 @@
 // ~1 VALU per weight against ~5 for the lookup kernel.
 // Schedule: as woq_gemv_i8.hip — one workgroup per 16-column tile, waves own contiguous K slices of up to TPW tiles of
 // BOTH planes, everything requested up front, the activation rows staged per wave into a wave-private LDS strip, one
-// barrier, bias in the epilogue. Scope (what the GPU tests of round 4 covered): per-128 groups or one group per column
-// (scale_mode 0), unshuffled aligned rows, K up to 8192 (four tiles per wave, up to sixteen waves); anything else keeps
-// the lookup kernel. (An eight-tiles-per-wave form for longer K ran the timings of r04ah but not a parity test before
-// the round's GPU time was spent; it is not in the tree.)
+// barrier, bias in the epilogue. Scope: per-128 groups or one group per column (scale_mode 0), unshuffled aligned rows, K up
+// to 8192 as four tiles per wave x up to sixteen waves, K up to 12288 as eight tiles per wave x up to twelve waves
+// (round 5: the 7B down_proj, K = 11008, with its parity test); anything else keeps the lookup kernel.
 #include <algorithm>
 #include <cstdlib>
 
@@ -57,8 +56,10 @@ __device__ __forceinline__ float4_t mfma_f8(i64_t a, i64_t b, float4_t c) {
 }
 
 // flags: bit 0 scales are bf16 (else fp16; ignored for fp32 scales), bits 2-3 activation rows 0 fp32 | 1 fp16 | 2 bf16
+// TPW = 4: up to sixteen waves (K <= 8192); TPW = 8 (round 5): up to twelve waves of eight tiles of both planes
+// (K <= 12288: a 7B down_proj's K = 11008 is eleven waves) — 128 weight registers per lane, hence the 768-thread bound
 template <int TPW, bool E5M2, bool S32>
-__global__ __launch_bounds__(1024) void gemv_fp8_kernel(
+__global__ __launch_bounds__(TPW == 8 ? 768 : 1024) void gemv_fp8_kernel(
     const u32x4* __restrict__ qhi, const u32x4* __restrict__ qlo, const void* __restrict__ scales,
     const void* __restrict__ x, int tiles_k, int K, int base_tiles, int rem_tiles, int n_groups, int tpg_shift,
     void* __restrict__ out, const float* __restrict__ bias, int N, int M, int ms, int lda, int ldo, int out_dtype,
@@ -279,11 +280,11 @@ static int launch_fp8_t(const F8Launch& a, hipStream_t st) {
   return 0;
 }
 
-// geometry: 4 tiles per wave, up to 16 waves (K <= 8192)
+// geometry: 4 tiles per wave and up to 16 waves (K <= 8192), else 8 tiles per wave and up to 12 waves (K <= 12288)
 static bool fp8_geometry(int tiles_k, int& nw, int& tpw) {
-  tpw = 4;
+  tpw = tiles_k > 64 ? 8 : 4;
   nw = (tiles_k + tpw - 1) / tpw;
-  return nw >= 1 && nw <= 16;
+  return nw >= 1 && nw <= (tpw == 8 ? 12 : 16);
 }
 
 // Does the fp8-MFMA kernel take this call? `hi` = the HI plane's header (scales; the LO plane has the same geometry).
@@ -333,6 +334,10 @@ int launch_gemv_fp8_mfma(const void* act, int act_dtype, int lda, int M, const v
   WOQ_F8_CASE(4, false, true)
   WOQ_F8_CASE(4, true, false)
   WOQ_F8_CASE(4, true, true)
+  WOQ_F8_CASE(8, false, false)
+  WOQ_F8_CASE(8, false, true)
+  WOQ_F8_CASE(8, true, false)
+  WOQ_F8_CASE(8, true, true)
 #undef WOQ_F8_CASE
   return woq::fail("QBits: bad fp8 GEMV configuration");
 }

@@ -153,7 +153,10 @@ template <int HD>
 __host__ __device__ constexpr int attn_lds_bytes() { return AKT * HD * 2 + HD * AVRB; }
 
 template <int KVD, int HD>
-__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const _Float16* __restrict__ qkv, int T, int start,
+#ifndef WOQ_ATTN_LB
+#define WOQ_ATTN_LB 2
+#endif
+__global__ __launch_bounds__(256, WOQ_ATTN_LB) void attn_prefill_kernel(const _Float16* __restrict__ qkv, int T, int start,
                                                               int heads, int kv_heads, const void* __restrict__ kcache,
                                                               const void* __restrict__ vcache, size_t seq_stride_elems,
                                                               _Float16* __restrict__ out, int n_qblocks, int window,

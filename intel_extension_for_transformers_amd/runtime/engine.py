@@ -587,7 +587,7 @@ def _device_view(ptr, shape, device, typestr="<f4"):
 
 def synth_llama_weights(engine, hidden, inter, heads, kv_heads, head_dim, layers, vocab, group=128, sym=True,
                         scale_dtype="fp16", seed=1234, model_dtype=torch.float16, embed_vocab=None,
-                        shared_seed=None, weight_dtype="int4_clip", compute_dtype="fp32"):
+                        shared_seed=None, weight_dtype="int4_clip", compute_dtype="fp32", act_order=False):
     """Synthetic random-init quantised Llama-shaped weights built directly on the device (no checkpoint, no
     network): int4 values uniform in [-8,7], scales ~ 0.02-ish/7 so dequantised weights look like N(0, 0.02^2),
     norms 1 + N(0, 0.02^2), embeddings N(0, 0.02^2). Returns the list of blobs (kept alive by the engine).
@@ -617,9 +617,16 @@ def synth_llama_weights(engine, hidden, inter, heads, kv_heads, head_dim, layers
         return q, s, z
 
     def pack(q, s, z):
+        # act_order: a GPTQ desc_act blob — every projection carries a random group assignment of its K rows (q / k / v and
+        # gate / up are fused, so each fused blob has one, the way a GPTQ run leaves them); the rows are synthetic, so
+        # "regrouped order" is whatever they are in
+        k = q.shape[0]
+        gsz = k if group == -1 else group
+        g_idx = torch.empty(0, dtype=torch.int32)
+        if act_order:
+            g_idx = (torch.randperm(k, generator=g, device=dev) // gsz).to(torch.int32)
         return qbits.repack_quantized_weight(q, s, z if z is not None else torch.empty(0, dtype=torch.int8),
-                                             torch.empty(0, dtype=torch.int32), weight_dtype, scale_dtype, compute_dtype,
-                                             z is not None, group)
+                                             g_idx, weight_dtype, scale_dtype, compute_dtype, z is not None, group)
 
     qkv_n = (heads + 2 * kv_heads) * head_dim
     for l in range(layers):
@@ -678,11 +685,16 @@ def _code_parts(mod):
 
 def _signed_parts(mod):
     """QuantizedLinearQBits -> (q int8 [K,N] in [-8,7], scales fp32 [G,N], zp int8 [G,N] signed or None, g_idx int32 [K]
-    or None). Act-order (GPTQ desc_act) modules hand their rows back in the regrouped order the blob holds, with the raw
-    g_idx that `repack_quantized_weight` turns into the activation shuffle (reference nn/modules.py:205-224)."""
+    or None). Act-order (GPTQ desc_act) modules: rows in the regrouped order the blob holds, plus the raw g_idx that
+    `repack_quantized_weight` turns into the activation shuffle (reference nn/modules.py:205-224)."""
     if getattr(mod, "weight_dtype", "int4_clip") in TABLE_WEIGHT_DTYPES:
         return _code_parts(mod) + (None,)
     int_w, scales, zeros, g_idx = mod.recover_qparms_kn()
+    if g_idx is not None:
+        # recover_qparms_kn hands the rows back in the CHECKPOINT's order; the blob wants them regrouped (group g owns
+        # rows [g * group, (g + 1) * group), in order of appearance) exactly as set_weights_bias does before it repacks
+        order = torch.argsort(g_idx.to(torch.int64), stable=True)
+        int_w = int_w[order.to(int_w.device)].contiguous()
     return (int_w - 8).to(torch.int8), scales, None if zeros is None else (zeros - 8).to(torch.int8), g_idx
 
 

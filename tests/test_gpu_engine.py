@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _tiny(group, asym, scale_dtype, seed=0, max_ctx=64, max_batch=1, head_dim=64, kv_dtype=torch.float16,
-          attn_splits=0, window=0, hidden=256, attn_grouped=False, weight_dtype="int4_clip", compute_dtype="fp32"):
+          attn_splits=0, window=0, hidden=256, attn_grouped=False, weight_dtype="int4_clip", compute_dtype="fp32",
+          act_order=False):
     from intel_extension_for_transformers_amd import qbits
     from intel_extension_for_transformers_amd.runtime import WoqDecoderEngine, fuse_gate_up
 
@@ -36,15 +37,20 @@ def _tiny(group, asym, scale_dtype, seed=0, max_ctx=64, max_batch=1, head_dim=64
             return orc.rtn_quantize_table(w, False, group, wt) + (None,)
         return orc.rtn_quantize(w, False, group, asym)
 
-    def gpu_pack(q, s, z):
+    def gpu_pack(q, s, z, g_idx=None):
         return qbits.repack_quantized_weight(torch.from_numpy(q).cuda(), torch.from_numpy(s).cuda(),
-                                             e8 if z is None else torch.from_numpy(z).cuda(), e32, weight_dtype,
+                                             e8 if z is None else torch.from_numpy(z).cuda(),
+                                             e32 if g_idx is None else torch.from_numpy(g_idx).cuda(), weight_dtype,
                                              scale_dtype, compute_dtype, z is not None, group)
 
-    def cpu_pack(q, s, z):
+    def cpu_pack(q, s, z, g_idx=None):
         if wt is not None:
             return orc.repack_table(q, s, wt, group, scale_type=st)
-        return orc.repack(q, s, z, None, group, scale_type=st)
+        shuf = None if g_idx is None else orc.convert_idx(g_idx, q.shape[0], q.shape[0] if group == -1 else group)
+        return orc.repack(q, s, z, shuf, group, scale_type=st)
+
+    def order_of(k):  # raw GPTQ g_idx of one (fused) projection: group id of every K row, act-order positions
+        return rng.permutation(np.arange(k, dtype=np.int32) // (k if group == -1 else group)).astype(np.int32)
 
     H, I, NH, KV, D = cfg["hidden"], cfg["inter"], cfg["heads"], cfg["kv_heads"], cfg["head_dim"]
     layers = []
@@ -52,16 +58,21 @@ def _tiny(group, asym, scale_dtype, seed=0, max_ctx=64, max_batch=1, head_dim=64
         ly = {}
         parts = {n: quant(k, nn) for n, (k, nn) in dict(q=(H, NH * D), k=(H, KV * D), v=(H, KV * D), o=(NH * D, H),
                                                           gate=(H, I), up=(H, I), down=(I, H)).items()}
+        # act-order: q / k / v share one permutation, gate / up another (same inputs -> same Hessian diagonal), o / down own
+        gi = {n: None for n in parts}
+        if act_order:
+            gq, gg = order_of(H), order_of(H)
+            gi = dict(q=gq, k=gq, v=gq, gate=gg, up=gg, o=order_of(NH * D), down=order_of(I))
         for n, (q, s, z) in parts.items():
-            ly[n] = cpu_pack(q, s, z)
+            ly[n] = cpu_pack(q, s, z, gi[n])
         cat = lambda i: np.concatenate([parts["q"][i], parts["k"][i], parts["v"][i]], 1)  # noqa: E731
-        qkv = gpu_pack(cat(0), cat(1), cat(2) if asym else None)
-        o = gpu_pack(*parts["o"])
+        qkv = gpu_pack(cat(0), cat(1), cat(2) if asym else None, gi["q"])
+        o = gpu_pack(*parts["o"], gi["o"])
         tt = lambda a: torch.from_numpy(a)  # noqa: E731
         gu = gpu_pack(fuse_gate_up(tt(parts["gate"][0]), tt(parts["up"][0])).numpy(),
                       fuse_gate_up(tt(parts["gate"][1]), tt(parts["up"][1])).numpy(),
-                      fuse_gate_up(tt(parts["gate"][2]), tt(parts["up"][2])).numpy() if asym else None)
-        down = gpu_pack(*parts["down"])
+                      fuse_gate_up(tt(parts["gate"][2]), tt(parts["up"][2])).numpy() if asym else None, gi["gate"])
+        down = gpu_pack(*parts["down"], gi["down"])
         ly["ln1"] = (1 + 0.1 * rng.standard_normal(H)).astype(np.float32)
         ly["ln2"] = (1 + 0.1 * rng.standard_normal(H)).astype(np.float32)
         eng.set_layer(l, qkv, o, gu, down, torch.from_numpy(ly["ln1"]), torch.from_numpy(ly["ln2"]))
@@ -552,6 +563,40 @@ def test_short_prompt_split_k_prompt_pass_equals_decode_steps(asym, group):
     torch.cuda.synchronize()
     assert (got - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
     assert int(got.argmax()) == int(ref.argmax())
+
+
+@pytest.mark.parametrize("group,asym,scale_dtype", [(128, False, "fp16"), (32, True, "fp32"), (64, True, "bf16")])
+def test_engine_act_order_layers_vs_oracle(group, asym, scale_dtype):
+    """GPTQ act-order (desc_act) layers INSIDE the fused engine (round 5): every projection carries a
+    g_idx; the decode step runs the fp32-activation tile GEMVs with the act-order gather (fused RMSNorm prologue,
+    residual / SiLU*mul epilogues unchanged), the prompt pass the MFMA GEMM whose pack pass gathers — logits and greedy
+    tokens against the oracle decoder, whose linears apply `index_select(x, 1, g_idx)` (autograd/functions.py:41-63),
+    eager bursts == graph replays."""
+    eng, oracle, cfg = _tiny(group, asym, scale_dtype, seed=11, act_order=True)
+    assert not eng.uses_xq() and not eng.uses_fused_attn()
+    prompt = [3, 17, 200, 5, 99, 42, 7]
+    for i, t in enumerate(prompt):
+        eng.token.fill_(t)
+        eng.pos.fill_(i)
+        eng.step(greedy=False)
+        got, ref = eng.logits.cpu().numpy(), oracle.forward_token(t, i)
+        assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-4, (i, np.abs(got - ref).max())
+        assert int(got.argmax()) == int(ref.argmax())
+    eng.launch = "eager"
+    eager = eng.generate(prompt, 10)
+    eng.launch = "graph"
+    graph = eng.generate(prompt, 10)
+    assert eager == graph and eng.status() == 0
+    oracle.reset()
+    logits = oracle.forward_prompt(prompt)
+    want = []
+    for j in range(10):
+        want.append(int(np.argmax(logits)))
+        logits = oracle.forward_token(want[-1], len(prompt) + j)
+    assert eager == want
+    oracle.reset()
+    got, ref = eng.prefill(prompt)[0].cpu().numpy(), oracle.forward_prompt(prompt)
+    assert np.abs(got - ref).max() <= 5e-3 * np.abs(ref).max() + 1e-4
 
 
 @pytest.mark.parametrize("weight_dtype,group,scale_dtype,compute_dtype",

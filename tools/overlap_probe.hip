@@ -36,32 +36,42 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // workgroup b publishes ONE flag word (write-through agent-scope store, the round number) when it is done; a consumer
 // wave waits for the flags of ITS K slice (the producer's n_prev flags cut evenly over the consumer's waves, one flag
 // per lane and load) — no atomics, no all-to-one counter. wait = 0: no dependency.
+// poll: 0 every wave polls the flags of its slice | 1 wave 0 polls ALL flags, the others wait at the workgroup barrier
+// publish: 0 nothing is stored (calibration against the engine's load-only twins) | 1 one flag word per workgroup
 __global__ __launch_bounds__(1024) void link_kernel(const u32x4* __restrict__ w, const unsigned int* prev, int n_prev,
                                                     unsigned int target, unsigned int* mine, unsigned int round_no,
-                                                    int wait, int work_clocks, int* status, unsigned int* sink) {
+                                                    int wait, int work_clocks, int* status, unsigned int* sink, int poll,
+                                                    int sleep_n, int publish, unsigned long long* stamps) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[0] = wall_clock64();
   const u32x4* p = w + ((size_t)blockIdx.x * nw + wid) * 8 * 64 + lane;
   u32x4 v[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) v[t] = __builtin_nontemporal_load(p + t * 64);
   if (wait) {
-    const int per = (n_prev + nw - 1) / nw, f0 = wid * per, cnt = max(0, min(per, n_prev - f0));
-    const unsigned long long t0 = wall_clock64();
-    for (;;) {
-      bool good = true;
-      for (int j = 0; j < cnt; j += 64)
-        if (lane + j < cnt) {
-          const unsigned int c = __hip_atomic_load(prev + f0 + j + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          good = good && (int)(c - target) >= 0;
+    const int per = poll == 1 ? n_prev : (n_prev + nw - 1) / nw, f0 = poll == 1 ? 0 : wid * per;
+    const int cnt = max(0, min(per, n_prev - f0));
+    if (poll == 0 || wid == 0) {
+      const unsigned long long t0 = wall_clock64();
+      for (;;) {
+        bool good = true;
+        for (int j = 0; j < cnt; j += 64)
+          if (lane + j < cnt) {
+            const unsigned int c = __hip_atomic_load(prev + f0 + j + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            good = good && (int)(c - target) >= 0;
+          }
+        if (__all(good)) break;
+        if (wall_clock64() - t0 > 100000ull) {  // 1 ms at 100 MHz: give up, say so
+          if (lane == 0) atomicOr(status, 1);
+          break;
         }
-      if (__all(good)) break;
-      if (wall_clock64() - t0 > 100000ull) {  // 1 ms at 100 MHz: give up, say so
-        if (lane == 0) atomicOr(status, 1);
-        break;
+        __builtin_amdgcn_s_sleep(1);
+        for (int q = 1; q < sleep_n; ++q) __builtin_amdgcn_s_sleep(1);
       }
-      __builtin_amdgcn_s_sleep(8);
     }
+    if (poll == 1) __syncthreads();
   }
+  if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[1] = wall_clock64();
   u32x4 acc = {0, 0, 0, 0};
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc |= v[t];
@@ -71,7 +81,9 @@ __global__ __launch_bounds__(1024) void link_kernel(const u32x4* __restrict__ w,
   }
   if ((acc.x & acc.y & acc.z & acc.w) == 0x9e3779b9u) sink[0] = 1;
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(mine + blockIdx.x, round_no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (publish && threadIdx.x == 0)
+    __hip_atomic_store(mine + blockIdx.x, round_no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[2] = wall_clock64();
 }
 
 struct Shape {
@@ -82,6 +94,8 @@ int main(int argc, char** argv) {
   const int layers = argc > 1 ? atoi(argv[1]) : 32;
   const int reps = argc > 2 ? atoi(argv[2]) : 5;
   const int work = argc > 3 ? atoi(argv[3]) : 0;
+  const int poll = argc > 4 ? atoi(argv[4]) : 0;
+  const int sleep_n = argc > 5 ? atoi(argv[5]) : 8;
   const Shape shapes[4] = {{768, 4}, {256, 4}, {688, 8}, {256, 11}};  // qkv, o, gate/up pairs, down (8 KiB per wave)
   const int n = layers * 4;
   std::vector<u32x4*> bufs(n);
@@ -104,14 +118,16 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  printf("chain of %d load-only launches (%d layers x qkv/o/gate_up/down shapes), %.1f MB per pass, tail work %d clocks\n",
-         n, layers, total_bytes / 1e6, work);
+  unsigned long long* stamps;
+  CK(hipMalloc((void**)&stamps, (size_t)n * 4 * 8));
+  printf("chain of %d load-only launches (%d layers x qkv/o/gate_up/down shapes), %.1f MB per pass, tail work %d clocks, "
+         "poll form %d, sleep %d x 64 clocks\n", n, layers, total_bytes / 1e6, work, poll, sleep_n);
   // modes: 0 serial, no waits | 1 serial + waits (always satisfied) | 2 any-order flag, one stream | 3 two streams in
   // rotation | 4 three streams in rotation
-  const char* names[5] = {"serial launches, no in-kernel wait", "serial launches + in-kernel wait",
+  const char* names[6] = {"serial launches, no wait, NO flag store (= engine twins)", "serial launches, no in-kernel wait", "serial launches + in-kernel wait",
                           "hipExtAnyOrderLaunch, one stream + in-kernel wait", "two streams in rotation + in-kernel wait",
                           "three streams in rotation + in-kernel wait"};
-  for (int mode = 0; mode < 5; ++mode) {
+  for (int mode = -1; mode < 5; ++mode) {
     CK(hipMemset(ctr, 0, (size_t)(n + 1) * 4096));
     CK(hipMemset(status, 0, 8));
     CK(hipDeviceSynchronize());
@@ -132,10 +148,11 @@ int main(int argc, char** argv) {
         if (mode == 2) {
           hipExtLaunchKernelGGL(link_kernel, dim3(s.grid), dim3(s.waves * 64), 0, s_use, nullptr, nullptr,
                                 hipExtAnyOrderLaunch, (const u32x4*)bufs[i], (const unsigned int*)prev, n_prev, target, mine,
-                                round + 1, wait, work, status, sink);
+                                round + 1, wait, work, status, sink, poll, sleep_n, 1, stamps + (size_t)i * 4);
         } else {
           hipLaunchKernelGGL(link_kernel, dim3(s.grid), dim3(s.waves * 64), 0, s_use, (const u32x4*)bufs[i],
-                             (const unsigned int*)prev, n_prev, target, mine, round + 1, wait, work, status, sink);
+                             (const unsigned int*)prev, n_prev, target, mine, round + 1, wait, work, status, sink, poll,
+                             sleep_n, mode >= 0 ? 1 : 0, stamps + (size_t)i * 4);
         }
       }
       ++round;
@@ -156,7 +173,16 @@ int main(int argc, char** argv) {
     }
     int hstat = 0;
     CK(hipMemcpy(&hstat, status, 4, hipMemcpyDeviceToHost));
-    printf("mode %d  %-52s  %8.1f us per pass  %6.2f us per launch  %6.2f TB/s  gave-up-waiting=%d\n", mode, names[mode],
+    if (mode == 1 || mode == 2) {  // timeline of launches 40..47 of the last pass, workgroup 0: start | flags seen | end
+      std::vector<unsigned long long> h((size_t)n * 4);
+      CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
+      const double t0 = (double)h[40 * 4];
+      printf("   timeline (us from launch 40's start; wall clock 100 MHz):");
+      for (int i = 40; i < 48; ++i)
+        printf("  [%d] %.2f %.2f %.2f", i, (h[i * 4] - t0) / 100.0, (h[i * 4 + 1] - t0) / 100.0, (h[i * 4 + 2] - t0) / 100.0);
+      printf("\n");
+    }
+    printf("mode %d  %-52s  %8.1f us per pass  %6.2f us per launch  %6.2f TB/s  gave-up-waiting=%d\n", mode, names[mode + 1],
            best * 1e3, best * 1e3 / n, total_bytes / (best * 1e-3) / 1e12, hstat);
   }
   return 0;
