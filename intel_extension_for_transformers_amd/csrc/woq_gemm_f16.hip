@@ -175,7 +175,10 @@ __device__ __forceinline__ void pack_row(const PackF16Args& a, int r, float* red
         g[0] = g0.x, g[1] = g0.y, g[2] = g0.z, g[3] = g0.w, g[4] = g1.x, g[5] = g1.y, g[6] = g1.z, g[7] = g1.w;
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] = a.norm_w[min(c * 8 + j, a.K - 1)];
+        for (int j = 0; j < 8; ++j) {  // act-order rows: element k of the gathered row is x[shuffle[k]], its weight too
+          const int k = min(c * 8 + j, a.K - 1);
+          g[j] = a.norm_w[MODE == 2 && a.shuffle != nullptr ? a.shuffle[k] : k];
+        }
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(GEN_NW * 64) void gemv_generic_kernel(GenArgs a) {
       float t = 0.f;
       for (int w2 = 0; w2 < GEN_NW; ++w2) t += red[w2];
       const float inv = 1.0f / sqrtf(t / (float)a.K + a.eps);  // HF LlamaRMSNorm
-      for (int k = tid; k < a.K; k += GEN_NW * 64) xs[(size_t)m * a.Kpad + k] *= inv * a.norm_w[k];
+      for (int k = tid; k < a.K; k += GEN_NW * 64)  // slot k holds x[shuffle[k]] under act-order: its weight goes with it
+        xs[(size_t)m * a.Kpad + k] *= inv * a.norm_w[a.shuffle ? a.shuffle[k] : k];
       __syncthreads();
     }
   }

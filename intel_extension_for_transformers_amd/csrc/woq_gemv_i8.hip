@@ -107,9 +107,12 @@ __host__ __device__ inline size_t tile_lds_bytes(int M, int nw, int TPW, int CB)
 // NDIG: 0 = int4 weights; 1 | 2 | 3 = a 4-bit table type (nf4 / fp4) as that many digit planes (woq_gemv_common.h LutArgs)
 // SHUF (round 5, batch 1, int4): GPTQ act-order blobs — weight row k meets activation x[shuffle[k]] (the converted
 // g_idx the blob carries; reference semantics: `index_select(x, 1, g_idx)` in autograd/functions.py:41-63 and BesTLA's
-// ShuffleActivation prologue, bestla_weightonly_dispatcher.cpp:138-142,163-166). The wave's slice of the index vector is
-// requested first; the activation (and RMSNorm weight) elements are gathered by index — dependent 4-byte requests that
-// queue behind the weight tiles — and staged exactly like a contiguous slice. Everything else is the kernel above.
+// ShuffleActivation prologue, bestla_weightonly_dispatcher.cpp:138-142,163-166). The workgroup first copies the WHOLE
+// activation vector (times the RMSNorm weight) into LDS with coalesced requests — a first form gathered straight from
+// memory, 32 four-byte requests per lane hitting 64 different lines each: 12.8 us per launch against 7.4 without the
+// gather (profiles/r05d_*) — then every wave picks its slice's elements out of LDS by the blob's index vector and stages
+// them exactly like a contiguous slice. One extra workgroup barrier, under the weight stream. Everything else is the
+// kernel above.
 template <int TPW, int CB, int SMODE, bool ASYM, bool S32, bool M1, int NDIG, bool SHUF = false>
 // register budget by workgroup size: 1024 threads -> 128 VGPRs (group-128 paths), 768 -> 168 (per-32 scales keep
 // 3 more registers per tile and twice the A fragments), 512 -> 256
@@ -207,10 +210,33 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
   const rsrc_t rg = make_rsrc(norm ? (const void*)(norm_w + kbase) : x, norm ? xlen * 4 : 0);
   float4_t xv0[XJ], gv[XJ];
   u32x4 idv[SHUF ? XJ : 1];  // act-order: indices of this lane's activations, elements kbase + 4 lane + 256 j + 0..3
+  float4_t xa[SHUF ? XJ : 1], ga[SHUF ? XJ : 1];  // act-order: this thread's share of the whole vector, natural order
   if constexpr (SHUF) {
     const rsrc_t ri = make_rsrc(shuffle + kbase, xlen * 4);
 #pragma unroll
     for (int j = 0; j < XJ; ++j) idv[j] = __builtin_amdgcn_raw_buffer_load_b128(ri, v16 + j * 1024, 0, 0);
+    // chunk c = tid + j * threads (four elements each): K / 4 chunks <= XJ per thread (tiles <= nw * TPW)
+    const int nthr = (int)blockDim.x;
+    const rsrc_t rxa = make_rsrc(x, WOQ_SKIP(7) ? 0 : K * (xdt == 0 ? 4 : 2));
+    const rsrc_t rga = make_rsrc(norm ? (const void*)norm_w : x, norm ? K * 4 : 0);
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      const int c = tid + j * nthr;
+      if (xdt == 0) {
+        xa[j] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rxa, c * 16, 0, 0));
+      } else {
+        const uint2 r = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rxa, c * 8, 0, 0));
+        const uint16_t hb[4] = {(uint16_t)r.x, (uint16_t)(r.x >> 16), (uint16_t)r.y, (uint16_t)(r.y >> 16)};
+        float f[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float fb = bf16_bits_to_f32(hb[i]), fh = f16_bits_to_f32(hb[i]);
+          f[i] = xdt == 2 ? fb : fh;
+        }
+        xa[j] = (float4_t){f[0], f[1], f[2], f[3]};
+      }
+      ga[j] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rga, c * 16, 0, 0));
+    }
   } else {
     load_row(0, xv0);
 #pragma unroll
@@ -269,31 +295,32 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
   for (int i = 0; i < PF && i < CB * TPW; ++i) issue_w(i);
   WOQ_STAMP(3);
 
+  float ss_coop = 0.f;  // act-order: this wave's share of sum x^2 over the whole vector (any partition sums to the same)
   if constexpr (SHUF) {
-    // gather: x[shuffle[k]] (and norm_w[shuffle[k]]) for this lane's 4 XJ elements; elements past the slice read
-    // through an out-of-range offset and return 0 (no clamp, no branch)
-    const int esz = xdt == 0 ? 4 : 2;
-    const rsrc_t rxa = make_rsrc(x, WOQ_SKIP(7) ? 0 : K * esz);
-    const rsrc_t rga = make_rsrc(norm ? (const void*)norm_w : x, norm ? K * 4 : 0);
+    float* xs = (float*)(smem_raw + ((tile_lds_bytes(1, nw, TPW, CB) + 15) & ~(size_t)15));  // [K] fp32: x * norm weight
+    const int nthr = (int)blockDim.x;
+    const float one = norm ? 0.f : 1.f;
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
-      float f[4], g4[4];
+      const int c = tid + j * nthr;
+      ss_coop = fmaf(xa[j].x, xa[j].x, fmaf(xa[j].y, xa[j].y, fmaf(xa[j].z, xa[j].z, fmaf(xa[j].w, xa[j].w, ss_coop))));
+      if (c * 4 < K) *(float4_t*)(xs + c * 4) = xa[j] * (ga[j] + one);  // no norm: ga reads as 0 (empty descriptor)
+    }
+    ss_coop = wave_sum_dpp(ss_coop);
+    __syncthreads();
+    // this lane's 4 XJ elements of the wave's slice, by index; elements past the slice are zero
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      float f[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bool live = lane * 4 + j * 256 + i < xlen;
-        const uint32_t id = idv[j][i];
-        const int off = live ? (int)id : 0x3fffffff;  // x 4 (or 2) lands beyond every descriptor's range
-        if (xdt == 0) {
-          f[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxa, off * 4, 0, 0));
-        } else {
-          const uint16_t hb = __builtin_amdgcn_raw_buffer_load_b16(rxa, off * 2, 0, 0);
-          const float fb = bf16_bits_to_f32(hb), fh = f16_bits_to_f32(hb);
-          f[i] = xdt == 2 ? fb : fh;
-        }
-        g4[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rga, off * 4, 0, 0));
+        const int id = live ? (int)idv[j][i] : 0;
+        const float v = xs[id];
+        f[i] = live ? v : 0.f;
       }
       xv0[j] = (float4_t){f[0], f[1], f[2], f[3]};
-      gv[j] = (float4_t){g4[0], g4[1], g4[2], g4[3]};
+      gv[j] = (float4_t){1.f, 1.f, 1.f, 1.f} * (norm ? 1.f : 0.f);  // stage_row multiplies by gv + addone = 1
     }
   }
   // ---- 2. stage this wave's K slice of the activation rows as three int8 limb rows in its LDS strip ----
@@ -347,6 +374,9 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
   my_ss = 0.f, my_unsc = 0.f;
   if (rs == 0) {
     if (!WOQ_SKIP(5)) stage_row(0, xv0);
+    if constexpr (SHUF) {
+      if (lane == 0) my_ss = ss_coop;  // the gathered slice holds x * g, not x: the RMSNorm sum comes from the copy pass
+    }
   } else {
     float4_t xv[XJ];
     load_row((size_t)(rs * TSETM) * lda, xv);
@@ -629,7 +659,9 @@ struct TileLaunch {
 
 template <int TPW, int CB, int SMODE, bool ASYM, bool S32, bool M1, int NDIG, bool SHUF = false>
 static int launch_tile_t(const TileLaunch& a, hipStream_t st) {
-  const size_t lds = tile_lds_bytes(a.M, a.nw, TPW, CB);
+  // act-order form: + the whole activation vector as fp32 behind the regular regions
+  const size_t lds = SHUF ? ((tile_lds_bytes(a.M, a.nw, TPW, CB) + 15) & ~(size_t)15) + (size_t)a.K * 4
+                          : tile_lds_bytes(a.M, a.nw, TPW, CB);
   if (lds > 160 * 1024) return woq::fail("QBits: activation rows do not fit LDS");
   auto kern = gemv_tile_kernel<TPW, CB, SMODE, ASYM, S32, M1, NDIG, SHUF>;
   static bool attr_set = false;
@@ -761,6 +793,7 @@ int gemv_tile_max_rows(const void* act, int act_dtype, int lda, const woq_blob_h
   int nw, tpw;
   const int chunks = gemv_tile_k_chunks(tiles_k, cb, (int)h.scale_mode, epi == 0 && !norm_w && out_dtype == WOQ_F32);
   if (chunks == 0 || !gemv_tile_geometry((tiles_k + chunks - 1) / chunks, cb, (int)h.scale_mode, nw, tpw)) return 0;
+  if (h.off_shuffle != 0 && chunks != 1) return 0;  // the act-order form copies the whole vector per launch: one K range
   if (h.scale_mode == 0 && h.n_groups > 1) {
     const int tpg = h.group / WOQ_TILE_K;
     if (tpg < 1 || (tpg & (tpg - 1)) != 0) return 0;  // tiles per group must be a power of two
@@ -771,7 +804,8 @@ int gemv_tile_max_rows(const void* act, int act_dtype, int lda, const woq_blob_h
     return v >= 1 && v <= TMAXM ? v : TMAXM;
   }();
   int m = h.off_shuffle != 0 ? 1 : cap;
-  while (m > 0 && tile_lds_bytes(m, nw, tpw, cb) > 150 * 1024) --m;
+  const size_t extra = h.off_shuffle != 0 ? (size_t)h.K * 4 + 16 : 0;  // the act-order form's copy of the vector
+  while (m > 0 && tile_lds_bytes(m, nw, tpw, cb) + extra > 150 * 1024) --m;
   return m;
 }
 

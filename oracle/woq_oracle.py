@@ -593,10 +593,19 @@ def attn_decode(q, kcache, vcache):
 
 def linear_rows(x, blob):
     """Many-row form of `woq_linear` for prompt-sized inputs: dequantise -> matmul (autograd/functions.py:41-63, the
-    reference's own definition), the contraction in fp64 through BLAS so that thousands of rows cost seconds. int4
-    blobs without an activation shuffle only (what the decoder composition uses)."""
+    reference's own definition), the contraction in fp64 through BLAS so that thousands of rows cost seconds. Act-order
+    (GPTQ g_idx) int4 blobs: the activation columns are gathered by the blob's stored shuffle first —
+    `index_select(x, 1, g_idx)` of that same definition (functions.py:48-50)."""
+    blob = _c(blob, np.uint8)
+    h = header(blob)
+    x = np.asarray(x, np.float64)
+    if h["off_shuffle"] and h["weight_type"] not in (W_INT8,) and h["weight_type"] not in FP8_TABLES:
+        idx = np.frombuffer(blob[h["off_shuffle"]:h["off_shuffle"] + 4 * h["K"]].tobytes(), dtype=np.int32)
+        x = x[:, idx]
+    elif h["off_shuffle"]:
+        raise NotImplementedError("linear_rows: act-order shuffle of composite blobs (use woq_linear)")
     w = dequantize_blob(blob).astype(np.float64)
-    return (np.asarray(x, np.float64) @ w).astype(np.float32)
+    return (x @ w).astype(np.float32)
 
 
 def attn_prompt(q, kcache, vcache, start, window=0, qblock=512):

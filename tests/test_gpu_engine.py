@@ -63,6 +63,10 @@ def _tiny(group, asym, scale_dtype, seed=0, max_ctx=64, max_batch=1, head_dim=64
         if act_order:
             gq, gg = order_of(H), order_of(H)
             gi = dict(q=gq, k=gq, v=gq, gate=gg, up=gg, o=order_of(NH * D), down=order_of(I))
+            if not isinstance(act_order, bool):  # a subset of {"qkv", "o", "gate_up", "down"} (diagnostics)
+                keep = {"qkv": ("q", "k", "v"), "o": ("o",), "gate_up": ("gate", "up"), "down": ("down",)}
+                live = {n for grp in act_order for n in keep[grp]}
+                gi = {n: (g if n in live else None) for n, g in gi.items()}
         for n, (q, s, z) in parts.items():
             ly[n] = cpu_pack(q, s, z, gi[n])
         cat = lambda i: np.concatenate([parts["q"][i], parts["k"][i], parts["v"][i]], 1)  # noqa: E731

@@ -305,3 +305,22 @@ def test_many_row_prompt_oracle_equals_the_token_loop(window):
     for i, t in enumerate(prompt + [nxt]):
         b = oracle.forward_token(t, i)
     assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max()
+
+
+def test_linear_rows_applies_the_act_order_shuffle():
+    """The oracle's many-row linear (prompt passes) gathers the activation columns by the blob's stored shuffle exactly
+    like its row-at-a-time `woq_linear` (reference definition: `index_select(x, 1, g_idx)`, autograd/functions.py:48-50;
+    qbits_ut/test_packq.py:71) — round 5 found it ignoring the shuffle, which only act-order prompt passes could see."""
+    rng = np.random.default_rng(0)
+    K, N, g = 256, 48, 64
+    q = rng.integers(-8, 8, (K, N), dtype=np.int8)
+    s = (rng.random((K // g, N), dtype=np.float32) + 0.5) * 0.01
+    z = rng.integers(-8, 8, (K // g, N), dtype=np.int8)
+    g_idx = rng.permutation(np.arange(K, dtype=np.int32) // g).astype(np.int32)
+    shuffle = orc.convert_idx(g_idx, K, g)
+    blob = orc.repack(q, s, z, shuffle, g)
+    x = rng.standard_normal((5, K)).astype(np.float32)
+    want = x[:, shuffle].astype(np.float64) @ orc.dequant_raw(q, s, z, g).astype(np.float64)
+    assert np.abs(orc.woq_linear(x, blob) - want).max() <= 1e-5
+    assert np.abs(orc.linear_rows(x, blob) - want).max() <= 1e-5
+    assert np.abs(orc.linear_rows(x, orc.repack(q, s, z, None, g)) - x.astype(np.float64) @ orc.dequant_raw(q, s, z, g)).max() <= 1e-5
