@@ -24,7 +24,8 @@
 // ~1 VALU per weight against ~5 for the lookup kernel.
 // Schedule: as woq_gemv_i8.hip — one workgroup per 16-column tile, waves own contiguous K slices of up to TPW tiles of
 // BOTH planes, everything requested up front, the activation rows staged per wave into a wave-private LDS strip, one
-// barrier, bias in the epilogue. Scope: per-128 groups or one group per column (scale_mode 0), unshuffled aligned rows, K up
+// barrier, bias in the epilogue. Scope: per-128 groups or one group per column (scale_mode 0) and, round 5, groups of
+// 32 / 64 / 96 (scale_mode 1: the reference's DEFAULT group size is 32, utils/config.py:794-842), unshuffled aligned rows, K up
 // to 8192 as four tiles per wave x up to sixteen waves, K up to 12288 as eight tiles per wave x up to twelve waves
 // (round 5: the 7B down_proj, K = 11008, with its parity test); anything else keeps the lookup kernel.
 #include <algorithm>
@@ -40,9 +41,11 @@ constexpr int F8_MAXM = 8;
 
 __host__ __device__ constexpr int f8_row_bytes(int TPW) { return TPW * 128 + 16; }
 // LDS: [nw zero blocks of 256][nw strips: F8_DIG * ms digit rows x row bytes][slab nrs x nw x F8_SETM x 16 f32]
-__host__ __device__ inline size_t f8_lds_bytes(int M, int ms, int nw, int TPW) {
+// (+ per-32 scales: one all-zero strip row per wave, so that masked A operands keep the live rows' constant offsets)
+__host__ __device__ inline size_t f8_lds_bytes(int M, int ms, int nw, int TPW, int smode = 0) {
   const int nrs = (M + ms - 1) / ms;
-  return (size_t)nw * 256 + (size_t)nw * F8_DIG * ms * f8_row_bytes(TPW) + (size_t)nrs * nw * F8_SETM * 16 * 4;
+  return (size_t)nw * 256 + (size_t)nw * F8_DIG * ms * f8_row_bytes(TPW) + (size_t)nrs * nw * F8_SETM * 16 * 4 +
+         (smode ? (size_t)nw * f8_row_bytes(TPW) : 0);
 }
 
 typedef long i64_t;
@@ -58,7 +61,11 @@ __device__ __forceinline__ float4_t mfma_f8(i64_t a, i64_t b, float4_t c) {
 // flags: bit 0 scales are bf16 (else fp16; ignored for fp32 scales), bits 2-3 activation rows 0 fp32 | 1 fp16 | 2 bf16
 // TPW = 4: up to sixteen waves (K <= 8192); TPW = 8 (round 5): up to twelve waves of eight tiles of both planes
 // (K <= 12288: a 7B down_proj's K = 11008 is eleven waves) — 128 weight registers per lane, hence the 768-thread bound
-template <int TPW, bool E5M2, bool S32>
+// SMODE 1 (round 5): groups of 32 / 64 / 96 — the blob carries one scale per 32-k block (include/woq_blob.h). A 32-k MFMA
+// of this kernel contracts over all four lane quarters of a 64-k half, i.e. over BOTH of its 32-k blocks, so each half is
+// issued twice with the A operand of the other block's two quarters read from the zero block (the int4 tile kernel's form
+// for per-32 scales at M > 1): two more MFMAs and one more recombination per half, the matrix pipe has the room.
+template <int TPW, bool E5M2, bool S32, int SMODE = 0>
 __global__ __launch_bounds__(TPW == 8 ? 768 : 1024) void gemv_fp8_kernel(
     const u32x4* __restrict__ qhi, const u32x4* __restrict__ qlo, const void* __restrict__ scales,
     const void* __restrict__ x, int tiles_k, int K, int base_tiles, int rem_tiles, int n_groups, int tpg_shift,
@@ -98,8 +105,8 @@ __global__ __launch_bounds__(TPW == 8 ? 768 : 1024) void gemv_fp8_kernel(
       wl[t] = __builtin_amdgcn_raw_buffer_load_b128(rl, v16 + t * 1024, kt0 * 1024, AUX_NT);
     }
   }
-  typename RawSc<0, S32>::type rsc[TPW];
-  {
+  typename RawSc<SMODE, S32>::type rsc[TPW];
+  if constexpr (SMODE == 0) {
     const rsrc_t rs = make_rsrc((const char*)scales + (size_t)tn * n_groups * 16 * ESZ, n_groups * 16 * ESZ);
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -109,8 +116,22 @@ __global__ __launch_bounds__(TPW == 8 ? 768 : 1024) void gemv_fp8_kernel(
       else
         rsc[t] = __builtin_amdgcn_raw_buffer_load_b16(rs, i16 * 2, grp * 32, 0);
     }
+  } else {  // four scales per (tile, column): [tn][kt][16][4]
+    const rsrc_t rs = make_rsrc((const char*)scales + (size_t)tn * tiles_k * 64 * ESZ, tiles_k * 64 * ESZ);
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      if constexpr (S32)
+        rsc[t] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, i16 * 16 + t * 256, kt0 * 256, 0));
+      else
+        rsc[t] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs, i16 * 8 + t * 128, kt0 * 128, 0));
+    }
   }
   ((uint32_t*)zero_blk)[lane] = 0u;
+  unsigned char* zrow = nullptr;  // per-32 scales: this wave's all-zero strip row (behind the slab)
+  if constexpr (SMODE == 1) {
+    zrow = (unsigned char*)(slab + (size_t)nrs * nw * F8_SETM * 16) + (size_t)wid * RB;
+    for (int j = lane; j < RB / 4; j += 64) ((uint32_t*)zrow)[j] = 0u;
+  }
 
   auto load_row = [&](size_t row_off, float4_t (&xv)[XJ]) {
     if (xdt == 0) {
@@ -194,6 +215,9 @@ __global__ __launch_bounds__(TPW == 8 ? 768 : 1024) void gemv_fp8_kernel(
     const bool a_live = a_m < Mrs;
     const unsigned char* a_base = a_live ? strip + (size_t)(F8_DIG * a_m + a_dg) * RB + kq * 16 : zero_blk + kq * 16;
     const int st_t = a_live ? 128 : 0, st_h = a_live ? 64 : 0, st_s = a_live ? 8 : 0;
+    const unsigned char* a_row = strip + (size_t)(F8_DIG * a_m + a_dg) * RB + kq * 16;
+    const unsigned char* a_blk0 = (SMODE == 1 && a_live && kq < 2) ? a_row : zrow + kq * 16;
+    const unsigned char* a_blk1 = (SMODE == 1 && a_live && kq >= 2) ? a_row : zrow + kq * 16;
     // this lane's four result rows as (activation row, digit): weights 16^digit of the recombination
     float c0[4], c1[4];
 #pragma unroll
@@ -218,18 +242,48 @@ __global__ __launch_bounds__(TPW == 8 ? 768 : 1024) void gemv_fp8_kernel(
         const uint32_t b1 = (h0 & 0xf0f0f0f0u) | (((l0 >> 4) & 0x0f0f0f0fu) ^ 0x08080808u);
         const uint32_t b2 = ((h1 & 0x0f0f0f0fu) << 4) | ((l1 & 0x0f0f0f0fu) ^ 0x08080808u);
         const uint32_t b3 = (h1 & 0xf0f0f0f0u) | (((l1 >> 4) & 0x0f0f0f0fu) ^ 0x08080808u);
-        const i64_t a_lo = *(const i64_t*)(a_base + t * st_t + h * st_h);
-        const i64_t a_hi = *(const i64_t*)(a_base + t * st_t + h * st_h + st_s);
-        acc = mfma_f8<E5M2>(a_lo, (i64_t)(((unsigned long)b1 << 32) | b0), acc);
-        acc = mfma_f8<E5M2>(a_hi, (i64_t)(((unsigned long)b3 << 32) | b2), acc);
+        const i64_t bq0 = (i64_t)(((unsigned long)b1 << 32) | b0), bq1 = (i64_t)(((unsigned long)b3 << 32) | b2);
+        if constexpr (SMODE == 0) {
+          const i64_t a_lo = *(const i64_t*)(a_base + t * st_t + h * st_h);
+          const i64_t a_hi = *(const i64_t*)(a_base + t * st_t + h * st_h + st_s);
+          acc = mfma_f8<E5M2>(a_lo, bq0, acc);
+          acc = mfma_f8<E5M2>(a_hi, bq1, acc);
+        } else {
+          // 32-k block g of this half = lane quarters 2 g, 2 g + 1: the other two quarters' A rows read as zeros
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            // live rows of the block's own quarters read the strip, everything else the zero row — at the SAME constant
+            // offsets, so the addresses are one base register per block + immediates (per-lane strides cost a VGPR per
+            // address: 130 spilled registers in the first form)
+            const unsigned char* ab = g == 0 ? a_blk0 : a_blk1;
+            float4_t ag = {0.f, 0.f, 0.f, 0.f};
+            ag = mfma_f8<E5M2>(*(const i64_t*)(ab + t * 128 + h * 64), bq0, ag);
+            ag = mfma_f8<E5M2>(*(const i64_t*)(ab + t * 128 + h * 64 + 8), bq1, ag);
+            float sg;
+            if constexpr (S32) {
+              const float4_t r4 = rsc[t];
+              sg = h == 0 ? (g == 0 ? r4.x : r4.y) : (g == 0 ? r4.z : r4.w);
+            } else {
+              const uint32_t r = h == 0 ? rsc[t].x : rsc[t].y;
+              sg = tscale16(g == 0 ? (r & 0xffffu) : (r >> 16), bf);
+            }
+            tot0 = fmaf(sg, fmaf(ag.x, c0[0], fmaf(ag.y, c0[1], fmaf(ag.z, c0[2], ag.w * c0[3]))), tot0);
+            tot1 = fmaf(sg, fmaf(ag.x, c1[0], fmaf(ag.y, c1[1], fmaf(ag.z, c1[2], ag.w * c1[3]))), tot1);
+          }
+        }
       }
-      float sc;
-      if constexpr (S32)
-        sc = rsc[t];
-      else
-        sc = tscale16(rsc[t], bf);
-      tot0 = fmaf(sc, fmaf(acc.x, c0[0], fmaf(acc.y, c0[1], fmaf(acc.z, c0[2], acc.w * c0[3]))), tot0);
-      tot1 = fmaf(sc, fmaf(acc.x, c1[0], fmaf(acc.y, c1[1], fmaf(acc.z, c1[2], acc.w * c1[3]))), tot1);
+      // (per-32 scales: left alone, the scheduler hoists the A-operand reads of every tile — 16 per tile — above the
+      // loop and spills; one tile's reads at a time)
+      if constexpr (SMODE == 1) __builtin_amdgcn_sched_barrier(0);
+      if constexpr (SMODE == 0) {
+        float sc;
+        if constexpr (S32)
+          sc = rsc[t];
+        else
+          sc = tscale16(rsc[t], bf);
+        tot0 = fmaf(sc, fmaf(acc.x, c0[0], fmaf(acc.y, c0[1], fmaf(acc.z, c0[2], acc.w * c0[3]))), tot0);
+        tot1 = fmaf(sc, fmaf(acc.x, c1[0], fmaf(acc.y, c1[1], fmaf(acc.z, c1[2], acc.w * c1[3]))), tot1);
+      }
     }
     // a row's six digit sums sit in two lane quarters: sum the four quarters (the unused ones hold zeros)
     tot0 = reduce_kq(tot0) * unsc[0];
@@ -263,10 +317,10 @@ struct F8Launch {
   const float* bias;
 };
 
-template <int TPW, bool E5M2, bool S32>
+template <int TPW, bool E5M2, bool S32, int SMODE>
 static int launch_fp8_t(const F8Launch& a, hipStream_t st) {
-  const size_t lds = f8_lds_bytes(a.M, a.ms, a.nw, TPW);
-  auto kern = gemv_fp8_kernel<TPW, E5M2, S32>;
+  const size_t lds = f8_lds_bytes(a.M, a.ms, a.nw, TPW, SMODE);
+  auto kern = gemv_fp8_kernel<TPW, E5M2, S32, SMODE>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -290,10 +344,11 @@ static bool fp8_geometry(int tiles_k, int& nw, int& tpw) {
 // Does the fp8-MFMA kernel take this call? `hi` = the HI plane's header (scales; the LO plane has the same geometry).
 bool gemv_fp8_mfma_supported(const void* act, int act_dtype, int lda, const woq_blob_header& hi) {
   static const bool off = getenv("WOQ_FP8_GENERIC") != nullptr;  // A/B switch: the lookup kernel
-  if (off || hi.off_shuffle != 0 || hi.off_zp != 0 || hi.scale_mode != 0 || (hi.K & 3) != 0 || (lda & 3) != 0 ||
+  if (off || hi.off_shuffle != 0 || hi.off_zp != 0 || hi.scale_mode > 1 || (hi.K & 3) != 0 || (lda & 3) != 0 ||
       (((uintptr_t)act) & (act_dtype == WOQ_F32 ? 15 : 7)) != 0)
     return false;
-  if (hi.n_groups > 1 && hi.group != WOQ_TILE_K) return false;  // per-128 groups, or one group per column
+  // scale_mode 0: per-128 groups or one group per column; scale_mode 1 (round 5): one scale per 32-k block (groups 32 / 64 / 96)
+  if (hi.scale_mode == 0 && hi.n_groups > 1 && hi.group != WOQ_TILE_K) return false;
   int nw, tpw;
   return fp8_geometry(hi.Kpad / WOQ_TILE_K, nw, tpw);
 }
@@ -324,12 +379,15 @@ int launch_gemv_fp8_mfma(const void* act, int act_dtype, int lda, int M, const v
   if (M < 1 || M > F8_MAXM || !fp8_geometry(a.tiles_k, a.nw, tpw))
     return woq::fail("QBits: shape not covered by the fp8 decode GEMV");
   a.ms = std::min(M, F8_SETM);
-  if (f8_lds_bytes(M, a.ms, a.nw, tpw) > 150 * 1024) a.ms = 1;  // long K: one activation row per set
-  if (f8_lds_bytes(M, a.ms, a.nw, tpw) > 150 * 1024) return woq::fail("QBits: activation rows do not fit LDS");
+  const int sm = (int)hi.scale_mode;
+  if (f8_lds_bytes(M, a.ms, a.nw, tpw, sm) > 150 * 1024) a.ms = 1;  // long K: one activation row per set
+  if (f8_lds_bytes(M, a.ms, a.nw, tpw, sm) > 150 * 1024) return woq::fail("QBits: activation rows do not fit LDS");
   a.grid = hi.Npad / WOQ_TILE_N;
   const bool e5m2 = fp8_type == WOQ_W_FP8_E5M2, s32 = hi.scale_type == WOQ_F32;
-#define WOQ_F8_CASE(T, E, S) \
-  if (tpw == T && e5m2 == E && s32 == S) return launch_fp8_t<T, E, S>(a, st);
+const int smode = (int)hi.scale_mode;
+#define WOQ_F8_CASE(T, E, S)                                                     \
+  if (tpw == T && e5m2 == E && s32 == S)                                         \
+    return smode == 0 ? launch_fp8_t<T, E, S, 0>(a, st) : launch_fp8_t<T, E, S, 1>(a, st);
   WOQ_F8_CASE(4, false, false)
   WOQ_F8_CASE(4, false, true)
   WOQ_F8_CASE(4, true, false)

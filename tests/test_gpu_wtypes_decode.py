@@ -72,14 +72,16 @@ def test_table_weight_types_decode_kernel(qbits, wname, K, N, group, sname):
 
 @pytest.mark.parametrize("wname,sname", [("fp8_e4m3", "fp32"), ("fp8_e4m3", "fp8_e8m0"), ("fp8_e5m2", "fp32"),
                                          ("fp8_e5m2", "fp8_e8m0")])
-@pytest.mark.parametrize("K,N,group", [(4096, 128, 128), (384, 64, -1), (11008, 64, 128), (8320, 32, 128)])
+@pytest.mark.parametrize("K,N,group", [(4096, 128, 128), (384, 64, -1), (11008, 64, 128), (8320, 32, 128),
+                                       (4096, 64, 32), (1024, 48, 64), (11008, 32, 32), (768, 32, 96)])
 def test_fp8_weight_types_decode_kernel(qbits, wname, sname, K, N, group):
     """Round 4: fp8 weights at decode row counts on the fp8 matrix cores (csrc/woq_gemv_fp8.hip): the code bytes are the
     B operand of v_mfma_f32_16x16x32_fp8_{fp8,bf8} as they are, the fp32 activation goes in as six balanced base-16
     digits (exact e4m3 values), fp32 recombination. 1..8 rows (one and two rows per MFMA row set, up to four sets),
     fp32 / fp16 / bf16 rows, fp32 and power-of-two scales, per-128 groups and one group per column; K = 11008 (a 7B
     down_proj: eleven waves of eight tiles — round 5's form for K > 8192) and K = 8320 (its shortest case: nine waves,
-    the last with one tile). Bound: 1e-5 of
+    the last with one tile); groups of 32 (the reference's default group size), 64 and 96 (round 5: one scale per 32-k
+    block, each 64-k half issued once per block with the other block's A rows read as zeros). Bound: 1e-5 of
     sum |x||w| + 1e-5 — the matrix core's accumulation is not an fp32 adder (it aligns a dot's 32 products to the largest
     one): measured 2e-6 on RTN weights like these, 4.6e-6 on a matrix holding every finite e4m3 code at full scale
     (profiles/r04ah_fp8_decode.txt); test_fp8_weight_types_quantize_dequant_linear holds the same kernel to 2e-6 at its
