@@ -85,7 +85,8 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
                             float eps, const float* residual, int ld_res, int epi, int nt, hipStream_t st);
 int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                     const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w, float eps,
-                    const float* residual, int ld_res, int epi, void* ws, int fp32_class, hipStream_t st, const void* fp8_lo = nullptr, uint32_t fp8_type = 0);
+                    const float* residual, int ld_res, int epi, void* ws, int fp32_class, hipStream_t st, const void* fp8_lo = nullptr, uint32_t fp8_type = 0,
+                    size_t ws_bytes = 0);
 int launch_gemv_fp8(const void* act, int act_dtype, int lda, const void* hi_blob, const woq_blob_header& hi,
                     const void* lo_q, uint32_t fp8_type, const float* bias, void* out, int out_dtype, int ldo, int M,
                     hipStream_t st);

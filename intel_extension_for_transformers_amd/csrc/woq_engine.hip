@@ -54,7 +54,9 @@ void launch_argmax_pairs(const float* pmax, const int32_t* pidx, int n, int32_t*
 size_t gemm_f16_workspace_bytes(int M, int Kpad, int Npad, int planes);
 int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                     const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w, float eps,
-                    const float* residual, int ld_res, int epi, void* ws, int fp32_class, hipStream_t st, const void* fp8_lo = nullptr, uint32_t fp8_type = 0);
+                    const float* residual, int ld_res, int epi, void* ws, int fp32_class, hipStream_t st, const void* fp8_lo = nullptr, uint32_t fp8_type = 0,
+                    size_t ws_bytes = 0);
+size_t gemm_f16_workspace_bytes_blob(int M, const woq_blob_header& h, int planes);
 void launch_embed_rows(const void* embed, int dtype, const int32_t* tokens, int M, int hidden, float* out,
                        hipStream_t st);
 int launch_rope_append(_Float16* qkv, int n_seq, int T, int start, int heads, int kv_heads, int HD, const float* cs,
@@ -443,13 +445,12 @@ static int engine_step_impl(woq_engine* e, int greedy, hipStream_t st) {
 // attention is one launch per layer over the KV cache (woq_prefill.hip). 6 launches + 4 pack passes per layer.
 static int engine_prefill_reserve(woq_engine* e, size_t rows) {
   const woq_engine_config& c = e->cfg;
-  const woq_layer_weights& w = e->layers[0];
-  int kpad = 0, npad = 0;
-  for (const woq_blob_header* h : {&w.qkv_hdr, &w.o_hdr, &w.gate_up_hdr, &w.down_hdr}) {
-    kpad = std::max(kpad, (int)h->Kpad);
-    npad = std::max(npad, (int)h->Npad);
-  }
-  const size_t ws = gemm_f16_workspace_bytes((int)rows, kpad, npad, 1);
+  // the largest call's workspace over EVERY layer's blobs: packed activation tiles + scales (+ the fragment image of a
+  // table-type blob, so that such prompt passes allocate nothing per call either)
+  size_t ws = 0;
+  for (const woq_layer_weights& w : e->layers)
+    for (const woq_blob_header* h : {&w.qkv_hdr, &w.o_hdr, &w.gate_up_hdr, &w.down_hdr})
+      ws = std::max(ws, gemm_f16_workspace_bytes_blob((int)rows, *h, 1));
   if (rows <= e->pf_rows && ws <= e->pf_ws_bytes) return 0;
   WOQ_HIP(hipDeviceSynchronize());
   for (void* p : {(void*)e->pf_h, (void*)e->pf_qkv, (void*)e->pf_attn, (void*)e->pf_act, e->pf_ws})
@@ -482,7 +483,7 @@ static int engine_prefill_impl(woq_engine* e, const int32_t* tokens, int n_seq, 
     uint8_t* kc = e->kcache + (size_t)l * e->kv_layer_bytes;
     uint8_t* vc = e->vcache + (size_t)l * e->kv_layer_bytes;
     if ((rc = launch_gemm_f16(e->pf_h, WOQ_F32, c.hidden, w.qkv_blob, w.qkv_hdr, nullptr, e->pf_qkv, WOQ_F16, qkv_n, M,
-                              w.ln1, c.rms_eps, nullptr, 0, 0, e->pf_ws, 0, st)) != 0)
+                              w.ln1, c.rms_eps, nullptr, 0, 0, e->pf_ws, 0, st, nullptr, 0, e->pf_ws_bytes)) != 0)
       return rc;
     if ((rc = launch_rope_append(e->pf_qkv, n_seq, T, start, c.heads, c.kv_heads, c.head_dim, e->cs, e->sn, kc, vc,
                                  c.kv_dtype, seq_stride, st)) != 0)
@@ -491,14 +492,14 @@ static int engine_prefill_impl(woq_engine* e, const int32_t* tokens, int n_seq, 
                                   seq_stride, e->pf_attn, e->window, st)) != 0)
       return rc;
     if ((rc = launch_gemm_f16(e->pf_attn, WOQ_F16, c.heads * c.head_dim, w.o_blob, w.o_hdr, nullptr, e->pf_h, WOQ_F32,
-                              c.hidden, M, nullptr, 0.f, res, c.hidden, 0, e->pf_ws, 0, st)) != 0)
+                              c.hidden, M, nullptr, 0.f, res, c.hidden, 0, e->pf_ws, 0, st, nullptr, 0, e->pf_ws_bytes)) != 0)
       return rc;
     if ((rc = engine_allreduce_rows(e, e->pf_h, (size_t)M * c.hidden, st)) != 0) return rc;
     if ((rc = launch_gemm_f16(e->pf_h, WOQ_F32, c.hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, e->pf_act, WOQ_F16,
-                              c.inter, M, w.ln2, c.rms_eps, nullptr, 0, 1, e->pf_ws, 0, st)) != 0)
+                              c.inter, M, w.ln2, c.rms_eps, nullptr, 0, 1, e->pf_ws, 0, st, nullptr, 0, e->pf_ws_bytes)) != 0)
       return rc;
     if ((rc = launch_gemm_f16(e->pf_act, WOQ_F16, c.inter, w.down_blob, w.down_hdr, nullptr, e->pf_h, WOQ_F32,
-                              c.hidden, M, nullptr, 0.f, res, c.hidden, 0, e->pf_ws, 0, st)) != 0)
+                              c.hidden, M, nullptr, 0.f, res, c.hidden, 0, e->pf_ws, 0, st, nullptr, 0, e->pf_ws_bytes)) != 0)
       return rc;
     if ((rc = engine_allreduce_rows(e, e->pf_h, (size_t)M * c.hidden, st)) != 0) return rc;
   }
@@ -1152,7 +1153,7 @@ int woq_engine_time_prefill_gemm(woq_engine* e, int layer, int n_rows, int reps,
     WOQ_HIP(hipEventRecord(c0, st));
     set_gemm_time_events(k0, k1);
     const int rc = launch_gemm_f16(e->pf_h, WOQ_F32, c.hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, e->pf_act, WOQ_F16,
-                                   c.inter, n_rows, w.ln2, c.rms_eps, nullptr, 0, 1, e->pf_ws, 0, st);
+                                   c.inter, n_rows, w.ln2, c.rms_eps, nullptr, 0, 1, e->pf_ws, 0, st, nullptr, 0, e->pf_ws_bytes);
     set_gemm_time_events(nullptr, nullptr);
     if (rc) return rc;
     WOQ_HIP(hipEventRecord(c1, st));

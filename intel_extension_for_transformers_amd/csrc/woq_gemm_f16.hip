@@ -959,6 +959,13 @@ size_t gemm_f16_workspace_bytes(int M, int Kpad, int Npad, int planes) {
   return ((base + 255) & ~(size_t)255) + SPLITK_WS;
 }
 
+// the same for one blob, fragment image of the float weight types included (4-8x the blob: what made table-type prompt
+// passes allocate per call while the engine's workspace sat unused — ADVICE r04)
+size_t gemm_f16_workspace_bytes_blob(int M, const woq_blob_header& h, int planes) {
+  const size_t tiles = (size_t)(h.Npad / WOQ_TILE_N) * (h.Kpad / WOQ_TILE_K);
+  return gemm_f16_workspace_bytes(M, h.Kpad, h.Npad, planes) + (is_table_type(h.weight_type) ? tiles * 4 * planes * 1024 : 0);
+}
+
 // out[M,N] = act[M,K] . W_deq (+ bias) with fp16 operands. `ws` = caller workspace of gemm_f16_workspace_bytes or
 // null (stream-ordered allocation per call, like the reference's per-call amalloc,
 // bestla_weightonly_dispatcher.cpp:108-118,179). norm_w/eps: RMSNorm fused into the pack pass (null = none);
@@ -966,7 +973,7 @@ size_t gemm_f16_workspace_bytes(int M, int Kpad, int Npad, int planes) {
 int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
                     const float* bias, void* out, int out_dtype, int ldo, int M, const float* norm_w, float eps,
                     const float* residual, int ld_res, int epi, void* ws, int fp32_class, hipStream_t st,
-                    const void* fp8_lo, uint32_t fp8_type) {
+                    const void* fp8_lo, uint32_t fp8_type, size_t ws_bytes) {
   const int planes = fp32_class ? 2 : 1;
   if (epi == 1 && (((h.Npad / WOQ_TILE_N) & 1) != 0 || (h.N & 31) != 0))
     return woq::fail("QBits: the SiLU*mul epilogue needs whole gate / up column-tile pairs");
@@ -1023,8 +1030,9 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   if (part_bytes > SPLITK_WS) kper = 0, nz = 1, part_bytes = 0;  // (cannot happen: see SPLITK_WS)
   const size_t total = base_bytes + frag_bytes + part_bytes;  // [tiles | row scales | column scales][fragments][partials]
   if (frag && h.off_zp != 0) return woq::fail("QBits: float weight types are symmetric (no zero points)");
-  // the fragment image (4-8x the blob) lives in per-call scratch: a caller's workspace is sized for the int4 path
-  if (frag) ws = nullptr;
+  // the fragment image (4-8x the blob): a caller's workspace holds it only when it says it is large enough (`ws_bytes`:
+  // the engine sizes its prompt-pass workspace with gemm_f16_workspace_bytes_blob); otherwise per-call scratch
+  if (frag && ws_bytes < total) ws = nullptr;
   unsigned char* w = (unsigned char*)ws;
   const bool mine = w == nullptr;  // no workspace passed in (the engine passes its own): take scratch
   bool own = false;
