@@ -338,9 +338,11 @@ def read_traffic():
         return None
     try:
         with open(os.path.join(pdir, best)) as fh:
-            return {"bytes": float(json.load(fh)["hbm_bytes_per_launch"]), "source": "profiles/" + best,
-                    "measured_in_this_run": False,
-                    "method": "rocprofv3 --pmc FETCH_SIZE pass of the same bench command, x2 gfx950 correction"}
+            rec = json.load(fh)
+        return {"bytes": float(rec["hbm_bytes_per_launch"]), "source": "profiles/" + best,
+                "measured_in_this_run": False,
+                "method": rec.get("method", "rocprofv3 --pmc FETCH_SIZE pass of the same bench command, x2 gfx950 "
+                                            "correction")}
     except Exception:
         return None
 
