@@ -107,6 +107,13 @@ struct woq_engine {
   size_t kv_layer_bytes = 0;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  // the same step captured `graph_unroll` times in a row (the token / position chain lives on the device, so k steps are
+  // one valid graph): a burst of n replays launches n / k of these and n % k single steps. Each hipGraphLaunch costs the
+  // device a few us between tokens (eager bursts read +0.6 % over one-step replays, profiles/r05z_*); 8 steps per launch
+  // amortise it. WOQ_ENGINE_GRAPH_UNROLL=1 turns it off.
+  hipGraph_t graph_k = nullptr;
+  hipGraphExec_t exec_k = nullptr;
+  int graph_unroll = 8;
   woq_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
   // XQ decode path (woq_xq.h): activations travel between the step's kernels as limb blocks written by the
@@ -785,6 +792,8 @@ void woq_engine_destroy(woq_engine* e) {
   if (!e) return;
   if (e->exec) hipGraphExecDestroy(e->exec);
   if (e->graph) hipGraphDestroy(e->graph);
+  if (e->exec_k) hipGraphExecDestroy(e->exec_k);
+  if (e->graph_k) hipGraphDestroy(e->graph_k);
   woq::persist_destroy(e->persist);
   if (e->wpf_stream) hipStreamDestroy(e->wpf_stream);
   if (e->wpf_fork) hipEventDestroy(e->wpf_fork);
@@ -928,12 +937,34 @@ int woq_engine_capture(woq_engine* e, int greedy, void* stream) {
     hipGraphDestroy(e->graph);
     e->graph = nullptr;
   }
+  if (e->exec_k) {
+    hipGraphExecDestroy(e->exec_k);
+    e->exec_k = nullptr;
+  }
+  if (e->graph_k) {
+    hipGraphDestroy(e->graph_k);
+    e->graph_k = nullptr;
+  }
   WOQ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
   rc = engine_step_impl(e, greedy, st);
   hipError_t ce = hipStreamEndCapture(st, &e->graph);
   if (rc) return rc;
   WOQ_HIP(ce);
   WOQ_HIP(hipGraphInstantiate(&e->exec, e->graph, nullptr, nullptr, 0));
+  {
+    const char* gu = getenv("WOQ_ENGINE_GRAPH_UNROLL");
+    if (gu) e->graph_unroll = std::max(1, std::min(32, atoi(gu)));
+  }
+  // k chained steps as one graph — greedy chains only (a non-greedy step leaves the next token to the host) and never
+  // with a host-side all-reduce callback in the step
+  if (greedy && e->graph_unroll > 1) {
+    WOQ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < e->graph_unroll && rc == 0; ++i) rc = engine_step_impl(e, greedy, st);
+    ce = hipStreamEndCapture(st, &e->graph_k);
+    if (rc) return rc;
+    WOQ_HIP(ce);
+    WOQ_HIP(hipGraphInstantiate(&e->exec_k, e->graph_k, nullptr, nullptr, 0));
+  }
   WOQ_END
 }
 
@@ -955,7 +986,10 @@ int woq_engine_steps(woq_engine* e, int n, int greedy, void* stream) {
 int woq_engine_replay(woq_engine* e, int n, void* stream) {
   WOQ_TRY
   WOQ_CHECK(e && e->exec, "QBits: engine graph not captured");
-  for (int i = 0; i < n; ++i) WOQ_HIP(hipGraphLaunch(e->exec, (hipStream_t)stream));
+  int left = n;
+  if (e->exec_k)
+    for (; left >= e->graph_unroll; left -= e->graph_unroll) WOQ_HIP(hipGraphLaunch(e->exec_k, (hipStream_t)stream));
+  for (; left > 0; --left) WOQ_HIP(hipGraphLaunch(e->exec, (hipStream_t)stream));
   WOQ_END
 }
 

@@ -26,7 +26,7 @@ def split(spec):  # "nf4:bf16" -> ("nf4", "bf16"): weight type and the compute t
     return (spec.split(":") + ["fp32"])[:2]
 
 
-def time_linear(spec, K, N, M, reps=200):
+def time_linear(spec, K, N, M, reps=200, group=128):
     wname, cname = split(spec)
     g = torch.Generator(device="cuda").manual_seed(1)
     table = wname != "int4_clip"
@@ -34,9 +34,9 @@ def time_linear(spec, K, N, M, reps=200):
         q = torch.randint(0, 0x78, (K, N), generator=g, device="cuda", dtype=torch.int8)
     else:
         q = torch.randint(0 if table else -8, 16 if table else 8, (K, N), generator=g, device="cuda", dtype=torch.int8)
-    s = (0.5 + torch.rand(K // 128, N, generator=g, device="cuda")) * 0.005
+    s = (0.5 + torch.rand(K // group, N, generator=g, device="cuda")) * 0.005
     blob = qbits.repack_quantized_weight(q, s, torch.empty(0, dtype=torch.int8), torch.empty(0, dtype=torch.int32),
-                                         wname, "fp32" if wname.startswith("fp8") else "fp16", cname, False, 128)
+                                         wname, "fp32" if wname.startswith("fp8") else "fp16", cname, False, group)
     x = torch.randn(M, K, device="cuda")
     out = torch.empty(M, N, device="cuda")
     e = torch.empty(0)
@@ -78,6 +78,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--engine", action="store_true")
     ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--group", type=int, default=128, help="group size of the per-projection timings (fp8: 128 / 64 / 32)")
     ap.add_argument("--types", default="int4_clip,nf4,nf4:bf16,fp4_e2m1,fp4_e2m1_bnb")
     args = ap.parse_args()
     mode = "generic fp32 VALU kernel" if os.environ.get("WOQ_TABLE_GENERIC") else "digit-plane MFMA kernel"
@@ -86,7 +87,7 @@ if __name__ == "__main__":
     for wname in args.types.split(","):
         row = {"weight_dtype": wname, "table_types_on": mode}
         for name, (K, N) in SHAPES.items():
-            row[name] = {"M=%d" % M: round(time_linear(wname, K, N, M), 2) for M in (1, 4, 8)}
+            row[name] = {"M=%d" % M: round(time_linear(wname, K, N, M, group=args.group), 2) for M in (1, 4, 8)}
         print(json.dumps(row), flush=True)
     if args.engine:
         for wname in args.types.split(","):
