@@ -467,3 +467,38 @@ def test_device_sampler_matches_hf_logits_processors():
                 assert (counts / 4000 - want_p).abs().max() < 0.04
             else:
                 assert int(sampler(logits, hist)) == int(want.argmax())
+
+
+def test_bench_configs_summary_carries_every_baseline_config():
+    """bench.py's `configs_summary`: <= 600 characters, one number per BASELINE.json config, built
+    from the line's own objects — checked on the round's recorded line (profiles/r05z_bench_steps20.json)."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    line = json.load(open(os.path.join(root, "profiles", "r05z_bench_steps20.json")))
+    s = bench.configs_summary(line)
+    assert s == line["configs_summary"] and len(s) <= 600
+    for needle in ("c1 7B g128 20-step", "128-step", "c1 pf 4x2048", "c2 g32asym", "c2 pf 32x2048", "c1@512", "c1@2048",
+                   "act-order", "c4 pf 8k chunked", "c4 Mistral 8k fp8KV", "c3 70B 1-GPU"):
+        assert needle in s, needle
+    order = list(bench.ordered_line(line))
+    assert order.index("configs_summary") == order.index("roofline") - 1  # right in front of the last object
+
+
+def test_fused_projections_must_share_their_act_order():
+    """optimize_transformers fuses q / k / v (and gate / up) along N: one activation shuffle per fused blob, so the
+    modules' g_idx must agree — equal -> that g_idx, none -> None, different -> RuntimeError (module path keeps the model)."""
+    from intel_extension_for_transformers_amd.runtime.engine import _same_order
+
+    a = torch.tensor([0, 1, 0, 1], dtype=torch.int32)
+    b = torch.tensor([1, 0, 0, 1], dtype=torch.int32)
+    part = lambda g: (None, None, None, g)  # noqa: E731
+    assert _same_order([part(None), part(None)], "x") is None
+    assert torch.equal(_same_order([part(a), part(a.clone()), part(a.clone())], "x"), a)
+    with pytest.raises(RuntimeError, match="different act-order permutations"):
+        _same_order([part(a), part(b)], "layers.0 q_proj / k_proj")
+    with pytest.raises(RuntimeError, match="different act-order permutations"):
+        _same_order([part(a), part(None)], "layers.0 gate_proj / up_proj")
