@@ -171,15 +171,15 @@ def test_eager_bursts_equal_graph_replays():
             eng.step(greedy=(i == 2))
         first = int(eng.token.item())
         if mode == "steps":
-            for _ in range(12):
+            for _ in range(24):
                 eng.step(greedy=True)
         else:
             eng.prepare_decode(greedy=True)
             assert eng.captured == (mode == "graph")
-            eng.replay(5)
-            eng.replay(7)
+            eng.replay(5)   # graph mode: five single-step launches
+            eng.replay(19)  # two launches of the 8-step graph + three single steps (round 5: woq_engine_replay)
         torch.cuda.synchronize()
-        outs[mode] = ([first] + eng.token_log()[3:15].tolist(), eng.logits.clone())
+        outs[mode] = ([first] + eng.token_log()[3:27].tolist(), eng.logits.clone())
         assert eng.status() == 0
     assert outs["graph"][0] == outs["eager"][0] == outs["steps"][0]
     assert torch.equal(outs["graph"][1], outs["eager"][1]) and torch.equal(outs["graph"][1], outs["steps"][1])

@@ -54,7 +54,9 @@ def e4m3_exact(d):
 
 
 @pytest.mark.parametrize("wt", [orc.W_FP8_E4M3, orc.W_FP8_E5M2])
-@pytest.mark.parametrize("K,N,group,tpw", [(512, 48, 128, 4), (384, 16, -1, 4), (2048, 32, 128, 4)])
+@pytest.mark.parametrize("K,N,group,tpw", [(512, 48, 128, 4), (384, 16, -1, 4), (2048, 32, 128, 4),
+                                           (11008, 16, 128, 8),  # round 5: K > 8192 as eleven waves of eight tiles
+                                           (512, 32, 32, 4), (768, 16, 64, 4), (768, 16, 96, 4)])  # one scale per 32-k block
 def test_fp8_decode_kernel_model_vs_oracle(wt, K, N, group, tpw):
     rng = np.random.default_rng(5)
     w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
@@ -66,6 +68,9 @@ def test_fp8_decode_kernel_model_vs_oracle(wt, K, N, group, tpw):
     g = K if group == -1 else group
     scales = s.astype(np.float32)  # [G, N]
     tiles_k = hh["Kpad"] // 128
+    assert tpw == (8 if tiles_k > 64 else 4)  # fp8_geometry (csrc/woq_gemv_fp8.hip)
+    blocks = hh["scale_mode"] == 1  # groups of 32 / 64 / 96: each 64-k half is issued once per 32-k block, the other
+    # block's two lane quarters read zero A rows, and every block is recombined and scaled on its own
     nw = (tiles_k + tpw - 1) // tpw
     base, rem = tiles_k // nw, tiles_k % nw
     x = rng.standard_normal(K).astype(np.float32)
@@ -96,12 +101,14 @@ def test_fp8_decode_kernel_model_vs_oracle(wt, K, N, group, tpw):
             a, b = (kt0 + t) * 128, min((kt0 + t + 1) * 128, K)
             if a >= b:
                 continue
-            acc = [(digits[j][a - lo:b - lo].astype(np.float32)[:, None] * vals[a:b]).sum(0, dtype=np.float32)
-                   for j in range(6)]
-            comb = np.zeros(N, np.float32)
-            for j in range(6):
-                comb += acc[j] * np.float32(16.0 ** j)
-            tot += scales[min(a // g, scales.shape[0] - 1)] * comb
+            for a2 in (range(a, b, 32) if blocks else (a,)):
+                b2 = min(a2 + 32, b) if blocks else b
+                acc = [(digits[j][a2 - lo:b2 - lo].astype(np.float32)[:, None] * vals[a2:b2]).sum(0, dtype=np.float32)
+                       for j in range(6)]
+                comb = np.zeros(N, np.float32)
+                for j in range(6):
+                    comb += acc[j] * np.float32(16.0 ** j)
+                tot += scales[min(a2 // g, scales.shape[0] - 1)] * comb
         out += tot * np.float32(2.0 ** (e - 21))
     ref = orc.woq_linear(x[None, :], blob, None)[0]
     mag = np.abs(x) @ np.abs(orc.dequantize_blob(blob))
@@ -159,3 +166,61 @@ def test_table_digit_plane_unpack_model_vs_oracle(wt, ct, tol):
                         got[kt * 128 + hh * 64 + kq * 16 + j16, tn * 16 + i16] = val[tn, kt]
     want = orc.LUTS[wt][orc._codes_of(blob)].astype(np.float64)
     assert np.abs(got[:K, :N] - want).max() <= tol * float(np.abs(orc.LUTS[wt]).max()) + 1e-12
+
+
+@pytest.mark.parametrize("K,N,group,nw,tpw", [(4096, 32, 128, 4, 8), (11008, 16, 128, 11, 8), (640, 16, 64, 2, 4),
+                                              (1536, 16, -1, 2, 8)])
+def test_act_order_gather_form_model_vs_oracle(K, N, group, nw, tpw):
+    """Host model of the act-order form of the tile GEMV (csrc/woq_gemv_i8.hip, SHUF; round 5): the workgroup's copy pass
+    (thread t, pass j -> four-element chunk t + j * threads, <= TPW / 2 chunks per thread) leaves x * norm_weight in LDS
+    in natural order; wave w, lane l then picks elements kbase + 4 l + 256 j + i of ITS slice through the blob's index
+    vector — `index_select(x, 1, g_idx)` of the parity definition (autograd/functions.py:41-63) — and the RMSNorm sum of
+    squares comes from the copy pass (any partition of the vector sums to the same). Against `oracle.woq_linear` on the
+    normalised row; the integer inner product itself is the GPU suite's."""
+    rng = np.random.default_rng(9)
+    q = rng.integers(-8, 8, (K, N), dtype=np.int8)
+    g = K if group == -1 else group
+    s = ((rng.random(((K + g - 1) // g, N), dtype=np.float32) + 0.5) * 0.01).astype(np.float32)
+    g_idx = rng.permutation(np.arange(K, dtype=np.int32) // g).astype(np.int32)
+    shuffle = orc.convert_idx(g_idx, K, g)
+    blob = orc.repack(q, s, None, shuffle, group)
+    x = rng.standard_normal(K).astype(np.float32)
+    gw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    threads, xj = nw * 64, tpw // 2
+    tiles = (K + 127) // 128
+    assert tiles <= nw * tpw and (K // 4 + threads - 1) // threads <= xj  # the chunk bound the kernel relies on
+    # copy pass: every chunk exactly once, sum of squares per thread
+    xs = np.full(K, np.nan, np.float32)
+    ss = 0.0
+    for t in range(threads):
+        for j in range(xj):
+            c = t + j * threads
+            if c * 4 < K:
+                assert np.isnan(xs[c * 4:c * 4 + 4]).all()
+                xs[c * 4:c * 4 + 4] = x[c * 4:c * 4 + 4] * gw[c * 4:c * 4 + 4]
+                ss += float((x[c * 4:c * 4 + 4].astype(np.float64) ** 2).sum())
+    assert not np.isnan(xs).any() and abs(ss - float((x.astype(np.float64) ** 2).sum())) <= 1e-6 * ss
+    # gather: wave slices as in the kernel (balanced contiguous K-tile ranges)
+    base, rem = tiles // nw, tiles % nw
+    row = np.zeros(K, np.float32)  # the activation each regrouped weight row meets
+    seen = np.zeros(K, bool)
+    for w in range(nw):
+        kt0 = w * base + min(w, rem)
+        cnt = base + (1 if w < rem else 0)
+        kbase = kt0 * 128
+        xlen = max(0, min(cnt * 128, K - kbase))
+        for lane in range(64):
+            for j in range(xj):
+                for i in range(4):
+                    off = lane * 4 + j * 256 + i
+                    if off < xlen:
+                        e = kbase + off
+                        assert not seen[e]
+                        seen[e] = True
+                        row[e] = xs[shuffle[e]]
+    assert seen.all()
+    inv = np.float32(1.0 / np.sqrt(ss / K + 1e-5))
+    got = (row.astype(np.float64) @ orc.dequantize_blob(blob).astype(np.float64)) * inv
+    normed = (x * inv * gw).astype(np.float32)
+    ref = orc.woq_linear(normed[None, :], blob, None)[0]
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-6
