@@ -50,6 +50,9 @@ void launch_lm_head(const float* hidden_in, const float* norm_w, float eps, cons
 void launch_argmax(const float* logits, int vocab, int32_t* token, int32_t* pos, hipStream_t st);
 void launch_argmax_pairs(const float* pmax, const int32_t* pidx, int n, int32_t* token, int32_t* pos, int32_t* log,
                          hipStream_t st);
+void launch_argmax_embed(const float* pmax, const int32_t* pidx, int n, int32_t* token, int32_t* pos, int32_t* log,
+                         const void* embed, int dtype, int hidden, float* out, const float* norm_w, const XqPtrs& xo,
+                         float* ssq_out, unsigned int* step_seq, int max_ctx, int* status, hipStream_t st);
 // prompt pass (woq_gemm_f16.hip, woq_prefill.hip)
 size_t gemm_f16_workspace_bytes(int M, int Kpad, int Npad, int planes);
 int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
@@ -321,11 +324,23 @@ static int engine_mlp_block(woq_engine* e, int l, hipStream_t st) {
                                  c.hidden, 1, nullptr, 0.f, res, c.hidden, 0, e->nt, st);
 }
 
-static int engine_head(woq_engine* e, int greedy, hipStream_t st) {
+// fuse_next: this step's greedy argmax and the NEXT step's embedding kernel as one launch (steps chained inside one
+// captured graph; one GPU, greedy) — woq_ops.hip argmax_embed_kernel
+static bool engine_can_fuse_next(const woq_engine* e, int greedy) {
+  return greedy && e->cfg.tp_size <= 1 && e->comm == nullptr && !e->wpf_on && !(engine_skip_mask() & 32);
+}
+static int engine_head(woq_engine* e, int greedy, hipStream_t st, bool fuse_next = false) {
   const woq_engine_config& c = e->cfg;
   if (engine_skip_mask() & 32) return 0;
   launch_lm_head(e->hidden, e->final_norm, c.rms_eps, e->lm_head, e->lm_dtype, c.hidden, c.vocab, e->logits,
                  greedy ? e->am_val : nullptr, greedy ? e->am_idx : nullptr, st);
+  if (fuse_next) {
+    const bool xq = e->use_xq();
+    launch_argmax_embed(e->am_val, e->am_idx, (c.vocab + 15) / 16, e->token, e->pos, e->tok_log, e->embed, e->embed_dtype,
+                        c.hidden, e->hidden, xq ? e->layers[0].ln1 : nullptr, xq ? e->xq_hidden : kNoXq,
+                        xq ? e->ssq_part : nullptr, e->step_seq, c.max_ctx, e->fuse_status, st);
+    return 0;
+  }
   if (greedy && e->comm && c.tp_size > 1)  // vocab-sharded head: one (max, global index) pair per rank
     return woq_comm_launch_greedy(e->comm, e->am_val, e->am_idx, (c.vocab + 15) / 16, e->vocab_offset, e->token,
                                   e->pos, e->tok_log, st);
@@ -411,14 +426,17 @@ int woq_engine::wpf_prepare() {
   return 0;
 }
 
-static int engine_step_impl(woq_engine* e, int greedy, hipStream_t st) {
+// chain bit 0: the previous step of the same captured graph already ran this step's embedding (its fused tail);
+// bit 1: this step's tail is fused with the next step's embedding
+static int engine_step_impl(woq_engine* e, int greedy, hipStream_t st, int chain = 0) {
   const woq_engine_config& c = e->cfg;
-  engine_embed(e, st);
+  const bool fuse_next = (chain & 2) != 0;
+  if (!(chain & 1)) engine_embed(e, st);
   if (woq::Persist* p = e->persist_get()) {  // embedding -> [all layers, one launch] -> head
     woq::persist_rebind(p, e->pos, e->hidden);
     const int rc = woq::persist_launch(p, st);
     if (rc) return rc;
-    return engine_head(e, greedy, st);
+    return engine_head(e, greedy, st, fuse_next);
   }
   const bool wpf = e->wpf_applies();
   if (wpf) {  // fork: the prefetcher depends on the embedding kernel only (it reads the step counter that kernel advanced)
@@ -440,7 +458,7 @@ static int engine_step_impl(woq_engine* e, int greedy, hipStream_t st) {
     if (rc) return rc;
     if ((rc = engine_allreduce_after(e, l, 1, st)) != 0) return rc;
   }
-  const int rc = engine_head(e, greedy, st);
+  const int rc = engine_head(e, greedy, st, fuse_next);
   if (wpf) WOQ_HIP(hipStreamWaitEvent(st, e->wpf_join, 0));  // join: the step ends when both branches have
   return rc;
 }
@@ -959,7 +977,11 @@ int woq_engine_capture(woq_engine* e, int greedy, void* stream) {
   // with a host-side all-reduce callback in the step
   if (greedy && e->graph_unroll > 1) {
     WOQ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < e->graph_unroll && rc == 0; ++i) rc = engine_step_impl(e, greedy, st);
+    // interior token boundaries of the chain: argmax + next embedding in one launch (WOQ_ENGINE_FUSE_TAIL=0: off)
+    static const bool fuse_tail = !(getenv("WOQ_ENGINE_FUSE_TAIL") && getenv("WOQ_ENGINE_FUSE_TAIL")[0] == '0');
+    const bool fuse = fuse_tail && engine_can_fuse_next(e, greedy);
+    for (int i = 0; i < e->graph_unroll && rc == 0; ++i)
+      rc = engine_step_impl(e, greedy, st, fuse ? ((i > 0 ? 1 : 0) | (i + 1 < e->graph_unroll ? 2 : 0)) : 0);
     ce = hipStreamEndCapture(st, &e->graph_k);
     if (rc) return rc;
     WOQ_HIP(ce);

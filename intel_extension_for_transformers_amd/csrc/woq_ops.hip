@@ -107,6 +107,65 @@ __global__ void embed_kernel(const void* __restrict__ embed, int dtype, const in
   }
 }
 
+// The greedy tail of step t and the head of step t + 1 in ONE launch (round 5; inside a graph of chained steps every
+// interior token boundary was argmax [1 workgroup] -> boundary -> embed [hidden / 256 workgroups]): every workgroup
+// reduces the lm_head's (max, index) pairs itself — vocab / 16 pairs, 8 per thread, the same tie rule (lowest index) in
+// the same order everywhere, so all agree — and embeds its 256 columns of the winner's row; workgroup 0 also does the
+// bookkeeping of both kernels (token, token log, position + 1, the new step's hand-off tag, the max_ctx guard).
+__global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restrict__ pmax, const int32_t* __restrict__ pidx,
+                                                           int n_pairs, int32_t* __restrict__ token,
+                                                           int32_t* __restrict__ pos, int32_t* __restrict__ log,
+                                                           const void* __restrict__ embed, int dtype, int hidden,
+                                                           float* __restrict__ out, const float* __restrict__ norm_w,
+                                                           XqPtrs xo, float* __restrict__ ssq_out,
+                                                           unsigned int* __restrict__ step_seq, int max_ctx,
+                                                           int* __restrict__ status) {
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int i = tid; i < n_pairs; i += 256) {
+    const float v = pmax[i];
+    const int ci = pidx[i];
+    if (v > best || (v == best && ci < idx)) best = v, idx = ci;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ov > best || (ov == best && oi < idx)) best = ov, idx = oi;
+  }
+  if (lane == 0) bv[wid] = best, bi[wid] = idx;
+  __syncthreads();
+  best = bv[0], idx = bi[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (bv[w] > best || (bv[w] == best && bi[w] < idx)) best = bv[w], idx = bi[w];
+  if (blockIdx.x == 0 && tid == 0) {
+    token[0] = idx;
+    int p = pos[0];
+    if (log != nullptr) log[p] = idx;
+    p += 1;
+    if (step_seq != nullptr) step_seq[0] = step_seq[0] + 1u;
+    if (p >= max_ctx) {  // the next step would start out of range: the embedding kernel's guard
+      p = max_ctx - 1;
+      if (status != nullptr) atomicOr(status, 2);
+    }
+    pos[0] = p;
+  }
+  const int i = blockIdx.x * 256 + tid;
+  if (i < hidden) {
+    const float v = load_f32(embed, (size_t)idx * hidden + i, dtype);
+    out[i] = v;
+    if (xo.limbs != nullptr) {
+      const float ss = row16_sum(v * v);
+      if ((i & 15) == 0) ssq_out[i >> 4] = ss;
+      xq_emit16(v * norm_w[i], xo, i >> 4, i & 15);
+    }
+  }
+}
+
 template <typename KV, int HD, bool SPLIT>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv, KV* __restrict__ kcache,
                                                           KV* __restrict__ vcache, const int32_t* __restrict__ pos_p,
@@ -189,6 +248,18 @@ __global__ __launch_bounds__(256) void lm_head_kernel(const float* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   float wbest = -INFINITY;  // this wave's best (logit, row) — rows ascend, so '>' keeps the lowest index on ties
   int wbi = 0x7fffffff;
+  // the wave's FIRST weight row is requested before the activation prologue (hidden -> LDS, sum of squares, two barriers:
+  // ~2 us during which every workgroup of the launch — they all start together — left HBM idle); hidden <= 4096 only
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int PRE = 8;
+  u32x4 pre[PRE];
+  const bool use_pre = hidden <= PRE * 512 && (int)blockIdx.x * 16 + wid < vocab;
+  if (use_pre) {
+    const uint16_t* wr0 = (const uint16_t*)W + (size_t)((int)blockIdx.x * 16 + wid) * hidden;
+#pragma unroll
+    for (int j = 0; j < PRE; ++j)
+      if (lane * 8 + j * 512 < hidden) pre[j] = __builtin_nontemporal_load((const u32x4*)(wr0 + lane * 8 + j * 512));
+  }
   float ss = 0.f;
   for (int i = tid; i < hidden; i += 256) {
     const float v = hidden_in[i];
@@ -202,35 +273,44 @@ __global__ __launch_bounds__(256) void lm_head_kernel(const float* __restrict__ 
   for (int i = tid; i < hidden; i += 256) xs[i] = xs[i] * inv * norm_w[i];
   __syncthreads();
   const int rows_per_wg = 16;
-  for (int r = wid; r < rows_per_wg; r += 4) {
-    const int v = blockIdx.x * rows_per_wg + r;
-    if (v >= vocab) break;
-    const uint16_t* wr = (const uint16_t*)W + (size_t)v * hidden;
-    float acc = 0.f;
-    for (int k0 = lane * 8; k0 < hidden; k0 += 512) {
-      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-      const u32x4 raw = __builtin_nontemporal_load((const u32x4*)(wr + k0));
-      const uint32_t rr[4] = {raw.x, raw.y, raw.z, raw.w};
+  auto consume = [&](const u32x4& raw, int k0, float& acc) {
+    const uint32_t rr[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float lo, hi;
-        if (w_dtype == WOQ_BF16) {
-          lo = bf16_bits_to_f32(rr[j] & 0xffff);
-          hi = bf16_bits_to_f32(rr[j] >> 16);
-        } else {
-          lo = f16_bits_to_f32(rr[j] & 0xffff);
-          hi = f16_bits_to_f32(rr[j] >> 16);
-        }
-        acc = fmaf(lo, xs[k0 + 2 * j], acc);
-        acc = fmaf(hi, xs[k0 + 2 * j + 1], acc);
+    for (int j = 0; j < 4; ++j) {
+      float lo, hi;
+      if (w_dtype == WOQ_BF16) {
+        lo = bf16_bits_to_f32(rr[j] & 0xffff);
+        hi = bf16_bits_to_f32(rr[j] >> 16);
+      } else {
+        lo = f16_bits_to_f32(rr[j] & 0xffff);
+        hi = f16_bits_to_f32(rr[j] >> 16);
       }
+      acc = fmaf(lo, xs[k0 + 2 * j], acc);
+      acc = fmaf(hi, xs[k0 + 2 * j + 1], acc);
     }
+  };
+  auto finish = [&](int v, float acc) {
     acc = wave_sum(acc);
     if (lane == 0) logits[v] = acc;
     if (acc > wbest) {
       wbest = acc;
       wbi = v;
     }
+  };
+  if (use_pre) {  // the row requested up front (row `wid` of the workgroup's sixteen)
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < PRE; ++j)
+      if (lane * 8 + j * 512 < hidden) consume(pre[j], lane * 8 + j * 512, acc);
+    finish((int)blockIdx.x * rows_per_wg + wid, acc);
+  }
+  for (int r = wid + (use_pre ? 4 : 0); r < rows_per_wg; r += 4) {
+    const int v = blockIdx.x * rows_per_wg + r;
+    if (v >= vocab) break;
+    const uint16_t* wr = (const uint16_t*)W + (size_t)v * hidden;
+    float acc = 0.f;
+    for (int k0 = lane * 8; k0 < hidden; k0 += 512) consume(__builtin_nontemporal_load((const u32x4*)(wr + k0)), k0, acc);
+    finish(v, acc);
   }
   // per-workgroup (max, index) for the greedy argmax: it then reduces vocab / 16 pairs instead of vocab logits
   if (pmax) {
@@ -399,6 +479,14 @@ void launch_argmax(const float* logits, int vocab, int32_t* token, int32_t* pos,
 void launch_argmax_pairs(const float* pmax, const int32_t* pidx, int n, int32_t* token, int32_t* pos, int32_t* log,
                          hipStream_t st) {
   hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, pmax, pidx, n, token, pos, log);
+}
+
+// greedy token of the step that just ran its lm_head + embedding row of the NEXT step, one launch (argmax_embed_kernel)
+void launch_argmax_embed(const float* pmax, const int32_t* pidx, int n, int32_t* token, int32_t* pos, int32_t* log,
+                         const void* embed, int dtype, int hidden, float* out, const float* norm_w, const XqPtrs& xo,
+                         float* ssq_out, unsigned int* step_seq, int max_ctx, int* status, hipStream_t st) {
+  hipLaunchKernelGGL(argmax_embed_kernel, dim3((hidden + 255) / 256), dim3(256), 0, st, pmax, pidx, n, token, pos, log,
+                     embed, dtype, hidden, out, norm_w, xo, ssq_out, step_seq, max_ctx, status);
 }
 
 }  // namespace woq
