@@ -251,7 +251,10 @@ WOQ_API void* woq_engine_kv_cache_ptr(woq_engine* e, int which);
 /* 1 when the decode step hands activations between its kernels as XQ limb blocks (csrc/woq_xq.h; every layer's blobs
  * qualify, one GPU, WOQ_ENGINE_XQ != 0), 0 when it runs the fp32-activation kernels. */
 WOQ_API int woq_engine_uses_xq(woq_engine* e);
-/* capture one step into a hipGraph and replay it `n` times (greedy chaining). */
+/* capture one step into a hipGraph and replay it `n` times (greedy chaining). Round 5: a greedy capture also holds the
+ * step chained 8 times as ONE graph (WOQ_ENGINE_GRAPH_UNROLL, 1 = off; interior token boundaries: argmax + next
+ * embedding as one launch); replay(n) then issues n / 8 launches of it and n % 8 single steps — same kernels, same
+ * tokens, +0.6 % tokens/s (each hipGraphLaunch costs the device a few us between tokens). */
 WOQ_API int woq_engine_capture(woq_engine* e, int greedy, void* stream);
 WOQ_API int woq_engine_replay(woq_engine* e, int n, void* stream);
 /* `n` decode steps issued eagerly back to back (no graph, no host synchronisation; with greedy != 0 the token /

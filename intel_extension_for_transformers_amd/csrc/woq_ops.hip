@@ -248,12 +248,15 @@ __global__ __launch_bounds__(256) void lm_head_kernel(const float* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   float wbest = -INFINITY;  // this wave's best (logit, row) — rows ascend, so '>' keeps the lowest index on ties
   int wbi = 0x7fffffff;
-  // the wave's FIRST weight row is requested before the activation prologue (hidden -> LDS, sum of squares, two barriers:
-  // ~2 us during which every workgroup of the launch — they all start together — left HBM idle); hidden <= 4096 only
+  // experiment (off, see WOQ_LM_PRE): the wave's FIRST weight row requested before the activation prologue (hidden ->
+  // LDS, sum of squares, two barriers: ~2 us during which every workgroup of the launch leaves HBM idle); hidden <= 4096
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   constexpr int PRE = 8;
   u32x4 pre[PRE];
-  const bool use_pre = hidden <= PRE * 512 && (int)blockIdx.x * 16 + wid < vocab;
+#ifndef WOQ_LM_PRE  // A/B builds: -DWOQ_LM_PRE=1. Measured SLOWER (kernel trace, same box, alternating: 51.0 / 51.3 us with
+#define WOQ_LM_PRE 0  // the preload against 48.7 / 47.3 without, profiles/r05i_*): off
+#endif
+  const bool use_pre = WOQ_LM_PRE && hidden <= PRE * 512 && (int)blockIdx.x * 16 + wid < vocab;
   if (use_pre) {
     const uint16_t* wr0 = (const uint16_t*)W + (size_t)((int)blockIdx.x * 16 + wid) * hidden;
 #pragma unroll
