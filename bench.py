@@ -397,29 +397,6 @@ def gemv_roofline(eng, traffic=None, ceiling=True):
     return out
 
 
-def launch_structures(eng, cfg, args):
-    """The same decode, the other way of cutting it into launches that this tree carries: all layers as ONE persistent
-    launch (csrc/woq_persist.hip: loader wave + LDS ring + granule hand-offs). Same prompt, same number of timed steps,
-    measured in this run right after the headline. A built and measured NEGATIVE: kept in the line so that the claim
-    "the launch structure is not where the time is" is re-measured every run."""
-    import torch
-
-    eng.set_persist(True)
-    if not eng.uses_persist():
-        eng.set_persist(False)
-        return {"persistent_launch": None, "note": "outside the persistent launch's scope on this model / device"}
-    feed_prompt(eng, cfg["vocab"], args.prompt)
-    eng.capture(greedy=True)
-    el = timed(eng.replay_graph, args.steps, args.warmup, torch.cuda.synchronize, condition=(eng, None))
-    status = eng.status()
-    eng.set_persist(False)
-    return {"persistent_launch": {"tokens_per_s": args.steps / el, "ms_per_step": el * 1e3 / args.steps,
-                                  "engine_status": status},
-            "note": "one launch for all layers instead of 4 per layer; correct (tests) and slower: with every weight "
-                    "prefetched into an LDS ring the layer is still five all-to-all hand-offs plus SIMD-issue-bound "
-                    "tile passes (DESIGN 3.2, profiles/r03ad_*)"}
-
-
 def read_traffic():
     """HBM bytes per dominant-kernel launch from the latest committed PMC pass (a separate rocprofv3 --pmc run: the
     counters cannot be read inside the timed run). None if there is none."""
@@ -964,7 +941,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (configs[2], [3] single GPU, [4])")
     ap.add_argument("--no-70b", action="store_true", help="skip the 70B single-GPU point of extra_configs")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--no-structures", action="store_true", help="skip other_launch_structures (the persistent launch)")
+    ap.add_argument("--no-structures", action="store_true", help="(no-op since round 6: the persistent launch left the library)")
     ap.add_argument("--graph", action="store_true", help="(the default: replays of the captured hipGraph on the current stream)")
     ap.add_argument("--no-graph", "--eager", dest="no_graph", action="store_true",
                     help="time eager bursts (one native call issuing every launch) instead of graph replays; same device "
@@ -1095,8 +1072,6 @@ def main():
                             "(1.17 vs 1.04 ms per token; profiles/r04g_graph_vs_eager_steps.txt found the gap, "
                             "profiles/r04ab_stream_mode_probe.txt its cause). Eager bursts cost ~0.34 ms of host launch "
                             "calls per token, issued ahead of the device; graph replays none"}
-    feed_prompt(eng, cfg["vocab"], args.prompt)
-    structures = launch_structures(eng, cfg, args) if not args.no_structures else None
     qbytes = algorithmic_bytes_per_token(cfg)
     out = dict(base, value=tok_s, ms_per_step=elapsed * 1e3 / args.steps, scaling="weak",
                data="synthetic (random-init int4 weights of the Llama-2-7B shape, random prompt ids)",
@@ -1110,8 +1085,6 @@ def main():
                hbm_frac_of_peak_end_to_end=qbytes * tok_s / 1e9 / HBM_PEAK_GBPS,
                hbm_frac_of_measured_copy_ceiling_end_to_end=qbytes * tok_s / 1e9 / HBM_COPY_GBPS,
                roofline=gemv_roofline(eng, read_traffic()))
-    if structures is not None:
-        out["other_launch_structures"] = structures
     if want_prefill:
         out["prefill"] = prefill_measure(eng, cfg, args.prefill_seqs, args.prefill_len, label=", same int4 g128 weights")
     if not args.no_parity:

@@ -42,10 +42,13 @@ extern "C" {
 #define WOQ_API __attribute__((visibility("default")))
 
 WOQ_API const char* woq_last_error(void);
-/* ABI revision of this header: 1 = rounds 1-3; 2 = round 4 (woq_engine_set_chain / woq_engine_chain removed;
- * woq_engine_steps, _set_attn_chunk, _clear_status, _set_time_eager, woq_table_digit_planes added); 3 = round 5
- * (woq_engine_set_prefetch / _prefetch / _mall_probe added). A client checks it against WOQ_ABI_VERSION at load time. */
-#define WOQ_ABI_VERSION 3
+/* ABI revision of this header: 1 = rounds 1-3; 2 = round 4; 3 = round 5; 4 = round 6: FROZEN to what the boundary
+ * needs (the qbits operator functions, the ops between the linears, the decode engine, the tensor-
+ * parallel exchange). Every lab switch and measurement hook left it — the persistent launch and the token-long
+ * prefetcher left the library altogether (tools/rejected/, both measured slower), the timing / probe entry points
+ * live in woq_hip_experimental.h, which is NOT covered by this number. A client checks woq_abi_version() against
+ * WOQ_ABI_VERSION at load time. */
+#define WOQ_ABI_VERSION 4
 WOQ_API int woq_abi_version(void);
 /* number of visible HIP devices (0 when there is no GPU); never fails. */
 WOQ_API int woq_device_count(void);
@@ -210,12 +213,6 @@ WOQ_API int woq_engine_attn_splits(woq_engine* e);
  * fp8 cache — silently the per-query-head slices otherwise). Default off. Same capture rule as attn_splits. */
 WOQ_API int woq_engine_set_attn_grouped(woq_engine* e, int on);
 WOQ_API int woq_engine_attn_grouped(woq_engine* e);
-/* grouped form only: `chunk` > 0 (a multiple of 32) = position-independent slice geometry — slice s owns the absolute
- * cached positions [s * chunk, (s + 1) * chunk) (the last slice also whatever lies beyond), so its K / V rows are
- * requested before the device-side position is read; 0 = slices cut evenly from the current span (the default; always
- * used with a sliding window). Pick splits >= ceil(positions / chunk). Same capture rule as attn_splits. */
-WOQ_API int woq_engine_set_attn_chunk(woq_engine* e, int chunk);
-WOQ_API int woq_engine_attn_chunk(woq_engine* e);
 /* decode step, XQ path: [RMSNorm + qkv GEMV] and [RoPE + KV append + attention] as ONE launch — the workgroup whose
  * column strip completes a head's q / k / v runs that head's attention (csrc/woq_gemv_attn.hip). Applies to multi-head
  * shapes (heads == kv_heads), head_dim 128, hidden 4096, one context slice, no sliding window; the two launches
@@ -223,23 +220,11 @@ WOQ_API int woq_engine_attn_chunk(woq_engine* e);
  * woq_engine_fuse_attn: 1 when the next step / capture will use it. */
 WOQ_API int woq_engine_set_fuse_attn(woq_engine* e, int on);
 WOQ_API int woq_engine_fuse_attn(woq_engine* e);
-/* decode step, XQ path: ALL layers of the step as one persistent launch (csrc/woq_persist.hip): one workgroup per CU,
- * a loader wave streaming the token's weights HBM -> LDS ring without stopping at operator boundaries, eleven consumer
- * waves doing the arithmetic, activation vectors handed between workgroups as tagged 8-byte granules (bounded waits,
- * woq_engine_status bit 0). Scope: one GPU, unpadded int4 blobs with one scale layout, head_dim 128, one attention
- * slice, no sliding window, activation vector + scales + a >= 64 KiB ring within 160 KiB of LDS; outside it the step keeps
- * its launches. WOQ_ENGINE_PERSIST=1 or woq_engine_set_persist turn it on. Same capture rule as attn_splits.
- * woq_engine_persist: 1 when the next step / capture will use it (0: woq_last_error says what is out of scope). */
-WOQ_API int woq_engine_set_persist(woq_engine* e, int on);
-WOQ_API int woq_engine_persist(woq_engine* e);
-/* diagnostics of the persistent launch: stamps_dev = device buffer of grid * layers * 4 * 32 uint64 that every later
- * step fills with 100 MHz wall-clock stamps per (workgroup, projection) — csrc/woq_persist.hip PS_STAMP lists the
- * slots — or NULL to turn them off; *grid / *ring_tiles (optional) report the launch geometry. */
-WOQ_API int woq_engine_persist_stamps(woq_engine* e, void* stamps_dev, int* grid, int* ring_tiles);
 /* sticky device-side status of the decode step, 0 = fine; bit 0: an attention workgroup of the fused launch gave up
  * waiting for its head's q / k / v after its bound (its outputs are then wrong); bit 1: a step started with its
  * position at or beyond max_ctx — it ran at max_ctx - 1 instead (outputs meaningless, nothing written out of bounds;
- * woq_engine_step / _replay cannot check a position that lives on the device); -1 = the read itself failed.
+ * woq_engine_step / _replay cannot check a position that lives on the device); bit 2: a greedy step found no
+ * winning logit (all NaN) and fed token 0; -1 = the read itself failed.
  * Synchronises `stream`. */
 WOQ_API int woq_engine_status(woq_engine* e, void* stream);
 /* resets the sticky status to 0 (stream-ordered): a caller that read a non-zero status, changed what caused it
@@ -302,46 +287,6 @@ WOQ_API int woq_engine_set_tp_options(woq_engine* e, int xq, int fused_push);
  * between them: phase 0 = embed + attention block up to o_proj partial, 1 = MLP block up to
  * down partial, 2 = head. layer ignored for phase 2. */
 WOQ_API int woq_engine_phase(woq_engine* e, int layer, int phase, int greedy, void* stream);
-/* time the dominant kernel (int4 GEMV) alone over all layers with HIP events on `stream`: one pass = every layer's 4
- * GEMV launches in the forms the decode step uses (same kernels, epilogues, XQ outputs, residual chaining), captured
- * into a hipGraph and replayed `reps` times between one event pair (after an untimed replay); returns total ms, the
- * algorithmic bytes of one pass and its launch count (average launch duration = total_ms / (reps * launches_per_pass),
- * boundaries included). Overwrites the residual stream / XQ vectors (the next step's embedding rewrites them). */
-WOQ_API int woq_engine_time_gemv(woq_engine* e, int reps, void* stream, float* total_ms, double* bytes_per_pass,
-                                 int* launches_per_pass);
-/* the same with a pass restricted to some of the layer's projections (mask bit 0 qkv, 1 o, 2 gate/up, 3 down): the
- * per-instantiation numbers rocprofv3's kernel stats list separately (bench.py roofline.by_projection) */
-WOQ_API int woq_engine_time_gemv_mask(woq_engine* e, int mask, int reps, void* stream, float* total_ms,
-                                      double* bytes_per_pass, int* launches_per_pass);
-/* the same four launches per layer with the arithmetic taken out, timed the same way (`reps` passes after a warm-up
- * pass, total milliseconds): mode 0 = load-only twins (same grids, waves, K slices, non-temporal 16-byte requests over
- * the engine's own blobs: what this launch structure reaches as a pure stream), mode 1 = empty kernels on the same
- * grids (what the launches cost before they do anything). bench.py reports both as roofline.ceiling. */
-WOQ_API int woq_engine_time_twin(woq_engine* e, int mode, int reps, void* stream, float* total_ms);
-/* Token-long weight prefetcher beside the decode step (csrc/woq_prefetch.hip; round 5): one low-occupancy kernel, a
- * dependency-free branch forked once per token behind the embedding kernel, walks the layers' blobs in consumption
- * order with default-policy loads so that the step's launches stream out of the Infinity Cache while HBM works through
- * their boundaries. grid workgroups x waves (1..4) x depth (4 | 8 | 16 | 32) KiB in flight; it runs at most `lead`
- * layers (+ projections 0..lead_kind of the next) ahead of the layer whose qkv the fused launch has published; wrap:
- * touch layer 0 again at the end, for the next token; head_mb: MiB of the lm_head behind the last layer. Applies to
- * one-GPU engines on the fused qkv + attention launch; woq_engine_prefetch() = 1 when the next step will use it.
- * No reference counterpart (launch structure around qbits.cpp:113-140's M = 1 calls). */
-WOQ_API int woq_engine_set_prefetch(woq_engine* e, int on, int grid, int waves, int depth, int lead, int lead_kind,
-                                    int wrap, int head_mb);
-WOQ_API int woq_engine_prefetch(woq_engine* e);
-/* measurement: projection `proj` (0 qkv, 1 o, 2 gate/up, 3 down) over every layer, cold vs read by another kernel
- * `lead` launches earlier: us[0] cold per launch, us[1] readers alone, us[2] readers + launches (hot = us[2] - us[1]);
- * twin != 0: the load-only twin instead of the GEMV */
-WOQ_API int woq_engine_mall_probe(woq_engine* e, int proj, int twin, int lead, int reps, void* stream, float* us);
-/* how woq_engine_time_gemv / _gemv_mask / _twin issue their timed passes: on != 0 (default) eagerly back to back on
- * the stream — the way decode bursts run by default since round 4 — else as replays of a captured graph. */
-WOQ_API int woq_engine_set_time_eager(woq_engine* e, int on);
-/* the prompt pass's dominant GEMM in place: the engine's own gate/up call of `layer` over n_rows rows of the residual
- * stream a preceding woq_engine_prefill left (RMSNorm pack pass + MFMA GEMM + SiLU * mul epilogue), the MEDIAN of `reps`
- * calls after a warm-up one: gemm_ms = the GEMM kernel alone (HIP events on the launch stream right around its launch),
- * call_ms = pack pass + GEMM. */
-WOQ_API int woq_engine_time_prefill_gemm(woq_engine* e, int layer, int n_rows, int reps, void* stream, float* gemm_ms,
-                                         float* call_ms);
 
 #ifdef __cplusplus
 }

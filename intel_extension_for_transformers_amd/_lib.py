@@ -62,19 +62,25 @@ class LayerWeights(ctypes.Structure):
 
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 
-# every symbol include/woq_hip.h declares (tests check the .so exports all of them)
+# every symbol include/woq_hip.h declares (tests check the .so exports all of them): ABI version 4, the frozen boundary
 EXPORTS = [
     "woq_last_error", "woq_abi_version", "woq_device_count", "woq_packed_weight_size",
     "woq_repack_quantized_weight", "woq_quantize_to_packed_weight", "woq_dequantize_packed_weight",
     "woq_read_header", "woq_blob_extract", "woq_linear", "woq_rmsnorm", "woq_rope", "woq_silu_mul", "woq_gelu",
     "woq_engine_create", "woq_engine_destroy", "woq_engine_set_layer", "woq_engine_set_head",
     "woq_engine_bind_io", "woq_engine_token_ptr", "woq_engine_pos_ptr", "woq_engine_logits_ptr", "woq_engine_hidden_ptr",
-    "woq_engine_step", "woq_engine_capture", "woq_engine_replay", "woq_engine_steps", "woq_engine_set_allreduce", "woq_engine_phase",
-    "woq_engine_time_gemv", "woq_engine_time_gemv_mask", "woq_engine_prefill", "woq_engine_prefill_logits_ptr", "woq_engine_kv_cache_ptr", "woq_engine_set_attn_splits", "woq_engine_attn_splits",
-    "woq_engine_set_attn_grouped", "woq_engine_attn_grouped", "woq_engine_set_attn_chunk", "woq_engine_attn_chunk", "woq_engine_set_persist", "woq_engine_persist", "woq_engine_set_prefetch", "woq_engine_prefetch", "woq_engine_mall_probe", "woq_engine_persist_stamps", "woq_engine_set_tp_options", "woq_engine_time_twin", "woq_engine_set_time_eager", "woq_engine_time_prefill_gemm", "woq_engine_set_fuse_attn", "woq_engine_fuse_attn", "woq_engine_status", "woq_engine_clear_status",
-    "woq_comm_create", "woq_comm_handle", "woq_comm_connect", "woq_comm_allreduce_f32", "woq_comm_status",
-    "woq_comm_set_timeout_ms", "woq_comm_destroy", "woq_engine_set_comm", "woq_set_workspace", "woq_engine_uses_xq",
-    "woq_engine_token_log_ptr", "woq_table_digit_planes",
+    "woq_engine_step", "woq_engine_capture", "woq_engine_replay", "woq_engine_steps", "woq_engine_set_allreduce",
+    "woq_engine_phase", "woq_engine_prefill", "woq_engine_prefill_logits_ptr", "woq_engine_kv_cache_ptr",
+    "woq_engine_set_attn_splits", "woq_engine_attn_splits", "woq_engine_set_attn_grouped", "woq_engine_attn_grouped",
+    "woq_engine_set_tp_options", "woq_engine_set_fuse_attn", "woq_engine_fuse_attn", "woq_engine_status",
+    "woq_engine_clear_status", "woq_comm_create", "woq_comm_handle", "woq_comm_connect", "woq_comm_allreduce_f32",
+    "woq_comm_status", "woq_comm_set_timeout_ms", "woq_comm_destroy", "woq_engine_set_comm", "woq_set_workspace",
+    "woq_engine_uses_xq", "woq_engine_token_log_ptr", "woq_table_digit_planes",
+]
+# include/woq_hip_experimental.h: measurement hooks and lab switches, outside WOQ_ABI_VERSION
+EXPERIMENTAL_EXPORTS = [
+    "woq_engine_set_attn_chunk", "woq_engine_attn_chunk", "woq_engine_time_gemv", "woq_engine_time_gemv_mask",
+    "woq_engine_time_twin", "woq_engine_set_time_eager", "woq_engine_time_prefill_gemm",
 ]
 
 _lib = None
@@ -120,9 +126,6 @@ def lib():
     L.woq_engine_replay.argtypes = [vp, ci, vp]
     L.woq_engine_steps.argtypes = [vp, ci, ci, vp]
     L.woq_engine_set_time_eager.argtypes = [vp, ci]
-    L.woq_engine_set_prefetch.argtypes = [vp] + [ci] * 8
-    L.woq_engine_prefetch.argtypes = [vp]
-    L.woq_engine_mall_probe.argtypes = [vp, ci, ci, ci, ci, vp, vp]
     L.woq_engine_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
     L.woq_engine_phase.argtypes = [vp, ci, ci, ci, vp]
     L.woq_engine_prefill.argtypes = [vp, vp, ci, ci, ci, ci, vp]
@@ -146,9 +149,6 @@ def lib():
                                             ctypes.POINTER(ci)]
     L.woq_engine_time_twin.argtypes = [vp, ci, ci, vp, ctypes.POINTER(cf)]
     L.woq_engine_set_tp_options.argtypes = [vp, ci, ci]
-    L.woq_engine_set_persist.argtypes = [vp, ci]
-    L.woq_engine_persist.argtypes = [vp]
-    L.woq_engine_persist_stamps.argtypes = [vp, vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
     L.woq_engine_time_prefill_gemm.argtypes = [vp, ci, ci, ci, vp, ctypes.POINTER(cf), ctypes.POINTER(cf)]
     L.woq_comm_create.argtypes = [ci, ci, cs, ctypes.POINTER(vp)]
     L.woq_comm_handle.argtypes = [vp, vp, cs]

@@ -18,7 +18,7 @@
 #include "woq_comm_dev.h"
 #include "woq_device.h"
 #include "woq_launch.h"
-#include "woq_persist.h"
+#include "../../include/woq_hip_experimental.h"
 #include "woq_xq.h"
 
 namespace woq {
@@ -69,13 +69,6 @@ int launch_attn_prefill(const _Float16* qkv, int n_seq, int T, int start, int he
                         const void* kcache, const void* vcache, int kv_dtype, size_t seq_stride_elems, _Float16* out,
                         int window, hipStream_t st);
 void set_gemm_time_events(hipEvent_t before, hipEvent_t after);
-// token-long weight prefetcher beside the decode step (woq_prefetch.hip)
-int launch_prefetch(const void* items_dev, int n_items, const unsigned long long* qkv_g, const unsigned int* seq,
-                    int lead, int lead_kind, int first_vlayer, int grid, int waves, int depth, unsigned int* sink,
-                    hipStream_t st);
-int prefetch_build_items(const std::vector<const void*>& ptrs, const std::vector<size_t>& bytes,
-                         const std::vector<int>& vlayer, const std::vector<int>& kind, void** items_dev, int* n);
-void launch_stream_read(const void* p, size_t bytes, unsigned int* sink, hipStream_t st);
 void launch_gather_last(const float* h, int n_seq, int T, int hidden, float* dst, hipStream_t st);
 }  // namespace woq
 // device-side tensor-parallel exchange (woq_comm.hip)
@@ -131,16 +124,10 @@ struct woq_engine {
   unsigned int* step_seq = nullptr;
   int* fuse_status = nullptr;
   bool fuse_attn = true;             // qkv GEMV + attention in one launch where the shape allows (woq_gemv_attn.hip)
-  // in-launch hand-off tags are (step counter << 6) | layer (woq_gemv_attn.hip, the persistent launch):
+  // in-launch hand-off tags are (step counter << 6) | layer (woq_gemv_attn.hip):
   // beyond 64 layers the layer bits would run into the counter and a stale granule could pass for a fresh one, so
   // deeper models keep the separate launches
   bool tags_ok() const { return cfg.layers <= 64; }
-  // all layers of the step as ONE persistent launch (woq_persist.hip): the weight stream runs through the operator
-  // boundaries. Built lazily at the first step (every layer must be set); null + persist_why when out of scope.
-  bool persist_on = false, persist_tried = false;
-  woq::Persist* persist = nullptr;
-  std::string persist_why;
-  woq::Persist* persist_get();
   // tensor parallel ranks take the XQ path when the exchange runs on the device (its all-reduce kernel then emits the
   // next XQ vector itself); with a host-side transport they keep the fp32-activation kernels
   bool tp_xq = true, tp_fused_push = true;
@@ -168,16 +155,6 @@ struct woq_engine {
   int attn_chunk = 0;           // grouped form: positions per slice of the position-independent geometry, 0 = adaptive
   bool time_eager = true;       // woq_engine_time_gemv / _twin: passes issued eagerly (how bursts run by default) or as a
                                 // replayed graph (round 3's measure; woq_engine_set_time_eager(e, 0))
-  // token-long weight prefetcher (woq_prefetch.hip): a dependency-free branch of the step, forked behind the embedding
-  // kernel and joined in front of the head's argmax; off by default (woq_engine_set_prefetch / WOQ_ENGINE_PREFETCH)
-  bool wpf_on = false;
-  int wpf_waves = 4, wpf_depth = 16, wpf_lead = 2, wpf_lead_kind = -1, wpf_wrap = 1, wpf_head_mb = 0, wpf_grid = 256;
-  void* wpf_items = nullptr;
-  int wpf_n = 0;
-  hipStream_t wpf_stream = nullptr;
-  hipEvent_t wpf_fork = nullptr, wpf_join = nullptr;
-  int wpf_prepare();
-  bool wpf_applies() const { return wpf_on && use_xq() && cfg.tp_size <= 1 && qkv_g != nullptr && tags_ok(); }
   int max_batch = 1;
   size_t pf_rows = 0, pf_ws_bytes = 0;
   float* pf_h = nullptr;        // fp32 residual stream [rows][hidden]
@@ -193,25 +170,6 @@ using namespace woq;
 
 const woq::CommDev* woq_engine::tp_push() const {
   return cfg.tp_size > 1 && comm != nullptr && tp_fused_push ? woq_comm_dev_ptr(comm) : nullptr;
-}
-
-woq::Persist* woq_engine::persist_get() {
-  if (!persist_on || !use_xq() || cfg.tp_size > 1 || qkv_g == nullptr || attn_grouped || attn_splits > 1 || window != 0 ||
-      !tags_ok())
-    return nullptr;
-  if (!persist_tried) {
-    persist_tried = true;
-    woq::PersistDesc d;
-    d.layers = cfg.layers, d.hidden = cfg.hidden, d.inter = cfg.inter, d.heads = cfg.heads, d.kv_heads = cfg.kv_heads;
-    d.head_dim = cfg.head_dim, d.kv_dtype = cfg.kv_dtype, d.max_ctx = cfg.max_ctx, d.window = window;
-    d.attn_splits = attn_splits, d.eps = cfg.rms_eps;
-    d.lw = layers.data();
-    d.kcache = kcache, d.vcache = vcache, d.kv_layer_bytes = kv_layer_bytes;
-    d.seq = step_seq, d.pos = pos, d.status = fuse_status, d.cs = cs, d.sn = sn;
-    d.x0 = xq_hidden, d.ssq0 = ssq_part, d.qkv_g = qkv_g, d.hidden_buf = hidden;
-    persist = woq::persist_create(d, &persist_why);
-  }
-  return persist;
 }
 
 static const XqPtrs kNoXq = {nullptr, nullptr, nullptr};
@@ -327,7 +285,7 @@ static int engine_mlp_block(woq_engine* e, int l, hipStream_t st) {
 // fuse_next: this step's greedy argmax and the NEXT step's embedding kernel as one launch (steps chained inside one
 // captured graph; one GPU, greedy) — woq_ops.hip argmax_embed_kernel
 static bool engine_can_fuse_next(const woq_engine* e, int greedy) {
-  return greedy && e->cfg.tp_size <= 1 && e->comm == nullptr && !e->wpf_on && !(engine_skip_mask() & 32);
+  return greedy && e->cfg.tp_size <= 1 && e->comm == nullptr && !(engine_skip_mask() & 32);
 }
 static int engine_head(woq_engine* e, int greedy, hipStream_t st, bool fuse_next = false) {
   const woq_engine_config& c = e->cfg;
@@ -394,62 +352,12 @@ static void engine_embed(woq_engine* e, hipStream_t st) {
                st);
 }
 
-// the prefetcher's work list: every layer's blobs in consumption order, the first MiB of the head, then (wrap) layer 0
-// again for the NEXT token — the weights are the same every token, so the tail of this token's prefetcher warms the
-// head of the next one and the next prefetcher starts at layer 1 (first_vlayer)
-int woq_engine::wpf_prepare() {
-  if (wpf_items != nullptr) return 0;
-  std::vector<const void*> ptrs;
-  std::vector<size_t> bytes;
-  std::vector<int> vl, kind;
-  auto add_layer = [&](int l, int v) {
-    const woq_layer_weights& w = layers[l];
-    const void* b[4] = {w.qkv_blob, w.o_blob, w.gate_up_blob, w.down_blob};
-    const woq_blob_header* h[4] = {&w.qkv_hdr, &w.o_hdr, &w.gate_up_hdr, &w.down_hdr};
-    for (int j = 0; j < 4; ++j) {
-      ptrs.push_back(b[j]), bytes.push_back((size_t)h[j]->total_bytes), vl.push_back(v), kind.push_back(j);
-    }
-  };
-  for (int l = 0; l < cfg.layers; ++l) add_layer(l, l);
-  if (wpf_head_mb > 0 && lm_head != nullptr) {
-    const size_t all = (size_t)cfg.vocab * cfg.hidden * 2;
-    ptrs.push_back(lm_head), bytes.push_back(std::min(all, (size_t)wpf_head_mb << 20)), vl.push_back(cfg.layers);
-    kind.push_back(4);
-  }
-  if (wpf_wrap) add_layer(0, cfg.layers);  // paced like the head: allowed once the last layer's qkv is out
-  int rc = prefetch_build_items(ptrs, bytes, vl, kind, &wpf_items, &wpf_n);
-  if (rc) return rc;
-  owned.push_back(wpf_items);
-  if (!wpf_stream) WOQ_HIP(hipStreamCreateWithFlags(&wpf_stream, hipStreamNonBlocking));
-  if (!wpf_fork) WOQ_HIP(hipEventCreateWithFlags(&wpf_fork, hipEventDisableTiming));
-  if (!wpf_join) WOQ_HIP(hipEventCreateWithFlags(&wpf_join, hipEventDisableTiming));
-  return 0;
-}
-
 // chain bit 0: the previous step of the same captured graph already ran this step's embedding (its fused tail);
 // bit 1: this step's tail is fused with the next step's embedding
 static int engine_step_impl(woq_engine* e, int greedy, hipStream_t st, int chain = 0) {
   const woq_engine_config& c = e->cfg;
   const bool fuse_next = (chain & 2) != 0;
   if (!(chain & 1)) engine_embed(e, st);
-  if (woq::Persist* p = e->persist_get()) {  // embedding -> [all layers, one launch] -> head
-    woq::persist_rebind(p, e->pos, e->hidden);
-    const int rc = woq::persist_launch(p, st);
-    if (rc) return rc;
-    return engine_head(e, greedy, st, fuse_next);
-  }
-  const bool wpf = e->wpf_applies();
-  if (wpf) {  // fork: the prefetcher depends on the embedding kernel only (it reads the step counter that kernel advanced)
-    int rc = e->wpf_prepare();
-    if (rc) return rc;
-    WOQ_HIP(hipEventRecord(e->wpf_fork, st));
-    WOQ_HIP(hipStreamWaitEvent(e->wpf_stream, e->wpf_fork, 0));
-    if ((rc = launch_prefetch(e->wpf_items, e->wpf_n, e->qkv_g, e->step_seq, e->wpf_lead, e->wpf_lead_kind,
-                              e->wpf_wrap ? 1 : 0, e->wpf_grid, e->wpf_waves, e->wpf_depth, (unsigned int*)e->am_idx,
-                              e->wpf_stream)) != 0)
-      return rc;
-    WOQ_HIP(hipEventRecord(e->wpf_join, e->wpf_stream));
-  }
   for (int l = 0; l < c.layers; ++l) {
     int rc = engine_attn_block(e, l, st);
     if (rc) return rc;
@@ -458,9 +366,7 @@ static int engine_step_impl(woq_engine* e, int greedy, hipStream_t st, int chain
     if (rc) return rc;
     if ((rc = engine_allreduce_after(e, l, 1, st)) != 0) return rc;
   }
-  const int rc = engine_head(e, greedy, st, fuse_next);
-  if (wpf) WOQ_HIP(hipStreamWaitEvent(st, e->wpf_join, 0));  // join: the step ends when both branches have
-  return rc;
+  return engine_head(e, greedy, st, fuse_next);
 }
 
 // ---- prompt pass -------------------------------------------------------------------------------------------------
@@ -649,33 +555,6 @@ int woq_engine_set_time_eager(woq_engine* e, int on) {
   e->time_eager = on != 0;
   WOQ_END
 }
-int woq_engine_set_persist(woq_engine* e, int on) {
-  WOQ_TRY
-  WOQ_CHECK(e != nullptr, "QBits: null engine");
-  e->persist_on = on != 0;  // takes effect at the next step / capture
-  WOQ_END
-}
-// 1 when the next step runs its layers as the persistent launch; 0 otherwise (woq_last_error() then says why, if the
-// model or device is outside its scope)
-int woq_engine_persist(woq_engine* e) {
-  if (!e || e->layers.empty()) return 0;
-  if (e->persist_get() != nullptr) return 1;
-  if (e->persist_on && e->persist_tried && !e->persist_why.empty())
-    woq::fail("QBits: persistent decode launch not used: " + e->persist_why);
-  return 0;
-}
-// diagnostics of the persistent launch: stamps_dev = device buffer of grid * layers * 4 * 32 uint64 (or null: off);
-// *grid / *ring_tiles (optional) report the launch's geometry. Fails when the persistent launch is not in use.
-int woq_engine_persist_stamps(woq_engine* e, void* stamps_dev, int* grid, int* ring_tiles) {
-  WOQ_TRY
-  WOQ_CHECK(e != nullptr, "QBits: null engine");
-  woq::Persist* p = e->persist_get();
-  WOQ_CHECK(p != nullptr, "QBits: the persistent decode launch is not in use");
-  woq::persist_set_stamps(p, (unsigned long long*)stamps_dev);
-  if (grid) *grid = woq::persist_grid(p);
-  if (ring_tiles) *ring_tiles = woq::persist_ring_tiles(p);
-  WOQ_END
-}
 int woq_engine_set_tp_options(woq_engine* e, int xq, int fused_push) {
   WOQ_TRY
   WOQ_CHECK(e != nullptr, "QBits: null engine");
@@ -775,10 +654,6 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
     e->xq_enabled = sw ? sw[0] != '0' : true;
     const char* fa = getenv("WOQ_ENGINE_FUSE_ATTN");
     e->fuse_attn = fa ? fa[0] != '0' : true;
-    const char* pe = getenv("WOQ_ENGINE_PERSIST");
-    e->persist_on = pe ? pe[0] != '0' : false;
-    const char* wp = getenv("WOQ_ENGINE_PREFETCH");
-    e->wpf_on = wp ? wp[0] != '0' : false;
     const char* tx = getenv("WOQ_TP_XQ");
     e->tp_xq = tx ? tx[0] != '0' : true;
     const char* tf = getenv("WOQ_TP_FUSED_PUSH");
@@ -812,10 +687,6 @@ void woq_engine_destroy(woq_engine* e) {
   if (e->graph) hipGraphDestroy(e->graph);
   if (e->exec_k) hipGraphExecDestroy(e->exec_k);
   if (e->graph_k) hipGraphDestroy(e->graph_k);
-  woq::persist_destroy(e->persist);
-  if (e->wpf_stream) hipStreamDestroy(e->wpf_stream);
-  if (e->wpf_fork) hipEventDestroy(e->wpf_fork);
-  if (e->wpf_join) hipEventDestroy(e->wpf_join);
   for (void* p : e->owned) hipFree(p);
   for (void* p : {(void*)e->pf_h, (void*)e->pf_qkv, (void*)e->pf_attn, (void*)e->pf_act, e->pf_ws})
     if (p) hipFree(p);
@@ -827,7 +698,7 @@ int woq_engine_set_layer(woq_engine* e, int layer, const woq_layer_weights* w) {
   WOQ_CHECK(e && w && layer >= 0 && layer < e->cfg.layers, "QBits: bad layer index");
   const woq_engine_config& c = e->cfg;
   // int4, or (round 4) a 4-bit table type: the same kernels with a digit-plane unpack (woq_gemv_common.h LutArgs); the
-  // fused qkv + attention launch and the persistent launch stay int4-only (their support checks say no)
+  // fused qkv + attention launch stays int4-only (its support check says no)
   auto takes = [](const woq_blob_header& h) {
     return h.weight_type == WOQ_W_INT4_CLIP || (is_table_type(h.weight_type) && h.off_zp == 0);
   };
@@ -843,12 +714,6 @@ int woq_engine_set_layer(woq_engine* e, int layer, const woq_layer_weights* w) {
             "QBits: gate_up blob shape mismatch (inter must be a multiple of 16)");
   WOQ_CHECK(w->down_hdr.K == c.inter && w->down_hdr.N == c.hidden, "QBits: down_proj blob shape mismatch");
   e->layers[layer] = *w;
-  e->wpf_items = nullptr;  // the prefetcher's work list holds the old layer's pointers (the buffer stays in `owned`)
-  if (e->persist_tried) {  // the plan holds the old layer's pointers
-    woq::persist_destroy(e->persist);
-    e->persist = nullptr;
-    e->persist_tried = false;
-  }
   e->xq_shapes_ok = e->xq_shapes_ok && gemv_xq_supported(w->qkv_hdr, 0) && gemv_xq_supported(w->o_hdr, 0) &&
                     gemv_xq_supported(w->gate_up_hdr, 1) && gemv_xq_supported(w->down_hdr, 0);
   WOQ_END
@@ -1084,81 +949,6 @@ int woq_engine_time_gemv_mask(woq_engine* e, int mask, int reps, void* stream, f
 int woq_engine_time_gemv(woq_engine* e, int reps, void* stream, float* total_ms, double* bytes_per_pass,
                          int* launches_per_pass) {
   return woq_engine_time_gemv_mask(e, 15, reps, stream, total_ms, bytes_per_pass, launches_per_pass);
-}
-
-// Token-long weight prefetcher beside the step (woq_prefetch.hip). waves x depth KiB in flight per workgroup, `grid`
-// workgroups; lead / lead_kind: how far ahead of the layer whose qkv has been published it may run (layers, and
-// projections of the last of them: -1 none ... 3 all); wrap: prefetch layer 0 again at the end, for the next token;
-// head_mb: MiB of the lm_head to touch after the last layer. Takes effect at the next step / capture.
-int woq_engine_set_prefetch(woq_engine* e, int on, int grid, int waves, int depth, int lead, int lead_kind, int wrap,
-                            int head_mb) {
-  WOQ_TRY
-  WOQ_CHECK(e != nullptr, "QBits: null engine");
-  WOQ_CHECK(grid >= 1 && grid <= 4096 && waves >= 1 && waves <= 4 && (depth == 4 || depth == 8 || depth == 16 || depth == 32),
-            "QBits: prefetch geometry out of range");
-  WOQ_CHECK(lead >= 1 && lead <= 8 && lead_kind >= -1 && lead_kind <= 3 && head_mb >= 0, "QBits: prefetch lead out of range");
-  e->wpf_on = on != 0;
-  e->wpf_grid = grid, e->wpf_waves = waves, e->wpf_depth = depth, e->wpf_lead = lead, e->wpf_lead_kind = lead_kind;
-  if ((e->wpf_wrap != (wrap != 0)) || e->wpf_head_mb != head_mb) e->wpf_items = nullptr;
-  e->wpf_wrap = wrap != 0, e->wpf_head_mb = head_mb;
-  WOQ_END
-}
-int woq_engine_prefetch(woq_engine* e) { return e && e->wpf_applies() ? 1 : 0; }
-
-// Measurement: one projection's decode launch over every layer, (i) as it runs in the step —
-// every blob cold, the model is 13x the Infinity Cache — and (ii) with each blob READ BY ANOTHER KERNEL `lead` launches
-// earlier (a full-chip default-policy streaming read, what a prefetcher leaves behind): us[0] = cold pass per launch,
-// us[1] = readers alone per launch, us[2] = readers + launches per launch; hot = us[2] - us[1]. proj 0 qkv (stand-alone
-// launch), 1 o, 2 gate/up, 3 down; twin = the load-only twin instead of the GEMV.
-int woq_engine_mall_probe(woq_engine* e, int proj, int twin, int lead, int reps, void* stream, float* us) {
-  WOQ_TRY
-  WOQ_CHECK(e && us && proj >= 0 && proj < 4 && lead >= 0 && reps >= 1 && e->use_xq(), "QBits: bad argument");
-  hipStream_t st = (hipStream_t)stream;
-  const woq_engine_config& c = e->cfg;
-  unsigned int* sink = (unsigned int*)e->am_idx;
-  auto blob_of = [&](int l, const woq_blob_header** h) -> const void* {
-    const woq_layer_weights& w = e->layers[l];
-    switch (proj) {
-      case 0: *h = &w.qkv_hdr; return w.qkv_blob;
-      case 1: *h = &w.o_hdr; return w.o_blob;
-      case 2: *h = &w.gate_up_hdr; return w.gate_up_blob;
-      default: *h = &w.down_hdr; return w.down_blob;
-    }
-  };
-  auto gemv = [&](int l, hipStream_t st) -> int {
-    const woq_blob_header* h;
-    const void* b = blob_of(l, &h);
-    if (twin) return launch_gemv_twin(b, *h, proj == 2 ? 1 : 0, 0, sink, st);
-    const woq_layer_weights& w = e->layers[l];
-    switch (proj) {
-      case 0: return engine_gemv_xq(e, e->xq_hidden, b, *h, e->qkv, e->ssq_part, nullptr, 0, kNoXq, nullptr, nullptr, st);
-      case 1: return engine_gemv_xq(e, e->xq_attn, b, *h, e->hidden, nullptr, e->hidden, 0, e->xq_hidden, w.ln2, e->ssq_part, st);
-      case 2: return engine_gemv_xq(e, e->xq_hidden, b, *h, nullptr, e->ssq_part, nullptr, 1, e->xq_act, nullptr, nullptr, st);
-      default: return engine_gemv_xq(e, e->xq_act, b, *h, e->hidden, nullptr, e->hidden, 0, kNoXq, nullptr, nullptr, st);
-    }
-  };
-  auto reader = [&](int l, hipStream_t st) {
-    const woq_blob_header* h;
-    const void* b = blob_of((l + lead) % c.layers, &h);
-    launch_stream_read(b, (size_t)h->total_bytes, sink, st);
-  };
-  for (int mode = 0; mode < 3; ++mode) {
-    auto pass = [&](hipStream_t st) -> int {
-      for (int l = 0; l < c.layers; ++l) {
-        if (mode >= 1) reader(l, st);
-        if (mode != 1) {
-          const int rc = gemv(l, st);
-          if (rc) return rc;
-        }
-      }
-      return 0;
-    };
-    float ms = 0.f;
-    const int rc = time_captured(st, reps, pass, &ms, true);
-    if (rc) return rc;
-    us[mode] = ms * 1e3f / (float)(reps * c.layers);
-  }
-  WOQ_END
 }
 
 // roofline.ceiling of bench.py: the decode step's four GEMV launches per layer with the arithmetic taken out — mode 0:

@@ -315,7 +315,9 @@ __global__ __launch_bounds__(CB * TPW > 8 ? 512 : (SMODE == 1 ? 768 : 1024)) voi
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bool live = lane * 4 + j * 256 + i < xlen;
-        const int id = live ? (int)idv[j][i] : 0;
+        // the blob's shuffle vector is foreign data (a checkpoint's g_idx): an index outside [0, K) must not read LDS
+        // out of range — clamp it (the result is then wrong for that row only, never an out-of-bounds access)
+        const int id = live ? min(max((int)idv[j][i], 0), K - 1) : 0;
         const float v = xs[id];
         f[i] = live ? v : 0.f;
       }

@@ -142,7 +142,11 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
 #pragma unroll
   for (int w = 1; w < 4; ++w)
     if (bv[w] > best || (bv[w] == best && bi[w] < idx)) best = bv[w], idx = bi[w];
+  // no candidate won (every logit NaN): the sentinel must not index the embedding table — token 0 and a status bit
+  const bool no_winner = idx < 0 || (size_t)idx >= (size_t)n_pairs * 16;
+  if (no_winner) idx = 0;
   if (blockIdx.x == 0 && tid == 0) {
+    if (no_winner && status != nullptr) atomicOr(status, 4);
     token[0] = idx;
     int p = pos[0];
     if (log != nullptr) log[p] = idx;
@@ -248,21 +252,7 @@ __global__ __launch_bounds__(256) void lm_head_kernel(const float* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   float wbest = -INFINITY;  // this wave's best (logit, row) — rows ascend, so '>' keeps the lowest index on ties
   int wbi = 0x7fffffff;
-  // experiment (off, see WOQ_LM_PRE): the wave's FIRST weight row requested before the activation prologue (hidden ->
-  // LDS, sum of squares, two barriers: ~2 us during which every workgroup of the launch leaves HBM idle); hidden <= 4096
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  constexpr int PRE = 8;
-  u32x4 pre[PRE];
-#ifndef WOQ_LM_PRE  // A/B builds: -DWOQ_LM_PRE=1. Measured SLOWER (kernel trace, same box, alternating: 51.0 / 51.3 us with
-#define WOQ_LM_PRE 0  // the preload against 48.7 / 47.3 without, profiles/r05i_*): off
-#endif
-  const bool use_pre = WOQ_LM_PRE && hidden <= PRE * 512 && (int)blockIdx.x * 16 + wid < vocab;
-  if (use_pre) {
-    const uint16_t* wr0 = (const uint16_t*)W + (size_t)((int)blockIdx.x * 16 + wid) * hidden;
-#pragma unroll
-    for (int j = 0; j < PRE; ++j)
-      if (lane * 8 + j * 512 < hidden) pre[j] = __builtin_nontemporal_load((const u32x4*)(wr0 + lane * 8 + j * 512));
-  }
   float ss = 0.f;
   for (int i = tid; i < hidden; i += 256) {
     const float v = hidden_in[i];
@@ -300,14 +290,7 @@ __global__ __launch_bounds__(256) void lm_head_kernel(const float* __restrict__ 
       wbi = v;
     }
   };
-  if (use_pre) {  // the row requested up front (row `wid` of the workgroup's sixteen)
-    float acc = 0.f;
-#pragma unroll
-    for (int j = 0; j < PRE; ++j)
-      if (lane * 8 + j * 512 < hidden) consume(pre[j], lane * 8 + j * 512, acc);
-    finish((int)blockIdx.x * rows_per_wg + wid, acc);
-  }
-  for (int r = wid + (use_pre ? 4 : 0); r < rows_per_wg; r += 4) {
+  for (int r = wid; r < rows_per_wg; r += 4) {
     const int v = blockIdx.x * rows_per_wg + r;
     if (v >= vocab) break;
     const uint16_t* wr = (const uint16_t*)W + (size_t)v * hidden;

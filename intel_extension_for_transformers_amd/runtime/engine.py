@@ -289,46 +289,6 @@ class WoqDecoderEngine:
             L.check(L.lib().woq_engine_set_attn_chunk(self._h, int(chunk)))
             self.captured = False
 
-    def set_prefetch(self, on=True, grid=256, waves=4, depth=16, lead=2, lead_kind=-1, wrap=True, head_mb=0):
-        """Token-long weight prefetcher beside the decode step (csrc/woq_prefetch.hip); re-capture afterwards."""
-        L.check(L.lib().woq_engine_set_prefetch(self._h, int(bool(on)), int(grid), int(waves), int(depth), int(lead),
-                                                int(lead_kind), int(bool(wrap)), int(head_mb)))
-        self.captured = False
-
-    def uses_prefetch(self):
-        return bool(L.lib().woq_engine_prefetch(self._h))
-
-    def mall_probe(self, proj, twin=False, lead=1, reps=10):
-        """(cold us, hot us) per launch of projection `proj` (0 qkv, 1 o, 2 gate/up, 3 down): every blob cold, as in the
-        step, vs read by another kernel `lead` launches earlier (tools/visits/r05a_mall.py)."""
-        us = (ctypes.c_float * 3)()
-        L.check(L.lib().woq_engine_mall_probe(self._h, int(proj), int(bool(twin)), int(lead), int(reps), L.stream_ptr(), us))
-        return us[0], us[2] - us[1], us[1]
-
-    def set_persist(self, on):
-        """Decode step: all layers as ONE persistent launch (csrc/woq_persist.hip) where the model fits its scope.
-        Invalidates a captured graph."""
-        L.check(L.lib().woq_engine_set_persist(self._h, int(bool(on))))
-        self.captured = False
-
-    def uses_persist(self):
-        """True when the next step / capture runs the persistent launch."""
-        return bool(L.lib().woq_engine_persist(self._h))
-
-    def persist_stamps(self, on=True):
-        """Diagnostics of the persistent launch: returns a uint64 tensor [grid, layers * 4, 32] that every later step
-        fills with 100 MHz wall-clock stamps per (workgroup, projection) (csrc/woq_persist.hip PS_STAMP), plus the
-        ring size in tiles; on=False turns the stamps off again."""
-        g, r = ctypes.c_int(), ctypes.c_int()
-        if not on:
-            L.check(L.lib().woq_engine_persist_stamps(self._h, None, ctypes.byref(g), ctypes.byref(r)))
-            self._stamps = None
-            return None, r.value
-        L.check(L.lib().woq_engine_persist_stamps(self._h, None, ctypes.byref(g), ctypes.byref(r)))
-        self._stamps = torch.zeros(g.value, int(self.cfg.layers) * 4, 32, dtype=torch.int64, device="cuda")
-        L.check(L.lib().woq_engine_persist_stamps(self._h, ctypes.c_void_p(self._stamps.data_ptr()), None, None))
-        return self._stamps, r.value
-
     def set_tp_options(self, xq=True, fused_push=True):
         """Tensor-parallel decode with a device communicator: `xq` = the XQ decode kernels with an XQ-emitting
         all-reduce kernel (off: the fp32-activation kernels), `fused_push` = o_proj / down_proj push their partial sums
