@@ -952,6 +952,14 @@ def main():
     args = ap.parse_args()
     global CONDITION_MS
     CONDITION_MS = args.condition_ms
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("WOQ_BENCH_BACKEND", "nccl") == "nccl":
+        import torch
+
+        seen = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if seen < args.gpus:  # before any rank is spawned or any device is touched
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible on this node; one rank per GPU over RCCL "
+                             "needs %d (the N > 1 line is configs[3], Llama-2-70B at tensor-parallel degree N: unmeasured "
+                             "on hardware until a node runs it)" % (args.gpus, seen, args.gpus))
     respawn = spawn_command(args.gpus, os.environ, sys.argv[1:])
     if respawn is not None:  # plain `python bench.py --gpus N`, N > 1: become torch.distributed.run's N ranks
         sys.stdout.flush()
@@ -967,6 +975,9 @@ def main():
                          "not be what was asked for" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if world > 1 and os.environ.get("WOQ_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible on this node (one rank per GPU over RCCL)"
+                         % (world, torch.cuda.device_count()))
     # WOQ_BENCH_BACKEND=gloo (development): the N > 1 code path with several ranks on ONE GPU — RCCL refuses that, the
     # device exchange does not need it (tests/test_gpu_tp_device.py). Never what the driver runs.
     backend = os.environ.get("WOQ_BENCH_BACKEND", "nccl")

@@ -23,7 +23,6 @@
 
 #include "woq_attn_decode.h"
 #include "woq_gemv_common.h"
-#include "woq_gemv_xqm.h"
 #include "woq_gemv_xqs.h"
 #include "woq_launch.h"
 #include "woq_xq.h"
@@ -48,53 +47,28 @@ struct FusedAttnArgs {
 #define WOQ_XQS_DEPTH 4
 #endif
 constexpr int FUSED_TPW = 8, FUSED_D = WOQ_XQS_DEPTH;
+// the fused launch's 14th argument dword: tpg_shift | flags << 8 | strips << 16 — the strip workgroups come first in the
+// grid, one attention workgroup per head behind them — so that the role test needs nothing but preloaded arguments
+// (gridDim is a hidden argument: it lives in the argument segment too)
+__device__ __forceinline__ int fa_strips_of_grid(int tpg_flags) { return (tpg_flags >> 16) & 0xffff; }
 
 template <int SMODE, bool ASYM, bool S32, typename KV>
 __global__ __launch_bounds__(256) void gemv_xqs_attn_kernel(
     const u32x4* __restrict__ q, const void* __restrict__ scales, const uint8_t* __restrict__ xlimbs,
-    const float* __restrict__ xu, int tiles_k, int kt_off, int base_tiles, int rem_tiles, int n_groups, int tpg_shift,
-    const uint8_t* __restrict__ zp, const float* __restrict__ xsx, unsigned long long* __restrict__ qkv_g,
-    const float* __restrict__ bias, float eps, int N, int K, int flags, const float* __restrict__ ssq_in, int n_ssq,
-    FusedAttnArgs fa) {
+    const float* __restrict__ xu, int tiles_k, int kt_off, int base_tiles, int rem_tiles, int n_groups, int tpg_flags,
+    XqsLate late_in_the_argument_segment, unsigned long long* __restrict__ qkv_g, int N, FusedAttnArgs fa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const unsigned int tag = (fa.seq[0] << 6) | (unsigned int)fa.layer;
-  const int n_strips = N >> 4;
+  const int n_strips = fa_strips_of_grid(tpg_flags);
   if ((int)blockIdx.x >= n_strips) {  // the attention workgroup of head blockIdx.x - n_strips
+    const unsigned int tag = (fa.seq[0] << 6) | (unsigned int)fa.layer;
     attn_decode_body<KV, 128, false>((float*)smem_raw, (int)blockIdx.x - n_strips, 0, 1,
                                      AttnGranule{qkv_g, tag, fa.status}, (KV*)fa.kcache, (KV*)fa.vcache, fa.pos, fa.cs,
                                      fa.sn, fa.heads, fa.kv_heads, fa.window, fa.spw, fa.attn_out, fa.xq_attn);
     return;
   }
-  const XqPtrs no_xq = {nullptr, nullptr, nullptr};
-  gemv_xqs_body<FUSED_TPW, 1, FUSED_D, SMODE, ASYM, S32, true>(
-      smem_raw, q, scales, xlimbs, xu, tiles_k, kt_off, base_tiles, rem_tiles, n_groups, tpg_shift, zp, xsx,
-      (float*)qkv_g, bias, nullptr, eps, N, K, flags, ssq_in, n_ssq, no_xq, nullptr, nullptr, tag);
-}
-
-// round 6: the strips as 256 long-lived workgroups (woq_gemv_xqm.h: 8 waves x 4 tiles, SMAX strips each, q strips
-// first) + the attention workgroups (4 of their 8 waves; the others retire at once)
-bool xqm_geometry(int tiles_k, int cb, int n_strips, bool s32, int& nw, int& tpw, int& n_wg, int& smax);
-template <int SMODE, bool ASYM, typename KV, int SMAX>
-__global__ __launch_bounds__(512) void gemv_xqm_attn_kernel(
-    const u32x4* __restrict__ q, const void* __restrict__ scales, const uint8_t* __restrict__ xlimbs,
-    const float* __restrict__ xu, int tiles_k, int kt_off, int base_tiles, int rem_tiles, int n_groups, int tpg_shift,
-    const uint8_t* __restrict__ zp, const float* __restrict__ xsx, unsigned long long* __restrict__ qkv_g,
-    const float* __restrict__ bias, float eps, int N, int K, int flags, const float* __restrict__ ssq_in, int n_ssq,
-    FusedAttnArgs fa, int n_wg) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const unsigned int tag = (fa.seq[0] << 6) | (unsigned int)fa.layer;
-  if ((int)blockIdx.x >= n_wg) {  // the attention workgroup of head blockIdx.x - n_wg
-    if (threadIdx.x >= 256) return;
-    attn_decode_body<KV, 128, false>((float*)smem_raw, (int)blockIdx.x - n_wg, 0, 1, AttnGranule{qkv_g, tag, fa.status},
-                                     (KV*)fa.kcache, (KV*)fa.vcache, fa.pos, fa.cs, fa.sn, fa.heads, fa.kv_heads,
-                                     fa.window, fa.spw, fa.attn_out, fa.xq_attn);
-    return;
-  }
-  const XqPtrs no_xq = {nullptr, nullptr, nullptr};
-  gemv_xqm_body<4, 1, SMODE, ASYM, false, true, SMAX>(smem_raw, q, scales, xlimbs, xu, tiles_k, kt_off, base_tiles,
-                                                      rem_tiles, n_groups, tpg_shift, zp, xsx, (float*)qkv_g, bias,
-                                                      nullptr, eps, N, K, flags, ssq_in, n_ssq, no_xq, nullptr, nullptr,
-                                                      nullptr, N >> 4, n_wg, tag);
+  gemv_xqs_body<FUSED_TPW, 1, FUSED_D, SMODE, ASYM, S32, true>(smem_raw, q, scales, xlimbs, xu, tiles_k, kt_off,
+                                                              base_tiles, rem_tiles, n_groups, tpg_flags & 0xff,
+                                                              (tpg_flags >> 8) & 0xff, 4, xqs_late_ptr());
 }
 
 // does the fused launch take this (blob, attention) combination?
@@ -141,9 +115,14 @@ static int launch_fused_t(const FusedLaunch& a, hipStream_t st) {
     if (e != hipSuccess) return woq::fail(std::string("QBits: hipFuncSetAttribute: ") + hipGetErrorString(e));
     attr_set = true;
   }
+  XqsLate late;
+  late.zp = (const uint8_t*)a.zp, late.xsx = a.xin.sx, late.out = (float*)a.out, late.bias = nullptr, late.residual = nullptr;
+  late.ssq_in = a.ssq_in, late.next_norm_w = nullptr, late.ssq_out = nullptr, late.tp = nullptr;
+  late.tag_seq = a.fa.seq, late.tag_layer = a.fa.layer, late.xo = XqPtrs{nullptr, nullptr, nullptr}, late.eps = a.eps;
+  late.N = a.N, late.K = a.K, late.n_ssq = a.n_ssq, late.lut = LutArgs{};
   hipLaunchKernelGGL(kern, dim3(a.N / 16 + a.fa.heads), dim3(256), a.lds, st, (const u32x4*)a.q, a.scales, a.xin.limbs, a.xin.u,
-                     a.tiles_k, 0, FUSED_TPW, 0, a.n_groups, a.tpg_shift, (const uint8_t*)a.zp, a.xin.sx, a.out,
-                     (const float*)nullptr, a.eps, a.N, a.K, a.flags, a.ssq_in, a.n_ssq, a.fa);
+                     a.tiles_k, 0, FUSED_TPW, 0, a.n_groups, a.tpg_shift | (a.flags << 8) | ((a.N / 16) << 16), late, a.out,
+                     a.N, a.fa);
   return 0;
 }
 
@@ -160,32 +139,6 @@ static int launch_fused_kv(const FusedLaunch& a, int smode, bool asym, bool s32,
   WOQ_FA_CASE(1, true, false)
   WOQ_FA_CASE(1, true, true)
 #undef WOQ_FA_CASE
-  return woq::fail("QBits: bad fused qkv + attention configuration");
-}
-
-template <int SMODE, bool ASYM, typename KV, int SMAX>
-static int launch_fused_m_t(const FusedLaunch& a, int n_wg, hipStream_t st) {
-  auto kern = gemv_xqm_attn_kernel<SMODE, ASYM, KV, SMAX>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return woq::fail(std::string("QBits: hipFuncSetAttribute: ") + hipGetErrorString(e));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(n_wg + a.fa.heads), dim3(512), a.lds, st, (const u32x4*)a.q, a.scales, a.xin.limbs,
-                     a.xin.u, a.tiles_k, 0, 4, 0, a.n_groups, a.tpg_shift, (const uint8_t*)a.zp, a.xin.sx, a.out,
-                     (const float*)nullptr, a.eps, a.N, a.K, a.flags, a.ssq_in, a.n_ssq, a.fa, n_wg);
-  return 0;
-}
-template <typename KV>
-static int launch_fused_m_kv(const FusedLaunch& a, int smode, bool asym, int n_wg, int smax, hipStream_t st) {
-#define WOQ_FM_CASE(SM, AS, SX) \
-  if (smode == SM && asym == AS && smax == SX) return launch_fused_m_t<SM, AS, KV, SX>(a, n_wg, st);
-  WOQ_FM_CASE(0, false, 1) WOQ_FM_CASE(0, false, 2) WOQ_FM_CASE(0, false, 3) WOQ_FM_CASE(0, false, 4)
-  WOQ_FM_CASE(0, true, 1) WOQ_FM_CASE(0, true, 2) WOQ_FM_CASE(0, true, 3) WOQ_FM_CASE(0, true, 4)
-  WOQ_FM_CASE(1, false, 1) WOQ_FM_CASE(1, false, 2) WOQ_FM_CASE(1, false, 3) WOQ_FM_CASE(1, false, 4)
-  WOQ_FM_CASE(1, true, 1) WOQ_FM_CASE(1, true, 2) WOQ_FM_CASE(1, true, 3) WOQ_FM_CASE(1, true, 4)
-#undef WOQ_FM_CASE
   return woq::fail("QBits: bad fused qkv + attention configuration");
 }
 
@@ -223,17 +176,6 @@ int launch_gemv_xq_attn(const XqPtrs& xin, const void* blob, const woq_blob_head
   const int spw = attn_dec_spw(max_ctx);
   a.fa = FusedAttnArgs{seq, layer, status, kcache, vcache, pos, cs, sn, heads, kv_heads, window, spw, attn_out, xq_attn};
   const size_t lds_attn = attn_dec_lds_floats(128, max_ctx) * 4;
-  {
-    int nw, tpw, n_wg, smax;
-    if (xqm_geometry(a.tiles_k, 1, a.N / 16, s32, nw, tpw, n_wg, smax) && tpw == 4 && nw == 8) {
-      a.lds = std::max(lds_attn, smode == 0 ? (asym ? XqmLds<4, 1, 0, true, false>::total(8, smax) : XqmLds<4, 1, 0, false, false>::total(8, smax))
-                                            : (asym ? XqmLds<4, 1, 1, true, false>::total(8, smax) : XqmLds<4, 1, 1, false, false>::total(8, smax)));
-      if (a.lds > 160 * 1024) return woq::fail("QBits: fused qkv + attention launch does not fit LDS");
-      if (kv_dtype == WOQ_F16) return launch_fused_m_kv<_Float16>(a, smode, asym, n_wg, smax, st);
-      if (kv_dtype == WOQ_FP8_E4M3) return launch_fused_m_kv<Fp8>(a, smode, asym, n_wg, smax, st);
-      return launch_fused_m_kv<__bf16>(a, smode, asym, n_wg, smax, st);
-    }
-  }
   size_t lds_gemv = 0;
   if (smode == 0)
     lds_gemv = asym ? (s32 ? XqsLds<FUSED_TPW, 1, 0, true, true>::total(4) : XqsLds<FUSED_TPW, 1, 0, true, false>::total(4))

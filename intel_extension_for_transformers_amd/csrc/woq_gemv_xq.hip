@@ -6,9 +6,18 @@
 #include <cstdlib>
 
 #include "woq_gemv_common.h"
-#include "woq_gemv_xqm.h"
+#ifdef WOQ_XQS_STAMPS  // measurement build only (tools/xqs_stamps.py): per-(workgroup, wave) wall-clock stamps of the stages
+__device__ unsigned long long* g_xqs_probe = nullptr;
+#endif
 #include "woq_gemv_xqs.h"
 #include "woq_xq.h"
+
+#ifdef WOQ_XQS_STAMPS
+extern "C" __attribute__((visibility("default"))) int woq_xqs_set_probe(void* buf_dev) {
+  unsigned long long* p = (unsigned long long*)buf_dev;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_xqs_probe), &p, sizeof(p), 0, hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
+}
+#endif
 
 namespace woq {
 
@@ -55,10 +64,13 @@ static int launch_xq_t(const XqLaunch& a, hipStream_t st) {
     attr_set = true;
   }
   const int base = a.kt_count / a.nw, rem = a.kt_count % a.nw;
+  XqsLate late;
+  late.zp = (const uint8_t*)a.zp, late.xsx = a.xin.sx, late.out = a.out, late.bias = a.bias, late.residual = a.residual;
+  late.ssq_in = a.ssq_in, late.next_norm_w = a.next_norm_w, late.ssq_out = a.ssq_out, late.tp = a.tp;
+  late.tag_seq = nullptr, late.tag_layer = 0, late.xo = a.xo, late.eps = a.eps, late.N = a.N, late.K = a.K;
+  late.n_ssq = a.n_ssq, late.lut = a.lut;
   hipLaunchKernelGGL(kern, dim3(a.grid), dim3(a.nw * 64), lds, st, (const u32x4*)a.q, a.scales, a.xin.limbs, a.xin.u,
-                     a.tiles_k, a.kt_begin, base, rem, a.n_groups, a.tpg_shift, (const uint8_t*)a.zp, a.xin.sx, a.out,
-                     a.bias, a.residual, a.eps, a.N, a.K, a.flags, a.ssq_in, a.n_ssq, a.xo, a.next_norm_w, a.ssq_out, a.tp,
-                     a.lut);
+                     a.tiles_k, a.kt_begin, base, rem, a.n_groups, a.tpg_shift | (a.flags << 8) | (a.nw << 16), late);
   return 0;
 }
 
@@ -90,92 +102,6 @@ static int launch_xq_sm(const XqLaunch& a, int smode, bool asym, bool s32, hipSt
   WOQ_XQ_CASE(1, false, true, 3)
 #undef WOQ_XQ_CASE
   return woq::fail("QBits: bad XQ GEMV configuration");
-}
-
-// ---- round 6: few long-lived workgroups (woq_gemv_xqm.h) ---------------------------------------------------------
-static int device_cus() {
-  static const int n = [] {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-      cus = 256;
-    return cus > 0 ? cus : 256;
-  }();
-  return n;
-}
-static int env_int(const char* name, int dflt) {
-  const char* s = getenv(name);
-  return s ? atoi(s) : dflt;
-}
-// The instantiations: (tiles per wave, column tiles per strip, waves admitted). nw waves x tpw tiles cover tiles_k; n_wg
-// workgroups walk n_strips strips (pairs), at most 4 each (more strips than 4 per CU: more workgroups).
-// WOQ_XQM=1 turns it on (default: the one-workgroup-per-strip kernel, see profiles/r06a_*); WOQ_XQM_WG_PER_CU,
-// WOQ_XQM_LONGK (8 | 12), WOQ_XQM_SHORTK (4 | 8): A/B runs.
-bool xqm_geometry(int tiles_k, int cb, int n_strips, bool s32, int& nw, int& tpw, int& n_wg, int& smax) {
-  static const int on = env_int("WOQ_XQM", 0), per_cu = env_int("WOQ_XQM_WG_PER_CU", 1), longk = env_int("WOQ_XQM_LONGK", 8),
-                   shortk = env_int("WOQ_XQM_SHORTK", 4);
-  if (!on || n_strips < 1 || s32) return false;  // fp32 scales keep the one-workgroup-per-strip kernel
-  if (cb == 1) {
-    if (tiles_k <= 32 && shortk == 8) tpw = 8;      // <8, 1, 12>: 4 waves
-    else if (tiles_k <= 64) tpw = 4;                // <4, 1, 16>
-    else if (tiles_k <= 96 && longk == 8) tpw = 8;  // <8, 1, 12>
-    else if (tiles_k <= 96) tpw = 12;               // <12, 1, 8>
-    else return false;
-  } else {
-    if (tiles_k <= 32 && shortk != 8) tpw = 4;  // <4, 2, 8>
-    else if (tiles_k <= 64) tpw = 8;            // <8, 2, 8>
-    else return false;
-  }
-  nw = (tiles_k + tpw - 1) / tpw;
-  n_wg = std::min(n_strips, device_cus() * std::max(1, per_cu));
-  smax = (n_strips + n_wg - 1) / n_wg;
-  if (smax > 4) {
-    n_wg = (n_strips + 3) / 4;
-    smax = (n_strips + n_wg - 1) / n_wg;
-  }
-  if (tpw == 12 && smax > 2) return false;  // <12, 1, 8> exists for 1 and 2 strips
-  return true;
-}
-
-template <int TPW, int CB, int SMODE, bool ASYM, int SMAX, int WMAX>
-static int launch_xqm_t(const XqLaunch& a, int n_wg, hipStream_t st) {
-  typedef XqmLds<TPW, CB, SMODE, ASYM, false> L;
-  const size_t lds = L::total(a.nw, SMAX);
-  if (lds > 160 * 1024 || a.nw > WMAX) return woq::fail("QBits: XQ GEMV geometry does not fit");
-  auto kern = gemv_xqm_kernel<TPW, CB, SMODE, ASYM, false, SMAX, WMAX>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return woq::fail(std::string("QBits: hipFuncSetAttribute: ") + hipGetErrorString(e));
-    attr_set = true;
-  }
-  const int base = a.kt_count / a.nw, rem = a.kt_count % a.nw;
-  hipLaunchKernelGGL(kern, dim3(n_wg), dim3(a.nw * 64), lds, st, (const u32x4*)a.q, a.scales, a.xin.limbs, a.xin.u,
-                     a.tiles_k, a.kt_begin, base, rem, a.n_groups, a.tpg_shift, (const uint8_t*)a.zp, a.xin.sx, a.out,
-                     a.bias, a.residual, a.eps, a.N, a.K, a.flags, a.ssq_in, a.n_ssq, a.xo, a.next_norm_w, a.ssq_out, a.tp,
-                     a.grid, n_wg);
-  return 0;
-}
-template <int TPW, int CB, int WMAX, int SMAX>
-static int launch_xqm_sm(const XqLaunch& a, int smode, bool asym, int n_wg, hipStream_t st) {
-  if (smode == 0) return asym ? launch_xqm_t<TPW, CB, 0, true, SMAX, WMAX>(a, n_wg, st) : launch_xqm_t<TPW, CB, 0, false, SMAX, WMAX>(a, n_wg, st);
-  return asym ? launch_xqm_t<TPW, CB, 1, true, SMAX, WMAX>(a, n_wg, st) : launch_xqm_t<TPW, CB, 1, false, SMAX, WMAX>(a, n_wg, st);
-}
-template <int TPW, int CB, int WMAX>
-static int launch_xqm_s(const XqLaunch& a, int smode, bool asym, int n_wg, int smax, hipStream_t st) {
-  if (smax == 1) return launch_xqm_sm<TPW, CB, WMAX, 1>(a, smode, asym, n_wg, st);
-  if (smax == 2) return launch_xqm_sm<TPW, CB, WMAX, 2>(a, smode, asym, n_wg, st);
-  if constexpr (TPW != 12) {
-    if (smax == 3) return launch_xqm_sm<TPW, CB, WMAX, 3>(a, smode, asym, n_wg, st);
-    if (smax == 4) return launch_xqm_sm<TPW, CB, WMAX, 4>(a, smode, asym, n_wg, st);
-  }
-  return woq::fail("QBits: bad XQ GEMV configuration");
-}
-static int launch_xqm(const XqLaunch& a, int cb, int tpw, int smode, bool asym, int n_wg, int smax, hipStream_t st) {
-  if (cb == 2) return tpw == 4 ? launch_xqm_s<4, 2, 8>(a, smode, asym, n_wg, smax, st) : launch_xqm_s<8, 2, 8>(a, smode, asym, n_wg, smax, st);
-  if (tpw == 4) return launch_xqm_s<4, 1, 16>(a, smode, asym, n_wg, smax, st);
-  if (tpw == 8) return launch_xqm_s<8, 1, 12>(a, smode, asym, n_wg, smax, st);
-  return launch_xqm_s<12, 1, 8>(a, smode, asym, n_wg, smax, st);
 }
 
 // Geometry: nw waves x tpw tiles cover a K range of tiles_k tiles. Measured per projection of the Llama-2-7B layer
@@ -264,20 +190,6 @@ int launch_gemv_xq(const XqPtrs& xin, const void* blob, const woq_blob_header& h
   if (chunks > 1 && (ssq_in != nullptr || out == nullptr))
     return woq::fail("QBits: a K range split over chained launches takes no norm and needs an fp32 output");
   a.grid = tiles_n / cb;
-  {  // one K range, int4: the long-lived-workgroup kernel (woq_gemv_xqm.h)
-    int tpw_m, n_wg, smax;
-    if (a.ndig == 0 && h.N == h.Npad && xqm_geometry(a.tiles_k, cb, a.grid, s32, a.nw, tpw_m, n_wg, smax)) {
-      a.kt_begin = 0;
-      a.kt_count = a.tiles_k;
-      a.out = out;
-      a.bias = bias;
-      a.residual = residual;
-      a.ssq_in = ssq_in;
-      a.xo = xo;
-      a.tp = tp;
-      return launch_xqm(a, cb, tpw_m, smode, asym, n_wg, smax, st);
-    }
-  }
   const int per = (a.tiles_k + chunks - 1) / chunks;
   for (int c = 0; c < chunks; ++c) {
     a.kt_begin = c * per;

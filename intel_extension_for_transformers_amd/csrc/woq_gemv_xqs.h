@@ -27,16 +27,28 @@
 
 #ifdef WOQ_XQS_STAMPS
 extern __device__ unsigned long long* g_xqs_probe;
+// the buffer pointer is read ONCE per wave (WOQ_XQS_STAMP_INIT, before stamp 0): a stamp that loads it itself waits a
+// global round trip (~0.5-1 us) in front of its clock read — round 6's first table (profiles/r06c_*) had that artefact
+#define WOQ_XQS_STAMP_INIT()                                                            \
+  unsigned long long* xqs_probe_ = g_xqs_probe;                                         \
+  {                                                                                     \
+    const unsigned long long a_ = (unsigned long long)xqs_probe_;                       \
+    xqs_probe_ = (unsigned long long*)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(a_ >> 32)) << 32) | \
+                                       (unsigned int)__builtin_amdgcn_readfirstlane((int)a_));                                  \
+  }
 #define WOQ_XQS_STAMP(k)                                                              \
   do {                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                \
-    if (g_xqs_probe && lane == 0) {                                                   \
-      unsigned long long* slot_ = g_xqs_probe + ((size_t)blockIdx.x * 16 + wid) * 16; \
+    if (xqs_probe_ && lane == 0) {                                                    \
+      unsigned long long* slot_ = xqs_probe_ + ((size_t)blockIdx.x * 16 + wid) * 16;  \
       slot_[(k)] = wall_clock64();                                                    \
     }                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                \
   } while (0)
 #else
+#define WOQ_XQS_STAMP_INIT() \
+  do {                       \
+  } while (0)
 #define WOQ_XQS_STAMP(k) \
   do {                   \
   } while (0)
@@ -59,6 +71,12 @@ extern __device__ unsigned long long* g_xqs_probe;
 #endif
 #ifndef WOQ_XQS_PRE
 #define WOQ_XQS_PRE 2
+#endif
+// 1: no workgroup barrier behind the stream — every wave leaves its partial sums in the slab and bumps an LDS counter,
+// the wave that arrives LAST runs the epilogue at once (A/B builds: tools/mkvariant_xq.sh last -DWOQ_XQS_LAST=1;
+// record: profiles/r06c_*)
+#ifndef WOQ_XQS_LAST
+#define WOQ_XQS_LAST 0
 #endif
 
 namespace woq {
@@ -110,6 +128,34 @@ struct XqsChain {
   int strip;    // this workgroup's column strip (pair) when the grid holds several roles; -1 = blockIdx.x
 };
 
+// The kernel arguments a wave does NOT need to put its window and its small requests out. A kernel's first read of its
+// argument segment costs ~1 us inside a replayed graph (profiles/r03d_kernarg_latency.txt), and hipcc loads every
+// declared argument at the top of the kernel — the stage stamps (profiles/r06c_xqs_stage_stamps.txt) showed each wave
+// sitting ~1 us between its first two weight requests and the rest of its window. So these travel as ONE by-value struct
+// that the kernel never touches as a parameter: the body reads its fields from the argument segment by hand
+// (XqsLatePtr, scalar loads) BEHIND the window. The first 14 argument dwords stay individual and preloaded.
+struct XqsLate {
+  const uint8_t* zp;  // read early by asymmetric blobs only
+  const float* xsx;   // "
+  float* out;         // fp32 [N], or (FUSED) {tag, fp32} granules
+  const float* bias;
+  const float* residual;
+  const float* ssq_in;
+  const float* next_norm_w;
+  float* ssq_out;
+  const CommDev* tp;
+  const unsigned int* tag_seq;  // FUSED: device-side step counter the granule tags are made of
+  XqPtrs xo;
+  float eps;
+  int N, K, n_ssq, tag_layer;
+  LutArgs lut;
+};
+static_assert(alignof(XqsLate) == 8, "the struct starts at byte 56 of the argument segment, behind 14 preloaded dwords");
+typedef const __attribute__((address_space(4))) XqsLate* XqsLatePtr;
+__device__ __forceinline__ XqsLatePtr xqs_late_ptr() {
+  return (XqsLatePtr)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + 56);
+}
+
 // FUSED (woq_gemv_attn.hip): the outputs are consumed by another workgroup of the SAME launch: `out` is then an array
 // of 8-byte {tag, fp32} granules, each written by ONE write-through agent-scope store (the data is its own flag).
 // NDIG: 0 = int4 weights; 1 | 2 | 3 = a 4-bit table type (nf4 / fp4) as that many digit planes (woq_gemv_common.h LutArgs)
@@ -117,19 +163,20 @@ template <int TPW, int CB, int D, int SMODE, bool ASYM, bool S32, bool FUSED, bo
 __device__ __forceinline__ void gemv_xqs_body(
     unsigned char* smem_raw, const u32x4* __restrict__ q, const void* __restrict__ scales,
     const uint8_t* __restrict__ xlimbs, const float* __restrict__ xu, int tiles_k, int kt_off, int base_tiles,
-    int rem_tiles, int n_groups, int tpg_shift, const uint8_t* __restrict__ zp, const float* __restrict__ xsx,
-    float* __restrict__ out, const float* __restrict__ bias, const float* residual, float eps, int N, int K, int flags,
-    const float* __restrict__ ssq_in, int n_ssq, const XqPtrs& xo, const float* __restrict__ next_norm_w,
-    float* __restrict__ ssq_out, unsigned int fused_tag = 0u, const CommDev* __restrict__ tp = nullptr,
-    const XqsChain& chain = XqsChain{nullptr, 0u, XqPub{nullptr, 0u}, nullptr, -1}, const LutArgs& lut = LutArgs{}) {
+    int rem_tiles, int n_groups, int tpg_shift, int flags, int nw, XqsLatePtr late,
+    const XqsChain& chain = XqsChain{nullptr, 0u, XqPub{nullptr, 0u}, nullptr, -1}) {
+  // asymmetric blobs: zero points and block sums are small requests of stage 2 — their pointers are read up front
+  const uint8_t* zp = ASYM ? late->zp : nullptr;
+  const float* xsx = ASYM ? late->xsx : nullptr;
   static_assert(!(ASYM && NDIG > 0), "table weight types are symmetric");
   typedef XqsLds<TPW, CB, SMODE, ASYM, S32> L;
   constexpr int ESZ = L::ESZ;
   constexpr int DD = D < TPW ? D : TPW;  // tiles requested before the first one is consumed
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = uni(tid >> 6);
-  const int nw = (int)blockDim.x >> 6;
+  // (nw = waves of the workgroup arrives in a preloaded dword: blockDim is a hidden argument, i.e. argument-segment memory)
   const int bx = chain.strip >= 0 ? chain.strip : (int)blockIdx.x;
+  WOQ_XQS_STAMP_INIT();
   WOQ_XQS_STAMP(0);
   const int kt0 = kt_off + wid * base_tiles + min(wid, rem_tiles);
   const int cnt = base_tiles + (wid < rem_tiles ? 1 : 0);
@@ -220,6 +267,38 @@ __device__ __forceinline__ void gemv_xqs_body(
     for (int j = 0; j < NSP; ++j) sl[cb][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, v16 + j * 1024, 0, 0);
     if constexpr (ASYM) zl[cb] = __builtin_amdgcn_raw_buffer_load_b128(rz, v16, 0, 0);
   }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = PRE; t < DD; ++t)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+      w[cb][t] = __builtin_amdgcn_raw_buffer_load_b128(rq[cb], v16 + t * 1024, kt0 * 1024, AUX_NT);
+  __builtin_amdgcn_sched_barrier(0);
+  // Everything above needs only the 14 PRELOADED kernel-argument dwords (symmetric blobs). The rest of the argument
+  // segment is read HERE, behind the window, and by wave 0 ALONE: it issues the epilogue's requests and runs the
+  // epilogue; the other waves never touch the segment (table weight types: their digit planes, all waves).
+  const float *residual = nullptr, *next_norm_w = nullptr, *ssq_in = nullptr, *bias = nullptr;
+  int n_ssq = 0, N = 0, K = 0;
+  float eps = 0.f;
+  float *out = nullptr, *ssq_out = nullptr;
+  const CommDev* tp = nullptr;
+  XqPtrs xo = {nullptr, nullptr, nullptr};
+  unsigned int fused_tag = 0u;
+  if (wid == 0 || WOQ_XQS_LAST) {  // (the rejected last-arriver form: any wave may run the epilogue)
+    residual = late->residual, next_norm_w = late->next_norm_w, ssq_in = late->ssq_in, bias = late->bias;
+    n_ssq = late->n_ssq, N = late->N, K = late->K, eps = late->eps;
+    out = late->out, ssq_out = late->ssq_out, tp = late->tp;
+    xo = XqPtrs{late->xo.limbs, late->xo.u, late->xo.sx};
+    if constexpr (FUSED) fused_tag = (late->tag_seq[0] << 6) | (unsigned int)late->tag_layer;
+  }
+  LutArgs lut;
+  if constexpr (NDIG > 0) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lut.d[j][i] = late->lut.d[j][i];
+    lut.wmul = late->lut.wmul;
+  }
   // epilogue inputs (wave 0 runs the epilogue on its lanes 0..15): residual element, next norm weight, RMSNorm
   // partials (256 per 16-B piece, only the pieces that exist) — requested now, used after the barrier
   const bool silu = (flags & 2) != 0;
@@ -248,11 +327,6 @@ __device__ __forceinline__ void gemv_xqs_body(
     }
   }
   __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int t = PRE; t < DD; ++t)
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
-      w[cb][t] = __builtin_amdgcn_raw_buffer_load_b128(rq[cb], v16 + t * 1024, kt0 * 1024, AUX_NT);
   WOQ_XQS_STAMP(1);
 
   // ---- 3. park the small pieces in the wave's LDS region (wave-private, in-order LDS: no workgroup barrier) ----
@@ -278,6 +352,11 @@ __device__ __forceinline__ void gemv_xqs_body(
       if (v16 < L::ZPB) *(u32x4*)(wbase + L::O_ZP + cb * L::ZPB + v16) = zl[cb];
   }
   __builtin_amdgcn_wave_barrier();
+#if WOQ_XQS_LAST
+  // red[1]: arrival counter, zero before any wave can bump it (LDS-only barrier: the weight window stays in flight)
+  if (tid == 0) ((unsigned int*)red)[1] = 0u;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
   // A-operand addresses: MFMA row r = lane & 15 -> quarter e = r >> 2, digit p = r & 3 (row 4 e + 3 stays zero);
   // a row is live in lane quarter kq == e only, everything else reads the zero block
   const int i16 = lane & 15, kq = lane >> 4;
@@ -392,11 +471,34 @@ __device__ __forceinline__ void gemv_xqs_body(
     const float s = wave_sum_dpp((t4.x + t4.y) + (t4.z + t4.w));
     if (lane == 0) red[0] = s;
   }
+#if WOQ_XQS_LAST
+  if (wid == 0 && lane < 16) {  // what the epilogue lanes need from wave 0's registers: in LDS before wave 0 arrives
+    red[16 + lane] = e_res;
+    red[32 + lane] = g_next;
+  }
+  asm volatile("" ::: "memory");
+  unsigned int arrived = 0u;
+  if (lane == 0) {
+    typedef __attribute__((address_space(3))) unsigned int lds_u32;
+    arrived = __hip_atomic_fetch_add((lds_u32*)((unsigned int*)red + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  asm volatile("" ::: "memory");
+  const bool finisher = uni((int)arrived) == nw - 1;  // LDS runs a wave's operations in order: the counter is behind the row
+  if (finisher) {
+    e_res = red[16 + (lane & 15)];
+    g_next = red[32 + (lane & 15)];
+  }
+  const int tid_e = finisher ? lane : 64;
+#else
   __syncthreads();
+  const int tid_e = tid;
+#endif
   WOQ_XQS_STAMP(5);
 
-  // ---- 5. finish (lanes 0..15 of wave 0): sum over waves, RMSNorm factor, bias, SiLU*mul, residual, store, XQ ----
-  if (tid < 16) {
+  // ---- 5. finish (lanes 0..15 of wave 0 | of the last wave to arrive): sum over waves, RMSNorm factor, bias, SiLU*mul,
+  // residual, store, XQ ----
+  if (tid_e < 16) {
+    const int tid = tid_e;
     float v = 0.f, up = 0.f;
 #pragma unroll 4
     for (int w2 = 0; w2 < nw; ++w2) {
@@ -447,22 +549,20 @@ __device__ __forceinline__ void gemv_xqs_body(
 }
 
 // flags: bit 0 scales are bf16 (else fp16; ignored for fp32 scales), bit 1 SiLU(gate)*up epilogue (CB == 2)
-// The first 14 argument dwords are preloaded into SGPRs (-amdgpu-kernarg-preload-count=14): everything the weight
-// requests need sits there.
+// The first 14 argument dwords are preloaded into SGPRs (-amdgpu-kernarg-preload-count=14): everything a wave needs to
+// put its whole window and its small requests out sits there — `flags` rides in the upper bits of the 14th
+// (tpg_flags = tpg_shift | flags << 8 | waves << 16), so the tile loop's scale conversion does not wait for the argument
+// segment either.
 // (three digit planes x two column tiles need more than the 128 registers of a 1024-thread workgroup: 512 there)
 template <int TPW, int CB, int D, int SMODE, bool ASYM, bool S32, int NDIG>
 __global__ __launch_bounds__((CB * TPW > 8 || (CB == 2 && NDIG == 3)) ? 512 : 1024) void gemv_xqs_kernel(
     const u32x4* __restrict__ q, const void* __restrict__ scales, const uint8_t* __restrict__ xlimbs,
-    const float* __restrict__ xu, int tiles_k, int kt_off, int base_tiles, int rem_tiles, int n_groups, int tpg_shift,
-    const uint8_t* __restrict__ zp, const float* __restrict__ xsx, float* __restrict__ out,
-    const float* __restrict__ bias, const float* residual, float eps, int N, int K, int flags,
-    const float* __restrict__ ssq_in, int n_ssq, XqPtrs xo, const float* __restrict__ next_norm_w,
-    float* __restrict__ ssq_out, const CommDev* __restrict__ tp, LutArgs lut) {
+    const float* __restrict__ xu, int tiles_k, int kt_off, int base_tiles, int rem_tiles, int n_groups, int tpg_flags,
+    XqsLate late_in_the_argument_segment) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  gemv_xqs_body<TPW, CB, D, SMODE, ASYM, S32, false, false, NDIG>(
-      smem_raw, q, scales, xlimbs, xu, tiles_k, kt_off, base_tiles, rem_tiles, n_groups, tpg_shift, zp, xsx, out, bias,
-      residual, eps, N, K, flags, ssq_in, n_ssq, xo, next_norm_w, ssq_out, 0u, tp,
-      XqsChain{nullptr, 0u, XqPub{nullptr, 0u}, nullptr, -1}, lut);
+  gemv_xqs_body<TPW, CB, D, SMODE, ASYM, S32, false, false, NDIG>(smem_raw, q, scales, xlimbs, xu, tiles_k, kt_off,
+                                                                 base_tiles, rem_tiles, n_groups, tpg_flags & 0xff,
+                                                                 (tpg_flags >> 8) & 0xff, tpg_flags >> 16, xqs_late_ptr());
 }
 
 }  // namespace woq

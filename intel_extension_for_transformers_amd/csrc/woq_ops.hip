@@ -174,9 +174,12 @@ template <typename KV, int HD, bool SPLIT>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv, KV* __restrict__ kcache,
                                                           KV* __restrict__ vcache, const int32_t* __restrict__ pos_p,
                                                           const float* __restrict__ cs, const float* __restrict__ sn,
-                                                          int heads, int kv_heads, int window, int spw,
+                                                          int hk, int window, int spw,
                                                           float* __restrict__ out, XqPtrs xo, AttnMerge mg) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  // hk = heads | kv_heads << 16: with `window` the 13th and 14th argument dwords — everything in front of the first
+  // K / V request is preloaded (the argument segment's first read costs ~1 us, profiles/r06c_xqs_stage_stamps.txt)
+  const int heads = hk & 0xffff, kv_heads = hk >> 16;
   // workgroup ids go round-robin over the 8 XCDs: give every XCD a run of consecutive heads, so that the query heads
   // sharing a kv head (GQA) share an L2 instead of pulling the same cache rows into several
   const int bx = (int)blockIdx.x;
@@ -396,8 +399,8 @@ static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int
       once = true;
     }
     const AttnMerge mg{merge_counters, out, xo};
-    hipLaunchKernelGGL(k, dim3(heads, splits), dim3(256), lds, st, qkv, (KV*)kcache, (KV*)vcache, pos, cs, sn, heads,
-                       kv_heads, window, spw, part, XqPtrs{nullptr, nullptr, nullptr}, mg);
+    hipLaunchKernelGGL(k, dim3(heads, splits), dim3(256), lds, st, qkv, (KV*)kcache, (KV*)vcache, pos, cs, sn,
+                       heads | (kv_heads << 16), window, spw, part, XqPtrs{nullptr, nullptr, nullptr}, mg);
     if (merge_counters == nullptr)
       hipLaunchKernelGGL(attn_combine_kernel<HD>, dim3(heads), dim3(256), 0, st, part, splits, out, xo);
     return 0;
@@ -408,8 +411,9 @@ static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     once = true;
   }
-  hipLaunchKernelGGL(k, dim3(heads), dim3(256), lds, st, qkv, (KV*)kcache, (KV*)vcache, pos, cs, sn, heads, kv_heads,
-                     window, spw, out, xo, AttnMerge{nullptr, nullptr, XqPtrs{nullptr, nullptr, nullptr}});
+  hipLaunchKernelGGL(k, dim3(heads), dim3(256), lds, st, qkv, (KV*)kcache, (KV*)vcache, pos, cs, sn,
+                     heads | (kv_heads << 16), window, spw, out, xo,
+                     AttnMerge{nullptr, nullptr, XqPtrs{nullptr, nullptr, nullptr}});
   return 0;
 }
 

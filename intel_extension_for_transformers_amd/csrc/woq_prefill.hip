@@ -431,9 +431,13 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const float* __re
                                                                void* __restrict__ vcache,
                                                                const int32_t* __restrict__ pos_p,
                                                                const float* __restrict__ cs,
-                                                               const float* __restrict__ sn, int heads, int kv_heads,
-                                                               int window, float* __restrict__ part, int chunk_fixed,
-                                                               int max_rows, AttnMerge mg) {
+                                                               const float* __restrict__ sn, int hkc, int window,
+                                                               float* __restrict__ part, int max_rows, AttnMerge mg) {
+  // hkc = heads | kv_heads << 8 | (chunk_fixed / 32) << 16: with `window` the 13th and 14th argument dwords, so that
+  // everything in front of the first K / V request is PRELOADED — a kernel's first read of its argument segment costs
+  // ~1 us inside a replayed graph (profiles/r06c_xqs_stage_stamps.txt), and heads / kv_heads / window / chunk_fixed
+  // used to sit behind the 14 preloaded dwords
+  const int heads = hkc & 0xff, kv_heads = (hkc >> 8) & 0xff, chunk_fixed = ((hkc >> 16) & 0xffff) * 32;
   static_assert(HD == 128 && REP <= 16, "one 16-column MFMA tile of query heads, head_dim 128");
   static_assert(16 * (HD + 2) * 4 <= HD * DVRB, "the merge record of a wave reuses its V^T tile");
   constexpr int DC = HD / 32, DT = HD / 16, half = HD / 2;
@@ -799,12 +803,14 @@ bool launch_attn_decode_mfma(const float* qkv, void* kcache, void* vcache, int k
                              float* part, int chunk_fixed, int max_ctx, const AttnMerge& mg, hipStream_t st) {
   const int rep = kv_heads > 0 ? heads / kv_heads : 0;
   if (D != 128 || splits <= 1 || splits > ATTN_MAX_SLICES || !(rep == 2 || rep == 4 || rep == 8)) return false;
+  if (heads > 255 || kv_heads > 255 || chunk_fixed / 32 > 65535) return false;  // the packed argument dword
   if (chunk_fixed % DST != 0) chunk_fixed = 0;
   const dim3 grid((unsigned)kv_heads, (unsigned)splits);
 #define WOQ_DEC_CASE(KVD, R)                                                                                       \
   if (kv_dtype == KVD && rep == R) {                                                                               \
     hipLaunchKernelGGL((attn_decode_mfma_kernel<KVD, 128, R>), grid, dim3(256), (attn_dec_lds_bytes<128, R>()), st, \
-                       qkv, kcache, vcache, pos, cs, sn, heads, kv_heads, window, part, chunk_fixed, max_ctx, mg);  \
+                       qkv, kcache, vcache, pos, cs, sn, heads | (kv_heads << 8) | ((chunk_fixed / 32) << 16), window, \
+                       part, max_ctx, mg);                                                                         \
     return true;                                                                                                   \
   }
   WOQ_DEC_CASE(WOQ_F16, 2) WOQ_DEC_CASE(WOQ_F16, 4) WOQ_DEC_CASE(WOQ_F16, 8)

@@ -17,10 +17,22 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _model(seed=0, group=32, asym=True):
+GEOMETRIES = {
+    # the round-2 toy: 2 kv heads, cut in two
+    "toy": dict(hidden=128, inter=256, heads=4, kv_heads=2, head_dim=32, layers=2, vocab=100, eps=1e-5, theta=10000.0),
+    # Llama-2-70B's head / group geometry scaled down (BASELINE configs[3]): 8 kv heads — ONE per rank
+    # at tensor-parallel degree 8 — with 2 query heads each; the row-parallel cuts fall on quantisation-group boundaries
+    # with an ODD number of groups per rank on the MLP side (70B: 28672 / 8 = 28 groups of 128; here 768 / 8 = 3 groups
+    # of 32) and the vocabulary does not divide by the rank count
+    "70b_like": dict(hidden=512, inter=768, heads=16, kv_heads=8, head_dim=32, layers=2, vocab=203, eps=1e-5,
+                     theta=10000.0),
+}
+
+
+def _model(seed=0, group=32, asym=True, geom="toy"):
     from oracle import woq_oracle as orc
 
-    cfg = dict(hidden=128, inter=256, heads=4, kv_heads=2, head_dim=32, layers=2, vocab=100, eps=1e-5, theta=10000.0)
+    cfg = dict(GEOMETRIES[geom])
     rng = np.random.default_rng(seed)
     H, I, NH, KV, D = cfg["hidden"], cfg["inter"], cfg["heads"], cfg["kv_heads"], cfg["head_dim"]
     layers = []
@@ -42,7 +54,7 @@ def _blobs(parts, group):
     return {n: orc.repack(q, s, z, None, group) for n, (q, s, z) in parts.items()}
 
 
-def _rank_main(rank, world, port, out_dir):
+def _rank_main(rank, world, port, out_dir, geom="toy"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -50,7 +62,8 @@ def _rank_main(rank, world, port, out_dir):
     from intel_extension_for_transformers_amd.runtime import tp
     from oracle import woq_oracle as orc
 
-    cfg, layers, embed, lm, norm, group = _model()
+    torch.set_num_threads(1)
+    cfg, layers, embed, lm, norm, group = _model(geom=geom)
     NH, KV, D = cfg["heads"] // world, cfg["kv_heads"] // world, cfg["head_dim"]
     shards = []
     for ly in layers:
@@ -110,6 +123,26 @@ def test_tp2_matches_unsharded_oracle(tmp_path):
         ref = full.forward_token(tok, pos)
         # same fp32 oracle arithmetic, different summation split (2 partial sums + all-reduce): 1e-5 relative
         assert np.abs(got[pos] - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-6
+        assert int(got[pos].argmax()) == int(ref.argmax())
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_tp4_tp8_match_unsharded_oracle_at_the_70b_head_geometry(tmp_path, world):
+    """the plan at tensor-parallel degrees 4 and 8 on the 70B head / group geometry (one kv head per
+    rank at 8), gloo ranks on the CPU, against the unsharded oracle decoder. No multi-GPU hardware has run this path:
+    the device exchange (csrc/woq_comm.hip) is covered separately by two ranks on one GPU (tests/test_gpu_tp_device.py)."""
+    from oracle import woq_oracle as orc
+
+    port = 33500 + (os.getpid() % 2000) + world
+    mp.spawn(_rank_main, args=(world, port, str(tmp_path), "70b_like"), nprocs=world, join=True)
+    got = np.load(tmp_path / "tp_logits.npy")
+    cfg, layers, embed, lm, norm, group = _model(geom="70b_like")
+    assert cfg["kv_heads"] // world >= 1 and (cfg["inter"] // world) % group == 0 and cfg["vocab"] % world != 0
+    full = orc.LlamaOracle(cfg, embed, [dict(_blobs(ly["parts"], group), ln1=ly["ln1"], ln2=ly["ln2"])
+                                        for ly in layers], norm, lm)
+    for pos, tok in enumerate([3, 17, 42, 7]):
+        ref = full.forward_token(tok, pos)
+        assert np.abs(got[pos] - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-6  # `world` partial sums + all-reduce
         assert int(got[pos].argmax()) == int(ref.argmax())
 
 
@@ -189,3 +222,16 @@ def test_bench_py_gpus_flag_spawns_its_own_ranks():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True,
                          text=True, timeout=300)
     assert res.returncode != 0 and "--gpus 4" in res.stderr and "2 rank" in res.stderr, res.stderr[-500:]
+
+
+def test_bench_py_refuses_more_gpus_than_are_visible():
+    """`python bench.py --gpus 8` on a box with fewer than 8 visible devices (here: none) must say so and exit non-zero
+    BEFORE it spawns ranks or touches a device — the N > 1 line is `unmeasured on hardware` until
+    a node runs it, and a silent fallback to fewer ranks would print a line with the wrong n_gpus."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode != 0 and res.stdout.strip() == ""
+    assert "--gpus 8" in res.stderr and "visible" in res.stderr, res.stderr[-500:]

@@ -1,4 +1,6 @@
-// woq_gemv_xqm.h — the batch-1 decode GEMV as FEW, LONG-LIVED workgroups (round 6).
+// woq_gemv_xqm.h — the batch-1 decode GEMV as FEW, LONG-LIVED workgroups (round 6). REJECTED: parity-green and
+// 0.6-1.2 us per launch slower than woq_gemv_xqs.h wherever it walks several strips (profiles/r06b_xqm_*); its host
+// side (geometry pick, launchers, the fused qkv + attention variant) is in git history at commit 504a3f3.
 //
 // Arithmetic and parity definition as woq_gemv_xqs.h (reference qbits.cpp:113-140, autograd/functions.py:41-63): exact
 // int8 x int8 -> int32 tile sums on v_mfma_i32_16x16x64_i8 over an XQ activation vector (woq_xq.h), one fp32

@@ -283,41 +283,7 @@ int main(int argc, char** argv) {
       printf("   eager / graph  empty kernel       %6.2f / %6.2f us per launch\n", timeit(empty), timeit_graph(empty));
       printf("   eager / graph  load-only twin     %6.2f / %6.2f us per launch\n", timeit(so), timeit_graph(so));
       printf("   eager / graph  lean tpw %d D 4     %6.2f / %6.2f us per launch\n", tpw, timeit(lean), timeit_graph(lean));
-  #ifdef WOQ_XQS_STAMPS
-    {  // the long-lived-workgroup kernel (woq_gemv_xqm.h) at the geometry the library picks: same stamp slots
-      woq::XqLaunch a = base_args(nb / 2);
-      int tpw, n_wg, smax;
-      if (woq::xqm_geometry(tiles_k, cb, a.grid, false, a.nw, tpw, n_wg, smax)) {
-        CK(hipMemsetAsync(probe, 0, probe_n * 8, st));
-        CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_xqs_probe), &probe, sizeof(probe), 0, hipMemcpyHostToDevice, st));
-        if (woq::launch_xqm(a, cb, tpw, 0, false, n_wg, smax, st)) printf("xqm launch failed: %s\n", woq::last_error_ref().c_str());
-        unsigned long long* nullp = nullptr;
-        CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_xqs_probe), &nullp, sizeof(nullp), 0, hipMemcpyHostToDevice, st));
-        CK(hipStreamSynchronize(st));
-        std::vector<unsigned long long> hp(probe_n);
-        CK(hipMemcpy(hp.data(), probe, probe_n * 8, hipMemcpyDeviceToHost));
-        unsigned long long t0 = ~0ull;
-        for (int g = 0; g < n_wg; ++g)
-          for (int w = 0; w < a.nw; ++w)
-            if (hp[((size_t)g * 16 + w) * 16]) t0 = std::min(t0, hp[((size_t)g * 16 + w) * 16]);
-        const char* names[6] = {"entry", "window out", "tile 0 done", "tiles done", "epilogue in", "end"};
-        printf("   xqm timeline tpw %d nw %d n_wg %d smax %d (us since the first wave's entry; 100 MHz clock)\n", tpw, a.nw, n_wg, smax);
-        for (int k = 0; k < 6; ++k) {
-          std::vector<double> v;
-          for (int g = 0; g < n_wg; ++g)
-            for (int w = 0; w < a.nw; ++w) {
-              const unsigned long long x = hp[((size_t)g * 16 + w) * 16 + k];
-              if (x) v.push_back((double)(x - t0) * 0.01);
-            }
-          if (v.empty()) continue;
-          std::sort(v.begin(), v.end());
-          printf("      %-13s min %6.2f  p10 %6.2f  med %6.2f  p90 %6.2f  max %6.2f  (%zu waves)\n", names[k], v[0],
-                 v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back(), v.size());
-        }
-      }
-    }
-#endif
-    for (int b = 0; b < nb; ++b) CK(hipFree(blobs[b]));
+      for (int b = 0; b < nb; ++b) CK(hipFree(blobs[b]));
       continue;
     }
     {  // the floor: an empty kernel on the same grid (launch + boundary)
@@ -455,40 +421,6 @@ int main(int argc, char** argv) {
         std::sort(v.begin(), v.end());
         printf("      %-13s min %6.2f  p10 %6.2f  med %6.2f  p90 %6.2f  max %6.2f  (%zu waves)\n", names[k], v[0],
                v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back(), v.size());
-      }
-    }
-#endif
-#ifdef WOQ_XQS_STAMPS
-    {  // the long-lived-workgroup kernel (woq_gemv_xqm.h) at the geometry the library picks: same stamp slots
-      woq::XqLaunch a = base_args(nb / 2);
-      int tpw, n_wg, smax;
-      if (woq::xqm_geometry(tiles_k, cb, a.grid, false, a.nw, tpw, n_wg, smax)) {
-        CK(hipMemsetAsync(probe, 0, probe_n * 8, st));
-        CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_xqs_probe), &probe, sizeof(probe), 0, hipMemcpyHostToDevice, st));
-        if (woq::launch_xqm(a, cb, tpw, 0, false, n_wg, smax, st)) printf("xqm launch failed: %s\n", woq::last_error_ref().c_str());
-        unsigned long long* nullp = nullptr;
-        CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_xqs_probe), &nullp, sizeof(nullp), 0, hipMemcpyHostToDevice, st));
-        CK(hipStreamSynchronize(st));
-        std::vector<unsigned long long> hp(probe_n);
-        CK(hipMemcpy(hp.data(), probe, probe_n * 8, hipMemcpyDeviceToHost));
-        unsigned long long t0 = ~0ull;
-        for (int g = 0; g < n_wg; ++g)
-          for (int w = 0; w < a.nw; ++w)
-            if (hp[((size_t)g * 16 + w) * 16]) t0 = std::min(t0, hp[((size_t)g * 16 + w) * 16]);
-        const char* names[6] = {"entry", "window out", "tile 0 done", "tiles done", "epilogue in", "end"};
-        printf("   xqm timeline tpw %d nw %d n_wg %d smax %d (us since the first wave's entry; 100 MHz clock)\n", tpw, a.nw, n_wg, smax);
-        for (int k = 0; k < 6; ++k) {
-          std::vector<double> v;
-          for (int g = 0; g < n_wg; ++g)
-            for (int w = 0; w < a.nw; ++w) {
-              const unsigned long long x = hp[((size_t)g * 16 + w) * 16 + k];
-              if (x) v.push_back((double)(x - t0) * 0.01);
-            }
-          if (v.empty()) continue;
-          std::sort(v.begin(), v.end());
-          printf("      %-13s min %6.2f  p10 %6.2f  med %6.2f  p90 %6.2f  max %6.2f  (%zu waves)\n", names[k], v[0],
-                 v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back(), v.size());
-        }
       }
     }
 #endif
