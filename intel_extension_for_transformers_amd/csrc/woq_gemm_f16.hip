@@ -64,6 +64,7 @@ struct GemmF16Args {
   const float* rs;     // [Mpad] 2^e per row; null = all 1 (raw-A)
   const float* cs;     // [Npad] 2^E per column
   int M, nb_m, nb_n, sup_n, n_sup;
+  int nb_m128;         // 128-row blocks of the packed layout (gemm_f16t_kernel counts nb_m / n_sup in 256-row blocks)
   void* out;
   int out_dtype, ldo;
   const float* bias;
@@ -905,6 +906,7 @@ static int launch_f16frag_t(GemmF16Args& a, hipStream_t st) {
 }
 
 #include "woq_gemm_f16p.h"
+#include "woq_gemm_f16t.h"
 
 template <int SMODE, bool ASYM, bool S32, int NP>
 static int launch_f16_t(GemmF16Args& a, hipStream_t st) {
@@ -928,13 +930,42 @@ static int launch_f16_t(GemmF16Args& a, hipStream_t st) {
 #undef WOQ_PICK
   }
 #endif
-  const int LDS = ring ? 3 * (FTILE_BYTES / 2) : 2 * FTILE_BYTES * (NP == 1 ? 1 : 2);
-  static const void* attr_set[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int LDS = ring ? 3 * (FTILE_BYTES / 2) : 2 * FTILE_BYTES * (NP == 1 ? 1 : 2);
+  // round 6: 256-row workgroup tiles (woq_gemm_f16t.h) — the ring layout's half-tile images (or the raw rows), twice the
+  // rows per wave, half the weight unpack per MFMA. From 2048 rows (below that the 128-row tiles fill the chip better);
+  // WOQ_GEMM_TALL=0: off (A/B runs).
+  [[maybe_unused]] bool tall = false;
+#if WOQ_GEMM_HANDSCHED
+  if constexpr (NP == 1 && !(SMODE == 1 && ASYM && S32)) {
+    static const bool tall_ok = !(getenv("WOQ_GEMM_TALL") && getenv("WOQ_GEMM_TALL")[0] == '0');
+    static const int tall_rows = getenv("WOQ_GEMM_TALL_ROWS") ? atoi(getenv("WOQ_GEMM_TALL_ROWS")) : 2048;
+    // raw-A calls (o / down of the prompt pass) keep the 128-row ring kernel: alone they gain 2-7 % on 256-row tiles, inside
+    // the engine's pass they lose (0.4915 vs 0.4975 with them on, profiles/r06i_*); WOQ_GEMM_TALL_RAW=1 turns them on
+    static const bool tall_raw = getenv("WOQ_GEMM_TALL_RAW") && getenv("WOQ_GEMM_TALL_RAW")[0] == '1';
+    static const int tall_wgs = getenv("WOQ_GEMM_TALL_WGS") ? atoi(getenv("WOQ_GEMM_TALL_WGS")) : 1024;
+    // enough 256-row workgroups for two full rounds of the chip's 512 slots (M = 2048 x N = 4096 is 256 of them: 132 us
+    // against 82 us for the 128-row tiles, profiles/r06h_*)
+    if (tall_ok && ring && a.M >= tall_rows && ((a.nb_m + 1) / 2) * a.nb_n >= tall_wgs && (tall_raw || !a.act_raw)) {
+      tall = true;
+#define WOQ_PICK_T(RAW_)                                                                   \
+  (S32 ? gemm_f16t_kernel<SMODE, ASYM, 2, RAW_>                                            \
+       : (a.scale_type == WOQ_BF16 ? gemm_f16t_kernel<SMODE, ASYM, 1, RAW_> : gemm_f16t_kernel<SMODE, ASYM, 0, RAW_>))
+      kern = a.act_raw ? WOQ_PICK_T(true) : WOQ_PICK_T(false);
+#undef WOQ_PICK_T
+      a.nb_m128 = a.nb_m;
+      a.nb_m = (a.nb_m + 1) / 2;
+      a.n_sup = ((a.nb_m + 7) / 8) * a.sup_n;
+      LDS = 2 * FTILE_BYTES;
+    }
+  }
+#endif
+  static const void* attr_set[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   static std::mutex attr_mu;  // (host threads launching concurrently)
   std::lock_guard<std::mutex> attr_lock(attr_mu);
   bool have = false;  // (attr_set: the kernels this instantiation can pick)
-  int free_slot = 7;
-  for (int i = 7; i >= 0; --i) {
+  int free_slot = 11;
+  for (int i = 11; i >= 0; --i) {
     have = have || attr_set[i] == (const void*)kern;
     if (attr_set[i] == nullptr) free_slot = i;
   }
@@ -991,6 +1022,7 @@ int launch_gemm_f16(const void* act, int act_dtype, int lda, const void* blob, c
   a.scale_type = (int)h.scale_type;
   a.M = M;
   a.nb_m = (M + FBM - 1) / FBM;
+  a.nb_m128 = a.nb_m;
   a.nb_n = (a.tiles_n * 16 + 127) / 128;
   const int sup_m = (a.nb_m + 7) / 8;
   a.sup_n = (a.nb_n + 7) / 8;

@@ -249,6 +249,35 @@ def test_prefill_gemm_at_measured_size_vs_oracle(name, K, N, group, asym, act_dt
     assert rel <= 2e-3, (name, group, asym, str(act_dtype), float(rel))
 
 
+@pytest.mark.parametrize("M", [2048, 2148, 2213, 4096 + 129])
+@pytest.mark.parametrize("group,asym", [(128, False), (32, True)])
+@pytest.mark.parametrize("act_dtype", [torch.float32, torch.float16])
+def test_prefill_gemm_256_row_tiles_ragged_rows_vs_oracle(M, group, asym, act_dtype):
+    """Round 6: from 2048 rows the one-product GEMM runs 256-row workgroup tiles (csrc/woq_gemm_f16t.h: two 128-row
+    half-tile images per LDS slot, packed and raw-A forms). Row counts that end inside the first image of the last
+    workgroup (2148: its second image does not exist and is clamped), inside its second image (2213), on a tile edge
+    (2048) and one past a 128-row edge (4225); EVERY row against oracle.woq_linear, NaN-poisoned output first."""
+    from intel_extension_for_transformers_amd import qbits
+
+    K, N = 512, 384
+    rng = np.random.default_rng(M + group)
+    q, s, z = _host_qsz(rng, K, N, group, asym)
+    e8, e32 = torch.empty(0, dtype=torch.int8), torch.empty(0, dtype=torch.int32)
+    blob = qbits.repack_quantized_weight(torch.from_numpy(q).cuda(), torch.from_numpy(s).cuda(),
+                                         e8 if z is None else torch.from_numpy(z).cuda(), e32, "int4_clip", "fp16",
+                                         "bf16", asym, group)
+    g = torch.Generator(device="cuda").manual_seed(M)
+    x = torch.randn(M, K, generator=g, device="cuda", dtype=torch.float32).to(act_dtype)
+    out = torch.full((M + 3, N), float("nan"), device="cuda", dtype=torch.float32)  # three guard rows behind the result
+    qbits.woq_linear(x, blob, torch.empty(0), out[:M], "bf16", "int4_clip", "fp16", asym)
+    torch.cuda.synchronize()
+    assert not torch.isnan(out[:M]).any(), "output elements left unwritten"
+    assert torch.isnan(out[M:]).all(), "rows past M were written"
+    ref = orc.woq_linear(x.float().cpu().numpy(), blob.cpu().numpy().view(np.uint8))
+    rel = (np.abs(out[:M].cpu().numpy() - ref).max(axis=1) / np.abs(ref).max(axis=1)).max()
+    assert rel <= 2e-3, (M, group, asym, str(act_dtype), float(rel))
+
+
 @pytest.mark.parametrize("group,asym", [(128, False), (32, True)])
 def test_prefill_gemm_qkv_at_32x2048_rows_vs_oracle(group, asym):
     """BASELINE configs[2]'s prompt pass feeds its GEMMs M = 32 x 2048 = 65 536 rows: the qkv projection at that M."""

@@ -23,7 +23,7 @@ def compile_isa(out):
 def check(isa_path):
     text = open(isa_path).read()
     problems, kernels = [], 0
-    for m in re.finditer(r"^(_ZN3woq(?:16gemm_f16[ps]|19gemm_f16frag)_kernel\w+):.*?\n(.*?)s_endpgm", text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN3woq(?:16gemm_f16[pst]|19gemm_f16frag)_kernel\w+):.*?\n(.*?)s_endpgm", text, re.S | re.M):
         name, body = m.group(1), m.group(2)
         lines = [l.strip() for l in body.splitlines() if l.strip() and not l.strip().startswith(";")]
         loop_labels = [i for i, l in enumerate(lines) if re.match(r"\.LBB\d+_\d+:", l)]
@@ -51,8 +51,17 @@ def check(isa_path):
         # the launcher never picks the ring form for group-32 asymmetric blobs with fp32 scales (SMODE 1, ASYM, ST 2)
         excluded = re.search(r"kernelILi1ELb1ELi2E", m.group(1)) is not None
         ring.append((m.group(1), v, sp, excluded))
-        if not excluded and (v > 168 or sp > 0):
+        if not excluded and (v > 168 or sp > 0):  # (gemm_f16p ring kernels)
             problems.append("%s: ring kernel at %d VGPRs, %d spilled (limit 168 / 0)" % (m.group(1), v, sp))
+    # round 6: the 256-row kernels (woq_gemm_f16t.h) run two workgroups per CU: <= 256 registers, no spills
+    for m in re.finditer(r"\.name:\s+(_ZN3woq16gemm_f16t_kernel\w+)", text):
+        blk = text[m.start():m.start() + 1500]
+        v = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
+        ag = int((re.search(r"\.agpr_count:\s+(\d+)", blk) or re.search(r"(0)", "0")).group(1))
+        sp = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))
+        ring.append((m.group(1), v + ag, sp, False))
+        if v + ag > 256 or sp > 0:
+            problems.append("%s: 256-row kernel at %d registers, %d spilled (limit 256 / 0)" % (m.group(1), v + ag, sp))
     return kernels, ring, problems
 
 
