@@ -412,7 +412,7 @@ def read_traffic():
         with open(os.path.join(pdir, best)) as fh:
             rec = json.load(fh)
         return {"bytes": float(rec["hbm_bytes_per_launch"]), "source": "profiles/" + best,
-                "measured_in_this_run": False,
+                "measured_in_this_run": False, "command": rec.get("command"),
                 "method": rec.get("method", "rocprofv3 --pmc FETCH_SIZE pass of the same bench command, x2 gfx950 "
                                             "correction")}
     except Exception:
@@ -949,6 +949,10 @@ def main():
     ap.add_argument("--condition-ms", type=float, default=800.0,
                     help="untimed replays before the warm-up steps so that sclk has left its idle ramp (0 = off)")
     ap.add_argument("--host-allreduce", action="store_true", help="N > 1: force the RCCL host-driven transport")
+    ap.add_argument("--counters-run", action="store_true",
+                    help="the headline path alone for a `rocprofv3 --pmc` pass: the same 32-layer engine, prompt, warm-up and "
+                         "timed decode steps issued eagerly (no graph capture: rocprofv3's counter tool crashed on the captured "
+                         "step in round 5), nothing else measured; prints a short line")
     args = ap.parse_args()
     global CONDITION_MS
     CONDITION_MS = args.condition_ms
@@ -1040,19 +1044,30 @@ def main():
     # ---- configs[1]: Llama-2-7B int4 sym g128, one GPU --------------------------------------------------------------
     cfg = dict(LLAMA2_7B, layers=args.layers or LLAMA2_7B["layers"])
     cpu = None
-    if not args.no_cpu_baseline:  # host-only leg first: the rest of the run keeps the GPU busy
+    if not args.no_cpu_baseline and not args.counters_run:  # host-only leg first: the rest of the run keeps the GPU busy
         cpu = cpu_baseline(LLAMA2_7B)
     max_ctx = 1 << max(9, (args.prompt + args.warmup + max(args.steps, 128) + 8).bit_length())
-    want_prefill = args.prefill_seqs > 0
+    want_prefill = args.prefill_seqs > 0 and not args.counters_run
     if want_prefill:
         max_ctx = max(max_ctx, args.prefill_len)
     eng = build_engine(cfg, max_ctx=max_ctx, max_batch=max(1, args.prefill_seqs) if want_prefill else 1,
                        layers=cfg["layers"])
     feed_prompt(eng, cfg["vocab"], args.prompt)
-    use_graph = not args.no_graph
+    use_graph = not args.no_graph and not args.counters_run
     if use_graph:
         eng.capture(greedy=True)
     run = eng.replay_graph if use_graph else eng.run  # eng.run(n): n steps issued eagerly by one native call
+    if args.counters_run:
+        run(args.warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"counters_run": True, "steps": args.steps, "warmup": args.warmup, "prompt": args.prompt,
+                          "tokens_per_s_under_the_profiler": args.steps / dt,
+                          "gemv_launches": (args.prompt + args.steps + args.warmup) * cfg["layers"] * 4}), flush=True)
+        return
 
     elapsed = timed(run, args.steps, args.warmup, torch.cuda.synchronize, condition=(eng, None))
     timed_region = list(LAST_TIMED_REGION)
