@@ -25,10 +25,11 @@ namespace woq {
 // the cached positions (the last slice also takes the new position) -> un-normalised partial (o[HD], max, sum) per
 // (head, slice) in `out`; attn_combine_kernel merges them. A lone workgroup per head streams the cache at one CU's
 // ~10 B/clk, which is why contexts beyond a few thousand positions need the slices.
-// LDS (floats): [4][HD] q copies | [HD] new v | [4][HD] partial outputs | [8] (max, sum) | [4][spw] scores
+// LDS (floats): [4][HD] q copies | [HD] new v | [4][HD] partial outputs | [12] (4 max, 4 sum, new position's score) |
+// [4][spw] scores
 __host__ __device__ inline int attn_dec_spw(int span) { return ((span + 63) / 64) * 16 + 16; }
 __host__ __device__ inline size_t attn_dec_lds_floats(int HD, int span) {
-  return (size_t)9 * HD + 8 + 4 * (size_t)attn_dec_spw(span);
+  return (size_t)9 * HD + 12 + 4 * (size_t)attn_dec_spw(span);
 }
 
 // Where q / k / v of the new token come from.
@@ -106,7 +107,7 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
   float* vn = sm + 4 * HD;                 // new v, rounded to the cache dtype (wave 0 writes and reads it)
   float* slab = sm + 5 * HD;               // [4][HD] partial outputs
   float* ml = sm + 9 * HD;                 // [4] maxima, [4] sums
-  float* scw = sm + 9 * HD + 8 + wid * spw;  // this wave's scores / probabilities, list order
+  float* scw = sm + 9 * HD + 12 + wid * spw;  // this wave's scores / probabilities, list order
   // this wave's cached positions: list index j <-> relative position 64 (j / 16) + 16 wid + (j % 16)
   const int n_w = 16 * (pos >> 6) + max(0, min((pos & 63) - 16 * wid, 16));
   const bool has_new = incl_new && wid == 0;
@@ -145,30 +146,27 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
       vpre2[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
     }
   }
-  // ---- RoPE of q (every wave for itself | wave 0 for all); wave 0 also rotates k, rounds k / v and appends them ----
+  // ---- RoPE of q (every wave for itself | wave 0 for all). The new position — k rotated, k / v rounded to the cache
+  // dtype and appended, its score — is wave 0's and enters the result as a FIFTH partial (max = its score, sum = 1,
+  // output = its v) in the merge at the end, not as an entry of wave 0's list (round 6): with a granule source its q
+  // strips land first and its k / v strips last (woq_gemv_attn.hip), so everything over the cache runs on q alone and
+  // only `new_position` below stands behind the launch's last strips. ----
   const float scale = 1.0f / sqrtf((float)HD);
   float s_new = 0.f;
-  if (lane < half && (!SRC::granules || wid == 0)) {
-    const float c = cs[(size_t)apos * half + lane], s = sn[(size_t)apos * half + lane];
-    const size_t oq = (size_t)h * HD + lane, ok = (size_t)(heads + kh) * HD + lane,
-                 ov = (size_t)(heads + kv_heads + kh) * HD + lane;
-    float qa, qb, ka = 0.f, kb = 0.f, va = 0.f, vb = 0.f;
+  float ra = 0.f, rb = 0.f, rc = 0.f, rs = 0.f;  // rotated, pre-scaled q halves and the cos / sin of this lane (lanes < half)
+  const bool q_lane = lane < half && (!SRC::granules || wid == 0);
+  if (q_lane) {
+    rc = cs[(size_t)apos * half + lane], rs = sn[(size_t)apos * half + lane];
+    const size_t oq = (size_t)h * HD + lane;
+    float qa, qb;
     if constexpr (SRC::granules) {
       const unsigned long long t0 = wall_clock64();
       for (;;) {
         const unsigned long long g0 = __hip_atomic_load(src.g + oq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long g1 = __hip_atomic_load(src.g + oq + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long g2 = __hip_atomic_load(src.g + ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long g3 = __hip_atomic_load(src.g + ok + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long g4 = __hip_atomic_load(src.g + ov, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long g5 = __hip_atomic_load(src.g + ov + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool good = (unsigned int)(g0 >> 32) == src.tag && (unsigned int)(g1 >> 32) == src.tag &&
-                          (unsigned int)(g2 >> 32) == src.tag && (unsigned int)(g3 >> 32) == src.tag &&
-                          (unsigned int)(g4 >> 32) == src.tag && (unsigned int)(g5 >> 32) == src.tag;
+        const bool good = (unsigned int)(g0 >> 32) == src.tag && (unsigned int)(g1 >> 32) == src.tag;
         qa = __uint_as_float((unsigned int)g0), qb = __uint_as_float((unsigned int)g1);
-        ka = __uint_as_float((unsigned int)g2), kb = __uint_as_float((unsigned int)g3);
-        va = __uint_as_float((unsigned int)g4), vb = __uint_as_float((unsigned int)g5);
-        if (__all(good)) break;  // every participating lane of the wave saw its six tags
+        if (__all(good)) break;  // every participating lane of the wave saw its tags
         if (wall_clock64() - t0 > 2000000ull) {  // 20 ms at 100 MHz: a producer is missing — say so, do not hang
           if (lane == 0) atomicOr(src.status, 1);
           break;
@@ -177,18 +175,44 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
       }
     } else {
       qa = src.qkv[oq], qb = src.qkv[oq + half];
-      if (has_new) {
+    }
+    // (explicit fused multiply-adds: hipcc contracts a * b + c * d by context, and the granule and plain sources of this
+    // body are different contexts — the fused launch and the separate launches must stay bit-identical)
+    ra = fmaf(qa, rc, -(qb * rs)) * scale, rb = fmaf(qb, rc, qa * rs) * scale;
+    qw[lane] = ra;
+    qw[lane + half] = rb;
+  }
+  // k / v of the new token (wave 0 of the workgroup that holds the new position): rotate k, round both through the cache
+  // dtype, append (the first query head of each kv group), score against the rotated q still in this lane's registers
+  auto new_position = [&]() {
+    if (lane < half) {
+      const size_t ok = (size_t)(heads + kh) * HD + lane, ov = (size_t)(heads + kv_heads + kh) * HD + lane;
+      float ka, kb, va, vb;
+      if constexpr (SRC::granules) {
+        const unsigned long long t0 = wall_clock64();
+        for (;;) {
+          const unsigned long long g2 = __hip_atomic_load(src.g + ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long g3 = __hip_atomic_load(src.g + ok + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long g4 = __hip_atomic_load(src.g + ov, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long g5 = __hip_atomic_load(src.g + ov + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const bool good = (unsigned int)(g2 >> 32) == src.tag && (unsigned int)(g3 >> 32) == src.tag &&
+                            (unsigned int)(g4 >> 32) == src.tag && (unsigned int)(g5 >> 32) == src.tag;
+          ka = __uint_as_float((unsigned int)g2), kb = __uint_as_float((unsigned int)g3);
+          va = __uint_as_float((unsigned int)g4), vb = __uint_as_float((unsigned int)g5);
+          if (__all(good)) break;
+          if (wall_clock64() - t0 > 2000000ull) {
+            if (lane == 0) atomicOr(src.status, 1);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      } else {
         ka = src.qkv[ok], kb = src.qkv[ok + half];
         va = src.qkv[ov], vb = src.qkv[ov + half];
       }
-    }
-    const float ra = (qa * c - qb * s) * scale, rb = (qb * c + qa * s) * scale;
-    qw[lane] = ra;
-    qw[lane + half] = rb;
-    if (has_new) {
-      const KV ka_r = (KV)(ka * c - kb * s), kb_r = (KV)(kb * c + ka * s);
+      const KV ka_r = (KV)fmaf(ka, rc, -(kb * rs)), kb_r = (KV)fmaf(kb, rc, ka * rs);
       const KV va_r = (KV)va, vb_r = (KV)vb;
-      s_new = ra * (float)ka_r + rb * (float)kb_r;
+      s_new = fmaf(ra, (float)ka_r, rb * (float)kb_r);
       vn[lane] = (float)va_r;
       vn[lane + half] = (float)vb_r;
       if (h % rep == 0) {
@@ -200,8 +224,16 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
         vd[lane + half] = vb_r;
       }
     }
+    s_new = wave_sum_dpp(s_new);
+    if (lane == 0) ml[8] = s_new;
+  };
+  if (wid == 0) {
+    if (!has_new) {
+      if (lane == 0) ml[8] = -INFINITY;  // this workgroup's slice does not hold the new position
+    } else if constexpr (!SRC::granules) {
+      new_position();  // its inputs are an earlier launch's: nothing to wait for
+    }
   }
-  if (has_new) s_new = wave_sum_dpp(s_new);
   if constexpr (SRC::granules)
     env.sync();  // q is wave 0's to give
   else
@@ -244,12 +276,8 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
       }
     }
   }
-  if (has_new) {
-    if (lane == 0) scw[n_w] = s_new;
-    lmax = fmaxf(lmax, s_new);
-  }
   const float m_w = wave_max_dpp(lmax);
-  const int n_l = n_w + (has_new ? 1 : 0);  // entries of this wave's list
+  const int n_l = n_w;  // entries of this wave's list (the new position is the merge's fifth partial)
   // round 4: the V rows of the third 16-position run are requested HERE — the K registers have just died, and the
   // exponentials below run under the request instead of in front of it (later runs are double-buffered in the loop)
   kv8 vnext[VU];
@@ -303,11 +331,6 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
       for (int u = 0; u < VU; ++u) pv(j0 + g + u * GP, vv[u]);
     }
   }
-  if (has_new && g == 0) {  // the new position
-    const float p = scw[n_w];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, vn[l8 * 8 + i], acc[i]);
-  }
   // sum over the GP row groups: lane groups of LPR lanes -> lanes 0 .. LPR - 1
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -328,15 +351,21 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
     ml[wid] = m_w;
     ml[4 + wid] = l_w;
   }
+  if constexpr (SRC::granules) {
+    if (has_new) new_position();  // wave 0: the launch's k / v strips are the last thing this workgroup waits for
+  }
   env.sync();
   // ---- merge the four waves' partials ----
   if (tid < HD) {
     const float m0 = ml[0], m1 = ml[1], m2 = ml[2], m3 = ml[3];
-    const float mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    const float s_n = ml[8];  // the new position's score, -inf when it is not this workgroup's
+    const float mx = fmaxf(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)), s_n);
+    const float e_n = s_n == -INFINITY ? 0.f : __expf(s_n - mx);
     const float e0 = m0 == -INFINITY ? 0.f : __expf(m0 - mx), e1 = m1 == -INFINITY ? 0.f : __expf(m1 - mx);
     const float e2 = m2 == -INFINITY ? 0.f : __expf(m2 - mx), e3 = m3 == -INFINITY ? 0.f : __expf(m3 - mx);
-    const float o = (slab[tid] * e0 + slab[HD + tid] * e1) + (slab[2 * HD + tid] * e2 + slab[3 * HD + tid] * e3);
-    const float den = (ml[4] * e0 + ml[5] * e1) + (ml[6] * e2 + ml[7] * e3);
+    const float o4 = fmaf(slab[tid], e0, slab[HD + tid] * e1) + fmaf(slab[2 * HD + tid], e2, slab[3 * HD + tid] * e3);
+    const float o = s_n == -INFINITY ? o4 : fmaf(vn[tid], e_n, o4);
+    const float den = (fmaf(ml[4], e0, ml[5] * e1) + fmaf(ml[6], e2, ml[7] * e3)) + e_n;
     if constexpr (SPLIT) {  // publish the slice's partial (woq_attn_merge.h); `out` is the partial buffer here
       st_agent(attn_part_o(out, h, slice, HD) + tid, o);
       if (tid == 0) {

@@ -46,7 +46,17 @@ struct FusedAttnArgs {
 #ifndef WOQ_XQS_DEPTH
 #define WOQ_XQS_DEPTH 4
 #endif
-constexpr int FUSED_TPW = 8, FUSED_D = WOQ_XQS_DEPTH;
+constexpr int FUSED_TPW = 8;
+// Round 6: the q strips of the fused launch are given the WHOLE slice as their window (8 tiles per wave up front) and the
+// k / v strips a shallower one, so that q lands while k / v are still streaming: the attention workgroups then run
+// everything over the cache on q alone (woq_attn_decode.h) and only the new position's score and value stand behind
+// the launch's last strips. A/B builds: -DWOQ_FUSED_DQ=4 -DWOQ_FUSED_DKV=4 is the round-5 order of arrival.
+#ifndef WOQ_FUSED_DQ
+#define WOQ_FUSED_DQ 8
+#endif
+#ifndef WOQ_FUSED_DKV
+#define WOQ_FUSED_DKV 1
+#endif
 // the fused launch's 14th argument dword: tpg_shift | flags << 8 | strips << 16 — the strip workgroups come first in the
 // grid, one attention workgroup per head behind them — so that the role test needs nothing but preloaded arguments
 // (gridDim is a hidden argument: it lives in the argument segment too)
@@ -55,7 +65,7 @@ __device__ __forceinline__ int fa_strips_of_grid(int tpg_flags) { return (tpg_fl
 template <int SMODE, bool ASYM, bool S32, typename KV>
 __global__ __launch_bounds__(256) void gemv_xqs_attn_kernel(
     const u32x4* __restrict__ q, const void* __restrict__ scales, const uint8_t* __restrict__ xlimbs,
-    const float* __restrict__ xu, int tiles_k, int kt_off, int base_tiles, int rem_tiles, int n_groups, int tpg_flags,
+    const float* __restrict__ xu, int tiles_k, int n_q_strips, int base_tiles, int rem_tiles, int n_groups, int tpg_flags,
     XqsLate late_in_the_argument_segment, unsigned long long* __restrict__ qkv_g, int N, FusedAttnArgs fa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n_strips = fa_strips_of_grid(tpg_flags);
@@ -66,9 +76,15 @@ __global__ __launch_bounds__(256) void gemv_xqs_attn_kernel(
                                      fa.sn, fa.heads, fa.kv_heads, fa.window, fa.spw, fa.attn_out, fa.xq_attn);
     return;
   }
-  gemv_xqs_body<FUSED_TPW, 1, FUSED_D, SMODE, ASYM, S32, true>(smem_raw, q, scales, xlimbs, xu, tiles_k, kt_off,
-                                                              base_tiles, rem_tiles, n_groups, tpg_flags & 0xff,
-                                                              (tpg_flags >> 8) & 0xff, 4, xqs_late_ptr());
+  // (the K range always starts at tile 0 here: the kt_off slot of the preloaded dwords carries the number of q strips)
+  if ((int)blockIdx.x < n_q_strips)
+    gemv_xqs_body<FUSED_TPW, 1, WOQ_FUSED_DQ, SMODE, ASYM, S32, true>(smem_raw, q, scales, xlimbs, xu, tiles_k, 0, base_tiles,
+                                                                     rem_tiles, n_groups, tpg_flags & 0xff,
+                                                                     (tpg_flags >> 8) & 0xff, 4, xqs_late_ptr());
+  else
+    gemv_xqs_body<FUSED_TPW, 1, WOQ_FUSED_DKV, SMODE, ASYM, S32, true>(smem_raw, q, scales, xlimbs, xu, tiles_k, 0, base_tiles,
+                                                                      rem_tiles, n_groups, tpg_flags & 0xff,
+                                                                      (tpg_flags >> 8) & 0xff, 4, xqs_late_ptr());
 }
 
 // does the fused launch take this (blob, attention) combination?
@@ -121,7 +137,7 @@ static int launch_fused_t(const FusedLaunch& a, hipStream_t st) {
   late.tag_seq = a.fa.seq, late.tag_layer = a.fa.layer, late.xo = XqPtrs{nullptr, nullptr, nullptr}, late.eps = a.eps;
   late.N = a.N, late.K = a.K, late.n_ssq = a.n_ssq, late.lut = LutArgs{};
   hipLaunchKernelGGL(kern, dim3(a.N / 16 + a.fa.heads), dim3(256), a.lds, st, (const u32x4*)a.q, a.scales, a.xin.limbs, a.xin.u,
-                     a.tiles_k, 0, FUSED_TPW, 0, a.n_groups, a.tpg_shift | (a.flags << 8) | ((a.N / 16) << 16), late, a.out,
+                     a.tiles_k, a.fa.heads * 8, FUSED_TPW, 0, a.n_groups, a.tpg_shift | (a.flags << 8) | ((a.N / 16) << 16), late, a.out,
                      a.N, a.fa);
   return 0;
 }
