@@ -43,7 +43,10 @@ bool gemv_xq_attn_supported(const woq_blob_header& h, int heads, int kv_heads, i
 int launch_gemv_xq_attn(const XqPtrs& xin, const void* blob, const woq_blob_header& h, unsigned long long* qkv_g,
                         const float* ssq_in, float eps, const unsigned int* seq, int layer, int* status, void* kcache,
                         void* vcache, int kv_dtype, const int32_t* pos, const float* cs, const float* sn, int heads,
-                        int kv_heads, int max_ctx, int window, float* attn_out, const XqPtrs& xq_attn, hipStream_t st);
+                        int kv_heads, int max_ctx, int window, float* attn_out, const XqPtrs& xq_attn, hipStream_t st,
+                        int splits = 1, float* part = nullptr);
+void launch_attn_combine(const float* part, int heads, int D, int splits, float* out, const XqPtrs& xo,
+                         hipStream_t st);
 int launch_gemv_twin(const void* blob, const woq_blob_header& h, int epi, int mode, unsigned int* sink, hipStream_t st);
 void launch_lm_head(const float* hidden_in, const float* norm_w, float eps, const void* W, int w_dtype, int hidden,
                     int vocab, float* logits, float* pmax, int32_t* pidx, hipStream_t st);
@@ -128,6 +131,10 @@ struct woq_engine {
   // beyond 64 layers the layer bits would run into the counter and a stale granule could pass for a fresh one, so
   // deeper models keep the separate launches
   bool tags_ok() const { return cfg.layers <= 64; }
+  // context slices as attention workgroups of the fused launch (round 6; WOQ_FUSE_SLICED=0: sliced contexts keep the
+  // three launches qkv | slices | combine — same-box A/B runs)
+  bool fuse_sliced = true;
+  bool fused_attn_applies(const woq_blob_header& qkv_hdr) const;
   // tensor parallel ranks take the XQ path when the exchange runs on the device (its all-reduce kernel then emits the
   // next XQ vector itself); with a host-side transport they keep the fp32-activation kernels
   bool tp_xq = true, tp_fused_push = true;
@@ -167,6 +174,13 @@ struct woq_engine {
 };
 
 using namespace woq;
+
+bool woq_engine::fused_attn_applies(const woq_blob_header& qkv_hdr) const {
+  if (!fuse_attn || qkv_g == nullptr || attn_grouped || !tags_ok()) return false;
+  if (attn_splits > 1 && (!fuse_sliced || attn_part == nullptr || attn_fold)) return false;
+  return gemv_xq_attn_supported(qkv_hdr, cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.kv_dtype, cfg.max_ctx, window,
+                                attn_splits);
+}
 
 const woq::CommDev* woq_engine::tp_push() const {
   return cfg.tp_size > 1 && comm != nullptr && tp_fused_push ? woq_comm_dev_ptr(comm) : nullptr;
@@ -210,28 +224,27 @@ static int engine_attn_block_xq(woq_engine* e, int l, hipStream_t st) {
   const woq_layer_weights& w = e->layers[l];
   const int skip = engine_skip_mask();
   int rc = 0;
-  if (!(skip & 3) && e->fuse_attn && e->qkv_g != nullptr && !e->attn_grouped && e->tags_ok() &&
-      gemv_xq_attn_supported(w.qkv_hdr, c.heads, c.kv_heads, c.head_dim, c.kv_dtype, c.max_ctx, e->window,
-                             e->attn_splits)) {
+  const int ns = e->attn_splits > 1 ? e->attn_splits : 1;  // context slices (round 6: attention workgroups of the fused launch)
+  if (!(skip & 3) && e->fused_attn_applies(w.qkv_hdr)) {
     rc = launch_gemv_xq_attn(e->xq_hidden, w.qkv_blob, w.qkv_hdr, e->qkv_g, e->ssq_part, c.rms_eps, e->step_seq, l,
                              e->fuse_status, e->kcache + (size_t)l * e->kv_layer_bytes,
                              e->vcache + (size_t)l * e->kv_layer_bytes,
                              c.kv_dtype, e->pos, e->cs, e->sn, c.heads, c.kv_heads, c.max_ctx, e->window, e->attn,
-                             e->xq_attn, st);
+                             e->xq_attn, st, ns, e->attn_part);
     if (rc) return rc;
-    if (skip & 4) return 0;
-    return engine_row_parallel_xq(e, e->xq_attn, w.o_blob, w.o_hdr, e->xq_hidden, w.ln2, e->ssq_part, st);
+    if (ns > 1) launch_attn_combine(e->attn_part, c.heads, c.head_dim, ns, e->attn, e->xq_attn, st);  // the slices' partials meet here
+  } else {
+    if (!(skip & 1))
+      rc = engine_gemv_xq(e, e->xq_hidden, w.qkv_blob, w.qkv_hdr, e->qkv, e->ssq_part, nullptr, 0, kNoXq, nullptr,
+                          nullptr, st);
+    if (rc) return rc;
+    if (!(skip & 2))
+      rc = launch_attn_decode(e->qkv, e->kcache + (size_t)l * e->kv_layer_bytes,
+                              e->vcache + (size_t)l * e->kv_layer_bytes, c.kv_dtype, e->pos, e->cs, e->sn, c.heads,
+                              c.kv_heads, c.head_dim, c.max_ctx, e->window, e->attn, e->attn_splits, e->attn_grouped,
+                              e->attn_part, e->xq_attn, st, e->attn_fold ? e->attn_cnt : nullptr, e->attn_chunk);
+    if (rc) return rc;
   }
-  if (!(skip & 1))
-    rc = engine_gemv_xq(e, e->xq_hidden, w.qkv_blob, w.qkv_hdr, e->qkv, e->ssq_part, nullptr, 0, kNoXq, nullptr, nullptr,
-                        st);
-  if (rc) return rc;
-  if (!(skip & 2))
-    rc = launch_attn_decode(e->qkv, e->kcache + (size_t)l * e->kv_layer_bytes,
-                            e->vcache + (size_t)l * e->kv_layer_bytes, c.kv_dtype, e->pos, e->cs, e->sn, c.heads,
-                            c.kv_heads, c.head_dim, c.max_ctx, e->window, e->attn, e->attn_splits, e->attn_grouped,
-                            e->attn_part, e->xq_attn, st, e->attn_fold ? e->attn_cnt : nullptr, e->attn_chunk);
-  if (rc) return rc;
   if (skip & 4) return 0;
   // hidden += attn . W_o ; the new hidden leaves as the MLP's XQ input (times ln2) with its sums of squares
   return engine_row_parallel_xq(e, e->xq_attn, w.o_blob, w.o_hdr, e->xq_hidden, w.ln2, e->ssq_part, st);
@@ -585,13 +598,8 @@ int woq_engine_clear_status(woq_engine* e, void* stream) {
   WOQ_END
 }
 int woq_engine_fuse_attn(woq_engine* e) {
-  if (!e || !e->fuse_attn || !e->use_xq() || e->qkv_g == nullptr || e->attn_grouped || e->layers.empty() || !e->tags_ok())
-    return 0;
-  const woq_engine_config& c = e->cfg;
-  return woq::gemv_xq_attn_supported(e->layers[0].qkv_hdr, c.heads, c.kv_heads, c.head_dim, c.kv_dtype, c.max_ctx,
-                                     e->window, e->attn_splits)
-             ? 1
-             : 0;
+  if (!e || !e->use_xq() || e->layers.empty()) return 0;
+  return e->fused_attn_applies(e->layers[0].qkv_hdr) ? 1 : 0;
 }
 void* woq_engine_kv_cache_ptr(woq_engine* e, int which) { return e ? (which ? e->vcache : e->kcache) : nullptr; }
 
@@ -633,6 +641,8 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
   {
     const char* af = getenv("WOQ_ATTN_FOLD");
     e->attn_fold = af ? af[0] != '0' : false;
+    const char* fs = getenv("WOQ_FUSE_SLICED");
+    e->fuse_sliced = fs ? fs[0] != '0' : true;
   }
   WOQ_HIP(hipMalloc((void**)&e->tok_log, (size_t)(cfg->max_ctx + 1) * 4));
   WOQ_HIP(hipMemset(e->tok_log, 0, (size_t)(cfg->max_ctx + 1) * 4));

@@ -39,8 +39,9 @@ struct FusedAttnArgs {
   const float* cs;
   const float* sn;
   int heads, kv_heads, window, spw;
-  float* attn_out;
+  float* attn_out;  // ns == 1: fp32 [heads * 128] attention output; ns > 1: the slices' partial buffer (woq_attn_merge.h)
   XqPtrs xq_attn;
+  int ns;           // context slices per head (round 6): heads * ns attention workgroups behind the strips
 };
 
 #ifndef WOQ_XQS_DEPTH
@@ -71,7 +72,27 @@ __global__ __launch_bounds__(256) void gemv_xqs_attn_kernel(
   const int n_strips = fa_strips_of_grid(tpg_flags);
   if ((int)blockIdx.x >= n_strips) {  // the attention workgroup of head blockIdx.x - n_strips
     const unsigned int tag = (fa.seq[0] << 6) | (unsigned int)fa.layer;
-    attn_decode_body<KV, 128, false>((float*)smem_raw, (int)blockIdx.x - n_strips, 0, 1,
+    const int a = (int)blockIdx.x - n_strips;
+    if (fa.ns > 1) {
+      // Context slices inside the fused launch (round 6, long contexts): heads * ns attention workgroups, each the
+      // per-head flash-decoding slice of woq_attn_decode.h on a granule source — its K / V rows (they depend on the
+      // position only) stream beside the launch's weight tiles while q is still in the making; partials go to the
+      // combine launch. Workgroup ids go round-robin over the 8 XCDs: the query heads that share a kv head AND a slice
+      // read the same cache rows, so they get ids that differ by multiples of 8 (one L2 pulls the rows from HBM once).
+      const int rep = fa.heads / fa.kv_heads, groups = fa.kv_heads * fa.ns;
+      int h, slice;
+      if ((groups & 7) == 0 && (n_strips & 7) == 0) {
+        const int y = a >> 3, gi = (a & 7) + 8 * (y / rep);
+        h = (gi / fa.ns) * rep + y % rep, slice = gi % fa.ns;
+      } else {
+        h = a / fa.ns, slice = a % fa.ns;
+      }
+      attn_decode_body<KV, 128, true>((float*)smem_raw, h, slice, fa.ns, AttnGranule{qkv_g, tag, fa.status},
+                                      (KV*)fa.kcache, (KV*)fa.vcache, fa.pos, fa.cs, fa.sn, fa.heads, fa.kv_heads,
+                                      fa.window, fa.spw, fa.attn_out, XqPtrs{nullptr, nullptr, nullptr});
+      return;
+    }
+    attn_decode_body<KV, 128, false>((float*)smem_raw, a, 0, 1,
                                      AttnGranule{qkv_g, tag, fa.status}, (KV*)fa.kcache, (KV*)fa.vcache, fa.pos, fa.cs,
                                      fa.sn, fa.heads, fa.kv_heads, fa.window, fa.spw, fa.attn_out, fa.xq_attn);
     return;
@@ -87,6 +108,12 @@ __global__ __launch_bounds__(256) void gemv_xqs_attn_kernel(
                                                                       (tpg_flags >> 8) & 0xff, 4, xqs_late_ptr());
 }
 
+// positions one attention workgroup of the fused launch may have to hold scores for (launch_attn_t's sizing)
+static int fused_attn_span(int max_ctx, int window, int splits) {
+  const int reach = window > 0 ? std::min(window, max_ctx) : max_ctx;
+  return splits > 1 ? ((((reach + splits - 1) / splits) + 63) & ~63) + 64 : reach;
+}
+
 // does the fused launch take this (blob, attention) combination?
 bool gemv_xq_attn_supported(const woq_blob_header& h, int heads, int kv_heads, int head_dim, int kv_dtype, int max_ctx,
                             int window, int splits) {
@@ -98,7 +125,8 @@ bool gemv_xq_attn_supported(const woq_blob_header& h, int heads, int kv_heads, i
   }
   // round 4: grouped-query shapes (Mistral-7B: 32 query / 8 kv heads) and a sliding window are taken as well — the
   // attention body always handled both (kh = h / rep, re-based cache pointers); round 3 simply had not tested them here
-  if (kv_heads < 1 || heads % kv_heads != 0 || head_dim != 128 || splits > 1) return false;
+  if (kv_heads < 1 || heads % kv_heads != 0 || head_dim != 128 || splits > ATTN_MAX_SLICES) return false;
+  if (splits > 1 && (heads + 2 * kv_heads) * 8 + heads * splits > 65535) return false;  // the packed strip count
   if (h.N != (heads + 2 * kv_heads) * head_dim) return false;
   (void)window;
   if (kv_dtype != WOQ_F16 && kv_dtype != WOQ_BF16 && kv_dtype != WOQ_FP8_E4M3) return false;
@@ -106,7 +134,7 @@ bool gemv_xq_attn_supported(const woq_blob_header& h, int heads, int kv_heads, i
   // the CUs that also hold an attention workgroup) inherit the attention's score buffer, which grows with max_ctx.
   // Up to 38 KiB (max_ctx 8192) four workgroups still share a CU's 160 KiB; beyond that the strips would lose
   // occupancy to a buffer they never touch, so such engines keep the two launches.
-  return attn_dec_lds_floats(128, max_ctx) * 4 <= 38 * 1024;
+  return attn_dec_lds_floats(128, fused_attn_span(max_ctx, window, splits)) * 4 <= 38 * 1024;
 }
 
 struct FusedLaunch {
@@ -136,7 +164,7 @@ static int launch_fused_t(const FusedLaunch& a, hipStream_t st) {
   late.ssq_in = a.ssq_in, late.next_norm_w = nullptr, late.ssq_out = nullptr, late.tp = nullptr;
   late.tag_seq = a.fa.seq, late.tag_layer = a.fa.layer, late.xo = XqPtrs{nullptr, nullptr, nullptr}, late.eps = a.eps;
   late.N = a.N, late.K = a.K, late.n_ssq = a.n_ssq, late.lut = LutArgs{};
-  hipLaunchKernelGGL(kern, dim3(a.N / 16 + a.fa.heads), dim3(256), a.lds, st, (const u32x4*)a.q, a.scales, a.xin.limbs, a.xin.u,
+  hipLaunchKernelGGL(kern, dim3(a.N / 16 + a.fa.heads * a.fa.ns), dim3(256), a.lds, st, (const u32x4*)a.q, a.scales, a.xin.limbs, a.xin.u,
                      a.tiles_k, a.fa.heads * 8, FUSED_TPW, 0, a.n_groups, a.tpg_shift | (a.flags << 8) | ((a.N / 16) << 16), late, a.out,
                      a.N, a.fa);
   return 0;
@@ -160,11 +188,15 @@ static int launch_fused_kv(const FusedLaunch& a, int smode, bool asym, bool s32,
 
 // qkv_g ({tag, fp32} granules [(heads + 2 kv_heads) * 128]) = xin . W_qkv_deq * rsqrt(mean(x^2) + eps); per head, as its granules
 // arrive: RoPE, KV append at *pos, attention over the cache -> attn_out (+ its XQ form).
+// splits > 1: `splits` context slices per head, their partials -> `part` (woq_attn_merge.h); the caller's combine launch
+// turns them into attn_out / xq_attn.
 int launch_gemv_xq_attn(const XqPtrs& xin, const void* blob, const woq_blob_header& h, unsigned long long* qkv_g,
                         const float* ssq_in, float eps, const unsigned int* seq, int layer, int* status, void* kcache,
                         void* vcache, int kv_dtype, const int32_t* pos, const float* cs, const float* sn, int heads,
-                        int kv_heads, int max_ctx, int window, float* attn_out, const XqPtrs& xq_attn, hipStream_t st) {
+                        int kv_heads, int max_ctx, int window, float* attn_out, const XqPtrs& xq_attn, hipStream_t st,
+                        int splits, float* part) {
   FusedLaunch a;
+  if (splits < 1) splits = 1;
   const uint8_t* b = (const uint8_t*)blob;
   a.q = b + h.off_q;
   a.scales = b + h.off_scale;
@@ -189,9 +221,11 @@ int launch_gemv_xq_attn(const XqPtrs& xin, const void* blob, const woq_blob_head
   a.out = qkv_g;
   const int smode = (int)h.scale_mode;
   const bool asym = a.zp != nullptr, s32 = h.scale_type == WOQ_F32;
-  const int spw = attn_dec_spw(max_ctx);
-  a.fa = FusedAttnArgs{seq, layer, status, kcache, vcache, pos, cs, sn, heads, kv_heads, window, spw, attn_out, xq_attn};
-  const size_t lds_attn = attn_dec_lds_floats(128, max_ctx) * 4;
+  const int span = fused_attn_span(max_ctx, window, splits);
+  const int spw = attn_dec_spw(span);
+  a.fa = FusedAttnArgs{seq, layer, status, kcache, vcache, pos, cs, sn, heads, kv_heads, window, spw,
+                       splits > 1 ? part : attn_out, xq_attn, splits};
+  const size_t lds_attn = attn_dec_lds_floats(128, span) * 4;
   size_t lds_gemv = 0;
   if (smode == 0)
     lds_gemv = asym ? (s32 ? XqsLds<FUSED_TPW, 1, 0, true, true>::total(4) : XqsLds<FUSED_TPW, 1, 0, true, false>::total(4))
@@ -205,5 +239,6 @@ int launch_gemv_xq_attn(const XqPtrs& xin, const void* blob, const woq_blob_head
   if (kv_dtype == WOQ_FP8_E4M3) return launch_fused_kv<Fp8>(a, smode, asym, s32, st);
   return launch_fused_kv<__bf16>(a, smode, asym, s32, st);
 }
+
 
 }  // namespace woq

@@ -269,8 +269,10 @@ class WoqDecoderEngine:
             L.check(L.lib().woq_engine_set_attn_splits(self._h, int(n)))
             self.captured = False
 
-    GROUPED_CTX = 4096  # cached positions from which the grouped-query (matrix-core) slices are used where they apply
-    # (measured at 8192, Mistral-7B shape, fp8 cache: 11.5 vs 13.8 us per layer, 1.82 vs 1.87 ms/token)
+    GROUPED_CTX = 6144  # cached positions from which the grouped-query (matrix-core) slices are used where they apply.
+    # Round 6 (context slices inside the fused qkv launch, profiles/r06s_*; Mistral-7B shape, fp8 cache, 16 layers, ms
+    # per token, fused per-head slices vs grouped slices in their own launch): 2048 -> 0.655 vs 0.716, 4096 -> 0.692 vs
+    # 0.728, 8192 -> 0.782 vs 0.766. (Round 4, both forms as launches of their own, had the crossover at 4096.)
 
     def set_attn_grouped(self, on):
         """Sliced regime only: one workgroup per (kv head, slice) for all the query heads of the group (head_dim 128,
@@ -342,8 +344,21 @@ class WoqDecoderEngine:
             self.set_attn_splits(max(2, min(64, -(-positions // self.GROUPED_CHUNK))))
         elif grouped:
             self.set_attn_splits(max(2, min(64, positions // 256)))
+        elif self.uses_fused_attn_sliced():
+            # slices as attention workgroups of the fused qkv launch (round 6): fewer, longer slices than launches of
+            # their own want — 7B shape 512 -> 4 (0.606 vs 0.632 / 0.621 / 0.614 ms for 2 / 3 / 8), 2048 -> 8 (0.680 vs
+            # 0.749 / 0.710 / 0.687 / 0.701 for 4 / 6 / 12 / 16), Mistral shape 2048 -> 8, 4096 -> 16 (profiles/r06s_*)
+            self.set_attn_splits(max(4, min(16, positions // 256)))
         else:
             self.set_attn_splits(max(2, min(32, 1024 // max(1, self.cfg.heads), positions // 64)))
+
+    def uses_fused_attn_sliced(self):
+        """True when a sliced context would ride in the fused qkv launch (probe: the engine's own predicate at two slices)."""
+        keep = L.lib().woq_engine_attn_splits(self._h)
+        L.check(L.lib().woq_engine_set_attn_splits(self._h, 2))
+        ok = bool(L.lib().woq_engine_fuse_attn(self._h))
+        L.check(L.lib().woq_engine_set_attn_splits(self._h, keep))
+        return ok
 
     def kv_cache(self, which="k"):
         """The engine's K or V cache as a torch view [max_batch, layers, max_ctx, kv_heads, head_dim] (no copy)."""

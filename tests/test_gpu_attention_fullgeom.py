@@ -124,7 +124,8 @@ def test_decode_step_sliced_regime_7b_attention_geometry_vs_oracle(ctx, sliced):
     """(iii) decode steps at a few hundred cached positions at the 7B attention geometry: `ctx` prompt tokens, then 3
     greedy steps in the regime `tune_attn_for` picks — below LONG_CTX the one-workgroup-per-head attention inside the
     fused qkv launch (five 16-position passes per wave at 300, three of them beyond the prefetched rows), above it context
-    slices per head + the combine launch — each against the oracle."""
+    slices per head (attention workgroups of the fused launch since round 6) + the combine launch — each against the
+    oracle."""
     eng, oracle, cfg = build_attention_geometry(max_ctx=640)
     rng = np.random.default_rng(ctx)
     prompt = rng.integers(0, cfg["vocab"], ctx).tolist()
@@ -132,7 +133,7 @@ def test_decode_step_sliced_regime_7b_attention_geometry_vs_oracle(ctx, sliced):
     ref = oracle.forward_prompt(prompt)
     assert np.abs(got - ref).max() <= PF_TOL * np.abs(ref).max() + 1e-3
     eng.tune_attn_for(ctx + 3)
-    assert (L_splits(eng) > 1) == sliced and eng.uses_fused_attn() == (not sliced)
+    assert (L_splits(eng) > 1) == sliced and eng.uses_fused_attn()  # round 6: the slices ride in the fused launch too
     nxt = int(ref.argmax())
     for j in range(3):
         assert int(eng.token.item()) == nxt
@@ -263,3 +264,45 @@ def test_fused_launch_takes_grouped_query_and_window_shapes(kv_dtype, window):
             assert np.abs(g - ref).max() <= PF_TOL * np.abs(ref).max() + 1e-3, j
             nxt = int(ref.argmax())
             assert int(out["fused"][1][j]) == nxt  # log[150 + j] = the token the step feeding position 150 + j produced
+
+
+@pytest.mark.parametrize("kv_heads,kv_dtype,window,splits,ctx", [(32, torch.float16, 0, 4, 300), (32, torch.float16, 0, 16, 700),
+                                                               (8, torch.float8_e4m3fn, 0, 8, 520),
+                                                               (8, torch.float16, 128, 3, 300), (8, torch.bfloat16, 0, 5, 200)])
+def test_fused_launch_with_context_slices_equals_separate_launches(kv_heads, kv_dtype, window, splits, ctx):
+    """Round 6: context slices as attention workgroups of the fused qkv launch (heads x splits of them behind the strips,
+    each the per-head flash-decoding slice on a granule source, partials to the combine launch) against the three
+    launches qkv | slices | combine of the same engine: logits and greedy tokens BIT-IDENTICAL, eager steps and graph
+    replays — multi-head and grouped-query (the XCD-aware head / slice order of the attention workgroups), fp16 / bf16 /
+    fp8 caches, a sliding window shorter than the context (slices move with the position; early slices empty), slice
+    counts that leave empty slices (16 x 64 positions > 700). fp16 / window-less cases also against the oracle."""
+    eng, oracle, cfg = build_attention_geometry(kv_heads=kv_heads, window=window, kv_dtype=kv_dtype, max_ctx=1024)
+    rng = np.random.default_rng(67)
+    prompt = rng.integers(0, cfg["vocab"], ctx).tolist()
+    eng.set_attn_grouped(False)
+    eng.set_attn_splits(splits)
+    out = {}
+    for mode in ("separate", "fused"):
+        eng.set_fuse_attn(mode == "fused")
+        assert eng.uses_fused_attn() == (mode == "fused") and L_splits(eng) == splits
+        eng.prefill(prompt, greedy=True)
+        logs = []
+        for _ in range(5):
+            eng.step(greedy=True)
+            logs.append(eng.logits.clone())
+        eng.capture(greedy=True)
+        eng.replay_graph(12)
+        torch.cuda.synchronize()
+        logs.append(eng.logits.clone())
+        out[mode] = (torch.stack(logs), eng.token_log()[ctx:ctx + 18].clone())
+    assert eng.status() == 0
+    assert torch.equal(out["fused"][0], out["separate"][0]) and torch.equal(out["fused"][1], out["separate"][1])
+    if kv_dtype == torch.float16 and window == 0:
+        ref = oracle.forward_prompt(prompt)
+        nxt = int(ref.argmax())
+        for j in range(5):
+            ref = oracle.forward_token(nxt, ctx + j)
+            g = out["fused"][0][j].cpu().numpy()
+            assert np.abs(g - ref).max() <= PF_TOL * np.abs(ref).max() + 1e-3, j
+            nxt = int(ref.argmax())
+            assert int(out["fused"][1][j]) == nxt

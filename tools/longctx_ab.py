@@ -16,9 +16,12 @@ from intel_extension_for_transformers_amd import _lib as L  # noqa: E402
 from intel_extension_for_transformers_amd.runtime.engine import WoqDecoderEngine, synth_llama_weights  # noqa: E402
 
 
-def run(layers, ctx, kv, fold, chunk, splits):
-    """chunk: 0 = adaptive slices, else the fixed slice length; splits: 0 = tune_attn_for's choice"""
+def run(layers, ctx, kv, fold, chunk, splits, fs=1, grouped=-1):
+    """chunk: 0 = adaptive slices, else the fixed slice length; splits: 0 = tune_attn_for's choice; fs: context slices
+    inside the fused qkv launch (round 6; WOQ_FUSE_SLICED is read at engine creation); grouped: -1 = tune_attn_for's
+    choice, 0 / 1 = per-query-head slices / the grouped matrix-core form"""
     os.environ["WOQ_ATTN_FOLD"] = "1" if fold else "0"
+    os.environ["WOQ_FUSE_SLICED"] = "1" if fs & 1 else "0"
     hidden, heads, hd, vocab = 4096, 32, 128, 32000
     kvh, inter = int(os.environ.get("LCAB_KVH", "8")), int(os.environ.get("LCAB_INTER", "14336"))  # 32 / 11008: Llama-2-7B
     eng = WoqDecoderEngine(hidden, inter, heads, kvh, hd, layers, vocab, max_ctx=ctx + 256,
@@ -34,6 +37,8 @@ def run(layers, ctx, kv, fold, chunk, splits):
             eng.set_attn_splits(splits)
         chunk = splits = 0
     eng.set_attn_chunk(chunk)
+    if grouped >= 0:
+        eng.set_attn_grouped(bool(grouped))
     if kvh == heads:
         pass
     elif splits:
@@ -71,7 +76,7 @@ def run(layers, ctx, kv, fold, chunk, splits):
         torch.cuda.synchronize()
         reps.append(round((time.perf_counter() - t0) / 64 * 1e3, 4))
     kptr = L.lib().woq_engine_kv_cache_ptr(eng._h, 0)
-    out = dict(fold=fold, splits=L.lib().woq_engine_attn_splits(eng._h), chunk=L.lib().woq_engine_attn_chunk(eng._h),
+    out = dict(fs=fs, fused=eng.uses_fused_attn(), grouped=bool(L.lib().woq_engine_attn_grouped(eng._h)), fold=fold, splits=L.lib().woq_engine_attn_splits(eng._h), chunk=L.lib().woq_engine_attn_chunk(eng._h),
                ms_per_token=round(dt * 1e3, 4), again=reps, token=int(eng.token.item()), status=eng.status(),
                kcache="%x" % kptr, qkv0="%x" % eng.layer_tensors[0]["qkv"].data_ptr(),
                gu0="%x" % eng.layer_tensors[0]["gate_up"].data_ptr())
@@ -88,8 +93,9 @@ def main():
     variants = sys.argv[4:] or ["0:0:0", "1:0:0", "0:256:0", "1:256:0", "0:0:16", "1:0:16", "0:0:24", "0:512:0", "0:0:0"]
     base = None
     for v in variants:
-        fold, chunk, splits = (int(x) for x in v.split(":"))
-        r = run(layers, ctx, kv, bool(fold), chunk, splits)
+        f = [int(x) for x in v.split(":")]  # fold:chunk:splits[:fs[:grouped]]
+        fold, chunk, splits = f[:3]
+        r = run(layers, ctx, kv, bool(fold), chunk, splits, f[3] if len(f) > 3 else 1, f[4] if len(f) > 4 else -1)
         if base is None:
             base = r["ms_per_token"]
         r["us_per_layer_vs_first"] = round((r["ms_per_token"] - base) * 1e3 / layers, 2)
