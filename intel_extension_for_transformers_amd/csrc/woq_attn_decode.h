@@ -48,7 +48,11 @@ struct AttnGranule {
   const unsigned long long* g;
   unsigned int tag;
   int* status;
+  unsigned long long* part_g = nullptr;  // SPLIT: the slices' partials as {tag, fp32} granules (attn_part_granule)
 };
+// SPLIT on a granule source (round 6): no combine launch — the slices of a head publish tagged partial granules
+// (part_g) and finalise the head's XQ blocks themselves (woq_attn_merge.h, all-to-all merge; at most 16 slices here).
+constexpr int ATTN_A2A_MAX_SLICES = 16;
 
 // Who runs the body. AttnWgEnv: a 256-thread workgroup of its own (the standalone and the fused launches) — thread ids
 // are the workgroup's, the two meeting points are workgroup barriers, the result leaves as fp32 (+ its XQ block).
@@ -247,9 +251,12 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
     const int t = 64 * i + 16 * wid + r16;
     float d = 0.f;
 #pragma unroll
-    for (int j = 0; j < DPL / 8; ++j)
+    for (int j = 0; j < DPL / 8; ++j) {
+      float kf[8];
+      kv8_to_f32(kv[j], kf);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) d = fmaf(qreg[j * 8 + e], (float)kv[j][e], d);
+      for (int e = 0; e < 8; ++e) d = fmaf(qreg[j * 8 + e], kf[e], d);
+    }
     d += WOQ_DPP_F32(d, 0xB1);  // quad_perm xor 1
     d += WOQ_DPP_F32(d, 0x4E);  // quad_perm xor 2: all four lanes of the position hold its score
     if (t < pos) {
@@ -309,8 +316,10 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
   };
   auto pv = [&](int j, const kv8& vv) {
     const float p = j < n_w ? scw[j] : 0.f;
+    float vf[8];
+    kv8_to_f32(vv, vf);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, (float)vv[i], acc[i]);
+    for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, vf[i], acc[i]);
   };
   if (n_w > 0) {
 #pragma unroll
@@ -366,7 +375,14 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
     const float o4 = fmaf(slab[tid], e0, slab[HD + tid] * e1) + fmaf(slab[2 * HD + tid], e2, slab[3 * HD + tid] * e3);
     const float o = s_n == -INFINITY ? o4 : fmaf(vn[tid], e_n, o4);
     const float den = (fmaf(ml[4], e0, ml[5] * e1) + fmaf(ml[6], e2, ml[7] * e3)) + e_n;
-    if constexpr (SPLIT) {  // publish the slice's partial (woq_attn_merge.h); `out` is the partial buffer here
+    if constexpr (SPLIT && SRC::granules) {  // the slice's partial as tagged granules; merged below, by the slices themselves
+      const AttnA2A a2a{src.part_g, src.tag, src.status};
+      attn_a2a_publish(a2a, h, slice, HD, tid, o);
+      if (tid == 0) {
+        attn_a2a_publish(a2a, h, slice, HD, HD, mx);
+        attn_a2a_publish(a2a, h, slice, HD, HD + 1, den);
+      }
+    } else if constexpr (SPLIT) {  // publish the slice's partial (woq_attn_merge.h); `out` is the partial buffer here
       st_agent(attn_part_o(out, h, slice, HD) + tid, o);
       if (tid == 0) {
         float* pml = attn_part_ml(out, heads, h, slice, HD);
@@ -376,6 +392,13 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
     } else {
       env.put(o / den, h * HD + tid);  // tid < HD is a whole number of 16-lane rows
     }
+  }
+  if constexpr (SPLIT && SRC::granules) {
+    // ---- all-to-all merge: DPP row R of waves 0 / 1 finalises block b = slice + R * ns of this head ----
+    const int R = wid * 4 + (lane >> 4), b = slice + R * n_slices;
+    if (wid < 2 && slice < HD / 16)  // (wave-uniform: some row of this wave has a block)
+      attn_a2a_finalize<HD, ATTN_A2A_MAX_SLICES>(AttnA2A{src.part_g, src.tag, src.status}, h, b, n_slices,
+                                                 b < HD / 16, [&](float v, int idx) { env.put(v, idx); });
   }
 }
 

@@ -24,7 +24,95 @@ struct AttnMerge {
   unsigned int* counter;  // [groups], zero between launches; null = do not merge here (the combine launch does it)
   float* out;             // [heads][HD] attention output
   XqPtrs xo;              // its XQ form for the o_proj GEMV (or all null)
+  // round 6, all-to-all merge (below): the slices publish tagged partial granules and finalise the blocks themselves
+  unsigned long long* part_g = nullptr;  // [heads][64][HD + 2] {tag, fp32}; null = off
+  const unsigned int* seq = nullptr;     // device-side step counter: tag = seq << 6 | layer
+  int layer = 0;
+  int* status = nullptr;                 // sticky give-up flag (bit 0)
 };
+
+// ---- all-to-all merge of context slices (round 6): no combine launch, no counter, no last arriver ---------------------
+// Slice workgroup (h, s) publishes its partial — o[HD], max, sum — as {tag, fp32} granules [head][64 slices][HD + 2]
+// (8-byte write-through agent-scope stores: the data is its own flag, cdna_hip_programming.md Guideline 16 form R2) and
+// then FINALISES a share of the 16-value output blocks: one DPP row per block polls the ns slices' granules of its 16
+// dims and runs attn_combine_kernel<128>'s sums in attn_combine_kernel's order (bit-identical to the combine launch).
+// Two dependent trips (store, load) on the launch's tail instead of a 5-us launch; the three-trip counter form of round
+// 4 (attn_slices_merge below) was slower than the launch. The slice workgroups of a head (group) wait for each other:
+// the caller guarantees they can all become resident (grid <= the chip's slots, or beside workgroups that never wait).
+struct AttnA2A {
+  unsigned long long* part_g;
+  unsigned int tag;
+  int* status;
+};
+__device__ __forceinline__ unsigned long long* attn_part_granule(unsigned long long* g, int h, int s, int HD) {
+  return g + ((size_t)h * ATTN_MAX_SLICES + s) * (HD + 2);
+}
+__device__ __forceinline__ void attn_a2a_publish(const AttnA2A& a, int h, int s, int HD, int d, float o) {
+  __hip_atomic_store(attn_part_granule(a.part_g, h, s, HD) + d, ((unsigned long long)a.tag << 32) | __float_as_uint(o),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Called by ALL 64 lanes of a wave; each DPP row (16 lanes) finalises block `b` of head `h` when `mine` (row-uniform).
+// put(value, index into [heads * HD]) is called by whole rows. MAXS: compile-time bound of ns (registers: 2 per slice).
+template <int HD, int MAXS, typename PUT>
+__device__ __forceinline__ void attn_a2a_finalize(const AttnA2A& a, int h, int b, int ns, bool mine, const PUT& put) {
+  static_assert(HD == 128, "the combine order reproduced here is attn_combine_kernel<128>'s (two thread groups)");
+  const int lane = threadIdx.x & 63, j = lane & 15;
+  const int dd = 16 * min(b, HD / 16 - 1) + j;
+  unsigned long long go[MAXS], gm[(MAXS + 15) / 16], gl[(MAXS + 15) / 16];
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
+    bool good = true;
+#pragma unroll
+    for (int s2 = 0; s2 < MAXS; ++s2) {
+      go[s2] = __hip_atomic_load(attn_part_granule(a.part_g, h, min(s2, ns - 1), HD) + dd, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+      good = good && (unsigned int)(go[s2] >> 32) == a.tag;
+    }
+#pragma unroll
+    for (int q = 0; q < (MAXS + 15) / 16; ++q) {  // lane j holds the (max, sum) of slices j, j + 16, ...
+      const unsigned long long* pm = attn_part_granule(a.part_g, h, min(j + 16 * q, ns - 1), HD) + HD;
+      gm[q] = __hip_atomic_load(pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      gl[q] = __hip_atomic_load(pm + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      good = good && (unsigned int)(gm[q] >> 32) == a.tag && (unsigned int)(gl[q] >> 32) == a.tag;
+    }
+    if (__all(good || !mine)) break;
+    if (wall_clock64() - t0 > 2000000ull) {  // 20 ms: a slice of this head is missing — say so, do not hang
+      if (lane == 0) atomicOr(a.status, 1);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  // attn_combine_kernel's arithmetic, in its order: m = max_s m_s; w_s = e^(m_s - m); l = sum_s (l_s w_s) ascending;
+  // o = (fma chain over even s ascending) + (fma chain over odd s ascending); result o / l
+  float m_j[(MAXS + 15) / 16], m = -INFINITY;
+#pragma unroll
+  for (int q = 0; q < (MAXS + 15) / 16; ++q) {
+    m_j[q] = j + 16 * q < ns ? __uint_as_float((unsigned int)gm[q]) : -INFINITY;
+    m = fmaxf(m, m_j[q]);
+  }
+  m = row16_max(m);
+  float w_j[(MAXS + 15) / 16], wl_j[(MAXS + 15) / 16];
+#pragma unroll
+  for (int q = 0; q < (MAXS + 15) / 16; ++q) {
+    w_j[q] = m_j[q] == -INFINITY ? 0.f : __expf(m_j[q] - m);
+    wl_j[q] = __uint_as_float((unsigned int)gl[q]) * w_j[q];
+  }
+  const int row0 = lane & ~15;
+  float l = 0.f, oe = 0.f, oo = 0.f;
+#pragma unroll
+  for (int s2 = 0; s2 < MAXS; ++s2) {
+    const float w_s = __shfl(w_j[s2 >> 4], row0 + (s2 & 15), 64), wl_s = __shfl(wl_j[s2 >> 4], row0 + (s2 & 15), 64);
+    if (s2 < ns) {
+      l += wl_s;
+      const float v = __uint_as_float((unsigned int)go[s2]);
+      if (s2 & 1)
+        oo = fmaf(v, w_s, oo);
+      else
+        oe = fmaf(v, w_s, oe);
+    }
+  }
+  if (mine) put((oe + oo) / l, h * HD + 16 * b + j);
+}
 
 __device__ __forceinline__ float* attn_part_o(float* part, int h, int s, int HD) {
   return part + ((size_t)h * ATTN_MAX_SLICES + s) * HD;

@@ -20,6 +20,7 @@
 #include "woq_launch.h"
 #include "../../include/woq_hip_experimental.h"
 #include "woq_xq.h"
+#include "woq_attn_merge.h"
 
 namespace woq {
 int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void* blob, const woq_blob_header& h,
@@ -31,7 +32,9 @@ void launch_embed(const void* embed, int dtype, const int32_t* token, int hidden
 int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
                        const float* cs, const float* sn, int heads, int kv_heads, int D, int max_ctx, int window,
                        float* out, int splits, int grouped, float* part, const XqPtrs& xo, hipStream_t st,
-                       unsigned int* merge_counters, int chunk_fixed);
+                       unsigned int* merge_counters, int chunk_fixed, const AttnA2A* a2a_grouped = nullptr,
+                       const unsigned int* seq = nullptr, int layer = 0);
+int attn_decode_mfma_slots(int kv_dtype, int rep);
 // batch-1 GEMV over an XQ activation vector (woq_gemv_xq.hip)
 bool gemv_xq_supported(const woq_blob_header& h, int epi);
 int launch_gemv_xq(const XqPtrs& xin, const void* blob, const woq_blob_header& h, const float* bias, float* out,
@@ -44,7 +47,7 @@ int launch_gemv_xq_attn(const XqPtrs& xin, const void* blob, const woq_blob_head
                         const float* ssq_in, float eps, const unsigned int* seq, int layer, int* status, void* kcache,
                         void* vcache, int kv_dtype, const int32_t* pos, const float* cs, const float* sn, int heads,
                         int kv_heads, int max_ctx, int window, float* attn_out, const XqPtrs& xq_attn, hipStream_t st,
-                        int splits = 1, float* part = nullptr);
+                        int splits = 1, unsigned long long* part_g = nullptr);
 void launch_attn_combine(const float* part, int heads, int D, int splits, float* out, const XqPtrs& xo,
                          hipStream_t st);
 int launch_gemv_twin(const void* blob, const woq_blob_header& h, int epi, int mode, unsigned int* sink, hipStream_t st);
@@ -134,7 +137,12 @@ struct woq_engine {
   // context slices as attention workgroups of the fused launch (round 6; WOQ_FUSE_SLICED=0: sliced contexts keep the
   // three launches qkv | slices | combine — same-box A/B runs)
   bool fuse_sliced = true;
+  unsigned long long* attn_part_g = nullptr;  // their partials as {tag, fp32} granules [heads][64][head_dim + 2]
   bool fused_attn_applies(const woq_blob_header& qkv_hdr) const;
+  // grouped matrix-core slices (a launch of their own) merging among themselves instead of a combine launch: every slice
+  // workgroup of the launch must be resident at once (they wait for each other) — WOQ_GROUPED_A2A=0: combine launch
+  bool grouped_a2a = true;
+  bool grouped_a2a_ok() const;
   // tensor parallel ranks take the XQ path when the exchange runs on the device (its all-reduce kernel then emits the
   // next XQ vector itself); with a host-side transport they keep the fp32-activation kernels
   bool tp_xq = true, tp_fused_push = true;
@@ -177,9 +185,16 @@ using namespace woq;
 
 bool woq_engine::fused_attn_applies(const woq_blob_header& qkv_hdr) const {
   if (!fuse_attn || qkv_g == nullptr || attn_grouped || !tags_ok()) return false;
-  if (attn_splits > 1 && (!fuse_sliced || attn_part == nullptr || attn_fold)) return false;
+  if (attn_splits > 1 && (!fuse_sliced || attn_part_g == nullptr || attn_fold)) return false;
   return gemv_xq_attn_supported(qkv_hdr, cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.kv_dtype, cfg.max_ctx, window,
                                 attn_splits);
+}
+
+bool woq_engine::grouped_a2a_ok() const {
+  if (!grouped_a2a || !attn_grouped || attn_fold || attn_part_g == nullptr || !tags_ok() || attn_splits < 2 || attn_splits > 32)
+    return false;
+  const int rep = cfg.kv_heads > 0 ? cfg.heads / cfg.kv_heads : 0;
+  return cfg.kv_heads * attn_splits <= attn_decode_mfma_slots(cfg.kv_dtype, rep);
 }
 
 const woq::CommDev* woq_engine::tp_push() const {
@@ -230,19 +245,20 @@ static int engine_attn_block_xq(woq_engine* e, int l, hipStream_t st) {
                              e->fuse_status, e->kcache + (size_t)l * e->kv_layer_bytes,
                              e->vcache + (size_t)l * e->kv_layer_bytes,
                              c.kv_dtype, e->pos, e->cs, e->sn, c.heads, c.kv_heads, c.max_ctx, e->window, e->attn,
-                             e->xq_attn, st, ns, e->attn_part);
+                             e->xq_attn, st, ns, e->attn_part_g);  // (slices merge among themselves: no combine launch)
     if (rc) return rc;
-    if (ns > 1) launch_attn_combine(e->attn_part, c.heads, c.head_dim, ns, e->attn, e->xq_attn, st);  // the slices' partials meet here
   } else {
     if (!(skip & 1))
       rc = engine_gemv_xq(e, e->xq_hidden, w.qkv_blob, w.qkv_hdr, e->qkv, e->ssq_part, nullptr, 0, kNoXq, nullptr,
                           nullptr, st);
     if (rc) return rc;
+    const AttnA2A a2a{e->attn_part_g, 0u, e->fuse_status};
     if (!(skip & 2))
       rc = launch_attn_decode(e->qkv, e->kcache + (size_t)l * e->kv_layer_bytes,
                               e->vcache + (size_t)l * e->kv_layer_bytes, c.kv_dtype, e->pos, e->cs, e->sn, c.heads,
                               c.kv_heads, c.head_dim, c.max_ctx, e->window, e->attn, e->attn_splits, e->attn_grouped,
-                              e->attn_part, e->xq_attn, st, e->attn_fold ? e->attn_cnt : nullptr, e->attn_chunk);
+                              e->attn_part, e->xq_attn, st, e->attn_fold ? e->attn_cnt : nullptr, e->attn_chunk,
+                              e->grouped_a2a_ok() ? &a2a : nullptr, e->step_seq, l);
     if (rc) return rc;
   }
   if (skip & 4) return 0;
@@ -641,6 +657,8 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
   {
     const char* af = getenv("WOQ_ATTN_FOLD");
     e->attn_fold = af ? af[0] != '0' : false;
+    const char* ga = getenv("WOQ_GROUPED_A2A");
+    e->grouped_a2a = ga ? ga[0] != '0' : true;
     const char* fs = getenv("WOQ_FUSE_SLICED");
     e->fuse_sliced = fs ? fs[0] != '0' : true;
   }
@@ -677,6 +695,9 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
       WOQ_HIP(hipMalloc((void**)&e->ssq_part, (size_t)(cfg->hidden / 16) * 4));
       WOQ_HIP(hipMalloc((void**)&e->qkv_g, (size_t)qkv_n * 8));
       WOQ_HIP(hipMemset(e->qkv_g, 0, (size_t)qkv_n * 8));  // tag 0 is never a live tag
+      const size_t pg_bytes = (size_t)cfg->heads * 64 * (cfg->head_dim + 2) * 8;
+      WOQ_HIP(hipMalloc((void**)&e->attn_part_g, pg_bytes));
+      WOQ_HIP(hipMemset(e->attn_part_g, 0, pg_bytes));
       WOQ_HIP(hipMemset(bh, 0, xq_bytes(cfg->hidden)));
       WOQ_HIP(hipMemset(ba, 0, xq_bytes(attn_k)));
       WOQ_HIP(hipMemset(bc, 0, xq_bytes(cfg->inter)));
@@ -684,7 +705,7 @@ int woq_engine_create(const woq_engine_config* cfg, woq_engine** out) {
       e->xq_hidden = xq_carve(bh, cfg->hidden);
       e->xq_attn = xq_carve(ba, attn_k);
       e->xq_act = xq_carve(bc, cfg->inter);
-      for (void* p : {bh, ba, bc, (void*)e->ssq_part, (void*)e->qkv_g}) e->owned.push_back(p);
+      for (void* p : {bh, ba, bc, (void*)e->ssq_part, (void*)e->qkv_g, (void*)e->attn_part_g}) e->owned.push_back(p);
     }
   }
   *out = e;

@@ -39,9 +39,10 @@ struct FusedAttnArgs {
   const float* cs;
   const float* sn;
   int heads, kv_heads, window, spw;
-  float* attn_out;  // ns == 1: fp32 [heads * 128] attention output; ns > 1: the slices' partial buffer (woq_attn_merge.h)
+  float* attn_out;  // fp32 [heads * 128] attention output
   XqPtrs xq_attn;
   int ns;           // context slices per head (round 6): heads * ns attention workgroups behind the strips
+  unsigned long long* part_g;  // ns > 1: the slices' partials as tagged granules (woq_attn_decode.h attn_part_granule)
 };
 
 #ifndef WOQ_XQS_DEPTH
@@ -76,7 +77,8 @@ __global__ __launch_bounds__(256) void gemv_xqs_attn_kernel(
     if (fa.ns > 1) {
       // Context slices inside the fused launch (round 6, long contexts): heads * ns attention workgroups, each the
       // per-head flash-decoding slice of woq_attn_decode.h on a granule source — its K / V rows (they depend on the
-      // position only) stream beside the launch's weight tiles while q is still in the making; partials go to the
+      // position only) stream beside the launch's weight tiles while q is still in the making; the slices of a head then
+      // merge among themselves (tagged partial granules, every slice finalises a share of the head's XQ blocks): no
       // combine launch. Workgroup ids go round-robin over the 8 XCDs: the query heads that share a kv head AND a slice
       // read the same cache rows, so they get ids that differ by multiples of 8 (one L2 pulls the rows from HBM once).
       const int rep = fa.heads / fa.kv_heads, groups = fa.kv_heads * fa.ns;
@@ -87,9 +89,9 @@ __global__ __launch_bounds__(256) void gemv_xqs_attn_kernel(
       } else {
         h = a / fa.ns, slice = a % fa.ns;
       }
-      attn_decode_body<KV, 128, true>((float*)smem_raw, h, slice, fa.ns, AttnGranule{qkv_g, tag, fa.status},
+      attn_decode_body<KV, 128, true>((float*)smem_raw, h, slice, fa.ns, AttnGranule{qkv_g, tag, fa.status, fa.part_g},
                                       (KV*)fa.kcache, (KV*)fa.vcache, fa.pos, fa.cs, fa.sn, fa.heads, fa.kv_heads,
-                                      fa.window, fa.spw, fa.attn_out, XqPtrs{nullptr, nullptr, nullptr});
+                                      fa.window, fa.spw, fa.attn_out, fa.xq_attn);
       return;
     }
     attn_decode_body<KV, 128, false>((float*)smem_raw, a, 0, 1,
@@ -125,7 +127,8 @@ bool gemv_xq_attn_supported(const woq_blob_header& h, int heads, int kv_heads, i
   }
   // round 4: grouped-query shapes (Mistral-7B: 32 query / 8 kv heads) and a sliding window are taken as well — the
   // attention body always handled both (kh = h / rep, re-based cache pointers); round 3 simply had not tested them here
-  if (kv_heads < 1 || heads % kv_heads != 0 || head_dim != 128 || splits > ATTN_MAX_SLICES) return false;
+  if (kv_heads < 1 || heads % kv_heads != 0 || head_dim != 128 || splits > ATTN_A2A_MAX_SLICES) return false;
+  if (splits > 1 && heads * splits > 512) return false;  // the slices of a head wait for each other: resident together
   if (splits > 1 && (heads + 2 * kv_heads) * 8 + heads * splits > 65535) return false;  // the packed strip count
   if (h.N != (heads + 2 * kv_heads) * head_dim) return false;
   (void)window;
@@ -164,9 +167,9 @@ static int launch_fused_t(const FusedLaunch& a, hipStream_t st) {
   late.ssq_in = a.ssq_in, late.next_norm_w = nullptr, late.ssq_out = nullptr, late.tp = nullptr;
   late.tag_seq = a.fa.seq, late.tag_layer = a.fa.layer, late.xo = XqPtrs{nullptr, nullptr, nullptr}, late.eps = a.eps;
   late.N = a.N, late.K = a.K, late.n_ssq = a.n_ssq, late.lut = LutArgs{};
-  hipLaunchKernelGGL(kern, dim3(a.N / 16 + a.fa.heads * a.fa.ns), dim3(256), a.lds, st, (const u32x4*)a.q, a.scales, a.xin.limbs, a.xin.u,
-                     a.tiles_k, a.fa.heads * 8, FUSED_TPW, 0, a.n_groups, a.tpg_shift | (a.flags << 8) | ((a.N / 16) << 16), late, a.out,
-                     a.N, a.fa);
+  hipLaunchKernelGGL(kern, dim3(a.N / 16 + a.fa.heads * a.fa.ns), dim3(256), a.lds, st, (const u32x4*)a.q, a.scales,
+                     a.xin.limbs, a.xin.u, a.tiles_k, a.fa.heads * 8, FUSED_TPW, 0, a.n_groups,
+                     a.tpg_shift | (a.flags << 8) | ((a.N / 16) << 16), late, a.out, a.N, a.fa);
   return 0;
 }
 
@@ -188,13 +191,13 @@ static int launch_fused_kv(const FusedLaunch& a, int smode, bool asym, bool s32,
 
 // qkv_g ({tag, fp32} granules [(heads + 2 kv_heads) * 128]) = xin . W_qkv_deq * rsqrt(mean(x^2) + eps); per head, as its granules
 // arrive: RoPE, KV append at *pos, attention over the cache -> attn_out (+ its XQ form).
-// splits > 1: `splits` context slices per head, their partials -> `part` (woq_attn_merge.h); the caller's combine launch
-// turns them into attn_out / xq_attn.
+// splits > 1: `splits` context slices per head; they merge among themselves through the tagged granules `part_g`
+// ([heads][64][130] x 8 B) and write attn_out / xq_attn — no combine launch.
 int launch_gemv_xq_attn(const XqPtrs& xin, const void* blob, const woq_blob_header& h, unsigned long long* qkv_g,
                         const float* ssq_in, float eps, const unsigned int* seq, int layer, int* status, void* kcache,
                         void* vcache, int kv_dtype, const int32_t* pos, const float* cs, const float* sn, int heads,
                         int kv_heads, int max_ctx, int window, float* attn_out, const XqPtrs& xq_attn, hipStream_t st,
-                        int splits, float* part) {
+                        int splits, unsigned long long* part_g) {
   FusedLaunch a;
   if (splits < 1) splits = 1;
   const uint8_t* b = (const uint8_t*)blob;
@@ -223,8 +226,9 @@ int launch_gemv_xq_attn(const XqPtrs& xin, const void* blob, const woq_blob_head
   const bool asym = a.zp != nullptr, s32 = h.scale_type == WOQ_F32;
   const int span = fused_attn_span(max_ctx, window, splits);
   const int spw = attn_dec_spw(span);
-  a.fa = FusedAttnArgs{seq, layer, status, kcache, vcache, pos, cs, sn, heads, kv_heads, window, spw,
-                       splits > 1 ? part : attn_out, xq_attn, splits};
+  if (splits > 1 && part_g == nullptr) return woq::fail("QBits: context slices in the fused launch need the partial granules");
+  a.fa = FusedAttnArgs{seq, layer, status, kcache, vcache, pos, cs, sn, heads, kv_heads, window, spw, attn_out, xq_attn,
+                       splits, part_g};
   const size_t lds_attn = attn_dec_lds_floats(128, span) * 4;
   size_t lds_gemv = 0;
   if (smode == 0)

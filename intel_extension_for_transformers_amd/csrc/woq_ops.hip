@@ -424,14 +424,20 @@ static int launch_attn_t(const float* qkv, void* kcache, void* vcache, const int
 int launch_attn_decode(const float* qkv, void* kcache, void* vcache, int kv_dtype, const int32_t* pos,
                        const float* cs, const float* sn, int heads, int kv_heads, int D, int max_ctx, int window,
                        float* out, int splits, int grouped, float* part, const XqPtrs& xo, hipStream_t st,
-                       unsigned int* merge_counters, int chunk_fixed) {
+                       unsigned int* merge_counters, int chunk_fixed, const AttnA2A* a2a_grouped, const unsigned int* seq,
+                       int layer) {
   if (D != 64 && D != 128) return woq::fail("QBits: attention head_dim must be 64 or 128");
   if (splits > ATTN_MAX_SLICES) return woq::fail("QBits: at most 64 context slices");
   // grouped-query form (woq_prefill.hip): only where it applies — head_dim 128, 2 / 4 / 8 query heads per kv head,
   // an fp16 or fp8 cache — anything else keeps the per-query-head slices
+  // a2a_grouped (round 6, nullable; grouped form only): the slices merge among themselves through tagged granules
+  // (woq_attn_merge.h) — no combine launch; the caller has checked that the grid can be resident at once
+  AttnMerge mg{merge_counters, out, xo};
+  const bool a2a = grouped && a2a_grouped != nullptr && merge_counters == nullptr && splits <= 32;
+  if (a2a) mg.part_g = a2a_grouped->part_g, mg.seq = seq, mg.layer = layer, mg.status = a2a_grouped->status;
   if (grouped && launch_attn_decode_mfma(qkv, kcache, vcache, kv_dtype, pos, cs, sn, heads, kv_heads, D, window, splits,
-                                          part, chunk_fixed, max_ctx, AttnMerge{merge_counters, out, xo}, st)) {
-    if (merge_counters == nullptr) launch_attn_combine(part, heads, D, splits, out, xo, st);
+                                          part, chunk_fixed, max_ctx, mg, st)) {
+    if (merge_counters == nullptr && !a2a) launch_attn_combine(part, heads, D, splits, out, xo, st);
     return 0;
   }
 #define WOQ_ATTN_DEC(T)                                                                                              \

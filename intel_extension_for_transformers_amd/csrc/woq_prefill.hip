@@ -704,14 +704,40 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const float* __re
         acc = fmaf(rec[h * HD + d], wt, acc);
         den = fmaf(rec[16 * HD + 16 + h], wt, den);
       }
+      const float m_nat = m == -INFINITY ? -INFINITY : m * 0.6931471805599453f;  // exp2 domain -> natural
+      if (mg.part_g != nullptr) {  // all-to-all merge (round 6): tagged granules, finalised below by the slices themselves
+        const AttnA2A a2a{mg.part_g, (mg.seq[0] << 6) | (unsigned int)mg.layer, mg.status};
+        attn_a2a_publish(a2a, kh * REP + h, sp, HD, d, acc);
+        if (d == 0) {
+          attn_a2a_publish(a2a, kh * REP + h, sp, HD, HD, m_nat);
+          attn_a2a_publish(a2a, kh * REP + h, sp, HD, HD + 1, den);
+        }
+        continue;
+      }
       // publish (woq_attn_merge.h: agent-scope write-through stores; the merging workgroup may sit on another XCD)
       st_agent(attn_part_o(part, kh * REP + h, sp, HD) + d, acc);
       if (d == 0) {
         float* ml = attn_part_ml(part, heads, kh * REP + h, sp, HD);
-        st_agent(ml, m == -INFINITY ? -INFINITY : m * 0.6931471805599453f);  // exp2 domain -> natural
+        st_agent(ml, m_nat);
         st_agent(ml + 1, den);
       }
     }
+  }
+  if (mg.part_g != nullptr) {
+    // the group's REP * 8 output blocks go round the slices: block B = sp + R * ns is DPP row R's — 16 rows per workgroup
+    // and pass, as many passes as REP * 8 / ns needs (REP = 8 in two slices: two)
+    constexpr int NB = REP * (HD / 16);
+    const AttnA2A a2a{mg.part_g, (mg.seq[0] << 6) | (unsigned int)mg.layer, mg.status};
+    for (int R0 = 0; sp + R0 * ns < NB; R0 += 16) {
+      if (sp + (R0 + wid * 4) * ns >= NB) continue;  // (wave-uniform: no row of this wave has a block in this pass)
+      const int B = sp + (R0 + wid * 4 + (lane >> 4)) * ns;
+      const int Bc = min(B, NB - 1);
+      attn_a2a_finalize<HD, 32>(a2a, kh * REP + Bc / (HD / 16), Bc % (HD / 16), ns, B < NB, [&](float v, int idx) {
+        mg.out[idx] = v;
+        if (mg.xo.limbs != nullptr) xq_emit16(v, mg.xo, idx >> 4, idx & 15);
+      });
+    }
+    return;
   }
   // the last slice workgroup of this kv head to get here merges the group's REP heads and emits the attention output
   if (mg.counter != nullptr) attn_slices_merge<HD, (REP < 2 ? REP : 2)>(part, heads, kh * REP, REP, ns, mg.counter + kh, mg, (float*)dsm_raw);
@@ -817,6 +843,31 @@ bool launch_attn_decode_mfma(const float* qkv, void* kcache, void* vcache, int k
   WOQ_DEC_CASE(WOQ_FP8_E4M3, 2) WOQ_DEC_CASE(WOQ_FP8_E4M3, 4) WOQ_DEC_CASE(WOQ_FP8_E4M3, 8)
 #undef WOQ_DEC_CASE
   return false;
+}
+
+// workgroups of the grouped decode attention kernel the chip holds at once (0 = shape not covered): the all-to-all
+// merge needs the whole grid resident
+int attn_decode_mfma_slots(int kv_dtype, int rep) {
+  static int cache[2][9] = {};  // [fp16 | fp8][rep], 0 = not asked yet, -1 = not covered
+  const int ci = kv_dtype == WOQ_FP8_E4M3 ? 1 : 0;
+  if ((kv_dtype != WOQ_F16 && kv_dtype != WOQ_FP8_E4M3) || rep < 0 || rep > 8) return 0;
+  if (cache[ci][rep] != 0) return std::max(cache[ci][rep], 0);
+  cache[ci][rep] = -1;
+  int per_cu = 0;
+#define WOQ_DEC_OCC(KVD, R)                                                                                          \
+  if (kv_dtype == KVD && rep == R) {                                                                                 \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_decode_mfma_kernel<KVD, 128, R>, 256,             \
+                                                     attn_dec_lds_bytes<128, R>()) != hipSuccess)                    \
+      per_cu = 0;                                                                                                    \
+  }
+  WOQ_DEC_OCC(WOQ_F16, 2) WOQ_DEC_OCC(WOQ_F16, 4) WOQ_DEC_OCC(WOQ_F16, 8)
+  WOQ_DEC_OCC(WOQ_FP8_E4M3, 2) WOQ_DEC_OCC(WOQ_FP8_E4M3, 4) WOQ_DEC_OCC(WOQ_FP8_E4M3, 8)
+#undef WOQ_DEC_OCC
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return 0;
+  if (per_cu * cus > 0) cache[ci][rep] = per_cu * cus;
+  return per_cu * cus;
 }
 
 void launch_gather_last(const float* h, int n_seq, int T, int hidden, float* dst, hipStream_t st) {

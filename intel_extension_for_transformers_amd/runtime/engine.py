@@ -263,16 +263,20 @@ class WoqDecoderEngine:
     # ---- decode attention regime -----------------------------------------------------------------------------
     LONG_CTX = 480  # cached positions beyond which the sliced decode attention wins (r04l, V runs double-buffered: 448 -> 0.617 vs 0.631, 512 -> 0.635 vs 0.634, 640 -> 0.661 vs 0.634). Round 4 (eager bursts, V rows of two runs prefetched; Llama-2-7B shape, 16 layers, ms per token, one workgroup per head inside the fused launch vs context slices + combine: 256 -> 0.593 vs 0.618, 384 -> 0.615 vs 0.621, 512 -> 0.644 vs 0.635; profiles/r04k_*). Round 1 had measured the crossover near 256 on the two-launch form
 
+    FUSED_SLICED_CTX = 192  # ... and where slices INSIDE the fused launch (self-merging, round 6) start to pay: 7B shape,
+    # 16 layers, ms per token, 1 vs 4 slices (profiles/r06t_*): 96 -> 0.544-0.549 vs 0.558, 160 -> 0.557-0.562 vs
+    # 0.561, 224 -> 0.570-0.574 vs 0.564, 320 -> 0.588 vs 0.570, 512 -> 0.625 vs 0.580
+
     def set_attn_splits(self, n):
         """1 = one workgroup per head, n > 1 = n context slices per head + combine. Invalidates a captured graph."""
         if int(n) != L.lib().woq_engine_attn_splits(self._h):
             L.check(L.lib().woq_engine_set_attn_splits(self._h, int(n)))
             self.captured = False
 
-    GROUPED_CTX = 6144  # cached positions from which the grouped-query (matrix-core) slices are used where they apply.
-    # Round 6 (context slices inside the fused qkv launch, profiles/r06s_*; Mistral-7B shape, fp8 cache, 16 layers, ms
-    # per token, fused per-head slices vs grouped slices in their own launch): 2048 -> 0.655 vs 0.716, 4096 -> 0.692 vs
-    # 0.728, 8192 -> 0.782 vs 0.766. (Round 4, both forms as launches of their own, had the crossover at 4096.)
+    GROUPED_CTX = 6144  # cached positions from which the grouped-query (matrix-core) slices are used where they apply
+    # (a launch of their own: 186-247 registers, they cannot share a kernel with the strips). Round 6, Mistral-7B shape,
+    # fp8 cache, 16 layers, ms per token, per-head slices inside the fused launch vs grouped slices: 2048 -> 0.628 vs
+    # 0.716, 4096 -> 0.665 vs 0.707, 8192 -> 0.750 vs 0.732 (both forms with self-merging slices, profiles/r06v_*)
 
     def set_attn_grouped(self, on):
         """Sliced regime only: one workgroup per (kv head, slice) for all the query heads of the group (head_dim 128,
@@ -338,17 +342,19 @@ class WoqDecoderEngine:
         fixed = (os.environ.get("WOQ_ATTN_FIXED_CHUNK", "0") not in ("", "0") and grouped and not self.cfg.reserved[2]
                  and self.cfg.kv_dtype == L.FP8_E4M3)
         self.set_attn_chunk(self.GROUPED_CHUNK if fixed else 0)
-        if positions <= self.LONG_CTX:
+        fused_sliced = not grouped and self.uses_fused_attn_sliced()
+        if positions <= (self.FUSED_SLICED_CTX if fused_sliced else self.LONG_CTX):
             self.set_attn_splits(1)
         elif fixed:  # enough fixed slices to cover `positions`; the last one takes what lies beyond
             self.set_attn_splits(max(2, min(64, -(-positions // self.GROUPED_CHUNK))))
-        elif grouped:
-            self.set_attn_splits(max(2, min(64, positions // 256)))
-        elif self.uses_fused_attn_sliced():
-            # slices as attention workgroups of the fused qkv launch (round 6): fewer, longer slices than launches of
-            # their own want — 7B shape 512 -> 4 (0.606 vs 0.632 / 0.621 / 0.614 ms for 2 / 3 / 8), 2048 -> 8 (0.680 vs
-            # 0.749 / 0.710 / 0.687 / 0.701 for 4 / 6 / 12 / 16), Mistral shape 2048 -> 8, 4096 -> 16 (profiles/r06s_*)
-            self.set_attn_splits(max(4, min(16, positions // 256)))
+        elif grouped:  # (round 6, slices merging among themselves: 8k -> 0.765 / 0.732 / 0.739 ms for 16 / 24 / 32 slices)
+            self.set_attn_splits(max(2, min(32, positions // 320)))
+        elif fused_sliced:
+            # slices as attention workgroups of the fused qkv launch, merging among themselves (round 6): fewer, longer
+            # slices than launches of their own want (profiles/r06t_*, 16 layers, ms per token) — 7B shape 512: 0.580 /
+            # 0.577 for 4 / 8 (0.594 for 2), 2048: 0.657 / 0.659 / 0.668 for 8 / 12 / 16 (0.707 for 4); Mistral shape
+            # 2048: 0.633 / 0.628 for 8 / 16, 4096: 0.689 / 0.670, 8192: 0.785 / 0.751 for 12 / 16
+            self.set_attn_splits(4 if positions < 1024 else 8 if positions < 3072 else 16)
         else:
             self.set_attn_splits(max(2, min(32, 1024 // max(1, self.cfg.heads), positions // 64)))
 

@@ -119,13 +119,13 @@ def test_prefill_attention_4x2048_32_heads_vs_oracle():
     assert eng.status() == 0
 
 
-@pytest.mark.parametrize("ctx,sliced", [(300, False), (520, True)])
-def test_decode_step_sliced_regime_7b_attention_geometry_vs_oracle(ctx, sliced):
+@pytest.mark.parametrize("ctx,sliced,force_one", [(150, False, False), (300, True, False), (300, False, True), (520, True, False)])
+def test_decode_step_sliced_regime_7b_attention_geometry_vs_oracle(ctx, sliced, force_one):
     """(iii) decode steps at a few hundred cached positions at the 7B attention geometry: `ctx` prompt tokens, then 3
-    greedy steps in the regime `tune_attn_for` picks — below LONG_CTX the one-workgroup-per-head attention inside the
-    fused qkv launch (five 16-position passes per wave at 300, three of them beyond the prefetched rows), above it context
-    slices per head (attention workgroups of the fused launch since round 6) + the combine launch — each against the
-    oracle."""
+    greedy steps in the regime `tune_attn_for` picks — below FUSED_SLICED_CTX the one-workgroup-per-head attention inside
+    the fused qkv launch, above it context slices per head as attention workgroups of the same launch, merging among
+    themselves (round 6: four slices at 300 and 520 positions); `force_one`: 300 positions unsliced all the same (five
+    16-position passes per wave, three of them beyond the prefetched rows) — each against the oracle."""
     eng, oracle, cfg = build_attention_geometry(max_ctx=640)
     rng = np.random.default_rng(ctx)
     prompt = rng.integers(0, cfg["vocab"], ctx).tolist()
@@ -133,6 +133,8 @@ def test_decode_step_sliced_regime_7b_attention_geometry_vs_oracle(ctx, sliced):
     ref = oracle.forward_prompt(prompt)
     assert np.abs(got - ref).max() <= PF_TOL * np.abs(ref).max() + 1e-3
     eng.tune_attn_for(ctx + 3)
+    if force_one:
+        eng.set_attn_splits(1)
     assert (L_splits(eng) > 1) == sliced and eng.uses_fused_attn()  # round 6: the slices ride in the fused launch too
     nxt = int(ref.argmax())
     for j in range(3):
@@ -306,3 +308,33 @@ def test_fused_launch_with_context_slices_equals_separate_launches(kv_heads, kv_
             assert np.abs(g - ref).max() <= PF_TOL * np.abs(ref).max() + 1e-3, j
             nxt = int(ref.argmax())
             assert int(out["fused"][1][j]) == nxt
+
+
+@pytest.mark.parametrize("kv_dtype,splits,ctx", [(torch.float8_e4m3fn, 32, 900), (torch.float16, 6, 300)])
+def test_grouped_slices_self_merge_at_the_mistral_geometry(kv_dtype, splits, ctx, monkeypatch):
+    """The grouped-query matrix-core slices at the Mistral-7B attention geometry (32 query / 8 kv heads, XQ decode path)
+    merging among themselves (round 6, csrc/woq_attn_merge.h; 8 x 32 = 256 slice workgroups resident at once) against an
+    engine created with WOQ_GROUPED_A2A=0 (combine launch): logits and tokens bit-identical, eager and replayed."""
+    rng = np.random.default_rng(73)
+    out = {}
+    for a2a in ("0", "1"):
+        monkeypatch.setenv("WOQ_GROUPED_A2A", a2a)
+        eng, _, cfg = build_attention_geometry(kv_heads=8, kv_dtype=kv_dtype, max_ctx=1024)
+        if a2a == "0":
+            prompt = rng.integers(0, cfg["vocab"], ctx).tolist()
+        eng.set_attn_splits(splits)
+        eng.set_attn_grouped(True)
+        assert eng.uses_xq() and not eng.uses_fused_attn()
+        eng.prefill(prompt, greedy=True)
+        logs = []
+        for _ in range(4):
+            eng.step(greedy=True)
+            logs.append(eng.logits.clone())
+        eng.capture(greedy=True)
+        eng.replay_graph(10)
+        torch.cuda.synchronize()
+        logs.append(eng.logits.clone())
+        out[a2a] = (torch.stack(logs), eng.token_log()[ctx:ctx + 15].clone())
+        assert eng.status() == 0
+        del eng
+    assert torch.equal(out["1"][0], out["0"][0]) and torch.equal(out["1"][1], out["0"][1])

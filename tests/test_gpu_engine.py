@@ -382,6 +382,41 @@ def test_grouped_attention_fixed_chunk_slices_vs_oracle(hidden, chunk, splits, m
     assert eng.status() == 0
 
 
+@pytest.mark.parametrize("hidden,splits,kv_dtype", [(512, 4, torch.float16), (1024, 7, torch.float16), (256, 32, torch.float16),
+                                                    (512, 5, torch.float8_e4m3fn)])
+def test_grouped_slices_merging_among_themselves_equal_the_combine_launch(hidden, splits, kv_dtype, monkeypatch):
+    """Round 6: the grouped-query matrix-core slices publish tagged partial granules and finalise the group's output
+    blocks themselves (csrc/woq_attn_merge.h, all-to-all merge: block B of the group's REP x 8 goes to slice B mod ns)
+    instead of ending in a combine launch (WOQ_GROUPED_A2A=0, read at engine creation) — same sums in the same order:
+    logits and greedy tokens BIT-IDENTICAL over 150 decode steps (empty slices, more slices than blocks: 32 > 16,
+    fewer: 4 < 32, a slice count that does not divide the blocks: 7), then as graph replays; status clean."""
+    engs = []
+    for a2a in ("0", "1"):
+        monkeypatch.setenv("WOQ_GROUPED_A2A", a2a)
+        engs.append(_tiny(128, False, "fp16", seed=6, max_ctx=256, head_dim=128, attn_splits=splits, hidden=hidden,
+                          attn_grouped=True, kv_dtype=kv_dtype)[0])
+    cfg_vocab = 384
+    rng = np.random.default_rng(9)
+    for i, t in enumerate(rng.integers(0, cfg_vocab, 150).tolist()):
+        outs = []
+        for e in engs:
+            e.token.fill_(t)
+            e.pos.fill_(i)
+            e.step(greedy=True)
+            outs.append((e.logits.clone(), int(e.token.item())))
+        assert outs[0][1] == outs[1][1], i
+        assert torch.equal(outs[0][0], outs[1][0]), i
+    toks = []
+    for e in engs:
+        e.pos.fill_(150)
+        e.capture(greedy=True)
+        e.replay_graph(10)
+        torch.cuda.synchronize()
+        toks.append((e.logits.clone(), e.token_log()[150:160].clone()))
+        assert e.status() == 0
+    assert torch.equal(toks[0][0], toks[1][0]) and torch.equal(toks[0][1], toks[1][1])
+
+
 @pytest.mark.parametrize("grouped,hidden,head_dim", [(False, 256, 64), (False, 256, 128), (True, 512, 128)])
 def test_slice_merge_by_last_workgroup_equals_the_combine_launch(grouped, hidden, head_dim, monkeypatch):
     """The two ways of merging context-slice partials — the last slice workgroup of a head (default) and the separate

@@ -22,6 +22,7 @@ def run(layers, ctx, kv, fold, chunk, splits, fs=1, grouped=-1):
     choice, 0 / 1 = per-query-head slices / the grouped matrix-core form"""
     os.environ["WOQ_ATTN_FOLD"] = "1" if fold else "0"
     os.environ["WOQ_FUSE_SLICED"] = "1" if fs & 1 else "0"
+    os.environ["WOQ_GROUPED_A2A"] = "1" if fs & 2 else "0"  # fs bit 1: grouped slices merge among themselves
     hidden, heads, hd, vocab = 4096, 32, 128, 32000
     kvh, inter = int(os.environ.get("LCAB_KVH", "8")), int(os.environ.get("LCAB_INTER", "14336"))  # 32 / 11008: Llama-2-7B
     eng = WoqDecoderEngine(hidden, inter, heads, kvh, hd, layers, vocab, max_ctx=ctx + 256,
