@@ -119,36 +119,43 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
   const int sub = lane & 3, r16 = lane >> 2;
   const int g = lane / LPR, l8 = lane % LPR;
   const int plast = max(pos - 1, 0);
-  kv8 kpre[DPL / 8];
-  {
-    const int tc = min(16 * wid + r16, plast);
-    const kv8* kp = (const kv8*)(kcache + ((size_t)tc * kv_heads + kh) * HD + sub * DPL);
-#pragma unroll
-    for (int j = 0; j < DPL / 8; ++j) kpre[j] = kp[j];
-  }
-  kv8 kb[DPL / 8];  // second score pass (positions 64 + 16 w + r): needs only `pos` as well
-  if (n_w > 16) {
-    const int tc = min(64 + 16 * wid + r16, plast);
-    const kv8* kp = (const kv8*)(kcache + ((size_t)tc * kv_heads + kh) * HD + sub * DPL);
-#pragma unroll
-    for (int j = 0; j < DPL / 8; ++j) kb[j] = kp[j];
-  }
+  // Two request schedules. 16-bit caches: round 4's — two K passes and two V runs requested up front, the third V run
+  // when the K registers die, double buffering in the loops (117 registers: four waves per SIMD, which the fused launch's
+  // strips need). e4m3 cache (round 6): RINGS of register sets — pass / run i lives in set i mod depth and the set is
+  // re-requested for i + depth as soon as it has been consumed; the sets are half the size, so four K passes and four V
+  // runs are in flight (at long contexts a slice is a latency chain of its passes: Mistral-7B shape at 8k, eight per wave).
+  constexpr bool kv8bit = sizeof(KV) == 1;
+  constexpr int KD = 4, VD = 4;
   constexpr int VU = 16 / GP;  // P.V passes that cover one 16-position run
-  kv8 vpre[VU];
+  auto kload = [&](int i, kv8 (&kv)[DPL / 8]) {
+    const int tc = min(64 * i + 16 * wid + r16, plast);
+    const kv8* kp = (const kv8*)(kcache + ((size_t)tc * kv_heads + kh) * HD + sub * DPL);
 #pragma unroll
-  for (int u = 0; u < VU; ++u) {
-    const int tc = min(16 * wid + g + u * GP, plast);
-    vpre[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
-  }
-  // round 4: the V rows of the SECOND 16-position run too (contexts 64 .. 128 used to pay one exposed round trip for
-  // them behind the q hand-off, on the launch's tail: the 128-step bench value sat 4 % under the 20-step one)
-  kv8 vpre2[VU];
-  if (n_w > 16) {
+    for (int j = 0; j < DPL / 8; ++j) kv[j] = kp[j];
+  };
+  auto vload_run = [&](int r, kv8 (&vv)[VU]) {  // run r = list entries 16 r .. 16 r + 15 = positions 64 r + 16 wid + ...
 #pragma unroll
     for (int u = 0; u < VU; ++u) {
-      const int tc = min(64 + 16 * wid + g + u * GP, plast);
-      vpre2[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
+      const int tc = min(64 * r + 16 * wid + g + u * GP, plast);
+      vv[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
     }
+  };
+  kv8 kr[kv8bit ? KD : 1][DPL / 8], vr[kv8bit ? VD : 1][VU];  // (the rings; one dead set for 16-bit caches)
+  kv8 kpre[DPL / 8], kb[DPL / 8], vpre[VU], vpre2[VU];          // (round 4's sets; dead for an e4m3 cache)
+  if constexpr (kv8bit) {
+#pragma unroll
+    for (int b2 = 0; b2 < KD; ++b2)
+      if (b2 == 0 || n_w > 16 * b2) kload(b2, kr[b2]);
+#pragma unroll
+    for (int b2 = 0; b2 < VD; ++b2)
+      if (b2 == 0 || n_w > 16 * b2) vload_run(b2, vr[b2]);
+  } else {
+    kload(0, kpre);
+    if (n_w > 16) kload(1, kb);  // second score pass (positions 64 + 16 w + r): needs only `pos` as well
+    vload_run(0, vpre);
+    // round 4: the V rows of the SECOND 16-position run too (contexts 64 .. 128 used to pay one exposed round trip for
+    // them behind the q hand-off, on the launch's tail: the 128-step bench value sat 4 % under the 20-step one)
+    if (n_w > 16) vload_run(1, vpre2);
   }
   // ---- RoPE of q (every wave for itself | wave 0 for all). The new position — k rotated, k / v rounded to the cache
   // dtype and appended, its score — is wave 0's and enters the result as a FIFTH partial (max = its score, sum = 1,
@@ -264,14 +271,19 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
       lmax = fmaxf(lmax, d);
     }
   };
-  auto kload = [&](int i, kv8 (&kv)[DPL / 8]) {
-    const int tc = min(64 * i + 16 * wid + r16, plast);
-    const kv8* kp = (const kv8*)(kcache + ((size_t)tc * kv_heads + kh) * HD + sub * DPL);
-#pragma unroll
-    for (int j = 0; j < DPL / 8; ++j) kv[j] = kp[j];
-  };
   const int n_it = (n_w + 15) >> 4;  // 16-position passes of this wave
-  if (n_it > 0) {
+  if constexpr (kv8bit) {
+    for (int i0 = 0; i0 < n_it; i0 += KD) {
+#pragma unroll
+      for (int b2 = 0; b2 < KD; ++b2) {
+        const int i = i0 + b2;
+        if (i < n_it) {
+          score(i, kr[b2]);
+          if (i + KD < n_it) kload(i + KD, kr[b2]);  // the set is free again: pass i + KD joins the ones in flight
+        }
+      }
+    }
+  } else if (n_it > 0) {
     score(0, kpre);
     // rows of pass i + 1 are in flight while pass i is scored
     for (int i = 1; i < n_it; i += 2) {
@@ -285,16 +297,11 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
   }
   const float m_w = wave_max_dpp(lmax);
   const int n_l = n_w;  // entries of this wave's list (the new position is the merge's fifth partial)
-  // round 4: the V rows of the third 16-position run are requested HERE — the K registers have just died, and the
-  // exponentials below run under the request instead of in front of it (later runs are double-buffered in the loop)
+  // round 4 (16-bit caches): the V rows of the third 16-position run are requested HERE — the K registers have just died,
+  // and the exponentials below run under the request instead of in front of it (later runs are double-buffered in the loop)
   kv8 vnext[VU];
-  if (n_w > 32) {
-#pragma unroll
-    for (int u = 0; u < VU; ++u) {
-      const int j = 32 + g + u * GP;
-      const int tc = min(64 * (j >> 4) + 16 * wid + (j & 15), plast);
-      vnext[u] = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
-    }
+  if constexpr (!kv8bit) {
+    if (n_w > 32) vload_run(2, vnext);
   }
   __builtin_amdgcn_wave_barrier();
   // ---- probabilities and their sum ----
@@ -310,10 +317,6 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  auto vload = [&](int j, kv8& vv) {
-    const int tc = min(64 * (j >> 4) + 16 * wid + (j & 15), plast);
-    vv = *(const kv8*)(vcache + ((size_t)tc * kv_heads + kh) * HD + l8 * 8);
-  };
   auto pv = [&](int j, const kv8& vv) {
     const float p = j < n_w ? scw[j] : 0.f;
     float vf[8];
@@ -321,7 +324,19 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, vf[i], acc[i]);
   };
-  if (n_w > 0) {
+  if constexpr (kv8bit) {
+    for (int r0 = 0; 16 * r0 < n_w; r0 += VD) {  // runs in ascending order; run r + VD is requested when run r has been consumed
+#pragma unroll
+      for (int b2 = 0; b2 < VD; ++b2) {
+        const int r = r0 + b2;
+        if (16 * r < n_w) {
+#pragma unroll
+          for (int u = 0; u < VU; ++u) pv(16 * r + g + u * GP, vr[b2][u]);
+          if (16 * (r + VD) < n_w) vload_run(r + VD, vr[b2]);
+        }
+      }
+    }
+  } else if (n_w > 0) {
 #pragma unroll
     for (int u = 0; u < VU; ++u) pv(g + u * GP, vpre[u]);
     if (n_w > 16) {
@@ -332,10 +347,7 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
       kv8 vv[VU];
 #pragma unroll
       for (int u = 0; u < VU; ++u) vv[u] = vnext[u];
-      if (j0 + 16 < n_w) {
-#pragma unroll
-        for (int u = 0; u < VU; ++u) vload(j0 + 16 + g + u * GP, vnext[u]);
-      }
+      if (j0 + 16 < n_w) vload_run((j0 >> 4) + 1, vnext);
 #pragma unroll
       for (int u = 0; u < VU; ++u) pv(j0 + g + u * GP, vv[u]);
     }

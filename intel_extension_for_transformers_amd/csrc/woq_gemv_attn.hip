@@ -65,7 +65,7 @@ constexpr int FUSED_TPW = 8;
 __device__ __forceinline__ int fa_strips_of_grid(int tpg_flags) { return (tpg_flags >> 16) & 0xffff; }
 
 template <int SMODE, bool ASYM, bool S32, typename KV>
-__global__ __launch_bounds__(256) void gemv_xqs_attn_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void gemv_xqs_attn_kernel(
     const u32x4* __restrict__ q, const void* __restrict__ scales, const uint8_t* __restrict__ xlimbs,
     const float* __restrict__ xu, int tiles_k, int n_q_strips, int base_tiles, int rem_tiles, int n_groups, int tpg_flags,
     XqsLate late_in_the_argument_segment, unsigned long long* __restrict__ qkv_g, int N, FusedAttnArgs fa) {

@@ -273,10 +273,10 @@ class WoqDecoderEngine:
             L.check(L.lib().woq_engine_set_attn_splits(self._h, int(n)))
             self.captured = False
 
-    GROUPED_CTX = 6144  # cached positions from which the grouped-query (matrix-core) slices are used where they apply
+    GROUPED_CTX = 10240  # cached positions from which the grouped-query (matrix-core) slices are used where they apply
     # (a launch of their own: 186-247 registers, they cannot share a kernel with the strips). Round 6, Mistral-7B shape,
-    # fp8 cache, 16 layers, ms per token, per-head slices inside the fused launch vs grouped slices: 2048 -> 0.628 vs
-    # 0.716, 4096 -> 0.665 vs 0.707, 8192 -> 0.750 vs 0.732 (both forms with self-merging slices, profiles/r06v_*)
+    # fp8 cache, 16 layers, ms per token, 16 per-head slices inside the fused launch vs grouped slices (both forms
+    # merge among themselves; profiles/r06t_*): 4096 -> 0.644 vs 0.707, 8192 -> 0.720 vs 0.745, 16384 -> 0.850 vs 0.789
 
     def set_attn_grouped(self, on):
         """Sliced regime only: one workgroup per (kv head, slice) for all the query heads of the group (head_dim 128,
