@@ -800,6 +800,19 @@ def extra_configs(args):
                                 LLAMA2_7B, eng, 64, 8, 128, False, "prompt 32"))
         del eng
         free_gpu()
+    # round 6: fp8_e4m3 WEIGHTS inside the engine (fp8 matrix-core GEMVs with RMSNorm / residual fused, csrc/woq_gemv_fp8.hip;
+    # 6 launches per layer on fp32 activations). One code byte per weight: the algorithmic bytes are twice the int4 payload.
+    eng = build_engine(LLAMA2_7B, group=128, sym=True, max_ctx=512, weight_dtype="fp8_e4m3")
+    feed_prompt(eng, LLAMA2_7B["vocab"], 32)
+    e = decode_entry("SURVEY 8(f)-4: Llama-2-7B fp8_e4m3 sym g128 (compute fp32), batch-1 decode", LLAMA2_7B, eng, 64, 8, 128,
+                     False, "prompt 32")
+    wb = e["algorithmic_weight_bytes_per_token"] + linear_params(LLAMA2_7B) // 2
+    for k in ("hbm_gbps_weights", "hbm_frac_weights", "hbm_frac_weights_plus_kv"):
+        e[k] *= wb / e["algorithmic_weight_bytes_per_token"]
+    e["algorithmic_weight_bytes_per_token"] = wb
+    out.append(e)
+    del eng
+    free_gpu()
     # configs[4]: Mistral-7B shape, int4 sym g128, fp8 (e4m3) KV cache, 8k context: chunked prompt pass then decode
     cfg, ctx = MISTRAL_7B, 8192
     eng = build_engine(cfg, group=128, sym=True, max_ctx=ctx + 256, kv_dtype=torch.float8_e4m3fn)

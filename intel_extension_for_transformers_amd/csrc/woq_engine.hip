@@ -50,6 +50,9 @@ int launch_gemv_xq_attn(const XqPtrs& xin, const void* blob, const woq_blob_head
                         int splits = 1, unsigned long long* part_g = nullptr);
 void launch_attn_combine(const float* part, int heads, int D, int splits, float* out, const XqPtrs& xo,
                          hipStream_t st);
+int launch_gemv_fp8_engine(const float* act, int lda, const void* hi_blob, const woq_blob_header& hi, const void* lo_q,
+                           uint32_t fp8_type, float* out, int ldo, const float* norm_w, float eps, const float* residual,
+                           int ld_res, int epi, float* gu_tmp, hipStream_t st);
 int launch_gemv_twin(const void* blob, const woq_blob_header& h, int epi, int mode, unsigned int* sink, hipStream_t st);
 void launch_lm_head(const float* hidden_in, const float* norm_w, float eps, const void* W, int w_dtype, int hidden,
                     int vocab, float* logits, float* pmax, int32_t* pidx, hipStream_t st);
@@ -137,6 +140,15 @@ struct woq_engine {
   // context slices as attention workgroups of the fused launch (round 6; WOQ_FUSE_SLICED=0: sliced contexts keep the
   // three launches qkv | slices | combine — same-box A/B runs)
   bool fuse_sliced = true;
+  // fp8-weight layers (round 6; bestla_weightonly_dispatcher.hpp:62-72): `layers` then holds the HI nibble plane's blob
+  // and header of every projection (include/woq_blob.h woq_fp8_headers), fp8_lo the LO planes' tile data. Such engines
+  // run the fp32-activation step (no XQ vectors): fp8 matrix-core GEMVs with RMSNorm / residual fused, 6 launches a layer
+  uint32_t fp8_type = 0;  // 0 = integer / table layers; WOQ_W_FP8_E4M3 | WOQ_W_FP8_E5M2
+  struct Fp8Lo {
+    const void* p[4];  // qkv, o, gate_up, down
+  };
+  std::vector<Fp8Lo> fp8_lo;
+  float* gu_tmp = nullptr;  // fp32 [2 * inter]: the fused gate/up projection's columns before SiLU * mul
   unsigned long long* attn_part_g = nullptr;  // their partials as {tag, fp32} granules [heads][64][head_dim + 2]
   bool fused_attn_applies(const woq_blob_header& qkv_hdr) const;
   // grouped matrix-core slices (a launch of their own) merging among themselves instead of a combine launch: every slice
@@ -281,12 +293,24 @@ static int engine_mlp_block_xq(woq_engine* e, int l, hipStream_t st) {
                                 last ? nullptr : e->layers[l + 1].ln1, last ? nullptr : e->ssq_part, st);
 }
 
+// one batch-1 projection of the fp32-activation step: integer / table blobs through the tile / generic GEMVs, fp8 layers
+// through the fp8 matrix-core GEMV (which: 0 qkv, 1 o, 2 gate_up, 3 down)
+static int engine_linear_f32(woq_engine* e, int l, int which, const float* act, int lda, const void* blob,
+                             const woq_blob_header& h, float* out, int ldo, const float* norm_w, const float* residual,
+                             int epi, hipStream_t st) {
+  const woq_engine_config& c = e->cfg;
+  if (e->fp8_type != 0)
+    return launch_gemv_fp8_engine(act, lda, blob, h, e->fp8_lo[l].p[which], e->fp8_type, out, ldo, norm_w, c.rms_eps,
+                                  residual, c.hidden, epi, e->gu_tmp, st);
+  return launch_gemv_from_header(act, WOQ_F32, lda, blob, h, nullptr, out, WOQ_F32, ldo, 1, norm_w, c.rms_eps, residual,
+                                 c.hidden, epi, e->nt, st);
+}
+
 static int engine_attn_block(woq_engine* e, int l, hipStream_t st) {
   if (e->use_xq()) return engine_attn_block_xq(e, l, st);
   const woq_engine_config& c = e->cfg;
   const woq_layer_weights& w = e->layers[l];
-  int rc = launch_gemv_from_header(e->hidden, WOQ_F32, c.hidden, w.qkv_blob, w.qkv_hdr, nullptr, e->qkv, WOQ_F32,
-                                   w.qkv_hdr.N, 1, w.ln1, c.rms_eps, nullptr, 0, 0, e->nt, st);
+  int rc = engine_linear_f32(e, l, 0, e->hidden, c.hidden, w.qkv_blob, w.qkv_hdr, e->qkv, w.qkv_hdr.N, w.ln1, nullptr, 0, st);
   if (rc) return rc;
   rc = launch_attn_decode(e->qkv, e->kcache + (size_t)l * e->kv_layer_bytes, e->vcache + (size_t)l * e->kv_layer_bytes,
                           c.kv_dtype, e->pos, e->cs, e->sn, c.heads, c.kv_heads, c.head_dim, c.max_ctx, e->window,
@@ -295,20 +319,17 @@ static int engine_attn_block(woq_engine* e, int l, hipStream_t st) {
   if (rc) return rc;
   // row-parallel o_proj: rank 0 carries the residual so that the sum over ranks adds it exactly once
   const float* res = (c.tp_size <= 1 || c.tp_rank == 0) ? e->hidden : nullptr;
-  return launch_gemv_from_header(e->attn, WOQ_F32, c.heads * c.head_dim, w.o_blob, w.o_hdr, nullptr, e->hidden,
-                                 WOQ_F32, c.hidden, 1, nullptr, 0.f, res, c.hidden, 0, e->nt, st);
+  return engine_linear_f32(e, l, 1, e->attn, c.heads * c.head_dim, w.o_blob, w.o_hdr, e->hidden, c.hidden, nullptr, res, 0, st);
 }
 
 static int engine_mlp_block(woq_engine* e, int l, hipStream_t st) {
   if (e->use_xq()) return engine_mlp_block_xq(e, l, st);
   const woq_engine_config& c = e->cfg;
   const woq_layer_weights& w = e->layers[l];
-  int rc = launch_gemv_from_header(e->hidden, WOQ_F32, c.hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, e->act,
-                                   WOQ_F32, c.inter, 1, w.ln2, c.rms_eps, nullptr, 0, 1, e->nt, st);
+  int rc = engine_linear_f32(e, l, 2, e->hidden, c.hidden, w.gate_up_blob, w.gate_up_hdr, e->act, c.inter, w.ln2, nullptr, 1, st);
   if (rc) return rc;
   const float* res = (c.tp_size <= 1 || c.tp_rank == 0) ? e->hidden : nullptr;
-  return launch_gemv_from_header(e->act, WOQ_F32, c.inter, w.down_blob, w.down_hdr, nullptr, e->hidden, WOQ_F32,
-                                 c.hidden, 1, nullptr, 0.f, res, c.hidden, 0, e->nt, st);
+  return engine_linear_f32(e, l, 3, e->act, c.inter, w.down_blob, w.down_hdr, e->hidden, c.hidden, nullptr, res, 0, st);
 }
 
 // fuse_next: this step's greedy argmax and the NEXT step's embedding kernel as one launch (steps chained inside one
@@ -410,7 +431,8 @@ static int engine_prefill_reserve(woq_engine* e, size_t rows) {
   size_t ws = 0;
   for (const woq_layer_weights& w : e->layers)
     for (const woq_blob_header* h : {&w.qkv_hdr, &w.o_hdr, &w.gate_up_hdr, &w.down_hdr})
-      ws = std::max(ws, gemm_f16_workspace_bytes_blob((int)rows, *h, 1));
+      ws = std::max(ws, gemm_f16_workspace_bytes_blob((int)rows, *h, 1) +
+                            (e->fp8_type ? (size_t)(h->Npad / WOQ_TILE_N) * (h->Kpad / WOQ_TILE_K) * 4 * 1024 : 0));
   if (rows <= e->pf_rows && ws <= e->pf_ws_bytes) return 0;
   WOQ_HIP(hipDeviceSynchronize());
   for (void* p : {(void*)e->pf_h, (void*)e->pf_qkv, (void*)e->pf_attn, (void*)e->pf_act, e->pf_ws})
@@ -438,12 +460,13 @@ static int engine_prefill_impl(woq_engine* e, const int32_t* tokens, int n_seq, 
   if (rc) return rc;
   launch_embed_rows(e->embed, e->embed_dtype, tokens, M, c.hidden, e->pf_h, st);
   const float* res = (c.tp_size <= 1 || c.tp_rank == 0) ? e->pf_h : nullptr;
+  auto lo_of = [&](int l, int which) -> const void* { return e->fp8_type ? e->fp8_lo[l].p[which] : nullptr; };
   for (int l = 0; l < c.layers; ++l) {
     const woq_layer_weights& w = e->layers[l];
     uint8_t* kc = e->kcache + (size_t)l * e->kv_layer_bytes;
     uint8_t* vc = e->vcache + (size_t)l * e->kv_layer_bytes;
     if ((rc = launch_gemm_f16(e->pf_h, WOQ_F32, c.hidden, w.qkv_blob, w.qkv_hdr, nullptr, e->pf_qkv, WOQ_F16, qkv_n, M,
-                              w.ln1, c.rms_eps, nullptr, 0, 0, e->pf_ws, 0, st, nullptr, 0, e->pf_ws_bytes)) != 0)
+                              w.ln1, c.rms_eps, nullptr, 0, 0, e->pf_ws, 0, st, lo_of(l, 0), e->fp8_type, e->pf_ws_bytes)) != 0)
       return rc;
     if ((rc = launch_rope_append(e->pf_qkv, n_seq, T, start, c.heads, c.kv_heads, c.head_dim, e->cs, e->sn, kc, vc,
                                  c.kv_dtype, seq_stride, st)) != 0)
@@ -452,14 +475,14 @@ static int engine_prefill_impl(woq_engine* e, const int32_t* tokens, int n_seq, 
                                   seq_stride, e->pf_attn, e->window, st)) != 0)
       return rc;
     if ((rc = launch_gemm_f16(e->pf_attn, WOQ_F16, c.heads * c.head_dim, w.o_blob, w.o_hdr, nullptr, e->pf_h, WOQ_F32,
-                              c.hidden, M, nullptr, 0.f, res, c.hidden, 0, e->pf_ws, 0, st, nullptr, 0, e->pf_ws_bytes)) != 0)
+                              c.hidden, M, nullptr, 0.f, res, c.hidden, 0, e->pf_ws, 0, st, lo_of(l, 1), e->fp8_type, e->pf_ws_bytes)) != 0)
       return rc;
     if ((rc = engine_allreduce_rows(e, e->pf_h, (size_t)M * c.hidden, st)) != 0) return rc;
     if ((rc = launch_gemm_f16(e->pf_h, WOQ_F32, c.hidden, w.gate_up_blob, w.gate_up_hdr, nullptr, e->pf_act, WOQ_F16,
-                              c.inter, M, w.ln2, c.rms_eps, nullptr, 0, 1, e->pf_ws, 0, st, nullptr, 0, e->pf_ws_bytes)) != 0)
+                              c.inter, M, w.ln2, c.rms_eps, nullptr, 0, 1, e->pf_ws, 0, st, lo_of(l, 2), e->fp8_type, e->pf_ws_bytes)) != 0)
       return rc;
     if ((rc = launch_gemm_f16(e->pf_act, WOQ_F16, c.inter, w.down_blob, w.down_hdr, nullptr, e->pf_h, WOQ_F32,
-                              c.hidden, M, nullptr, 0.f, res, c.hidden, 0, e->pf_ws, 0, st, nullptr, 0, e->pf_ws_bytes)) != 0)
+                              c.hidden, M, nullptr, 0.f, res, c.hidden, 0, e->pf_ws, 0, st, lo_of(l, 3), e->fp8_type, e->pf_ws_bytes)) != 0)
       return rc;
     if ((rc = engine_allreduce_rows(e, e->pf_h, (size_t)M * c.hidden, st)) != 0) return rc;
   }
@@ -733,8 +756,18 @@ int woq_engine_set_layer(woq_engine* e, int layer, const woq_layer_weights* w) {
   auto takes = [](const woq_blob_header& h) {
     return h.weight_type == WOQ_W_INT4_CLIP || (is_table_type(h.weight_type) && h.off_zp == 0);
   };
-  WOQ_CHECK(takes(w->qkv_hdr) && takes(w->o_hdr) && takes(w->gate_up_hdr) && takes(w->down_hdr),
-            "QBits: the fused engine takes int4_clip / nf4 / fp4 layers");
+  // round 6: fp8_e4m3 / fp8_e5m2 layers (all four projections of every layer the same type; one GPU)
+  const bool fp8 = woq_weight_is_fp8(w->qkv_hdr.weight_type);
+  if (fp8) {
+    WOQ_CHECK(w->o_hdr.weight_type == w->qkv_hdr.weight_type && w->gate_up_hdr.weight_type == w->qkv_hdr.weight_type &&
+                  w->down_hdr.weight_type == w->qkv_hdr.weight_type,
+              "QBits: an fp8 layer needs all four projections in the same fp8 type");
+    WOQ_CHECK(c.tp_size <= 1, "QBits: fp8-weight layers run on one GPU (no tensor-parallel decode path)");
+  } else {
+    WOQ_CHECK(takes(w->qkv_hdr) && takes(w->o_hdr) && takes(w->gate_up_hdr) && takes(w->down_hdr),
+              "QBits: the fused engine takes int4_clip / nf4 / fp4 / fp8 layers");
+  }
+
   WOQ_CHECK(w->qkv_hdr.magic == WOQ_BLOB_MAGIC && w->o_hdr.magic == WOQ_BLOB_MAGIC &&
                 w->gate_up_hdr.magic == WOQ_BLOB_MAGIC && w->down_hdr.magic == WOQ_BLOB_MAGIC,
             "QBits: layer weights must be WQH1 blobs");
@@ -745,6 +778,34 @@ int woq_engine_set_layer(woq_engine* e, int layer, const woq_layer_weights* w) {
             "QBits: gate_up blob shape mismatch (inter must be a multiple of 16)");
   WOQ_CHECK(w->down_hdr.K == c.inter && w->down_hdr.N == c.hidden, "QBits: down_proj blob shape mismatch");
   e->layers[layer] = *w;
+  if (fp8) {
+    // the composite container [outer header][HI blob][LO blob] (include/woq_blob.h): the engine keeps the HI plane as the
+    // layer's blob / header and the LO plane's tile data beside it; its headers follow from the outer one's parameters
+    if (e->fp8_lo.empty()) e->fp8_lo.resize(c.layers, woq_engine::Fp8Lo{{nullptr, nullptr, nullptr, nullptr}});
+    WOQ_CHECK(e->fp8_type == 0 || e->fp8_type == w->qkv_hdr.weight_type, "QBits: one fp8 type per engine");
+    e->fp8_type = w->qkv_hdr.weight_type;
+    woq_layer_weights& d = e->layers[layer];
+    const void** blobs[4] = {&d.qkv_blob, &d.o_blob, &d.gate_up_blob, &d.down_blob};
+    woq_blob_header* hdrs[4] = {&d.qkv_hdr, &d.o_hdr, &d.gate_up_hdr, &d.down_hdr};
+    for (int i = 0; i < 4; ++i) {
+      const woq_blob_header outer = *hdrs[i];
+      woq_blob_header o2, hi, lo;
+      WOQ_CHECK(outer.off_shuffle == 0, "QBits: fp8 layers with g_idx stay on the module path");
+      WOQ_CHECK(woq_fp8_headers(&o2, &hi, &lo, outer.K, outer.N, outer.group, outer.weight_type, outer.scale_type,
+                                outer.compute_type, 0) == 0, "QBits: corrupt fp8 header");
+      const uint8_t* base = (const uint8_t*)*blobs[i];
+      *blobs[i] = base + outer.off_q;                                   // the HI plane's blob
+      *hdrs[i] = hi;
+      e->fp8_lo[layer].p[i] = base + outer.off_scale + lo.off_q;        // the LO plane's tile data
+    }
+    if (e->gu_tmp == nullptr) {
+      WOQ_HIP(hipMalloc((void**)&e->gu_tmp, (size_t)2 * c.inter * 4));
+      e->owned.push_back(e->gu_tmp);
+    }
+    e->xq_shapes_ok = false;  // fp8 layers run the fp32-activation step
+    return 0;
+  }
+  WOQ_CHECK(e->fp8_type == 0, "QBits: fp8 and integer layers cannot be mixed in one engine");
   e->xq_shapes_ok = e->xq_shapes_ok && gemv_xq_supported(w->qkv_hdr, 0) && gemv_xq_supported(w->o_hdr, 0) &&
                     gemv_xq_supported(w->gate_up_hdr, 1) && gemv_xq_supported(w->down_hdr, 0);
   WOQ_END

@@ -257,7 +257,8 @@ int launch_gemv_from_header(const void* act, int act_dtype, int lda, const void*
 bool gemv_fp8_mfma_supported(const void* act, int act_dtype, int lda, const woq_blob_header& hi);
 int launch_gemv_fp8_mfma(const void* act, int act_dtype, int lda, int M, const void* hi_blob, const woq_blob_header& hi,
                          const void* lo_q, uint32_t fp8_type, const float* bias, void* out, int out_dtype, int ldo,
-                         hipStream_t st);
+                         hipStream_t st, const float* norm_w = nullptr, float eps = 0.f, const float* residual = nullptr,
+                         int ld_res = 0);
 
 // fp8 weights at decode row counts: the fp8-MFMA kernel (woq_gemv_fp8.hip: code bytes straight into the matrix cores,
 // activations as base-16 digits; round 4) where it takes the call, rows in chunks of 8; otherwise (per-32 / per-64 /
@@ -286,6 +287,31 @@ int launch_gemv_fp8(const void* act, int act_dtype, int lda, const void* hi_blob
     if (rc) return rc;
   }
   return 0;
+}
+
+void launch_silu_mul_tiles(const float* gu, int inter, float* act, hipStream_t st);
+
+// One batch-1 projection of an fp8-weight layer inside the decode engine (round 6): fp32 activation row in, fp32 out,
+// with the engine's fused prologue / epilogues — RMSNorm (norm_w, eps), residual add, and for the fused gate/up
+// projection (epi 1) SiLU(gate) * up. The fp8 matrix-core kernel (woq_gemv_fp8.hip) carries the norm and the residual
+// itself; its gate/up call writes the 2 * inter interleaved columns to `gu_tmp` and a small launch pairs them. Blobs it
+// does not take (g_idx, groups of 256, K beyond 12288) run the lookup kernel, which has all three built in.
+int launch_gemv_fp8_engine(const float* act, int lda, const void* hi_blob, const woq_blob_header& hi, const void* lo_q,
+                           uint32_t fp8_type, float* out, int ldo, const float* norm_w, float eps, const float* residual,
+                           int ld_res, int epi, float* gu_tmp, hipStream_t st) {
+  if (gemv_fp8_mfma_supported(act, WOQ_F32, lda, hi) && (epi != 1 || gu_tmp != nullptr)) {
+    if (epi == 1) {
+      const int rc = launch_gemv_fp8_mfma(act, WOQ_F32, lda, 1, hi_blob, hi, lo_q, fp8_type, nullptr, gu_tmp, WOQ_F32,
+                                          hi.N, st, norm_w, eps, nullptr, 0);
+      if (rc) return rc;
+      launch_silu_mul_tiles(gu_tmp, hi.N / 2, out, st);
+      return 0;
+    }
+    return launch_gemv_fp8_mfma(act, WOQ_F32, lda, 1, hi_blob, hi, lo_q, fp8_type, nullptr, out, WOQ_F32, ldo, st, norm_w,
+                                eps, residual, ld_res);
+  }
+  return launch_gemv_generic(act, WOQ_F32, lda, 1, hi_blob, hi, nullptr, out, WOQ_F32, ldo, norm_w, eps, residual, ld_res,
+                             epi, st, lo_q, fp8_type);
 }
 
 }  // namespace woq

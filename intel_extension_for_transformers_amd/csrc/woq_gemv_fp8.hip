@@ -65,13 +65,26 @@ __device__ __forceinline__ float4_t mfma_f8(i64_t a, i64_t b, float4_t c) {
 // of this kernel contracts over all four lane quarters of a 64-k half, i.e. over BOTH of its 32-k blocks, so each half is
 // issued twice with the A operand of the other block's two quarters read from the zero block (the int4 tile kernel's form
 // for per-32 scales at M > 1): two more MFMAs and one more recombination per half, the matrix pipe has the room.
+// Round 6 (fp8-weight layers inside the decode engine): the epilogues the engine's launches carry. norm_w (fp32 [K],
+// fp32 activation rows only): HF LlamaRMSNorm folded in — the rows are staged as x * norm_w (every wave sums the squares
+// of the RAW x of its slice on the way) and the result is multiplied by rsqrt(mean(x^2) + eps) in the epilogue, where
+// the scale factors already sit (the factor is one number per row: it commutes with the inner product). residual (fp32
+// [M][ld_res]): out = residual + result (may alias out: a column is read and written by the same thread).
+struct F8Fused {
+  const float* norm_w;
+  float eps;
+  const float* residual;
+  int ld_res;
+};
+
 template <int TPW, bool E5M2, bool S32, int SMODE = 0>
 __global__ __launch_bounds__(TPW == 8 ? 768 : 1024) void gemv_fp8_kernel(
     const u32x4* __restrict__ qhi, const u32x4* __restrict__ qlo, const void* __restrict__ scales,
     const void* __restrict__ x, int tiles_k, int K, int base_tiles, int rem_tiles, int n_groups, int tpg_shift,
     void* __restrict__ out, const float* __restrict__ bias, int N, int M, int ms, int lda, int ldo, int out_dtype,
-    int flags) {
+    int flags, F8Fused fz) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ float ssq_l[F8_MAXM][16];  // RMSNorm: partial sums of squares of row m's slice, per wave
   constexpr int RB = f8_row_bytes(TPW);
   constexpr int XJ = TPW / 2;  // float4 loads per lane per row covering TPW * 128 activations
   constexpr int ESZ = S32 ? 4 : 2;
@@ -133,12 +146,24 @@ __global__ __launch_bounds__(TPW == 8 ? 768 : 1024) void gemv_fp8_kernel(
     for (int j = lane; j < RB / 4; j += 64) ((uint32_t*)zrow)[j] = 0u;
   }
 
-  auto load_row = [&](size_t row_off, float4_t (&xv)[XJ]) {
+  auto load_row = [&](size_t row_off, float4_t (&xv)[XJ], int m_abs) {
     if (xdt == 0) {
       const rsrc_t rx = make_rsrc((const float*)x + row_off + kbase, xlen * 4);
 #pragma unroll
       for (int j = 0; j < XJ; ++j)
         xv[j] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, v16 + j * 1024, 0, 0));
+      if (fz.norm_w != nullptr) {
+        const rsrc_t rg = make_rsrc(fz.norm_w + kbase, xlen * 4);
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+          const float4_t g4 = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, v16 + j * 1024, 0, 0));
+          ss = fmaf(xv[j].x, xv[j].x, fmaf(xv[j].y, xv[j].y, fmaf(xv[j].z, xv[j].z, fmaf(xv[j].w, xv[j].w, ss))));
+          xv[j] = xv[j] * g4;
+        }
+        ss = wave_sum_dpp(ss);
+        if (lane == 0) ssq_l[m_abs][wid] = ss;
+      }
     } else {
       const rsrc_t rx = make_rsrc((const uint16_t*)x + row_off + kbase, xlen * 2);
 #pragma unroll
@@ -199,7 +224,7 @@ __global__ __launch_bounds__(TPW == 8 ? 768 : 1024) void gemv_fp8_kernel(
     float unsc[F8_SETM] = {0.f, 0.f};
     for (int m = 0; m < Mrs; ++m) {
       float4_t xv[XJ];
-      load_row((size_t)(rs * ms + m) * lda, xv);
+      load_row((size_t)(rs * ms + m) * lda, xv, rs * ms + m);
       const float u = stage_row(m, xv);
       if (m == 0)
         unsc[0] = u;
@@ -304,7 +329,13 @@ __global__ __launch_bounds__(TPW == 8 ? 768 : 1024) void gemv_fp8_kernel(
     for (int w2 = 0; w2 < nw; ++w2) v += slab[(((size_t)e_rs * nw + w2) * F8_SETM + e_mi) * 16 + e_i];
     const int n = tn * 16 + e_i;
     if (n < N) {
+      if (fz.norm_w != nullptr) {
+        float ss = 0.f;
+        for (int w2 = 0; w2 < nw; ++w2) ss += ssq_l[e_m][w2];
+        v *= 1.0f / sqrtf(ss / (float)K + fz.eps);  // HF LlamaRMSNorm
+      }
       if (bias) v += bias[n];
+      if (fz.residual != nullptr) v += fz.residual[(size_t)e_m * fz.ld_res + n];
       store_f32(out, (size_t)e_m * ldo + n, out_dtype, v);
     }
   }
@@ -315,6 +346,7 @@ struct F8Launch {
   int tiles_k, K, N, n_groups, tpg_shift, M, ms, lda, ldo, out_dtype, flags, nw, grid;
   void* out;
   const float* bias;
+  F8Fused fz;
 };
 
 template <int TPW, bool E5M2, bool S32, int SMODE>
@@ -323,14 +355,15 @@ static int launch_fp8_t(const F8Launch& a, hipStream_t st) {
   auto kern = gemv_fp8_kernel<TPW, E5M2, S32, SMODE>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       158 * 1024);  // the kernel also holds 512 B of static LDS (the RMSNorm partials)
     if (e != hipSuccess) return woq::fail(std::string("QBits: hipFuncSetAttribute: ") + hipGetErrorString(e));
     attr_set = true;
   }
   const int base = a.tiles_k / a.nw, rem = a.tiles_k % a.nw;
   hipLaunchKernelGGL(kern, dim3(a.grid), dim3(a.nw * 64), lds, st, (const u32x4*)a.qhi, (const u32x4*)a.qlo, a.scales,
                      a.x, a.tiles_k, a.K, base, rem, a.n_groups, a.tpg_shift, a.out, a.bias, a.N, a.M, a.ms, a.lda,
-                     a.ldo, a.out_dtype, a.flags);
+                     a.ldo, a.out_dtype, a.flags, a.fz);
   return 0;
 }
 
@@ -356,8 +389,10 @@ bool gemv_fp8_mfma_supported(const void* act, int act_dtype, int lda, const woq_
 // rows 0..M-1 (M <= 8) of an fp8 weight: act [M, lda], out [M, ldo]
 int launch_gemv_fp8_mfma(const void* act, int act_dtype, int lda, int M, const void* hi_blob, const woq_blob_header& hi,
                          const void* lo_q, uint32_t fp8_type, const float* bias, void* out, int out_dtype, int ldo,
-                         hipStream_t st) {
+                         hipStream_t st, const float* norm_w, float eps, const float* residual, int ld_res) {
   F8Launch a;
+  if (norm_w != nullptr && act_dtype != WOQ_F32) return woq::fail("QBits: the fp8 GEMV's fused RMSNorm takes fp32 rows");
+  a.fz = F8Fused{norm_w, eps, residual, ld_res};
   const uint8_t* b = (const uint8_t*)hi_blob;
   a.qhi = b + hi.off_q;
   a.qlo = lo_q;
@@ -398,6 +433,20 @@ const int smode = (int)hi.scale_mode;
   WOQ_F8_CASE(8, true, true)
 #undef WOQ_F8_CASE
   return woq::fail("QBits: bad fp8 GEMV configuration");
+}
+
+// act[p * 16 + i] = SiLU(gu[(2 p) * 16 + i]) * gu[(2 p + 1) * 16 + i]: the fused gate/up projection's 16-column tiles
+// alternate gate / up (include/woq_hip.h woq_layer_weights) — the fp8 GEMV writes them as they come, this pairs them
+__global__ __launch_bounds__(256) void silu_mul_tiles_kernel(const float* __restrict__ gu, int inter, float* __restrict__ act) {
+  const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (i < inter) {
+    const int p = i >> 4, c = i & 15;
+    const float g = gu[(size_t)(2 * p) * 16 + c], u = gu[(size_t)(2 * p + 1) * 16 + c];
+    act[i] = g / (1.0f + __expf(-g)) * u;
+  }
+}
+void launch_silu_mul_tiles(const float* gu, int inter, float* act, hipStream_t st) {
+  hipLaunchKernelGGL(silu_mul_tiles_kernel, dim3((inter + 255) / 256), dim3(256), 0, st, gu, inter, act);
 }
 
 }  // namespace woq

@@ -580,7 +580,8 @@ def synth_llama_weights(engine, hidden, inter, heads, kv_heads, head_dim, layers
     scales sized so that the dequantised weights keep the same spread; `compute_dtype` is recorded in the blobs (nf4
     decodes with three digit planes at "fp32", two at "bf16" / "fp16" / "int8": csrc/woq_gemv_common.h)."""
     table = weight_dtype in TABLE_WEIGHT_DTYPES
-    if table and not sym:
+    fp8 = weight_dtype in FP8_WEIGHT_DTYPES
+    if (table or fp8) and not sym:
         raise RuntimeError("QBits: float weight types are symmetric")
     dev = engine.device
     g = torch.Generator(device=dev)
@@ -591,8 +592,13 @@ def synth_llama_weights(engine, hidden, inter, heads, kv_heads, head_dim, layers
         gs.manual_seed(shared_seed)
 
     def rand_q(k, n):
-        q = torch.randint(0 if table else -8, 16 if table else 8, (k, n), generator=g, device=dev, dtype=torch.int8)
         kg = (k + (k if group == -1 else group) - 1) // (k if group == -1 else group)
+        if fp8:  # fp8 codes of N(0, 64^2) values (finite by construction), scales so that the weights look like N(0, 0.02^2)
+            v = (64.0 * torch.randn(k, n, generator=g, device=dev)).clamp_(-400.0, 400.0)
+            q = v.to(FP8_WEIGHT_DTYPES[weight_dtype]).view(torch.int8)
+            s = (0.5 + torch.rand(kg, n, generator=g, device=dev)) * (0.02 / 64.0)
+            return q, s, None
+        q = torch.randint(0 if table else -8, 16 if table else 8, (k, n), generator=g, device=dev, dtype=torch.int8)
         s = (0.5 + torch.rand(kg, n, generator=g, device=dev)) * (0.02 / (TABLE_WEIGHT_DTYPES[weight_dtype] if table else 4.0))
         z = None if sym else torch.randint(-8, 8, (kg, n), generator=g, device=dev, dtype=torch.int8)
         return q, s, z
@@ -634,6 +640,8 @@ def synth_llama_weights(engine, hidden, inter, heads, kv_heads, head_dim, layers
 # ---- fused decode engine from a quantised HF model (the `ipex.optimize_transformers` analogue) ---------------------
 # 4-bit table weight types the engine takes (round 4) -> the rms of their table over uniform codes (synthetic weights)
 TABLE_WEIGHT_DTYPES = {"nf4": 0.5, "fp4_e2m1": 2.9, "fp4_e2m1_bnb": 0.47}
+# 8-bit float weight types the engine takes (round 6; reference strings bestla_weightonly_dispatcher.hpp:62-72) -> torch dtype
+FP8_WEIGHT_DTYPES = {"fp8_e4m3": torch.float8_e4m3fn, "fp8_e5m2": torch.float8_e5m2}
 _TABLES = {
     "nf4": [-1.0, -0.6961928009986877, -0.5250730514526367, -0.39491748809814453, -0.28444138169288635,
             -0.18477343022823334, -0.09105003625154495, 0.0, 0.07958029955625534, 0.16093020141124725,
@@ -664,12 +672,30 @@ def _code_parts(mod):
     return order[pos].to(torch.int8), scales, None
 
 
+def _fp8_parts(mod):
+    """QuantizedLinearQBits of an fp8 weight type -> (code bytes int8 [K,N], scales fp32 [G,N], None): dequantised / scale
+    IS an fp8 value up to an fp32 rounding of the quotient, so casting it to the torch fp8 dtype returns the code."""
+    w = mod.weight.data
+    info = lambda t: qbits.acquire_packed_weight_info(w, t)  # noqa: E731
+    k, n = int(info(2)[0]), int(info(3)[0])
+    if int(info(4)[0]):
+        raise RuntimeError("QBits: the fused decode engine does not take act-order (g_idx) layers")
+    scales = info(9)
+    deq = torch.empty(k, n, dtype=torch.float32, device=w.device)
+    qbits.dequantize_packed_weight(w, deq, False, mod.compute_dtype, mod.weight_dtype, mod.scale_dtype)
+    s = scales[torch.arange(k, device=w.device) // int(info(1)[0])]
+    x = deq / torch.where(s == 0, torch.ones_like(s), s)
+    return x.to(FP8_WEIGHT_DTYPES[mod.weight_dtype]).view(torch.int8), scales, None
+
+
 def _signed_parts(mod):
     """QuantizedLinearQBits -> (q int8 [K,N] in [-8,7], scales fp32 [G,N], zp int8 [G,N] signed or None, g_idx int32 [K]
     or None). Act-order (GPTQ desc_act) modules: rows in the regrouped order the blob holds, plus the raw g_idx that
     `repack_quantized_weight` turns into the activation shuffle (reference nn/modules.py:205-224)."""
     if getattr(mod, "weight_dtype", "int4_clip") in TABLE_WEIGHT_DTYPES:
         return _code_parts(mod) + (None,)
+    if getattr(mod, "weight_dtype", "int4_clip") in FP8_WEIGHT_DTYPES:
+        return _fp8_parts(mod) + (None,)
     int_w, scales, zeros, g_idx = mod.recover_qparms_kn()
     if g_idx is not None:
         # recover_qparms_kn hands the rows back in the CHECKPOINT's order; the blob wants them regrouped (group g owns
@@ -710,8 +736,9 @@ def optimize_transformers(model, max_ctx=2048, kv_dtype=torch.float16):
     layers = model.model.layers
     first = layers[0].self_attn.q_proj
     wdt = getattr(first, "weight_dtype", "int4_clip")
-    if getattr(first, "bits", 4) != 4 or (wdt != "int4_clip" and wdt not in TABLE_WEIGHT_DTYPES):
-        raise RuntimeError("QBits: the fused decode engine takes int4_clip / nf4 / fp4 layers (int8 / fp8 models run "
+    fp8 = wdt in FP8_WEIGHT_DTYPES
+    if not fp8 and (getattr(first, "bits", 4) != 4 or (wdt != "int4_clip" and wdt not in TABLE_WEIGHT_DTYPES)):
+        raise RuntimeError("QBits: the fused decode engine takes int4_clip / nf4 / fp4 / fp8 layers (int8 models run "
                            "on the module path)")
     hidden, inter = cfg.hidden_size, cfg.intermediate_size
     heads = cfg.num_attention_heads
@@ -740,9 +767,9 @@ def optimize_transformers(model, max_ctx=2048, kv_dtype=torch.float16):
                 raise RuntimeError("QBits: the fused decode engine needs one quantisation recipe for every projection; "
                                    "layers.%d.%s is %r, layers.0.q_proj is %r" %
                                    (l, name, _sig(m) if hasattr(m, "blocksize") else type(m).__name__, _sig(first)))
-    if wdt in TABLE_WEIGHT_DTYPES and first.scheme == "asym":
-        raise RuntimeError("QBits: the 4-bit table weight types are symmetric only (reference utils/config.py:360-370)")
-    asym = first.scheme == "asym" and wdt not in TABLE_WEIGHT_DTYPES
+    if (wdt in TABLE_WEIGHT_DTYPES or fp8) and first.scheme == "asym":
+        raise RuntimeError("QBits: the float weight types are symmetric only (reference utils/config.py:360-370)")
+    asym = first.scheme == "asym" and wdt not in TABLE_WEIGHT_DTYPES and not fp8
     group, sdt = first.blocksize, first.scale_dtype
     # the blobs' compute type picks nf4's digit-plane count (three at fp32, two otherwise); int4 kernels do not read it
     cdt = getattr(first, "compute_dtype", "fp32") if wdt in TABLE_WEIGHT_DTYPES else "fp32"

@@ -30,9 +30,13 @@ def _tiny(group, asym, scale_dtype, seed=0, max_ctx=64, max_batch=1, head_dim=64
     e8, e32 = torch.empty(0, dtype=torch.int8), torch.empty(0, dtype=torch.int32)
 
     wt = {"nf4": orc.W_NF4, "fp4_e2m1": orc.W_FP4_E2M1, "fp4_e2m1_bnb": orc.W_FP4_E2M1_BNB}.get(weight_dtype)
+    f8 = {"fp8_e4m3": orc.W_FP8_E4M3, "fp8_e5m2": orc.W_FP8_E5M2}.get(weight_dtype)
 
     def quant(k, n):
         w = rng.standard_normal((k, n)).astype(np.float32) * 0.05
+        if f8 is not None:  # fp8 code bytes (as int8), symmetric
+            q, s = orc.rtn_quantize_fp8(w, False, group, f8)
+            return q.view(np.int8), s, None
         if wt is not None:  # 4-bit table type: codes 0..15, symmetric
             return orc.rtn_quantize_table(w, False, group, wt) + (None,)
         return orc.rtn_quantize(w, False, group, asym)
@@ -44,6 +48,8 @@ def _tiny(group, asym, scale_dtype, seed=0, max_ctx=64, max_batch=1, head_dim=64
                                              scale_dtype, compute_dtype, z is not None, group)
 
     def cpu_pack(q, s, z, g_idx=None):
+        if f8 is not None:
+            return orc.repack_fp8(q.view(np.uint8), s, f8, None, group, scale_type=st)
         if wt is not None:
             return orc.repack_table(q, s, wt, group, scale_type=st)
         shuf = None if g_idx is None else orc.convert_idx(g_idx, q.shape[0], q.shape[0] if group == -1 else group)
@@ -690,3 +696,48 @@ def test_engine_table_weight_types_vs_oracle(weight_dtype, group, scale_dtype, c
         eng0.step(greedy=False)
         got, ref = eng0.logits.cpu().numpy(), oracle0.forward_token(t, i)
         assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-4
+
+
+@pytest.mark.parametrize("weight_dtype,group,scale_dtype,hidden", [("fp8_e4m3", 128, "fp16", 256), ("fp8_e4m3", 32, "fp32", 256),
+                                                                 ("fp8_e5m2", -1, "bf16", 256), ("fp8_e4m3", 128, "fp32", 512)])
+def test_engine_fp8_weight_layers_vs_oracle(weight_dtype, group, scale_dtype, hidden):
+    """Round 6 (reference weight strings bestla_weightonly_dispatcher.hpp:62-72): fp8_e4m3 / fp8_e5m2
+    layers INSIDE the decode engine. set_layer takes the composite containers (HI / LO nibble planes), the decode step
+    runs the fp8 matrix-core GEMVs with RMSNorm / residual fused (csrc/woq_gemv_fp8.hip F8Fused) and a SiLU * mul pairing
+    launch, the prompt pass the MFMA GEMM over the pre-dequantised fragment image. Token-by-token decode, a prompt pass
+    and graph replays against the fp32 oracle decoder on the SAME code bytes and scales: decode logits within
+    2e-3 * max|logit| + 1e-4 (the engine tolerance), prompt-pass logits within the fp16-operand bound, greedy tokens equal.
+    Per-128 groups (the fp8 kernel's fast form), per-32 groups (its per-32-scale form), one group per column with e5m2."""
+    eng, oracle, cfg = _tiny(group, False, scale_dtype, seed=13, max_ctx=96, head_dim=64, hidden=hidden,
+                             weight_dtype=weight_dtype)
+    assert not eng.uses_xq() and not eng.uses_fused_attn()
+    rng = np.random.default_rng(17)
+    toks = rng.integers(0, cfg["vocab"], 24).tolist()
+    for i, t in enumerate(toks):
+        eng.token.fill_(t)
+        eng.pos.fill_(i)
+        eng.step(greedy=True)
+        ref = oracle.forward_token(t, i)
+        got = eng.logits.cpu().numpy()
+        assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-4, i
+        assert int(eng.token.item()) == int(ref.argmax()), i
+    # graph replays continue the same sequence
+    nxt = int(ref.argmax())
+    eng.capture(greedy=True)
+    for j in range(4):
+        eng.replay(1)
+        ref = oracle.forward_token(nxt, 24 + j)
+        nxt = int(ref.argmax())
+        assert int(eng.token.item()) == nxt
+    # prompt pass over fresh tokens (fp16-operand GEMMs over the dequantised fragment image)
+    oracle.reset()
+    prompt = rng.integers(0, cfg["vocab"], 40).tolist()
+    got = eng.prefill(prompt, greedy=True)[0].cpu().numpy()
+    ref = oracle.forward_prompt(prompt)
+    assert np.abs(got - ref).max() <= 1e-2 * np.abs(ref).max() + 1e-3
+    assert int(got.argmax()) == int(ref.argmax())
+    eng.step(greedy=True)
+    ref = oracle.forward_token(int(ref.argmax()), 40)
+    assert np.abs(eng.logits.cpu().numpy() - ref).max() <= 1e-2 * np.abs(ref).max() + 1e-3
+    assert eng.status() == 0
+
