@@ -229,6 +229,12 @@ def convert_to_quantized_model(model, config, device="cuda"):
             "load a pre-quantised checkpoint or use RtnConfig" % type(config).__name__)
     if str(device) == "cpu":
         raise RuntimeError("QBits: the MI355X backend has no CPU path (device must be 'cuda')")
+    if getattr(config, "compute_dtype", None) == "int8":
+        # SURVEY §8 a7 / VERDICT r05: say so loudly rather than compute at another precision in silence
+        logger.warning("compute_dtype='int8' selects the reference's dynamic u8 activation quantisation cores "
+                       "(bestla_weightonly_dispatcher.cpp:131-149); the MI355X path accepts the string but multiplies "
+                       "with one fp16-class product per weight (HIGHER precision than the reference's u8 activations): "
+                       "outputs follow the fp32 dequantise -> matmul definition, not the reference's int8 numerics.")
     orig_dtype = next((p.dtype for p in model.parameters()), torch.float32)
     model = replace_linear(model, None, None, config, device=device)
     model.to(device)

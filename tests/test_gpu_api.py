@@ -804,3 +804,25 @@ def test_plain_c_client_device_leg(tmp_path):
     res = subprocess.run([exe, "gpu"], capture_output=True, text=True)
     assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)
     assert "gpu checks ok" in res.stdout
+
+
+def test_compute_dtype_int8_is_accepted_and_says_what_it_computes(tmp_path, caplog):
+    """compute_dtype="int8" names the reference's dynamic u8-activation cores
+    (bestla_weightonly_dispatcher.cpp:131-149). The MI355X path accepts the string and follows the fp32 dequantise ->
+    matmul definition at a higher precision — and says so at conversion time (loudly, not silently)."""
+    import logging
+
+    from intel_extension_for_transformers_amd.transformers import AutoModelForCausalLM, RtnConfig
+
+    fp = _tiny_llama()
+    src = tmp_path / "fp"
+    fp.save_pretrained(str(src))
+    with caplog.at_level(logging.WARNING):
+        qmodel = AutoModelForCausalLM.from_pretrained(str(src), quantization_config=RtnConfig(
+            bits=4, group_size=32, compute_dtype="int8"), use_neural_speed=False)
+    assert any("compute_dtype='int8'" in r.getMessage() and "HIGHER precision" in r.getMessage() for r in caplog.records)
+    ids = torch.tensor([[5, 17, 200, 3]], device="cuda")
+    with torch.no_grad():
+        logits = qmodel(ids).logits.float()
+        ref = _dequantised_twin(qmodel, fp)(ids).logits.float()
+    assert (logits - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-5
