@@ -78,6 +78,9 @@ extern __device__ unsigned long long* g_xqs_probe;
 #ifndef WOQ_XQS_LAST
 #define WOQ_XQS_LAST 0
 #endif
+#ifndef WOQ_XQS_GU_WAVES  // A/B builds: -DWOQ_XQS_GU_WAVES=1 = the compiler's own choice (82 registers, five waves per SIMD)
+#define WOQ_XQS_GU_WAVES 6
+#endif
 
 namespace woq {
 
@@ -554,8 +557,12 @@ __device__ __forceinline__ void gemv_xqs_body(
 // (tpg_flags = tpg_shift | flags << 8 | waves << 16), so the tile loop's scale conversion does not wait for the argument
 // segment either.
 // (three digit planes x two column tiles need more than the 128 registers of a 1024-thread workgroup: 512 there)
+// (round 6: the int4 gate/up pairs — 688 workgroups of 8 waves at the 7B shape — need SIX waves per SIMD for three workgroups
+// per CU, i.e. the whole grid resident in one round; at 82 registers the compiler stopped two short of that)
 template <int TPW, int CB, int D, int SMODE, bool ASYM, bool S32, int NDIG>
-__global__ __launch_bounds__((CB * TPW > 8 || (CB == 2 && NDIG == 3)) ? 512 : 1024) void gemv_xqs_kernel(
+__global__ __launch_bounds__((CB * TPW > 8 || (CB == 2 && NDIG == 3)) ? 512 : 1024)
+__attribute__((amdgpu_waves_per_eu((CB == 2 && TPW == 4 && NDIG == 0 && SMODE == 0 && !ASYM && !S32) ? WOQ_XQS_GU_WAVES : 1)))
+void gemv_xqs_kernel(
     const u32x4* __restrict__ q, const void* __restrict__ scales, const uint8_t* __restrict__ xlimbs,
     const float* __restrict__ xu, int tiles_k, int kt_off, int base_tiles, int rem_tiles, int n_groups, int tpg_flags,
     XqsLate late_in_the_argument_segment) {
