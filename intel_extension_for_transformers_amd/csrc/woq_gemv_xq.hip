@@ -43,8 +43,10 @@ struct XqLaunch {
 };
 
 // window depth by tiles per wave (tools/xq_probe.hip grid, profiles/r03c_xq_probe.txt)
-#ifndef WOQ_XQS_DEPTH  // A/B builds: tools/mkvariant_xq.sh -DWOQ_XQS_DEPTH=6 | 8 (all of a wave's tiles up front)
-#define WOQ_XQS_DEPTH 4
+// round 6 (profiles/r06ad_gemv_occupancy_and_window.txt): 6 — same-box A/Bs on the round-6 kernel read 4 / 6 / 8 -> 993.5 / 1001.5 / 992.6 tokens/s and
+// 4 / 5 / 7 -> 999.8 / 1002.7 / 1003.2 (round 4 had measured no difference); it only reaches the 8-tile waves (o, down)
+#ifndef WOQ_XQS_DEPTH  // A/B builds: tools/mkvariant_xq.sh -DWOQ_XQS_DEPTH=4 | 8 (all of a wave's tiles up front)
+#define WOQ_XQS_DEPTH 6
 #endif
 template <int TPW>
 struct XqsDepth {
