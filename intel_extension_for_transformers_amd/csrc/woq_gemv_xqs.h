@@ -69,8 +69,21 @@ extern __device__ unsigned long long* g_xqs_probe;
 #ifndef WOQ_CHAIN_SLEEP
 #define WOQ_CHAIN_SLEEP 8
 #endif
+// Round 6 re-measured them on the round-6 kernel (profiles/r06ad_gemv_occupancy_and_window.txt, same-box A/Bs): single
+// column tiles 2 -> 1 (0 / 1 / 2 / 4 / 6: 998 / 1005 / 1001 / 987 / 981 tokens/s), the gate/up pairs all of the window -> 0,
+// the small requests first (0 / 1 / 2 beside singles at 1: 1016 / 1005 / 1000); the fused launch's q strips stay at 1
+// (0 / 1 / 2: 995 / 998 / 997) and its one-tile k / v strips go to 0 (1003 vs 998)
 #ifndef WOQ_XQS_PRE
-#define WOQ_XQS_PRE 2
+#define WOQ_XQS_PRE 1
+#endif
+#ifndef WOQ_XQS_PRE_PAIR
+#define WOQ_XQS_PRE_PAIR 0
+#endif
+#ifndef WOQ_XQS_PRE_Q
+#define WOQ_XQS_PRE_Q 1
+#endif
+#ifndef WOQ_XQS_PRE_KV
+#define WOQ_XQS_PRE_KV 0
 #endif
 // 1: no workgroup barrier behind the stream — every wave leaves its partial sums in the slab and bumps an LDS counter,
 // the wave that arrives LAST runs the epilogue at once (A/B builds: tools/mkvariant_xq.sh last -DWOQ_XQS_LAST=1;
@@ -194,7 +207,8 @@ __device__ __forceinline__ void gemv_xqs_body(
                        WOQ_XK(8) ? 0 : uni(min(kt0 + cnt, tiles_k) * 1024));
   // weight tiles requested in front of the small requests: two for single column tiles, all D for the gate/up pairs
   // (same-box A/B builds of tools/xq_probe.hip, profiles/r03i_xq_issue_order.txt)
-  constexpr int PRE = (CB == 2 || CHAIN_IN) ? DD : (WOQ_XQS_PRE < DD ? WOQ_XQS_PRE : DD);
+  constexpr int PRE_WANT = CB == 2 ? WOQ_XQS_PRE_PAIR : !FUSED ? WOQ_XQS_PRE : D == 1 ? WOQ_XQS_PRE_KV : WOQ_XQS_PRE_Q;
+  constexpr int PRE = CHAIN_IN ? DD : (PRE_WANT < DD ? PRE_WANT : DD);
 #pragma unroll
   for (int t = 0; t < PRE; ++t)
 #pragma unroll
