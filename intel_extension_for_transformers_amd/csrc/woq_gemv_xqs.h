@@ -88,6 +88,13 @@ extern __device__ unsigned long long* g_xqs_probe;
 // 1: no workgroup barrier behind the stream — every wave leaves its partial sums in the slab and bumps an LDS counter,
 // the wave that arrives LAST runs the epilogue at once (A/B builds: tools/mkvariant_xq.sh last -DWOQ_XQS_LAST=1;
 // record: profiles/r06c_*)
+// A/B builds (tools/mkvariant_xq.sh): the scale / zero-point requests in front of the limb requests; their cache policy
+#ifndef WOQ_XQS_SC_FIRST
+#define WOQ_XQS_SC_FIRST 0
+#endif
+#ifndef WOQ_XQS_SC_AUX
+#define WOQ_XQS_SC_AUX 0
+#endif
 #ifndef WOQ_XQS_LAST
 #define WOQ_XQS_LAST 0
 #endif
@@ -240,16 +247,20 @@ __device__ __forceinline__ void gemv_xqs_body(
     }
   }
   u32x4 xl[XP];
-  {
+  float uw[UL], sxw[UL];
+  constexpr int NSP = (L::SCB + 1023) / 1024;
+  u32x4 sl[CB][NSP];
+  u32x4 zl[CB];
+  int g0 = 0;
+  if constexpr (SMODE == 0) g0 = min(kt0 >> tpg_shift, n_groups - 1);
+  auto req_x = [&]() {
     const rsrc_t rl =
         make_rsrc(xlimbs + (size_t)kt0 * 384, WOQ_XK(4) ? 0 : uni(max(0, min(cnt, tiles_k - kt0)) * 384));
 #pragma unroll
     for (int j = 0; j < XP; ++j) xl[j] = __builtin_amdgcn_raw_buffer_load_b128(rl, v16 + j * 1024, 0, AUX_IN);
-  }
   // block factors of the slice: lane L holds blocks kt0 * 8 + L (+ 64 ...) (8 blocks per tile; reads past the slice
   // return 0 through the descriptor, so tiles past the slice end contribute exactly 0)
   const rsrc_t ru = make_rsrc(xu + (size_t)kt0 * 8, nblk * 4);
-  float uw[UL], sxw[UL];
 #pragma unroll
   for (int j = 0; j < UL; ++j) {
     uw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ru, (lane + 64 * j) * 4, 0, AUX_IN));
@@ -261,12 +272,9 @@ __device__ __forceinline__ void gemv_xqs_body(
     for (int j = 0; j < UL; ++j)
       sxw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, (lane + 64 * j) * 4, 0, AUX_IN));
   }
+  };
   // the wave's slice of scales (and zero points) of each column tile: one vector request per KiB
-  constexpr int NSP = (L::SCB + 1023) / 1024;
-  u32x4 sl[CB][NSP];
-  u32x4 zl[CB];
-  int g0 = 0;
-  if constexpr (SMODE == 0) g0 = min(kt0 >> tpg_shift, n_groups - 1);
+  auto req_s = [&]() {
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
     const int tn = bx * CB + cb;
@@ -281,9 +289,18 @@ __device__ __forceinline__ void gemv_xqs_body(
       rz = make_rsrc(zp + ((size_t)tn * tiles_k + kt0) * 64, left * 64);
     }
 #pragma unroll
-    for (int j = 0; j < NSP; ++j) sl[cb][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, v16 + j * 1024, 0, 0);
-    if constexpr (ASYM) zl[cb] = __builtin_amdgcn_raw_buffer_load_b128(rz, v16, 0, 0);
+    for (int j = 0; j < NSP; ++j) sl[cb][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, v16 + j * 1024, 0, WOQ_XQS_SC_AUX);
+    if constexpr (ASYM) zl[cb] = __builtin_amdgcn_raw_buffer_load_b128(rz, v16, 0, WOQ_XQS_SC_AUX);
   }
+  };
+#if WOQ_XQS_SC_FIRST
+  req_s();
+  __builtin_amdgcn_sched_barrier(0);
+  req_x();
+#else
+  req_x();
+  req_s();
+#endif
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int t = PRE; t < DD; ++t)
