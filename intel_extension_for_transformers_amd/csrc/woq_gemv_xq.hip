@@ -123,6 +123,13 @@ static bool xq_geometry(int tiles_k, int cb, int smode, int& nw, int& tpw, int n
     return s ? atoi(s) : 0;
   }();
   if (cb == 1 && tiles_k <= 32 && (forced_short == 4 || forced_short == 8)) tpw = forced_short;
+#ifdef WOQ_XQ_TPW6
+  static const int forced_long = [] {
+    const char* s = getenv("WOQ_XQ_TPW_LONG");
+    return s ? atoi(s) : 0;
+  }();
+  if (cb == 1 && tiles_k > 32 && tiles_k <= 96 && forced_long == 6 && ndig == 0) tpw = 6;
+#endif
   const bool wide = cb == 2 && ndig == 3;  // table weights, three digit planes, column-tile pairs: 512-thread launches
   if (wide && tiles_k > 32 && smode == 0) tpw = 8;
   nw = (tiles_k + tpw - 1) / tpw;
@@ -211,7 +218,13 @@ int launch_gemv_xq(const XqPtrs& xin, const void* blob, const woq_blob_header& h
     if (cb == 2)
       rc = tpw == 4 ? launch_xq_sm<4, 2>(a, smode, asym, s32, st) : launch_xq_sm<8, 2>(a, smode, asym, s32, st);
     else
+#ifdef WOQ_XQ_TPW6  // A/B build (tools/mkvariant_xq.sh t6 -DWOQ_XQ_TPW6=1, WOQ_XQ_TPW_LONG=6): 6-tile waves for long K
+      rc = tpw == 6   ? launch_xq_sm<6, 1>(a, smode, asym, s32, st)
+           : tpw == 4 ? launch_xq_sm<4, 1>(a, smode, asym, s32, st)
+                      : launch_xq_sm<8, 1>(a, smode, asym, s32, st);
+#else
       rc = tpw == 4 ? launch_xq_sm<4, 1>(a, smode, asym, s32, st) : launch_xq_sm<8, 1>(a, smode, asym, s32, st);
+#endif
     if (rc) return rc;
   }
   return 0;
