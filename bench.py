@@ -34,6 +34,7 @@ import argparse
 import gc
 import json
 import os
+import re
 import sys
 import time
 
@@ -403,7 +404,11 @@ def read_traffic():
     pdir = os.path.join(ROOT, "profiles")
     best = None
     if os.path.isdir(pdir):
-        for f in sorted(os.listdir(pdir)):
+        def visit_key(name):  # r06k < r06z < r06aa < r06ab: round number, then the visit letters in spreadsheet order
+            m = re.match(r"r(\d+)([a-z]*)_", name)
+            return (int(m.group(1)), len(m.group(2)), m.group(2)) if m else (-1, 0, name)
+
+        for f in sorted(os.listdir(pdir), key=visit_key):
             if f.endswith("_pmc_traffic.json"):
                 best = f
     if not best:

@@ -53,3 +53,14 @@ def test_emit_writes_the_full_record_beside_the_line(tmp_path, monkeypatch, caps
     with open(tmp_path / bench.EXTRA_FILE) as fh:
         full = json.load(fh)
     assert len(full["extra_configs"]) == len(rec["extra_configs"]) and "launch_modes" in full
+
+
+def test_traffic_comes_from_the_latest_counter_pass(tmp_path, monkeypatch):
+    """Visit names sort like spreadsheet columns (r06k < r06z < r06aa < r06ab), not as plain strings."""
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    for name, b in (("r05z", 1.0), ("r06k", 2.0), ("r06ab", 3.0), ("r06aa", 4.0)):
+        with open(tmp_path / "profiles" / (name + "_pmc_traffic.json"), "w") as fh:
+            json.dump({"hbm_bytes_per_launch": b, "command": "c"}, fh)
+    t = bench.read_traffic()
+    assert t["source"] == "profiles/r06ab_pmc_traffic.json" and t["bytes"] == 3.0 and t["measured_in_this_run"] is False
