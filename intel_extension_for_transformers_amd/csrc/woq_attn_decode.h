@@ -6,6 +6,11 @@
 #include "woq_device.h"
 #include "woq_xq.h"
 
+// polling interval of a wave that re-reads its granules, in units of 64 clocks (A/B builds: r06ap)
+#ifndef WOQ_ATTN_POLL_SLEEP
+#define WOQ_ATTN_POLL_SLEEP 2
+#endif
+
 namespace woq {
 
 // Single-query attention for one new token: one workgroup (4 waves) per query head.
@@ -182,7 +187,7 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
           if (lane == 0) atomicOr(src.status, 1);
           break;
         }
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(WOQ_ATTN_POLL_SLEEP);
       }
     } else {
       qa = src.qkv[oq], qb = src.qkv[oq + half];
@@ -215,7 +220,7 @@ __device__ __forceinline__ void attn_decode_env(float* sm, int h, int slice, int
             if (lane == 0) atomicOr(src.status, 1);
             break;
           }
-          __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_s_sleep(WOQ_ATTN_POLL_SLEEP);
         }
       } else {
         ka = src.qkv[ok], kb = src.qkv[ok + half];
