@@ -212,8 +212,9 @@ __device__ __forceinline__ void gemv_xqs_body(
   for (int cb = 0; cb < CB; ++cb)
     rq[cb] = make_rsrc(q + (size_t)(bx * CB + cb) * tiles_k * 64,
                        WOQ_XK(8) ? 0 : uni(min(kt0 + cnt, tiles_k) * 1024));
-  // weight tiles requested in front of the small requests: two for single column tiles, all D for the gate/up pairs
-  // (same-box A/B builds of tools/xq_probe.hip, profiles/r03i_xq_issue_order.txt)
+  // weight tiles requested in front of the small requests (WOQ_XQS_PRE* above): one for single column tiles and the fused
+  // launch's q strips, none for the gate/up pairs and the one-tile-deep k / v strips (round 3 had two / all of the window:
+  // profiles/r03i_xq_issue_order.txt; re-measured on the round-6 kernel: profiles/r06ad_gemv_occupancy_and_window.txt)
   constexpr int PRE_WANT = CB == 2 ? WOQ_XQS_PRE_PAIR : !FUSED ? WOQ_XQS_PRE : D == 1 ? WOQ_XQS_PRE_KV : WOQ_XQS_PRE_Q;
   constexpr int PRE = CHAIN_IN ? DD : (PRE_WANT < DD ? PRE_WANT : DD);
 #pragma unroll
